@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz by running the REAL reference classes.
+
+Run in the build container only (it needs /root/reference):
+
+    python -m oracle.gen_golden
+
+The reference (pure Python on torch + pytorch_lightning + torchmetrics +
+torchvision) is imported from /root/reference with the stand-in packages in
+oracle/shims ahead of it on sys.path (none of the three third-party packages is
+installed here).  Its own ``Pix2Pix`` / ``Unet`` / ``Discriminator`` classes and
+its own ``UnetWrapper.training_step`` / ``validation_step`` then run on CPU.
+Only inputs/outputs (data) are written; no reference source is copied.
+
+Reference defect handled as SURVEY Q1 prescribes: ``UnetWrapper.__init__``
+builds ``Discriminator()`` with in_channels=3 (models/wrapper.py:34), which
+cannot run on 1-channel data, so the discriminator is rebuilt with
+in_channels=1 after construction.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(HERE, "shims"))
+    sys.path.insert(0, ROOT)
+    from models.pix2pix import Pix2Pix            # noqa
+    from models.wrapper import Discriminator     # noqa
+    from models.utils import init_weights        # noqa
+    return Pix2Pix, Discriminator, init_weights
+
+
+def synth_batch(seed, n, size):
+    """The canonical synthetic pair: numpy default_rng, U[0,1) -> [-1,1)."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, 1, size, size), dtype=np.float32) * 2 - 1
+    t = rng.random((n, 1, size, size), dtype=np.float32) * 2 - 1
+    return torch.from_numpy(x), torch.from_numpy(t)
+
+
+def build_reference_model(mults, loss_type, seed):
+    from oracle.pix2pix_ref import make_unet_state, make_disc_state, init_state_portable
+    Pix2Pix, Discriminator, init_weights = _REF
+    m = Pix2Pix(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=0.0,
+                loss_type=loss_type)
+    g_st = init_state_portable(make_unet_state(1, 1, mults), seed, perturb_bn=True)
+    missing = m.unet.load_state_dict(g_st, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    if loss_type == "gan":
+        m.discriminator = Discriminator(in_channels=1)
+        d_st = init_state_portable(make_disc_state(1), seed + 1)
+        m.discriminator.load_state_dict(d_st, strict=True)
+    m.train()
+    return m
+
+
+def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors):
+    from oracle.fingerprint import fingerprint
+    m = build_reference_model(mults, loss_type, seed)
+    x, t = synth_batch(seed + 100, n, size)
+    rec = OrderedDict()
+    rec["meta.mults"] = np.array(mults)
+    rec["meta.size"] = np.array(size)
+    rec["meta.n"] = np.array(n)
+    rec["meta.seed"] = np.array(seed)
+    rec["meta.steps"] = np.array(steps)
+    rec["meta.loss_type"] = np.array(loss_type)
+    for s in range(steps):
+        m.logged = {}
+        m.training_step((x, t), s)
+        for k, v in m.logged.items():
+            rec[f"step{s}.log.{k}"] = np.array(float(v), dtype=np.float64)
+        for k, p in m.unet.named_parameters():
+            rec[f"step{s}.ggrad.{k}"] = fingerprint(p.grad)
+        if m.discriminator is not None:
+            for k, p in m.discriminator.named_parameters():
+                rec[f"step{s}.dgrad.{k}"] = fingerprint(p.grad)
+        for k, v in m.unet.state_dict().items():
+            rec[f"step{s}.gstate.{k}"] = fingerprint(v)
+        if m.discriminator is not None:
+            for k, v in m.discriminator.state_dict().items():
+                rec[f"step{s}.dstate.{k}"] = fingerprint(v)
+    # eval-mode forward + validation metrics with the trained running stats
+    m.eval()
+    m.logged = {}
+    with torch.no_grad():
+        m.validation_step((x, t), 0)
+        pred_eval = m(x)
+    for k, v in m.logged.items():
+        rec[f"val.log.{k}"] = np.array(float(v), dtype=np.float64)
+    rec["val.pred"] = fingerprint(pred_eval)
+    if full_tensors:
+        rec["val.pred_full"] = pred_eval.numpy()
+        for k, v in m.unet.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                rec[f"final.gstate_full.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("wrote", name, {k: float(v) for k, v in rec.items() if ".log." in k})
+
+
+def run_forward_case(name, mults, size, n, seed):
+    """Train-mode forward only: per-level activations of the reference Unet and
+    the PatchGAN logits, recorded with forward hooks on the reference modules."""
+    from oracle.fingerprint import fingerprint
+    m = build_reference_model(mults, "gan", seed)
+    x, t = synth_batch(seed + 100, n, size)
+    rec = OrderedDict()
+    rec["meta.mults"] = np.array(mults)
+    rec["meta.size"] = np.array(size)
+    rec["meta.n"] = np.array(n)
+    rec["meta.seed"] = np.array(seed)
+    acts = {}
+    hooks = []
+    for i, enc in enumerate(m.unet.encoders):
+        hooks.append(enc.register_forward_hook(lambda mod, a, out, i=i: acts.__setitem__(f"enc{i}", out.detach())))
+    for j, dec in enumerate(m.unet.decoders):
+        hooks.append(dec.register_forward_hook(lambda mod, a, out, j=j: acts.__setitem__(f"dec{j}", out.detach())))
+    with torch.no_grad():
+        pred = m.unet(x)
+        logits_fake = m.discriminator(x, pred)
+        logits_real = m.discriminator(x, t)
+    for h in hooks:
+        h.remove()
+    for k, v in acts.items():
+        rec[f"act.{k}"] = fingerprint(v)
+    rec["pred"] = fingerprint(pred)
+    rec["pred_full"] = pred.numpy()
+    rec["logits_fake_full"] = logits_fake.numpy()
+    rec["logits_real_full"] = logits_real.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("wrote", name)
+
+
+def run_metric_kats():
+    """SSIM/PSNR/RMSE through the reference's own wrappers (models/utils.py:38-47)."""
+    sys.path.insert(0, REF)
+    from models.utils import ssim, psnr, rmse, denormalize
+    rng = np.random.default_rng(0)
+    a = rng.random((4, 1, 256, 256), dtype=np.float32)
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape).astype(np.float32), 0, 1)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    rec = {"a_seed": np.array(0),
+           "ssim": np.array(float(ssim(tb, ta))), "psnr": np.array(float(psnr(tb, ta))),
+           "rmse": np.array(float(rmse(tb, ta)))}
+    z = torch.from_numpy(rng.standard_normal((2, 1, 64, 64)).astype(np.float32) * 1.5)
+    rec["denorm_in"] = z.numpy()
+    rec["denorm_out"] = denormalize(z).numpy()
+    np.savez_compressed(os.path.join(OUT, "metric_kats.npz"), **rec)
+    print("wrote metric_kats", rec["ssim"], rec["psnr"], rec["rmse"])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    _REF = _import_reference()
+    run_metric_kats()
+    run_forward_case("ref_forward_tiny", (1, 2, 2, 4), 32, 4, seed=11)
+    run_case("ref_gan_tiny", (1, 2, 2, 4), 32, 4, "gan", seed=21, steps=3, full_tensors=True)
+    for lt in ("ssim", "psnr", "ssim+psnr", "mse"):
+        run_case("ref_" + lt.replace("+", "_") + "_tiny", (1, 2, 2, 4), 32, 4, lt, seed=31, steps=2,
+                 full_tensors=False)
+    run_forward_case("ref_forward_full", (1, 2, 4, 8, 8, 8, 8, 8), 256, 4, seed=41)
+    run_case("ref_gan_full", (1, 2, 4, 8, 8, 8, 8, 8), 256, 4, "gan", seed=51, steps=2, full_tensors=False)

@@ -1,0 +1,127 @@
+"""CPU: the oracle (oracle/) must reproduce what the REAL reference produced
+(tests/golden/*.npz, made by oracle/gen_golden.py) and the independent
+scikit-image SSIM values.  This is what pins the oracle."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.fingerprint import fingerprint, fingerprint_close
+from oracle.gen_golden import synth_batch
+from oracle.gen_ssim_skimage import pairs  # numpy only at import? (skimage imported lazily below)
+
+RTOL = 2e-5   # same torch, same CPU ops: only thread-count reduction-order noise expected
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _states(meta_mults, seed, gan=True):
+    g = oracle.init_state_portable(oracle.make_unet_state(1, 1, tuple(int(v) for v in meta_mults)),
+                                   seed, perturb_bn=True)
+    d = oracle.init_state_portable(oracle.make_disc_state(1), seed + 1) if gan else None
+    return g, d
+
+
+def _check_fp(got_t, want_fp, what, rtol=RTOL):
+    ok, worst = fingerprint_close(fingerprint(got_t), want_fp, rtol)
+    assert ok, f"{what}: fingerprint mismatch, worst err/tol = {worst:.3g}"
+
+
+@pytest.mark.parametrize("name", ["ref_forward_tiny", "ref_forward_full"])
+def test_forward_matches_reference(golden_dir, name):
+    z = _load(golden_dir, name)
+    seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
+    g, d = _states(z["meta.mults"], seed)
+    x, t = synth_batch(seed + 100, n, size)
+    with torch.no_grad():
+        pred, acts = oracle.unet_forward(g, x, training=True, return_feats=True)
+        lf = oracle.disc_forward(d, x, pred)
+        lr = oracle.disc_forward(d, x, t)
+    for k in z.files:
+        if k.startswith("act."):
+            key = k[4:]
+            if key in acts:
+                _check_fp(acts[key], z[k], k)
+    np.testing.assert_allclose(pred.numpy(), z["pred_full"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lf.numpy(), z["logits_fake_full"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lr.numpy(), z["logits_real_full"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["ref_gan_tiny", "ref_ssim_tiny", "ref_psnr_tiny",
+                                  "ref_ssim_psnr_tiny", "ref_mse_tiny", "ref_gan_full"])
+def test_training_step_matches_reference(golden_dir, name):
+    z = _load(golden_dir, name)
+    seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
+    steps, loss_type = int(z["meta.steps"]), str(z["meta.loss_type"])
+    g, d = _states(z["meta.mults"], seed, gan=(loss_type == "gan"))
+    x, t = synth_batch(seed + 100, n, size)
+    og, od = oracle.AdamState(), oracle.AdamState()
+    for s in range(steps):
+        logs, grads = oracle.gan_training_step(g, d, og, od, x, t, loss_type=loss_type,
+                                               return_grads=True)
+        for k, v in logs.items():
+            want = float(z[f"step{s}.log.{k}"])
+            assert abs(float(v) - want) <= 5e-5 * max(1.0, abs(want)), (s, k, float(v), want)
+        for k, gr in grads["g"].items():
+            if gr is None:
+                continue
+            # conv bias in front of a BatchNorm has an analytically zero gradient:
+            # what is stored is cancellation noise, compare it on the weight-grad scale
+            _check_fp(gr, z[f"step{s}.ggrad.{k}"], f"step{s} ggrad {k}",
+                      rtol=RTOL if not _bias_before_bn(k, g) else 1.0)
+        if "d" in grads:
+            for k, gr in grads["d"].items():
+                _check_fp(gr, z[f"step{s}.dgrad.{k}"], f"step{s} dgrad {k}")
+        for k, v in g.items():
+            if _bias_before_bn(k, g):
+                continue
+            _check_fp(v, z[f"step{s}.gstate.{k}"], f"step{s} gstate {k}", rtol=1e-4)
+        if d is not None:
+            for k, v in d.items():
+                _check_fp(v, z[f"step{s}.dstate.{k}"], f"step{s} dstate {k}", rtol=1e-4)
+    for k, v in g.items():
+        if k.endswith("num_batches_tracked"):
+            # two generator forwards per GAN step
+            assert int(v) == (2 if loss_type == "gan" else 1) * steps
+    logs = oracle.validation_step(g, x, t)
+    for k, v in logs.items():
+        want = float(z[f"val.log.{k}"])
+        assert abs(float(v) - want) <= 5e-5 * max(1.0, abs(want)), (k, float(v), want)
+
+
+def _bias_before_bn(k, st):
+    if not k.endswith(".1.bias"):
+        return False
+    return (k[:-len(".1.bias")] + ".2.weight") in st
+
+
+def test_metric_kats(golden_dir):
+    z = _load(golden_dir, "metric_kats")
+    rng = np.random.default_rng(int(z["a_seed"]))
+    a = rng.random((4, 1, 256, 256), dtype=np.float32)
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape).astype(np.float32), 0, 1)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    assert abs(float(oracle.ssim(tb, ta)) - float(z["ssim"])) < 1e-6
+    assert abs(float(oracle.psnr(tb, ta)) - float(z["psnr"])) < 1e-5
+    assert abs(float(oracle.rmse(tb, ta)) - float(z["rmse"])) < 1e-7
+    np.testing.assert_array_equal(oracle.denormalize(torch.from_numpy(z["denorm_in"])).numpy(),
+                                  z["denorm_out"])
+
+
+@pytest.mark.parametrize("case", ["c256", "c64x48", "strip16"])
+def test_ssim_against_scikit_image(golden_dir, case):
+    """Independent pin of the restated torchmetrics SSIM (cropped per-image mean)."""
+    z = _load(golden_dir, "ssim_skimage")
+    seed, n, h, w = (int(v) for v in z[case + ".cfg"])
+    a, b = pairs(seed, n, h, w)
+    per64, _ = oracle.ssim_full(torch.from_numpy(b).double(), torch.from_numpy(a).double())
+    np.testing.assert_allclose(per64.numpy(), z[case + ".ssim"], rtol=0, atol=1e-12)
+    per32, _ = oracle.ssim_full(torch.from_numpy(b), torch.from_numpy(a))
+    np.testing.assert_allclose(per32.numpy(), z[case + ".ssim"], rtol=0, atol=2e-6)
+    # ordering of the per-image values is part of the parity criterion
+    assert (np.argsort(per32.numpy()) == np.argsort(z[case + ".ssim"])).all()
