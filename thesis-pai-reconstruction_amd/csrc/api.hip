@@ -1,0 +1,248 @@
+// C-ABI entry points of libpai_hip.so: argument checking, problem construction and
+// kernel selection for the convolution family (include/pai_hip.h).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void pai_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* pai_last_error(void) { return g_err; }
+extern "C" int pai_version(void) { return 100; }
+
+extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    PAI_CHECK(e == hipSuccess, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    PAI_CHECK(e == hipSuccess, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, p.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+static int check_desc(const pai_conv_desc* d) {
+    PAI_CHECK(d != nullptr, "null descriptor");
+    PAI_CHECK(d->dtype == PAI_F32 || d->dtype == PAI_BF16, "bad dtype %d", d->dtype);
+    PAI_CHECK(d->kernel == 4 && d->pad == 1, "only kernel=4 pad=1 supported (got k=%d p=%d)",
+              d->kernel, d->pad);
+    PAI_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0,
+              "bad shape N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2,
+              d->Cout);
+    if (d->transposed) {
+        PAI_CHECK(d->stride == 2, "ConvTranspose2d needs stride 2");
+    } else {
+        PAI_CHECK(d->stride == 1 || d->stride == 2, "Conv2d stride must be 1 or 2");
+        if (d->stride == 2)
+            PAI_CHECK((d->H % 2) == 0 && (d->W % 2) == 0, "stride-2 Conv2d needs even H, W");
+        else
+            PAI_CHECK(d->H >= 3 && d->W >= 3, "k4 s1 p1 Conv2d needs H, W >= 3");
+    }
+    PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
+    return 0;
+}
+
+extern "C" int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW) {
+    if (check_desc(d)) return 1;
+    if (d->transposed) {
+        *OH = d->H * 2;
+        *OW = d->W * 2;
+    } else {
+        *OH = (d->H + 2 * d->pad - d->kernel) / d->stride + 1;
+        *OW = (d->W + 2 * d->pad - d->kernel) / d->stride + 1;
+    }
+    return 0;
+}
+
+// phase decomposition of a k4 s2 p1 transposed gather: output index o = 2a + ph receives
+// taps kh with kh == ph+1 (mod 2), from source index a + off.
+static void phase_taps(int ph, int kh[2], int off[2]) {
+    if (ph == 0) {
+        kh[0] = 1; off[0] = 0;
+        kh[1] = 3; off[1] = -1;
+    } else {
+        kh[0] = 0; off[0] = 1;
+        kh[1] = 2; off[1] = 0;
+    }
+}
+
+static void fill_conv_taps(GG* g, int S, int off0) {
+    // stride-S conv form: source = grid*S + (kh + off0)
+    g->S = S;
+    g->nphase = 1;
+    g->ntaps = 16;
+    g->OS = 1;
+    g->poy[0] = g->pox[0] = 0;
+    for (int kh = 0; kh < 4; ++kh)
+        for (int kw = 0; kw < 4; ++kw) {
+            int t = kh * 4 + kw;
+            g->dy[0][t] = (signed char)(kh + off0);
+            g->dx[0][t] = (signed char)(kw + off0);
+            g->wt[0][t] = (signed char)t;
+        }
+}
+
+static void fill_phase_taps(GG* g) {
+    g->S = 1;
+    g->nphase = 4;
+    g->ntaps = 4;
+    g->OS = 2;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            int p = ph * 2 + pw;
+            g->poy[p] = (signed char)ph;
+            g->pox[p] = (signed char)pw;
+            int khs[2], offy[2], kws[2], offx[2];
+            phase_taps(ph, khs, offy);
+            phase_taps(pw, kws, offx);
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    int t = a * 2 + b;
+                    g->dy[p][t] = (signed char)offy[a];
+                    g->dx[p][t] = (signed char)offx[b];
+                    g->wt[p][t] = (signed char)(khs[a] * 4 + kws[b]);
+                }
+        }
+}
+
+int gg_build_fwd(const pai_conv_desc* d, GG* g) {
+    if (check_desc(d)) return 1;
+    memset(g, 0, sizeof(*g));
+    g->N = d->N; g->H = d->H; g->W = d->W;
+    g->C1 = d->C1; g->C2 = d->C2; g->Cin = d->C1 + d->C2;
+    g->Cout = d->Cout;
+    g->D1 = d->Cout; g->D2 = 0;
+    g->wtaps = 16;
+    g->relu1 = d->relu1; g->relu2 = d->relu2;
+    int OH, OW;
+    pai_conv_out_hw(d, &OH, &OW);
+    g->OH = OH; g->OW = OW;
+    if (!d->transposed) {
+        g->OHg = OH; g->OWg = OW;
+        fill_conv_taps(g, d->stride, -d->pad);
+    } else {
+        // out[2a+ph] gathers in[a + off]  (models/pix2pix.py:99-105 semantics)
+        g->OHg = d->H; g->OWg = d->W;
+        fill_phase_taps(g);
+    }
+    g->M = g->N * g->OHg * g->OWg;
+    return 0;
+}
+
+int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
+    if (check_desc(d)) return 1;
+    memset(g, 0, sizeof(*g));
+    int OH, OW;
+    pai_conv_out_hw(d, &OH, &OW);
+    // source = dy [N, OH, OW, Cout];  destination = dx [N, H, W, C1|C2]
+    g->N = d->N; g->H = OH; g->W = OW;
+    g->C1 = d->Cout; g->C2 = 0; g->Cin = d->Cout;
+    g->Cout = d->C1 + d->C2;
+    g->D1 = d->C1; g->D2 = d->C2;
+    g->wtaps = 16;
+    g->OH = d->H; g->OW = d->W;
+    if (!d->transposed) {
+        if (d->stride == 2) {
+            // dx[2a+ph] = sum_kh dy[a + off] w[kh]  -- same phase structure as ConvTranspose2d
+            g->OHg = d->H / 2; g->OWg = d->W / 2;
+            fill_phase_taps(g);
+        } else {
+            // dx[i] = sum_kh dy[i + pad - kh] w[kh]
+            g->OHg = d->H; g->OWg = d->W;
+            g->S = 1; g->nphase = 1; g->ntaps = 16; g->OS = 1;
+            for (int kh = 0; kh < 4; ++kh)
+                for (int kw = 0; kw < 4; ++kw) {
+                    int t = kh * 4 + kw;
+                    g->dy[0][t] = (signed char)(d->pad - kh);
+                    g->dx[0][t] = (signed char)(d->pad - kw);
+                    g->wt[0][t] = (signed char)t;
+                }
+        }
+    } else {
+        // d in[i] = sum_kh d out[2i - 1 + kh] w[kh]  -- stride-2 conv form over d out
+        g->OHg = d->H; g->OWg = d->W;
+        fill_conv_taps(g, 2, -d->pad);
+    }
+    g->M = g->N * g->OHg * g->OWg;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+static bool use_mfma(int dtype, const GG& g, const FwdArgs& a) { return fwd_mfma_ok(dtype, g, a); }
+
+extern "C" int pai_conv_fwd_stats_rows(const pai_conv_desc* d) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return -1;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y1 = (void*)1;  // raw output present
+    a.stats = (float*)1;
+    int mt = use_mfma(d->dtype, g, a) ? fwd_mfma_mtiles(g) : fwd_simt_mtiles(g);
+    return mt * g.nphase;
+}
+
+static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
+    if (use_mfma(dtype, g, a)) return launch_fwd_mfma(g, a, s);
+    return launch_fwd_simt(dtype, g, a, s);
+}
+
+extern "C" int pai_conv_fwd(const pai_conv_desc* d, const void* x1, const void* x2,
+                            const void* w_fwd, const float* bias, void* y_raw, void* y_act,
+                            float* y_f32, float* stats, void* stream) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return 1;
+    PAI_CHECK(x1 && w_fwd, "pai_conv_fwd: null x1 / w");
+    PAI_CHECK(d->C2 == 0 || x2, "pai_conv_fwd: C2 > 0 but x2 is null");
+    PAI_CHECK(y_raw || y_act || y_f32, "pai_conv_fwd: no output requested");
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = x1; a.x2 = x2; a.w = w_fwd; a.bias = bias;
+    a.y1 = y_raw; a.y2 = nullptr; a.yact = y_act; a.yf32 = y_f32; a.stats = stats;
+    a.eact = d->epilogue_act;
+    return run_fwd(d->dtype, g, a, (hipStream_t)stream);
+}
+
+extern "C" int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void* w_dgrad,
+                              void* dx1, void* dx2, int only_c2, void* stream) {
+    GG g;
+    if (gg_build_dgrad(d, &g)) return 1;
+    PAI_CHECK(dy && w_dgrad, "pai_conv_dgrad: null dy / w");
+    PAI_CHECK(only_c2 ? (dx2 && d->C2 > 0) : (dx1 != nullptr), "pai_conv_dgrad: missing output");
+    PAI_CHECK(d->C2 == 0 || dx2, "pai_conv_dgrad: C2 > 0 but dx2 is null");
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = dy; a.w = w_dgrad;
+    a.y1 = dx1; a.y2 = dx2;
+    a.skip_d1 = only_c2;
+    return run_fwd(d->dtype, g, a, (hipStream_t)stream);
+}
+
+extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2,
+                              const void* dy, float* dw, float* dbias, void* stream) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return 1;
+    PAI_CHECK(x1 && dy && dw, "pai_conv_wgrad: null pointer");
+    PAI_CHECK(d->C2 == 0 || x2, "pai_conv_wgrad: C2 > 0 but x2 is null");
+    WgradArgs a;
+    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias;
+    hipStream_t s = (hipStream_t)stream;
+    if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+        int chunks = g.Cin / 8;
+        if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);
+    }
+    if (wgrad_mfma_ok(d->dtype, g)) return launch_wgrad_mfma(g, a, s);
+    return launch_wgrad_simt(d->dtype, g, a, s);
+}

@@ -1,0 +1,381 @@
+// BatchNorm2d training/eval kernels (HBM-bound elementwise + per-channel reductions).
+// Replaces aten::native_batch_norm / native_batch_norm_backward issued by nn.BatchNorm2d at
+// models/pix2pix.py:70,106.  The batch statistics themselves come from the convolution
+// epilogues as per-tile partial sums (see gg_*.hip); nothing here re-reads the activation to
+// compute them.
+#include "common.h"
+
+constexpr int STAGE_ROWS = 64;
+
+// ---- forward statistics --------------------------------------------------------------
+__global__ void bn_stats_stage1_k(const float* stats, int R, int C2, int per, double* out) {
+    const int col = blockIdx.y * 256 + threadIdx.x;
+    if (col >= C2) return;
+    const int r0 = blockIdx.x * per, r1 = min(R, r0 + per);
+    double s = 0.0;
+    for (int r = r0; r < r1; ++r) s += (double)stats[(size_t)r * C2 + col];
+    out[(size_t)blockIdx.x * C2 + col] = s;
+}
+
+__global__ void bn_finalize_k(const float* stats, const double* stage, int R, int C, double count,
+                              const float* gamma, const float* beta, float eps, float momentum,
+                              int n_updates, float* running_mean, float* running_var,
+                              int64_t* nbt, float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += n_updates;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    if (stage) {
+        for (int r = 0; r < STAGE_ROWS; ++r) {
+            s += stage[(size_t)r * 2 * C + c];
+            q += stage[(size_t)r * 2 * C + C + c];
+        }
+    } else {
+        for (int r = 0; r < R; ++r) {
+            s += (double)stats[(size_t)r * 2 * C + c];
+            q += (double)stats[(size_t)r * 2 * C + C + c];
+        }
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    scale_o[c] = sc;
+    shift_o[c] = b - (float)mean * sc;
+    if (running_mean && running_var) {
+        const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+        float rm = running_mean[c], rv = running_var[c];
+        for (int u = 0; u < n_updates; ++u) {
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
+extern "C" int pai_bn_stats_buffer_rows(int rows) { return rows + 2 * STAGE_ROWS; }
+
+extern "C" int pai_bn_finalize(const float* stats, int rows, int C, int64_t count, const float* gamma,
+                               const float* beta, float eps, float momentum, int n_updates,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* mean, float* rstd, float* scale, float* shift, void* stream) {
+    PAI_CHECK(stats && mean && rstd && scale && shift, "pai_bn_finalize: null pointer");
+    PAI_CHECK(rows > 0 && C > 0 && count > 0, "pai_bn_finalize: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const double* stage = nullptr;
+    if (rows > STAGE_ROWS) {
+        // scratch = the 2*STAGE_ROWS float rows that follow the partials (pai_bn_stats_buffer_rows)
+        double* scratch = (double*)(stats + (size_t)rows * 2 * C);
+        const int per = cdiv(rows, STAGE_ROWS);
+        hipLaunchKernelGGL(bn_stats_stage1_k, dim3(STAGE_ROWS, cdiv(2 * C, 256)), dim3(256), 0, s, stats,
+                           rows, 2 * C, per, scratch);
+        PAI_LAUNCH_CHECK();
+        stage = scratch;
+    }
+    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, s, stats, stage, rows, C,
+                       (double)count, gamma, beta, eps, momentum, n_updates, running_mean, running_var,
+                       num_batches_tracked, mean, rstd, scale, shift);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bn_eval_coeffs_k(int C, const float* gamma, const float* beta, const float* rm,
+                                 const float* rv, float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * rstd;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+extern "C" int pai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift,
+                                  void* stream) {
+    PAI_CHECK(running_mean && running_var && scale && shift, "pai_bn_eval_coeffs: null pointer");
+    hipLaunchKernelGGL(bn_eval_coeffs_k, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma,
+                       beta, running_mean, running_var, eps, scale, shift);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- 8-wide vector access ----------------------------------------------------------------
+template <typename T> struct V8;
+template <> struct V8<float> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) {
+        float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* v) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct V8<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        uint4 v = *(const uint4*)p;
+        unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(u[i] << 16);
+            o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *(uint4*)p = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+// ---- forward apply -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_k(const T* z, int64_t nvec, int C, const float* scale,
+                                                  const float* shift, int act, T* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((i * 8) % C);
+        float v[8], sc[8], sh[8];
+        V8<T>::ld(z + i * 8, v);
+        V8<float>::ld(scale + c0, sc);
+        V8<float>::ld(shift + c0, sh);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act);
+        V8<T>::st(out + i * 8, v);
+    }
+}
+
+static int ew_grid(int64_t nvec) {
+    int64_t b = (nvec + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const float* scale,
+                            const float* shift, int act, void* out, void* stream) {
+    PAI_CHECK(z && out && scale && shift, "pai_bn_apply: null pointer");
+    PAI_CHECK(C % 8 == 0, "pai_bn_apply: C=%d must be a multiple of 8", C);
+    const int64_t nvec = M * C / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(bn_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)z, nvec, C,
+                           scale, shift, act, (float*)out);
+    else
+        hipLaunchKernelGGL(bn_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)z, nvec,
+                           C, scale, shift, act, (bf16_t*)out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- backward -------------------------------------------------------------------------------
+constexpr int BWD_MAX_PARTIAL = 256;
+
+extern "C" int pai_bn_bwd_partial_rows(int64_t M) {
+    int64_t r = (M + 63) / 64;
+    if (r > BWD_MAX_PARTIAL) r = BWD_MAX_PARTIAL;
+    if (r < 1) r = 1;
+    return (int)r;
+}
+
+// thread = (8-channel group, row lane); block = one contiguous slab of rows
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, const T* g2, int act2,
+                                                       const T* a, const T* z, int64_t M, int C,
+                                                       int64_t rows_per_block, const float* mean,
+                                                       const float* rstd, T* du, float* partials) {
+    __shared__ float red[2][256][8];
+    const int groups = C / 8;
+    const int tid = threadIdx.x;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    // C/8 may exceed 256 (C = 4096 not expected) -> loop over channel groups in strides
+    for (int cg0 = 0; cg0 < groups; cg0 += 256) {
+        const int per_pass = min(groups - cg0, 256);
+        const int lanes = 256 / per_pass;  // per_pass is a power of two <= 256
+        const int cg = cg0 + tid % per_pass, rl = tid / per_pass;
+        float mu[8], rs[8];
+        V8<float>::ld(mean + cg * 8, mu);
+        V8<float>::ld(rstd + cg * 8, rs);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+        if (rl < lanes) {
+            for (int64_t r = r0 + rl; r < r1; r += lanes) {
+                const int64_t off = r * C + cg * 8;
+                float gv[8], zv[8], d[8];
+                V8<T>::ld(g1 + off, gv);
+                V8<T>::ld(z + off, zv);
+                if (a) {
+                    float av[8];
+                    V8<T>::ld(a + off, av);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d[k] = gv[k] * act_grad(av[k], act1);
+                    if (g2) {
+                        float g2v[8];
+                        V8<T>::ld(g2 + off, g2v);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) d[k] = fmaf(g2v[k], act_grad(av[k], act2), d[k]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d[k] = gv[k];
+                    if (g2) {
+                        float g2v[8];
+                        V8<T>::ld(g2 + off, g2v);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) d[k] += g2v[k];
+                    }
+                }
+                V8<T>::st(du + off, d);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    // statistics from the value as stored (what pass 2 will read back)
+                    float dd = d[k];
+                    if (sizeof(T) == 2) dd = bf2f(f2bf(dd));
+                    s1[k] += dd;
+                    s2[k] = fmaf(dd, (zv[k] - mu[k]) * rs[k], s2[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[0][tid][k] = s1[k]; red[1][tid][k] = s2[k]; }
+        __syncthreads();
+        if (tid < per_pass) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int l = 0; l < lanes; ++l) { t1 += red[0][tid + l * per_pass][k]; t2 += red[1][tid + l * per_pass][k]; }
+                // partial row layout: [block][0]=sum(du) -> dbeta, [block][1]=sum(du*xhat) -> dgamma
+                partials[((size_t)blockIdx.x * 2 + 0) * C + cg * 8 + k] = t1;
+                partials[((size_t)blockIdx.x * 2 + 1) * C + cg * 8 + k] = t2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_k(const float* partials, int rows, int C, float* sums, float* dgamma,
+                                  float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s1 += (double)partials[((size_t)r * 2 + 0) * C + c];
+        s2 += (double)partials[((size_t)r * 2 + 1) * C + c];
+    }
+    sums[c] = (float)s1;
+    sums[C + c] = (float)s2;
+    if (dbeta) dbeta[c] += (float)s1;
+    if (dgamma) dgamma[c] += (float)s2;
+}
+
+extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int act2,
+                                 const void* a, const void* z, int64_t M, int C, const float* mean,
+                                 const float* rstd, void* du, float* partials, float* sums,
+                                 float* dgamma, float* dbeta, void* stream) {
+    PAI_CHECK(g1 && z && du && partials && sums && mean && rstd, "pai_bn_bwd_reduce: null pointer");
+    PAI_CHECK(C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "pai_bn_bwd_reduce: C=%d must be 8 * 2^k", C);
+    PAI_CHECK(a || (act1 == PAI_ACT_NONE && act2 == PAI_ACT_NONE), "pai_bn_bwd_reduce: act without a");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = pai_bn_bwd_partial_rows(M);
+    const int64_t rpb = (M + rows - 1) / rows;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
+                           (const float*)g2, act2, (const float*)a, (const float*)z, M, C, rpb, mean, rstd,
+                           (float*)du, partials);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1, act1,
+                           (const bf16_t*)g2, act2, (const bf16_t*)a, (const bf16_t*)z, M, C, rpb, mean, rstd,
+                           (bf16_t*)du, partials);
+    PAI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, s, partials, rows, C, sums, dgamma,
+                       dbeta);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* du, const T* z, int64_t nvec, int C,
+                                                      float inv_m, const float* mean, const float* rstd,
+                                                      const float* gamma, const float* sums, T* dz) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((i * 8) % C);
+        float d[8], zv[8], mu[8], rs[8], gm[8], sb[8], sg[8];
+        V8<T>::ld(du + i * 8, d);
+        V8<T>::ld(z + i * 8, zv);
+        V8<float>::ld(mean + c0, mu);
+        V8<float>::ld(rstd + c0, rs);
+        V8<float>::ld(sums + c0, sb);
+        V8<float>::ld(sums + C + c0, sg);
+        if (gamma) V8<float>::ld(gamma + c0, gm);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (zv[k] - mu[k]) * rs[k];
+            const float g = gamma ? gm[k] : 1.f;
+            d[k] = g * rs[k] * (d[k] - sb[k] * inv_m - xh * sg[k] * inv_m);
+        }
+        V8<T>::st(dz + i * 8, d);
+    }
+}
+
+extern "C" int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
+                                const float* mean, const float* rstd, const float* gamma,
+                                const float* sums, void* dz, void* stream) {
+    PAI_CHECK(du && z && dz && mean && rstd && sums, "pai_bn_bwd_apply: null pointer");
+    PAI_CHECK(C % 8 == 0, "pai_bn_bwd_apply: C=%d must be a multiple of 8", C);
+    const int64_t nvec = M * C / 8;
+    const float inv_m = (float)(1.0 / (double)M);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)du,
+                           (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)du,
+                           (const bf16_t*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (bf16_t*)dz);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- activation backward without a norm ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_k(const T* g1, int act1, const T* g2, int act2, const T* a,
+                                                 int64_t nvec, T* du) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float gv[8], av[8], d[8];
+        V8<T>::ld(g1 + i * 8, gv);
+        V8<T>::ld(a + i * 8, av);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = gv[k] * act_grad(av[k], act1);
+        if (g2) {
+            float g2v[8];
+            V8<T>::ld(g2 + i * 8, g2v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = fmaf(g2v[k], act_grad(av[k], act2), d[k]);
+        }
+        V8<T>::st(du + i * 8, d);
+    }
+}
+
+extern "C" int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
+                           int64_t numel, void* du, void* stream) {
+    PAI_CHECK(g1 && a && du, "pai_act_bwd: null pointer");
+    PAI_CHECK(numel % 8 == 0, "pai_act_bwd: numel must be a multiple of 8");
+    const int64_t nvec = numel / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(act_bwd_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1, act1,
+                           (const float*)g2, act2, (const float*)a, nvec, (float*)du);
+    else
+        hipLaunchKernelGGL(act_bwd_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1, act1,
+                           (const bf16_t*)g2, act2, (const bf16_t*)a, nvec, (bf16_t*)du);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

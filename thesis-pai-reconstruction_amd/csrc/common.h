@@ -1,0 +1,132 @@
+// Shared device/host helpers for libpai_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pai_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+void pai_set_error(const char* fmt, ...);
+
+#define PAI_CHECK(cond, ...)                 \
+    do {                                     \
+        if (!(cond)) {                       \
+            pai_set_error(__VA_ARGS__);      \
+            return 1;                        \
+        }                                    \
+    } while (0)
+
+#define PAI_LAUNCH_CHECK()                                              \
+    do {                                                                \
+        hipError_t e_ = hipGetLastError();                              \
+        if (e_ != hipSuccess) {                                         \
+            pai_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, \
+                          hipGetErrorString(e_));                       \
+            return 2;                                                   \
+        }                                                               \
+    } while (0)
+
+// ---- bf16 <-> f32 -----------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Conv;
+template <> struct Conv<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Conv<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case PAI_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+        case PAI_ACT_RELU: return v > 0.f ? v : 0.f;
+        case PAI_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative expressed through the sign of the stored (activated or raw) value
+__device__ __forceinline__ float act_grad(float a, int act) {
+    switch (act) {
+        case PAI_ACT_LRELU: return a > 0.f ? 1.f : 0.2f;
+        case PAI_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- gather-GEMM problem ------------------------------------------------------
+// out[m, co] = sum_{t < ntaps} sum_{ci < Cin} A(m, t, ci) * Wp[co][wt[ph][t]][ci]
+//   m = (n, gy, gx) over the per-phase output grid OHg x OWg
+//   A(m,t,ci) = act(src[n][gy*S + dy[ph][t]][gx*S + dx[ph][t]][ci]) (0 outside)
+//   src = x1 for ci < C1, x2 otherwise
+//   destination pixel = (gy*OS + poy[ph], gx*OS + pox[ph]) of an OH x OW image,
+//   destination channels split D1 | D2 over two tensors.
+struct GG {
+    int N, H, W;
+    int C1, C2, Cin;
+    int OHg, OWg;
+    int Cout;
+    int S;
+    int nphase, ntaps;
+    int OH, OW, OS;
+    int D1, D2;
+    int wtaps;
+    int relu1, relu2;
+    int M;  // rows per phase = N*OHg*OWg
+    signed char dy[4][16], dx[4][16], wt[4][16];
+    signed char poy[4], pox[4];
+};
+
+// forward gather of a pai_conv_desc (Conv2d or ConvTranspose2d)
+int gg_build_fwd(const pai_conv_desc* d, GG* g);
+// input-gradient gather: source = dy of the layer, destination = dx
+int gg_build_dgrad(const pai_conv_desc* d, GG* g);
+
+// launchers (implemented in the .hip files)
+struct FwdArgs {
+    const void *x1, *x2, *w;
+    const float* bias;
+    void *y1, *y2;  // raw output (storage dtype), split D1|D2
+    void* yact;     // activated output (storage dtype)
+    float* yf32;    // activated output fp32
+    float* stats;   // [nphase*mtiles][2][Cout]
+    int eact;
+    int skip_d1;    // only write the D2 part (pai_conv_dgrad only_c2)
+};
+int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
+int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
+int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s);
+int fwd_simt_mtiles(const GG& g);
+int fwd_mfma_mtiles(const GG& g);
+bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);
+bool fwd_rowdot_ok(const GG& g, const FwdArgs& a);
+
+struct WgradArgs {
+    const void *x1, *x2, *dy;
+    float* dw;
+    float* dbias;
+};
+int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
+int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
+int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s);
+bool wgrad_mfma_ok(int dtype, const GG& g);

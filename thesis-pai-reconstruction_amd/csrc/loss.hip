@@ -1,0 +1,119 @@
+// Mean-reduced losses with fused gradients (HBM-bound, one pass).
+// Replaces F.binary_cross_entropy_with_logits / F.l1_loss / F.mse_loss at
+// models/wrapper.py:45-49,66,84-93 and the tanh backward of models/pix2pix.py:216.
+#include "common.h"
+
+__device__ __forceinline__ void block_atomic_add(double v, double* dst) {
+    __shared__ double wsum[4];
+    // wave reduce in double
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wsum[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dst, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+enum { L_BCE = 0, L_L1 = 1, L_MSE = 2 };
+
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_k(const float* x, const float* t, float tconst, int64_t numel,
+                                              double loss_scale_over_n, double* loss, float gscale,
+                                              float* grad) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float xv = x[i];
+        float l, g;
+        if (KIND == L_BCE) {
+            // max(x,0) - x*t + log1p(exp(-|x|));  d/dx = sigmoid(x) - t
+            l = fmaxf(xv, 0.f) - xv * tconst + log1pf(expf(-fabsf(xv)));
+            g = 1.f / (1.f + expf(-xv)) - tconst;
+        } else if (KIND == L_L1) {
+            const float d = xv - t[i];
+            l = fabsf(d);
+            g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else {
+            const float d = xv - t[i];
+            l = d * d;
+            g = 2.f * d;
+        }
+        acc += (double)l;
+        if (grad) grad[i] = g * gscale;
+    }
+    block_atomic_add(acc * loss_scale_over_n, loss);
+}
+
+template <int KIND>
+static int launch_loss(const float* x, const float* t, float tconst, int64_t numel, float loss_scale,
+                       double* loss, float grad_scale, float* grad, void* stream) {
+    PAI_CHECK(x && loss && numel > 0, "loss: null pointer / empty");
+    int64_t blocks = (numel + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(loss_k<KIND>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, t, tconst,
+                       numel, (double)loss_scale / (double)numel, loss,
+                       (float)((double)grad_scale / (double)numel), grad);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pai_bce_logits(const float* logits, int64_t numel, float target, float loss_scale,
+                              double* loss, float grad_scale, float* grad, void* stream) {
+    return launch_loss<L_BCE>(logits, nullptr, target, numel, loss_scale, loss, grad_scale, grad, stream);
+}
+extern "C" int pai_l1(const float* pred, const float* target, int64_t numel, float loss_scale, double* loss,
+                      float grad_scale, float* grad, void* stream) {
+    PAI_CHECK(target, "pai_l1: null target");
+    return launch_loss<L_L1>(pred, target, 0.f, numel, loss_scale, loss, grad_scale, grad, stream);
+}
+extern "C" int pai_mse(const float* pred, const float* target, int64_t numel, float loss_scale, double* loss,
+                       float grad_scale, float* grad, void* stream) {
+    PAI_CHECK(target, "pai_mse: null target");
+    return launch_loss<L_MSE>(pred, target, 0.f, numel, loss_scale, loss, grad_scale, grad, stream);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_k(const float* pred, const float* ga, const float* gb,
+                                                  int64_t numel, T* dh) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float y = pred[i];
+        float g = (ga ? ga[i] : 0.f) + (gb ? gb[i] : 0.f);
+        Conv<T>::st(dh + i, g * (1.f - y * y));
+    }
+}
+
+extern "C" int pai_tanh_bwd(int dtype, const float* pred, const float* g_a, const float* g_b, int64_t numel,
+                            void* dh, void* stream) {
+    PAI_CHECK(pred && dh && (g_a || g_b), "pai_tanh_bwd: null pointer");
+    int64_t blocks = (numel + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(tanh_bwd_k<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, pred, g_a,
+                           g_b, numel, (float*)dh);
+    else
+        hipLaunchKernelGGL(tanh_bwd_k<bf16_t>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, pred,
+                           g_a, g_b, numel, (bf16_t*)dh);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// denormalize (models/utils.py:11): out = clamp(x*0.5+0.5, 0, 1); backward: g*0.5 inside [0,1]
+__global__ __launch_bounds__(256) void denorm_k(const float* x, const float* g, int64_t numel, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float u = x[i] * 0.5f + 0.5f;
+        if (g) out[i] = (u >= 0.f && u <= 1.f) ? 0.5f * g[i] : 0.f;
+        else out[i] = fminf(fmaxf(u, 0.f), 1.f);
+    }
+}
+
+extern "C" int pai_denormalize(const float* x, const float* grad_out_or_null, int64_t numel, float* out,
+                               void* stream) {
+    PAI_CHECK(x && out, "pai_denormalize: null pointer");
+    int64_t blocks = (numel + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(denorm_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, grad_out_or_null,
+                       numel, out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,157 @@
+// Utility kernels: dtype casts, filter re-packing, fp64 row reduction, column sums, fused Adam.
+#include "common.h"
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_k(const S* src, D* dst, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
+        Conv<D>::st(dst + i, Conv<S>::ld(src + i));
+}
+
+extern "C" int pai_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t numel,
+                        void* stream) {
+    PAI_CHECK(src && dst, "pai_cast: null pointer");
+    int64_t blocks = (numel + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((int)blocks), b(256);
+    if (src_dtype == PAI_F32 && dst_dtype == PAI_BF16)
+        hipLaunchKernelGGL((cast_k<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, numel);
+    else if (src_dtype == PAI_BF16 && dst_dtype == PAI_F32)
+        hipLaunchKernelGGL((cast_k<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, numel);
+    else if (src_dtype == PAI_F32 && dst_dtype == PAI_F32)
+        hipLaunchKernelGGL((cast_k<float, float>), g, b, 0, s, (const float*)src, (float*)dst, numel);
+    else if (src_dtype == PAI_BF16 && dst_dtype == PAI_BF16)
+        hipLaunchKernelGGL((cast_k<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, numel);
+    else
+        PAI_CHECK(false, "pai_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// master [Cout][taps][Cin] fp32 -> fwd pack (same order) and dgrad pack [Cin][taps][Cout]
+template <typename D>
+__global__ __launch_bounds__(256) void pack_k(const float* w, int Cout, int taps, int Cin, D* wf, D* wd) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const size_t idx = ((size_t)co * taps + t) * Cin + ci;
+            v = w[idx];
+            if (wf) Conv<D>::st(wf + idx, v);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (wd) {
+        for (int r = ty; r < 32; r += 8) {
+            const int ci = ci0 + r, co = co0 + tx;
+            if (ci < Cin && co < Cout) Conv<D>::st(wd + ((size_t)ci * taps + t) * Cout + co, tile[tx][r]);
+        }
+    }
+}
+
+extern "C" int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,
+                                void* w_fwd, void* w_dgrad, void* stream) {
+    PAI_CHECK(w_master && (w_fwd || w_dgrad), "pai_pack_weights: null pointer");
+    dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), taps);
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(pack_k<float>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
+                           (float*)w_fwd, (float*)w_dgrad);
+    else
+        hipLaunchKernelGGL(pack_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
+                           (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void reduce_rows_k(const float* partial, int rows, int C, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+extern "C" int pai_reduce_rows(const float* partial, int rows, int C, float* out, int accumulate,
+                               void* stream) {
+    PAI_CHECK(partial && out, "pai_reduce_rows: null pointer");
+    hipLaunchKernelGGL(reduce_rows_k, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
+                       out, accumulate);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[c] += sum_rows x[row][c]; block = slab of rows, thread = (channel, row lane)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T* x, int64_t rows, int C, int64_t rows_per_block,
+                                                float* out) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int width = min(C - c0, 256);
+        // largest power of two <= 256/width row lanes
+        int lanes = 1;
+        while (lanes * 2 * width <= 256) lanes *= 2;
+        const int c = tid % width, rl = tid / width;
+        float s = 0.f;
+        if (rl < lanes)
+            for (int64_t r = r0 + rl; r < r1; r += lanes) s += Conv<T>::ld(x + r * C + c0 + c);
+        red[tid] = (rl < lanes) ? s : 0.f;
+        __syncthreads();
+        if (tid < width) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += red[tid + l * width];
+            atomicAdd(out + c0 + tid, t);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hipStream_t s) {
+    int64_t blocks = (rows + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(colsum_k<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, rows, C, rpb,
+                           out);
+    else
+        hipLaunchKernelGGL(colsum_k<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, rows, C,
+                           rpb, out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m, float* v, int64_t numel,
+                                              float lr_over_bc1, float beta1, float beta2, float eps,
+                                              float inv_sqrt_bc2) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+extern "C" int pai_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                        float lr, float beta1, float beta2, float eps, int step_count, void* stream) {
+    PAI_CHECK(param && grad && exp_avg && exp_avg_sq && step_count >= 1, "pai_adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step_count);
+    const double bc2 = 1.0 - pow((double)beta2, step_count);
+    int64_t blocks = (numel + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, numel, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,652 @@
+"""Layer executors: run the reference's generator and PatchGAN topologies on the HIP kernels.
+
+``UnetEngine`` restates the data flow of ``Unet.forward`` (reference models/pix2pix.py:198-216)
+and its autograd backward as an explicit schedule of C-ABI calls; ``DiscEngine`` does the same
+for ``Discriminator.forward`` (reference models/wrapper.py:236-238).  Nothing is computed in
+Python: the engines only own buffers (torch tensors as device memory), filter packs, the flat
+gradient arena and the launch order.
+
+Data layout in HBM
+  * activations NHWC in the compute dtype (fp32 or bf16); for every BatchNorm layer both the raw
+    convolution output ``z`` (needed by the BN backward) and the normalised+activated tensor
+    ``a`` (what the consumers read) are kept;
+  * ``torch.cat`` is never materialised: consumers read two tensors, input gradients are
+    written to two tensors (reference models/pix2pix.py:212);
+  * parameters stay fp32 ``nn.Parameter``s with the reference's logical shapes and state-dict
+    keys, but are physically stored in the kernels' "fwd pack" [Cout][kh][kw][Cin]; gradients
+    are views into one flat fp32 arena laid out in backward-completion order so that
+    data-parallel buckets are contiguous ranges that become ready front to back.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
+
+BN_EPS_DEFAULT = 1e-5
+
+
+# --------------------------------------------------------------------------------------
+# parameter layout helpers
+# --------------------------------------------------------------------------------------
+def _fwd_pack_strides(mod) -> tuple:
+    if isinstance(mod, nn.ConvTranspose2d):
+        cin, cout, kh, kw = mod.weight.shape
+        return (1, kh * kw * cin, kw * cin, cin)
+    cout, cin, kh, kw = mod.weight.shape
+    return (kh * kw * cin, 1, kw * cin, cin)
+
+
+def _strides_match(t: torch.Tensor, want: tuple) -> bool:
+    return all(s == w or n == 1 for s, w, n in zip(t.stride(), want, t.shape))
+
+
+def to_fwd_pack_(mod) -> None:
+    """Re-stride ``mod.weight`` in place to physical [Cout][kh][kw][Cin] (logical shape unchanged)."""
+    w = mod.weight
+    if _strides_match(w, _fwd_pack_strides(mod)) and w.permute(_phys_perm(mod)).is_contiguous():
+        return
+    with torch.no_grad():
+        w.data = w.data.permute(_phys_perm(mod)).contiguous().permute(_logical_perm(mod))
+
+
+def _phys_perm(mod):
+    return (1, 2, 3, 0) if isinstance(mod, nn.ConvTranspose2d) else (0, 2, 3, 1)
+
+
+def _logical_perm(mod):
+    return (3, 0, 1, 2) if isinstance(mod, nn.ConvTranspose2d) else (0, 3, 1, 2)
+
+
+def _cin_cout(mod):
+    if isinstance(mod, nn.ConvTranspose2d):
+        return mod.weight.shape[0], mod.weight.shape[1]
+    return mod.weight.shape[1], mod.weight.shape[0]
+
+
+class GradArena:
+    """One flat fp32 buffer holding every parameter gradient of a network, ordered by the
+    point in the backward pass at which it becomes final."""
+
+    ALIGN = 64
+
+    def __init__(self, entries, device):
+        # entries: list of (param, conv_module_or_None)
+        self.offsets = {}
+        off = 0
+        for p, _ in entries:
+            self.offsets[id(p)] = (off, p.numel())
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.views = {}
+        self.params = []
+        for p, mod in entries:
+            o, n = self.offsets[id(p)]
+            seg = self.flat[o:o + n]
+            if mod is not None and p.dim() == 4:
+                cin, cout = _cin_cout(mod)
+                v = seg.view(cout, 4, 4, cin).permute(_logical_perm(mod))
+            else:
+                v = seg.view(p.shape)
+            self.views[id(p)] = v
+            self.params.append(p)
+
+    def view(self, p):
+        return self.views[id(p)]
+
+    def seg(self, p):
+        o, n = self.offsets[id(p)]
+        return self.flat[o:o + n]
+
+    def end_of(self, p) -> int:
+        o, n = self.offsets[id(p)]
+        return (o + n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+
+    def begin_backward(self, params) -> None:
+        """Zero the arena unless ``params`` already carry this arena's views (gradient
+        accumulation across several backward passes)."""
+        grads = [p.grad for p in params if p.requires_grad]
+        if all(g is None for g in grads):
+            self.flat.zero_()
+            return
+        for p in params:
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.view(p).data_ptr()):
+                raise ops.PaiError("gradient arena: parameters carry foreign .grad tensors; call "
+                                   "zero_grad(set_to_none=True) before backward")
+
+    def attach(self, params) -> None:
+        for p in params:
+            if p.requires_grad:
+                p.grad = self.view(p)
+
+
+class _Packs:
+    """Compute-dtype filter packs of one conv layer, refreshed when the master weight changes."""
+
+    def __init__(self, mod, need_dgrad: bool):
+        self.mod = mod
+        self.need_dgrad = need_dgrad
+        self.version = None
+        self.dtype = None
+        self.wf = None
+        self.wd = None
+
+    def get(self, dtype):
+        w = self.mod.weight
+        ver = (w._version, w.data_ptr())
+        if self.version != ver or self.dtype != dtype:
+            to_fwd_pack_(self.mod)
+            w = self.mod.weight
+            cin, cout = _cin_cout(self.mod)
+            if dtype == torch.float32:
+                self.wf = w  # the parameter storage IS the fp32 fwd pack
+                wf_out = None
+            else:
+                if self.wf is None or self.wf.dtype != dtype or self.wf is w:
+                    self.wf = torch.empty(w.numel(), dtype=dtype, device=w.device)
+                wf_out = self.wf
+            wd_out = None
+            if self.need_dgrad:
+                if self.wd is None or self.wd.dtype != dtype:
+                    self.wd = torch.empty(w.numel(), dtype=dtype, device=w.device)
+                wd_out = self.wd
+            if wf_out is not None or wd_out is not None:
+                ops.pack_weights(dtype, w, cout, 16, cin, wf_out, wd_out)
+            self.version = (w._version, w.data_ptr())
+            self.dtype = dtype
+        return self.wf, self.wd
+
+
+class _BNState:
+    """Per-slot BatchNorm side tensors."""
+
+    def __init__(self, C, device):
+        self.mean = torch.empty(C, dtype=torch.float32, device=device)
+        self.rstd = torch.empty(C, dtype=torch.float32, device=device)
+        self.scale = torch.empty(C, dtype=torch.float32, device=device)
+        self.shift = torch.empty(C, dtype=torch.float32, device=device)
+        self.sums = torch.empty(2 * C, dtype=torch.float32, device=device)
+
+
+def _bn_forward(bn: nn.BatchNorm2d, st: _BNState, stats, rows, count, training, n_updates):
+    C = bn.num_features
+    if training:
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        ops.bn_finalize(stats, rows, C, count, bn.weight, bn.bias, float(bn.eps), float(mom), n_updates,
+                        bn.running_mean, bn.running_var, bn.num_batches_tracked, st.mean, st.rstd,
+                        st.scale, st.shift)
+    else:
+        ops.bn_eval_coeffs(C, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                           st.scale, st.shift)
+
+
+# --------------------------------------------------------------------------------------
+# generator
+# --------------------------------------------------------------------------------------
+class UnetEngine:
+    def __init__(self, unet: nn.Module):
+        self.unet = unet
+        encs, decs = list(unet.encoders), list(unet.decoders)
+        self.L = len(encs)
+        assert len(decs) == self.L
+        self.enc_conv = [encs[0]] + [e.encode[1] for e in encs[1:]]
+        self.enc_bn = [None] + [e.encode[2] if isinstance(e.encode[2], nn.BatchNorm2d) else None
+                                for e in encs[1:]]
+        self.dec_conv = [d.decode[1] for d in decs[:-1]] + [decs[-1]]
+        self.dec_bn = [d.decode[2] for d in decs[:-1]] + [None]
+        for d in decs[:-1]:
+            if isinstance(d.decode[3], nn.Dropout2d) and d.decode[3].p > 0:
+                raise ops.PaiError("Dropout2d > 0 is not supported by the HIP generator path yet")
+        self.in_ch = self.enc_conv[0].weight.shape[1]
+        self.out_ch = self.dec_conv[-1].weight.shape[1]
+        self.enc_c = [c.weight.shape[0] for c in self.enc_conv]
+        self.dec_c = [c.weight.shape[1] for c in self.dec_conv]
+        self.enc_packs = [_Packs(c, need_dgrad=(i > 0)) for i, c in enumerate(self.enc_conv)]
+        self.dec_packs = [_Packs(c, need_dgrad=True) for c in self.dec_conv]
+        self._plans = {}
+        self._arena: Optional[GradArena] = None
+        self.grad_ready_hook: Optional[Callable[[GradArena, int], None]] = None
+
+    # ---- parameters -------------------------------------------------------------------
+    def ordered_params(self):
+        """(param, conv module) in backward-completion order."""
+        out = []
+        L = self.L
+        for j in range(L - 1, -1, -1):
+            if self.dec_bn[j] is not None:
+                out += [(self.dec_bn[j].weight, None), (self.dec_bn[j].bias, None)]
+            out += [(self.dec_conv[j].weight, self.dec_conv[j]), (self.dec_conv[j].bias, None)]
+        for i in range(L - 1, -1, -1):
+            if self.enc_bn[i] is not None:
+                out += [(self.enc_bn[i].weight, None), (self.enc_bn[i].bias, None)]
+            out += [(self.enc_conv[i].weight, self.enc_conv[i]), (self.enc_conv[i].bias, None)]
+        return out
+
+    def arena(self) -> GradArena:
+        dev = self.enc_conv[0].weight.device
+        if self._arena is None or self._arena.flat.device != dev:
+            for c in self.enc_conv + self.dec_conv:
+                to_fwd_pack_(c)
+            self._arena = GradArena(self.ordered_params(), dev)
+        return self._arena
+
+    # ---- plan / buffers ------------------------------------------------------------------
+    def _plan(self, N, H, W, dtype, device):
+        key = (N, H, W, dtype, str(device))
+        if key in self._plans:
+            return self._plans[key]
+        L = self.L
+        if H % (1 << L) or W % (1 << L):
+            raise ops.PaiError(f"input {H}x{W} must be divisible by 2^{L}")
+        P = {"N": N, "H": H, "W": W, "dtype": dtype, "device": device, "slots": [], "free": []}
+        eh = [H >> (i + 1) for i in range(L)]
+        ew = [W >> (i + 1) for i in range(L)]
+        P["eh"], P["ew"] = eh, ew
+        P["enc_desc"] = []
+        cin = self.in_ch
+        for i in range(L):
+            hin = H >> i
+            win = W >> i
+            act = ACT_LRELU if i == 0 else ACT_NONE
+            P["enc_desc"].append(ops.make_desc(dtype, 0, N, hin, win, cin, 0, self.enc_c[i], 2, 0, 0, act))
+            cin = self.enc_c[i]
+        P["dec_desc"] = []
+        for j in range(L):
+            hin, win = eh[L - 1 - j], ew[L - 1 - j]
+            if j == 0:
+                c1, c2, r1, r2 = self.enc_c[L - 1], 0, 1, 0
+            else:
+                c1, c2 = self.dec_c[j - 1], self.enc_c[L - 1 - j]
+                r1, r2 = 0, 1
+            act = ACT_NONE
+            if j == L - 1:
+                r1, r2, act = 0, 0, ACT_TANH
+            P["dec_desc"].append(ops.make_desc(dtype, 1, N, hin, win, c1, c2, self.dec_c[j], 2, r1, r2, act))
+        rows = 1
+        for i in range(L):
+            if self.enc_bn[i] is not None:
+                rows = max(rows, ops.conv_fwd_stats_rows(P["enc_desc"][i]) * 2 * self.enc_c[i]
+                           + 2 * 64 * 2 * self.enc_c[i])
+        for j in range(L):
+            if self.dec_bn[j] is not None:
+                rows = max(rows, ops.conv_fwd_stats_rows(P["dec_desc"][j]) * 2 * self.dec_c[j]
+                           + 2 * 64 * 2 * self.dec_c[j])
+        P["stats"] = torch.empty(rows, dtype=torch.float32, device=device)
+        mx = 1
+        for i in range(L):
+            if self.enc_bn[i] is not None:
+                mx = max(mx, ops.bn_bwd_partial_rows(N * eh[i] * ew[i]) * 2 * self.enc_c[i])
+        for j in range(L):
+            if self.dec_bn[j] is not None:
+                mx = max(mx, ops.bn_bwd_partial_rows(N * 4 * eh[L - 1 - j] * ew[L - 1 - j]) * 2 * self.dec_c[j])
+        P["bwd_partials"] = torch.empty(mx, dtype=torch.float32, device=device)
+        self._plans[key] = P
+        return P
+
+    def _new_slot(self, P):
+        L, N, dt, dev = self.L, P["N"], P["dtype"], P["device"]
+        eh, ew = P["eh"], P["ew"]
+
+        def buf(h, w, c, dtype=dt):
+            return torch.empty(N * h * w * c, dtype=dtype, device=dev)
+
+        S = {"P": P}
+        S["x"] = buf(P["H"], P["W"], self.in_ch)
+        S["z"] = [buf(eh[i], ew[i], self.enc_c[i]) for i in range(L)]
+        S["a"] = [buf(eh[i], ew[i], self.enc_c[i]) if i < L - 1 else None for i in range(L)]
+        S["ebn"] = [_BNState(self.enc_c[i], dev) if self.enc_bn[i] is not None else None for i in range(L)]
+        dh = [eh[L - 1 - j] * 2 for j in range(L)]
+        dw = [ew[L - 1 - j] * 2 for j in range(L)]
+        S["dh"], S["dw"] = dh, dw
+        S["w"] = [buf(dh[j], dw[j], self.dec_c[j]) if j < L - 1 else None for j in range(L)]
+        S["r"] = [buf(dh[j], dw[j], self.dec_c[j]) if j < L - 1 else None for j in range(L)]
+        S["dbn"] = [_BNState(self.dec_c[j], dev) if self.dec_bn[j] is not None else None for j in range(L)]
+        S["pred"] = torch.empty(N, self.out_ch, P["H"], P["W"], dtype=torch.float32, device=dev)
+        S["grads"] = None
+        return S
+
+    def _grad_bufs(self, S):
+        if S["grads"] is not None:
+            return S["grads"]
+        P = S["P"]
+        L, N, dt, dev = self.L, P["N"], P["dtype"], P["device"]
+        eh, ew = P["eh"], P["ew"]
+        G = {}
+        G["ga"] = [torch.empty_like(S["z"][i]) if i < L - 1 else None for i in range(L)]      # wrt a_i
+        G["gskip"] = [torch.empty_like(S["z"][i]) if i < L - 1 else None for i in range(L)]   # skip part
+        G["gz_last"] = torch.empty_like(S["z"][L - 1])                                       # wrt relu(z_last)
+        G["gr"] = [torch.empty_like(S["w"][j]) if j < L - 1 else None for j in range(L)]      # wrt r_j
+        biggest = max([S["z"][i].numel() for i in range(L)] + [S["w"][j].numel() for j in range(L - 1)]
+                      + [S["pred"].numel()])
+        G["du"] = torch.empty(biggest, dtype=dt, device=dev)
+        G["dz"] = torch.empty(biggest, dtype=dt, device=dev)
+        S["grads"] = G
+        return G
+
+    def acquire(self, N, H, W, dtype, device):
+        P = self._plan(N, H, W, dtype, device)
+        if P["free"]:
+            return P["free"].pop()
+        S = self._new_slot(P)
+        P["slots"].append(S)
+        return S
+
+    def release(self, S):
+        S["P"]["free"].append(S)
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, training: bool, bn_updates: int, dtype: torch.dtype):
+        """x: fp32 [N, Cin, H, W] on the HIP device.  Returns (pred fp32 [N,Cout,H,W], slot)."""
+        if not x.is_cuda:
+            raise ops.PaiError("Unet (HIP) needs a HIP device tensor; there is no CPU path")
+        N, Ci, H, W = x.shape
+        if Ci != self.in_ch:
+            raise ops.PaiError(f"expected {self.in_ch} input channels, got {Ci}")
+        L = self.L
+        S = self.acquire(N, H, W, dtype, x.device)
+        P = S["P"]
+        xs = x.to(torch.float32)
+        xs = xs.contiguous() if Ci == 1 else xs.permute(0, 2, 3, 1).contiguous()
+        if dtype == torch.float32:
+            S["x"] = xs.reshape(-1)
+        else:
+            ops.cast(xs, S["x"])
+        eh, ew = P["eh"], P["ew"]
+
+        # encoder 0: bare Conv2d (reference models/pix2pix.py:141-147); raw + LeakyReLU copies
+        wf, _ = self.enc_packs[0].get(dtype)
+        ops.conv_fwd(P["enc_desc"][0], S["x"], None, wf, self.enc_conv[0].bias, y_raw=S["z"][0],
+                     y_act=S["a"][0] if L > 1 else None)
+        for i in range(1, L):
+            wf, _ = self.enc_packs[i].get(dtype)
+            bn = self.enc_bn[i]
+            d = P["enc_desc"][i]
+            if bn is not None:
+                M = N * eh[i] * ew[i]
+                if training:
+                    rows = ops.conv_fwd_stats_rows(d)
+                    ops.conv_fwd(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, y_raw=S["z"][i],
+                                 stats=P["stats"])
+                    _bn_forward(bn, S["ebn"][i], P["stats"], rows, M, True, bn_updates)
+                else:
+                    ops.conv_fwd(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, y_raw=S["z"][i])
+                    _bn_forward(bn, S["ebn"][i], None, 0, M, False, 0)
+                ops.bn_apply(dtype, S["z"][i], M, self.enc_c[i], S["ebn"][i].scale, S["ebn"][i].shift,
+                             ACT_LRELU, S["a"][i])
+            else:
+                ops.conv_fwd(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, y_raw=S["z"][i])
+                if i < L - 1:
+                    # norm-less inner encoder (not produced by the reference topology, kept general)
+                    raise ops.PaiError("only the last encoder may be norm-free")
+        # decoders
+        for j in range(L):
+            wf, _ = self.dec_packs[j].get(dtype)
+            d = P["dec_desc"][j]
+            if j == 0:
+                x1, x2 = S["z"][L - 1], None
+            else:
+                x1 = S["r"][j - 1]
+                skip = L - 1 - j
+                x2 = S["a"][skip] if skip > 0 else S["z"][0]
+                if j == L - 1:
+                    x2 = S["z"][0]  # raw encoder-0 output, no activation (pix2pix.py:185-193)
+            if j < L - 1:
+                bn = self.dec_bn[j]
+                M = N * S["dh"][j] * S["dw"][j]
+                if training:
+                    rows = ops.conv_fwd_stats_rows(d)
+                    ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_raw=S["w"][j], stats=P["stats"])
+                    _bn_forward(bn, S["dbn"][j], P["stats"], rows, M, True, bn_updates)
+                else:
+                    ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_raw=S["w"][j])
+                    _bn_forward(bn, S["dbn"][j], None, 0, M, False, 0)
+                act = ACT_RELU if j < L - 2 else ACT_NONE
+                ops.bn_apply(dtype, S["w"][j], M, self.dec_c[j], S["dbn"][j].scale, S["dbn"][j].shift, act,
+                             S["r"][j])
+            else:
+                ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_f32=S["pred"])
+        if L == 1:
+            raise ops.PaiError("Unet needs at least two levels")
+        pred = S["pred"]
+        if self.out_ch != 1:
+            pred = pred.view(N, H, W, self.out_ch).permute(0, 3, 1, 2)
+        return pred, S
+
+    # ---- backward ---------------------------------------------------------------------------
+    def backward(self, S, gpred: torch.Tensor):
+        """Accumulates every parameter gradient into the arena.  gpred: fp32, pred's shape."""
+        P = S["P"]
+        L, N, dtype = self.L, P["N"], P["dtype"]
+        eh, ew = P["eh"], P["ew"]
+        G = self._grad_bufs(S)
+        A = self.arena()
+        hook = self.grad_ready_hook
+        if self.out_ch != 1:
+            gpred = gpred.permute(0, 2, 3, 1)
+        gpred = gpred.contiguous()
+        if gpred.dtype != torch.float32:
+            gpred = gpred.float()
+
+        def done(p):
+            if hook is not None:
+                hook(A, A.end_of(p))
+
+        # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
+        j = L - 1
+        dh = G["dz"][:S["pred"].numel()]
+        ops.tanh_bwd(dtype, S["pred"], gpred, None, dh)
+        d = P["dec_desc"][j]
+        x1 = S["r"][j - 1]
+        x2 = S["z"][0]
+        conv = self.dec_conv[j]
+        ops.conv_wgrad(d, x1, x2, dh, A.seg(conv.weight), A.seg(conv.bias))
+        done(conv.bias)
+        _, wd = self.dec_packs[j].get(dtype)
+        ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
+        # BN decoders
+        for j in range(L - 2, -1, -1):
+            bn, st, conv = self.dec_bn[j], S["dbn"][j], self.dec_conv[j]
+            M = N * S["dh"][j] * S["dw"][j]
+            C = self.dec_c[j]
+            n = M * C
+            act = ACT_RELU if j < L - 2 else ACT_NONE
+            du, dz = G["du"][:n], G["dz"][:n]
+            ops.bn_bwd_reduce(dtype, G["gr"][j], act, None, ACT_NONE, S["r"][j] if act != ACT_NONE else None,
+                              S["w"][j], M, C, st.mean, st.rstd, du, P["bwd_partials"], st.sums,
+                              A.seg(bn.weight), A.seg(bn.bias))
+            ops.bn_bwd_apply(dtype, du, S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
+            d = P["dec_desc"][j]
+            if j == 0:
+                x1, x2 = S["z"][L - 1], None
+            else:
+                skip = L - 1 - j
+                x1, x2 = S["r"][j - 1], (S["a"][skip] if skip > 0 else S["z"][0])
+            ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias))
+            done(conv.bias)
+            _, wd = self.dec_packs[j].get(dtype)
+            if j == 0:
+                ops.conv_dgrad(d, dz, wd, G["gz_last"], None)
+            else:
+                ops.conv_dgrad(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j])
+        # last encoder (no norm): d relu(z_last) -> dz_last
+        i = L - 1
+        conv = self.enc_conv[i]
+        n = S["z"][i].numel()
+        dz = G["dz"][:n]
+        ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n, dz)
+        d = P["enc_desc"][i]
+        ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), A.seg(conv.bias))
+        done(conv.bias)
+        _, wd = self.enc_packs[i].get(dtype)
+        ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
+        # BN encoders
+        for i in range(L - 2, 0, -1):
+            bn, st, conv = self.enc_bn[i], S["ebn"][i], self.enc_conv[i]
+            M = N * eh[i] * ew[i]
+            C = self.enc_c[i]
+            n = M * C
+            du, dz = G["du"][:n], G["dz"][:n]
+            ops.bn_bwd_reduce(dtype, G["ga"][i], ACT_LRELU, G["gskip"][i], ACT_RELU, S["a"][i], S["z"][i], M, C,
+                              st.mean, st.rstd, du, P["bwd_partials"], st.sums, A.seg(bn.weight),
+                              A.seg(bn.bias))
+            ops.bn_bwd_apply(dtype, du, S["z"][i], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
+            d = P["enc_desc"][i]
+            ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), A.seg(conv.bias))
+            done(conv.bias)
+            _, wd = self.enc_packs[i].get(dtype)
+            ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
+        # encoder 0: d z0 = lrelu'(z0) * g_enc + g_skip   (skip consumed raw by the last decoder)
+        conv = self.enc_conv[0]
+        n = S["z"][0].numel()
+        dz = G["dz"][:n]
+        ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n, dz)
+        ops.conv_wgrad(P["enc_desc"][0], S["x"], None, dz, A.seg(conv.weight), A.seg(conv.bias))
+        done(conv.bias)
+
+
+# --------------------------------------------------------------------------------------
+# PatchGAN discriminator
+# --------------------------------------------------------------------------------------
+class DiscEngine:
+    def __init__(self, disc: nn.Module):
+        seq = disc.discriminator
+        self.convs = [seq[i].block[0] for i in range(4)] + [seq[4]]
+        self.in_ch = self.convs[0].weight.shape[1] // 2
+        self.chans = [c.weight.shape[0] for c in self.convs]
+        self.packs = [_Packs(c, need_dgrad=True) for c in self.convs]
+        self._plans = {}
+        self._arena = None
+        self.grad_ready_hook = None
+
+    def ordered_params(self):
+        out = [(self.convs[4].weight, self.convs[4])]
+        for k in range(3, -1, -1):
+            out += [(self.convs[k].weight, self.convs[k]), (self.convs[k].bias, None)]
+        return out
+
+    def arena(self) -> GradArena:
+        dev = self.convs[0].weight.device
+        if self._arena is None or self._arena.flat.device != dev:
+            for c in self.convs:
+                to_fwd_pack_(c)
+            self._arena = GradArena(self.ordered_params(), dev)
+        return self._arena
+
+    def _plan(self, N, H, W, dtype, device):
+        key = (N, H, W, dtype, str(device))
+        if key in self._plans:
+            return self._plans[key]
+        if H % 16 or W % 16 or H < 32 or W < 32:
+            raise ops.PaiError(f"discriminator input {H}x{W} must be a multiple of 16 and >= 32")
+        P = {"N": N, "H": H, "W": W, "dtype": dtype, "device": device, "free": [], "desc": []}
+        c = self.in_ch
+        P["desc"].append(ops.make_desc(dtype, 0, N, H, W, c, c, self.chans[0], 2, 0, 0, ACT_LRELU))
+        for k in range(1, 4):
+            P["desc"].append(ops.make_desc(dtype, 0, N, H >> k, W >> k, self.chans[k - 1], 0, self.chans[k], 2, 0, 0,
+                                           ACT_LRELU))
+        P["desc"].append(ops.make_desc(dtype, 0, N, H >> 4, W >> 4, self.chans[3], 0, 1, 1, 0, 0, ACT_NONE))
+        P["oh"], P["ow"] = (H >> 4) - 1, (W >> 4) - 1
+        self._plans[key] = P
+        return P
+
+    def acquire(self, N, H, W, dtype, device):
+        P = self._plan(N, H, W, dtype, device)
+        if P["free"]:
+            return P["free"].pop()
+        S = {"P": P}
+        S["x"] = torch.empty(N * H * W * self.in_ch, dtype=dtype, device=device)
+        S["y"] = torch.empty(N * H * W * self.in_ch, dtype=dtype, device=device)
+        S["a"] = [torch.empty(N * (H >> (k + 1)) * (W >> (k + 1)) * self.chans[k], dtype=dtype, device=device)
+                  for k in range(4)]
+        S["logits"] = torch.empty(N, 1, P["oh"], P["ow"], dtype=torch.float32, device=device)
+        S["grads"] = None
+        return S
+
+    def release(self, S):
+        S["P"]["free"].append(S)
+
+    def _to_nhwc(self, t, dst, dtype):
+        t = t.to(torch.float32)
+        t = t.contiguous() if t.shape[1] == 1 else t.permute(0, 2, 3, 1).contiguous()
+        if dtype == torch.float32:
+            return t.reshape(-1)
+        ops.cast(t, dst)
+        return dst
+
+    def forward(self, x, y, dtype):
+        if not (x.is_cuda and y.is_cuda):
+            raise ops.PaiError("Discriminator (HIP) needs HIP device tensors; there is no CPU path")
+        N, C, H, W = x.shape
+        if C != self.in_ch or y.shape != x.shape:
+            raise ops.PaiError(f"Discriminator expects two [N,{self.in_ch},H,W] tensors, got {tuple(x.shape)} "
+                               f"and {tuple(y.shape)}")
+        S = self.acquire(N, H, W, dtype, x.device)
+        P = S["P"]
+        S["xin"] = self._to_nhwc(x, S["x"], dtype)
+        S["yin"] = self._to_nhwc(y, S["y"], dtype)
+        wf, _ = self.packs[0].get(dtype)
+        ops.conv_fwd(P["desc"][0], S["xin"], S["yin"], wf, self.convs[0].bias, y_act=S["a"][0])
+        for k in range(1, 4):
+            wf, _ = self.packs[k].get(dtype)
+            ops.conv_fwd(P["desc"][k], S["a"][k - 1], None, wf, self.convs[k].bias, y_act=S["a"][k])
+        wf, _ = self.packs[4].get(dtype)
+        ops.conv_fwd(P["desc"][4], S["a"][3], None, wf, None, y_f32=S["logits"])
+        return S["logits"], S
+
+    def backward(self, S, glogits, need_params: bool, need_dy: bool):
+        P = S["P"]
+        N, H, W, dtype, dev = P["N"], P["H"], P["W"], P["dtype"], P["device"]
+        if S["grads"] is None:
+            G = {"g": [torch.empty_like(a) for a in S["a"]],
+                 "du": [torch.empty_like(a) for a in S["a"]],
+                 "dl": torch.empty(S["logits"].numel(), dtype=dtype, device=dev),
+                 "dy": torch.empty(N * H * W * self.in_ch, dtype=dtype, device=dev)}
+            S["grads"] = G
+        G = S["grads"]
+        A = self.arena() if need_params else None
+        hook = self.grad_ready_hook
+        glogits = glogits.contiguous().float()
+        if dtype == torch.float32:
+            dl = glogits.reshape(-1)
+        else:
+            ops.cast(glogits, G["dl"])
+            dl = G["dl"]
+        d = P["desc"][4]
+        if need_params:
+            ops.conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
+            if hook is not None:
+                hook(A, A.end_of(self.convs[4].weight))
+        _, wd = self.packs[4].get(dtype)
+        ops.conv_dgrad(d, dl, wd, G["g"][3], None)
+        for k in range(3, -1, -1):
+            n = S["a"][k].numel()
+            ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n, G["du"][k])
+            d = P["desc"][k]
+            conv = self.convs[k]
+            if need_params:
+                if k == 0:
+                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
+                else:
+                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                if hook is not None:
+                    hook(A, A.end_of(conv.bias))
+            if k > 0:
+                _, wd = self.packs[k].get(dtype)
+                ops.conv_dgrad(d, G["du"][k], wd, G["g"][k - 1], None)
+            elif need_dy:
+                _, wd = self.packs[0].get(dtype)
+                ops.conv_dgrad(d, G["du"][0], wd, None, G["dy"], only_c2=True)
+        if not need_dy:
+            return None
+        gy = torch.empty(N * H * W * self.in_ch, dtype=torch.float32, device=dev)
+        if dtype == torch.float32:
+            gy.copy_(G["dy"])
+        else:
+            ops.cast(G["dy"], gy)
+        if self.in_ch == 1:
+            return gy.view(N, 1, H, W)
+        return gy.view(N, H, W, self.in_ch).permute(0, 3, 1, 2)

@@ -1,0 +1,226 @@
+"""torch.autograd bridges: PyTorch supplies the tape, libpai_hip.so supplies every number.
+
+Each Function's forward/backward is a fixed sequence of C-ABI launches on the current
+stream; nothing here synchronises with the host.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+# --------------------------------------------------------------------------------------
+# networks
+# --------------------------------------------------------------------------------------
+class UnetFunction(torch.autograd.Function):
+    """Generator forward/backward through UnetEngine.  Parameter gradients are written into
+    the engine's gradient arena and attached as ``p.grad`` directly (autograd receives None
+    for them), so that data-parallel buckets can be reduced in place while the backward runs."""
+
+    @staticmethod
+    def forward(ctx, x, engine, training, bn_updates, dtype, *params):
+        pred, slot = engine.forward(x, training, bn_updates, dtype)
+        keep = any(ctx.needs_input_grad)
+        if ctx.needs_input_grad[0]:
+            raise ops.PaiError("gradient w.r.t. the generator input is not supported")
+        if keep:
+            ctx.engine, ctx.slot, ctx.params = engine, slot, params
+        else:
+            engine.release(slot)
+        return pred
+
+    @staticmethod
+    def backward(ctx, gpred):
+        engine, slot, params = ctx.engine, ctx.slot, ctx.params
+        arena = engine.arena()
+        arena.begin_backward(params)
+        engine.backward(slot, gpred)
+        arena.attach(params)
+        engine.release(slot)
+        return (None,) * (5 + len(params))
+
+
+class DiscFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, engine, dtype, *params):
+        logits, slot = engine.forward(x, y, dtype)
+        if ctx.needs_input_grad[0]:
+            raise ops.PaiError("gradient w.r.t. the conditioning image is not supported")
+        if any(ctx.needs_input_grad):
+            ctx.engine, ctx.slot, ctx.params = engine, slot, params
+            ctx.need_dy = ctx.needs_input_grad[1]
+            ctx.need_params = any(ctx.needs_input_grad[4:])
+        else:
+            engine.release(slot)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        engine, slot, params = ctx.engine, ctx.slot, ctx.params
+        if ctx.need_params:
+            arena = engine.arena()
+            arena.begin_backward(params)
+        gy = engine.backward(slot, glogits, ctx.need_params, ctx.need_dy)
+        if ctx.need_params:
+            arena.attach(params)
+        engine.release(slot)
+        return (None, gy, None, None) + (None,) * len(params)
+
+
+# --------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------
+def _check_f32_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise ops.PaiError("pai losses/metrics need HIP device tensors (no CPU fallback exists)")
+
+
+class _MeanLoss(torch.autograd.Function):
+    """loss = mean-reduced {bce-with-logits vs a constant target, l1, mse}; the gradient is
+    produced by the same kernel pass and scaled by grad_out in backward."""
+
+    @staticmethod
+    def forward(ctx, kind, x, target):
+        _check_f32_cuda(x)
+        xc = x.contiguous().float()
+        acc = torch.zeros((), dtype=torch.float64, device=x.device)
+        need = ctx.needs_input_grad[1]
+        grad = torch.empty_like(xc) if need else None
+        if kind == "bce":
+            ops.bce_logits(xc, float(target), 1.0, acc, 1.0, grad)
+        else:
+            tc = target.contiguous().float()
+            (ops.l1 if kind == "l1" else ops.mse)(xc, tc, 1.0, acc, 1.0, grad)
+        if need:
+            ctx.save_for_backward(grad)
+        return acc.float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return None, grad * gout, None
+
+
+def bce_with_logits_const(logits: torch.Tensor, target: float) -> torch.Tensor:
+    """F.binary_cross_entropy_with_logits(logits, full_like(logits, target)) (reference
+    models/wrapper.py:45-48,84-93)."""
+    return _MeanLoss.apply("bce", logits, target)
+
+
+def l1_loss(pred, target):
+    """F.l1_loss (reference models/wrapper.py:49)."""
+    return _MeanLoss.apply("l1", pred, target)
+
+
+def mse_loss(pred, target):
+    """F.mse_loss (reference models/wrapper.py:66)."""
+    return _MeanLoss.apply("mse", pred, target)
+
+
+class _Denormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check_f32_cuda(x)
+        xc = x.contiguous().float()
+        out = torch.empty_like(xc)
+        ops.denormalize(xc, None, out)
+        ctx.save_for_backward(xc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        out = torch.empty_like(xc)
+        ops.denormalize(xc, g.contiguous().float(), out)
+        return out
+
+
+def denormalize(x):
+    """clamp(x*0.5+0.5, 0, 1) (reference models/utils.py:11)."""
+    return _Denormalize.apply(x)
+
+
+# --------------------------------------------------------------------------------------
+# metrics (differentiable where the reference uses them as losses)
+# --------------------------------------------------------------------------------------
+def _ssim_sse(pred, target, denorm, per_image=False, full=False):
+    _check_f32_cuda(pred, target)
+    p = pred.contiguous().float()
+    t = target.contiguous().float()
+    n, c, h, w = p.shape
+    out2 = torch.zeros(2, dtype=torch.float64, device=p.device)
+    per = torch.zeros(n * c, dtype=torch.float64, device=p.device) if per_image else None
+    fm = torch.empty(n, c, h, w, dtype=torch.float32, device=p.device) if full else None
+    ops.ssim_sse(p, t, n * c, h, w, denorm, out2, per, fm)
+    return p, t, out2, per, fm
+
+
+class _SsimPsnr(torch.autograd.Function):
+    """value = w_ssim * SSIM + w_psnr * PSNR (data_range 1) of (optionally denormalised) images."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w_ssim, w_psnr, denorm):
+        p, t, out2, _, _ = _ssim_sse(pred, target, denorm)
+        n, c, h, w = p.shape
+        ssim_v = out2[0] / (n * c)
+        psnr_v = -torch.log(out2[1] / p.numel()) * (10.0 / math.log(10.0))
+        ctx.save_for_backward(p, t, out2)
+        ctx.cfg = (w_ssim, w_psnr, denorm)
+        return (w_ssim * ssim_v + w_psnr * psnr_v).float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, out2 = ctx.saved_tensors
+        w_ssim, w_psnr, denorm = ctx.cfg
+        n, c, h, w = p.shape
+        ws = torch.empty(ops.ssim_bwd_workspace_floats(n * c, h, w), dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        # the kernel returns d[-(w_ssim*SSIM + w_psnr*PSNR)]/dpred
+        ops.ssim_psnr_bwd(p, t, n * c, h, w, denorm, w_ssim, w_psnr, out2[1:], grad, ws)
+        return grad * (-gout), None, None, None, None
+
+
+def ssim(pred, target):
+    """structural_similarity_index_measure(pred, target, data_range=1.0) (reference
+    models/utils.py:38-39).  Inputs are already denormalised."""
+    return _SsimPsnr.apply(pred, target, 1.0, 0.0, 0)
+
+
+def psnr(pred, target):
+    """peak_signal_noise_ratio(pred, target, data_range=1.0) (reference models/utils.py:42-43)."""
+    return _SsimPsnr.apply(pred, target, 0.0, 1.0, 0)
+
+
+def rmse(pred, target):
+    """mean_squared_error(pred, target, squared=False) (reference models/utils.py:46-47)."""
+    p, t, out2, _, _ = _ssim_sse(pred.detach(), target.detach(), 0)
+    return torch.sqrt(out2[1] / p.numel()).float()
+
+
+def ssim_psnr_of_normalized(pred, target, w_ssim, w_psnr):
+    """w_ssim*SSIM + w_psnr*PSNR of denormalize(pred), denormalize(target) with the
+    denormalisation fused into the metric kernel (differentiable w.r.t. pred)."""
+    return _SsimPsnr.apply(pred, target, float(w_ssim), float(w_psnr), 1)
+
+
+def metrics_of_normalized(pred, target):
+    """(ssim, psnr, rmse) of the denormalised pair in ONE pass over the images, no graph
+    (the per-step logging of reference models/wrapper.py:150-156,168-173)."""
+    p, t, out2, _, _ = _ssim_sse(pred.detach(), target.detach(), 1)
+    n, c = p.shape[:2]
+    mse_v = out2[1] / p.numel()
+    return ((out2[0] / (n * c)).float(), (-torch.log(mse_v) * (10.0 / math.log(10.0))).float(),
+            torch.sqrt(mse_v).float())
+
+
+def ssim_per_image(pred, target, return_full_image=False):
+    """reduction='none' SSIM (reference report.py:78-84,207-212): per-image values and,
+    optionally, the un-cropped SSIM map."""
+    p, t, out2, per, fm = _ssim_sse(pred.detach(), target.detach(), 0, per_image=True, full=return_full_image)
+    n, c = p.shape[:2]
+    vals = per.view(n, c).mean(dim=1).float()
+    return (vals, fm) if return_full_image else vals

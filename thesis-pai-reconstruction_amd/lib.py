@@ -1,0 +1,101 @@
+"""ctypes binding of libpai_hip.so (the C ABI declared in include/pai_hip.h).
+
+The library is mandatory: there is no CPU or eager-PyTorch fallback behind these
+calls.  ``load()`` raises if the shared object is missing, and every wrapper raises
+``PaiError`` with the library's message when a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpai_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+
+class PaiError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """struct pai_conv_desc (include/pai_hip.h)."""
+    _fields_ = [("dtype", C.c_int32), ("transposed", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C1", C.c_int32), ("C2", C.c_int32), ("Cout", C.c_int32),
+                ("kernel", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("relu1", C.c_int32), ("relu2", C.c_int32), ("epilogue_act", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  Every symbol declared in include/pai_hip.h is listed here;
+# tests/test_abi.py checks the two against each other and against the built library.
+SIGNATURES = {
+    "pai_last_error": (C.c_char_p, []),
+    "pai_version": (_I, []),
+    "pai_device_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
+    "pai_conv_out_hw": (_I, [_D, C.POINTER(_I), C.POINTER(_I)]),
+    "pai_conv_fwd_stats_rows": (_I, [_D]),
+    "pai_bn_stats_buffer_rows": (_I, [_I]),
+    "pai_conv_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pai_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _I, _P]),
+    "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
+    "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "pai_bn_apply": (_I, [_I, _P, _L, _I, _P, _P, _I, _P, _P]),
+    "pai_bn_bwd_partial_rows": (_I, [_L]),
+    "pai_bn_bwd_reduce": (_I, [_I, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pai_bn_bwd_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "pai_act_bwd": (_I, [_I, _P, _I, _P, _I, _P, _L, _P, _P]),
+    "pai_bce_logits": (_I, [_P, _L, _F, _F, _P, _F, _P, _P]),
+    "pai_l1": (_I, [_P, _P, _L, _F, _P, _F, _P, _P]),
+    "pai_mse": (_I, [_P, _P, _L, _F, _P, _F, _P, _P]),
+    "pai_tanh_bwd": (_I, [_I, _P, _P, _P, _L, _P, _P]),
+    "pai_denormalize": (_I, [_P, _P, _L, _P, _P]),
+    "pai_ssim_sse": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pai_ssim_psnr_bwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "pai_ssim_bwd_workspace_floats": (_L, [_I, _I, _I]),
+    "pai_cast": (_I, [_I, _P, _I, _P, _L, _P]),
+    "pai_reduce_rows": (_I, [_P, _I, _I, _P, _I, _P]),
+    "pai_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libpai_hip.so and attach the signatures.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PaiError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().pai_last_error()
+        raise PaiError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,193 @@
+"""``UnetWrapper`` / ``Discriminator`` -- the reference's plugin surface
+(reference models/wrapper.py:9-238) on the MI355X kernels.
+
+Same class names, constructor signatures, attribute names, hooks and state-dict keys as the
+reference.  Differences, all on this side of the boundary:
+  * ``Discriminator`` receives ``in_channels`` from the generator instead of the reference's
+    hard-coded default of 3, which cannot run on 1-channel data (Q1); key names are unchanged.
+  * with dropout == 0 the two generator forwards of a GAN step are bit-identical, so ONE
+    forward is run and the BatchNorm running statistics are updated twice (Q5/Q6).  Set
+    ``reuse_generator_forward = False`` to execute the literal two-forward schedule.
+"""
+from typing import Literal
+
+import torch
+import torch.nn as nn
+
+from .. import functional as PF
+from ..engine import DiscEngine
+from ..lightning import LightningModule
+from .utils import denormalize, init_weights, psnr, rmse, ssim  # noqa: F401
+
+L1_WEIGHT = 50  # reference models/wrapper.py:51
+
+
+class UnetWrapper(LightningModule):
+    """U-net wrapper with different loss functions (reference models/wrapper.py:9-173).
+
+    :param unet: any ``nn.Module`` mapping [N x C x H x W] -> [N x C x H x W].
+    :param loss_type: one of "gan", "ssim", "psnr", "mse", "ssim+psnr".
+    """
+
+    def __init__(self, unet: nn.Module,
+                 loss_type: Literal["gan", "ssim", "psnr", "ssim+psnr", "mse"] = "gan"):
+        super().__init__()
+        self.automatic_optimization = False
+        self.unet = unet
+        self.loss_type = loss_type
+        self.reuse_generator_forward = True
+
+        self.discriminator = None
+        if loss_type == "gan":
+            self.discriminator = Discriminator(in_channels=getattr(unet, "in_channels", 1))
+            self.discriminator.apply(init_weights)
+        self.unet.apply(init_weights)
+
+    def forward(self, x):
+        return self.unet(x)
+
+    def loss(self, x, pred, target):
+        """Reference models/wrapper.py:42-66."""
+        if self.loss_type == "gan":
+            pred_label = self.discriminator(x, pred)
+            bce_loss = PF.bce_with_logits_const(pred_label, 1.0)
+            l1_loss = PF.l1_loss(pred, target)
+            return bce_loss + L1_WEIGHT * l1_loss
+        if self.loss_type == "ssim":
+            return -PF.ssim_psnr_of_normalized(pred, target, 1.0, 0.0)
+        if self.loss_type == "psnr":
+            return -PF.ssim_psnr_of_normalized(pred, target, 0.0, 1.0)
+        if self.loss_type == "ssim+psnr":
+            return -PF.ssim_psnr_of_normalized(pred, target, 30.0, 1.0)
+        if self.loss_type == "mse":
+            return PF.mse_loss(pred, target)
+        raise ValueError(f"unknown loss_type {self.loss_type!r}")
+
+    def discriminator_loss(self, pred_label: torch.Tensor, target_label: torch.Tensor) -> torch.Tensor:
+        """Reference models/wrapper.py:68-95: fake -> 0, real -> 1."""
+        pred_loss = PF.bce_with_logits_const(pred_label, 0.0)
+        target_loss = PF.bce_with_logits_const(target_label, 1.0)
+        return pred_loss + target_loss
+
+    def configure_optimizers(self):
+        """Reference models/wrapper.py:97-115."""
+        opt_g = torch.optim.Adam(self.unet.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+        if self.discriminator is not None:
+            opt_d = torch.optim.Adam(self.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+            return opt_g, opt_d
+        return opt_g
+
+    def _can_reuse_forward(self):
+        return (self.reuse_generator_forward and getattr(self.unet, "supports_forward_reuse", False)
+                and self.unet.training)
+
+    def training_step(self, batch, batch_idx):
+        """Reference models/wrapper.py:117-162 (manual optimisation, D step then G step)."""
+        x, target = batch
+        reuse = self.loss_type == "gan" and self._can_reuse_forward()
+        pred_g = None
+
+        if self.loss_type == "gan":
+            opt_d = self.optimizers()[1]
+            if reuse:
+                # one generator forward serves both phases; BN running stats advance twice (Q6)
+                self.unet.bn_updates_per_forward = 2
+                try:
+                    pred_g = self.unet(x)
+                finally:
+                    self.unet.bn_updates_per_forward = 1
+
+            # Train discriminator.
+            self.toggle_optimizer(opt_d)
+            pred = pred_g.detach() if reuse else self.unet(x)
+            target_label = self.discriminator(x, target)
+            pred_label = self.discriminator(x, pred)
+            d_loss = self.discriminator_loss(pred_label, target_label)
+            self.log("d_loss", d_loss, prog_bar=True)
+            self.discriminator.zero_grad(set_to_none=True)
+            self.manual_backward(d_loss)
+            opt_d.step()
+            self.untoggle_optimizer(opt_d)
+
+        opt_g = self.optimizers()
+        if isinstance(opt_g, list):
+            opt_g = opt_g[0]
+
+        # Train U-net
+        self.toggle_optimizer(opt_g)
+        pred = pred_g if reuse else self.unet(x)
+        loss = self.loss(x, pred, target)
+
+        self.log("loss", loss, prog_bar=True)
+        if pred.is_cuda:
+            s, p, r = PF.metrics_of_normalized(pred, target)
+        else:
+            den_pred, den_target = denormalize(pred), denormalize(target)
+            s, p, r = ssim(den_pred, den_target), psnr(den_pred, den_target), rmse(den_pred, den_target)
+        self.log("train_ssim", s, prog_bar=True)
+        self.log("train_psnr", p, prog_bar=True)
+        self.log("train_rmse", r, prog_bar=True)
+
+        self.unet.zero_grad(set_to_none=True)
+        self.manual_backward(loss)
+        opt_g.step()
+        self.untoggle_optimizer(opt_g)
+
+    def validation_step(self, batch, batch_idx):
+        """Reference models/wrapper.py:164-173."""
+        x, target = batch
+        pred = self.forward(x)
+        s, p, r = PF.metrics_of_normalized(pred, target)
+        self.log("val_ssim", s, prog_bar=True)
+        self.log("val_psnr", p, prog_bar=True)
+        self.log("val_rmse", r, prog_bar=True)
+
+
+class DiscriminatorBlock(nn.Module):
+    """Conv2d(k4,s2,p1) -> (InstanceNorm2d | Identity) -> LeakyReLU(0.2)
+    (reference models/wrapper.py:176-209).  Parameter container; the arithmetic runs in
+    ``Discriminator.forward`` through DiscEngine.  ``norm=True`` is dead code in the reference
+    (never enabled) and is rejected here."""
+
+    def __init__(self, in_channels: int, out_channels: int, norm: bool = False):
+        super().__init__()
+        if norm:
+            raise NotImplementedError("DiscriminatorBlock(norm=True) is never used by the reference")
+        self.block = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=4, stride=2, padding=1),
+            nn.Identity(),
+            nn.LeakyReLU(0.2),
+        )
+
+
+class Discriminator(nn.Module):
+    """PatchGAN discriminator (reference models/wrapper.py:212-238).
+
+    :input x: [N x in_channels x H x W] conditioning image
+    :input y: [N x in_channels x H x W] real or generated image
+    :output: [N x 1 x (H/16 - 1) x (W/16 - 1)] logits
+    """
+
+    def __init__(self, in_channels: int = 3):
+        super().__init__()
+        self.in_channels = in_channels
+        self.compute_dtype = torch.float32
+        self.discriminator = nn.Sequential(
+            DiscriminatorBlock(in_channels * 2, 64, norm=False),
+            DiscriminatorBlock(64, 128),
+            DiscriminatorBlock(128, 256),
+            DiscriminatorBlock(256, 512),
+            nn.Conv2d(512, 1, kernel_size=4, padding=1, bias=False),
+        )
+        self._engine = None
+
+    @property
+    def engine(self) -> DiscEngine:
+        if self._engine is None:
+            object.__setattr__(self, "_engine", DiscEngine(self))
+        return self._engine
+
+    def forward(self, x, y):
+        eng = self.engine
+        params = [p for p, _ in eng.ordered_params()]
+        return PF.DiscFunction.apply(x, y, eng, self.compute_dtype, *params)

@@ -1,0 +1,182 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point).
+
+Tensors only supply device memory and the stream; all arithmetic happens in
+libpai_hip.so.  Every wrapper insists on CUDA(HIP) tensors -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, BF16, F32, ConvDesc, PaiError  # noqa: F401
+
+
+def code_of(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise PaiError(f"unsupported storage dtype {dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PaiError("pai ops need HIP device tensors (no CPU fallback exists)")
+    if dtype is not None and t.dtype != dtype:
+        raise PaiError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def make_desc(dtype, transposed, N, H, W, C1, C2, Cout, stride=2, relu1=0, relu2=0, act=ACT_NONE) -> ConvDesc:
+    d = ConvDesc()
+    d.dtype = code_of(dtype)
+    d.transposed = int(transposed)
+    d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
+    d.kernel, d.stride, d.pad = 4, stride, 1
+    d.relu1, d.relu2, d.epilogue_act = int(relu1), int(relu2), int(act)
+    return d
+
+
+def conv_out_hw(d: ConvDesc):
+    oh, ow = C.c_int(), C.c_int()
+    L.check(L.load().pai_conv_out_hw(C.byref(d), C.byref(oh), C.byref(ow)), "pai_conv_out_hw")
+    return oh.value, ow.value
+
+
+def conv_fwd_stats_rows(d: ConvDesc) -> int:
+    r = L.load().pai_conv_fwd_stats_rows(C.byref(d))
+    if r < 0:
+        L.check(1, "pai_conv_fwd_stats_rows")
+    return r
+
+
+def bn_stats_buffer_rows(rows: int) -> int:
+    return L.load().pai_bn_stats_buffer_rows(rows)
+
+
+def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None):
+    L.check(L.load().pai_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(w), _p(bias, torch.float32), _p(y_raw),
+                                  _p(y_act), _p(y_f32, torch.float32), _p(stats, torch.float32), _stream()),
+            "pai_conv_fwd")
+
+
+def conv_dgrad(d, dy, w_dgrad, dx1, dx2=None, only_c2=False):
+    L.check(L.load().pai_conv_dgrad(C.byref(d), _p(dy), _p(w_dgrad), _p(dx1), _p(dx2), int(only_c2), _stream()),
+            "pai_conv_dgrad")
+
+
+def conv_wgrad(d, x1, x2, dy, dw, dbias=None):
+    L.check(L.load().pai_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw, torch.float32),
+                                    _p(dbias, torch.float32), _stream()), "pai_conv_wgrad")
+
+
+def pack_weights(dtype, w_master, Cout, taps, Cin, w_fwd=None, w_dgrad=None):
+    L.check(L.load().pai_pack_weights(code_of(dtype), _p(w_master, torch.float32), Cout, taps, Cin, _p(w_fwd),
+                                      _p(w_dgrad), _stream()), "pai_pack_weights")
+
+
+def bn_finalize(stats, rows, C_, count, gamma, beta, eps, momentum, n_updates, running_mean, running_var,
+                nbt, mean, rstd, scale, shift):
+    L.check(L.load().pai_bn_finalize(_p(stats), rows, C_, count, _p(gamma), _p(beta), eps, momentum, n_updates,
+                                     _p(running_mean), _p(running_var), _p(nbt, torch.int64), _p(mean),
+                                     _p(rstd), _p(scale), _p(shift), _stream()), "pai_bn_finalize")
+
+
+def bn_eval_coeffs(C_, gamma, beta, running_mean, running_var, eps, scale, shift):
+    L.check(L.load().pai_bn_eval_coeffs(C_, _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps,
+                                        _p(scale), _p(shift), _stream()), "pai_bn_eval_coeffs")
+
+
+def bn_apply(dtype, z, M, C_, scale, shift, act, out):
+    L.check(L.load().pai_bn_apply(code_of(dtype), _p(z), M, C_, _p(scale), _p(shift), act, _p(out), _stream()),
+            "pai_bn_apply")
+
+
+def bn_bwd_partial_rows(M) -> int:
+    return L.load().pai_bn_bwd_partial_rows(M)
+
+
+def bn_bwd_reduce(dtype, g1, act1, g2, act2, a, z, M, C_, mean, rstd, du, partials, sums, dgamma, dbeta):
+    L.check(L.load().pai_bn_bwd_reduce(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), _p(z), M, C_, _p(mean),
+                                       _p(rstd), _p(du), _p(partials), _p(sums), _p(dgamma), _p(dbeta),
+                                       _stream()), "pai_bn_bwd_reduce")
+
+
+def bn_bwd_apply(dtype, du, z, M, C_, mean, rstd, gamma, sums, dz):
+    L.check(L.load().pai_bn_bwd_apply(code_of(dtype), _p(du), _p(z), M, C_, _p(mean), _p(rstd), _p(gamma),
+                                      _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply")
+
+
+def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
+    L.check(L.load().pai_act_bwd(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), numel, _p(du), _stream()),
+            "pai_act_bwd")
+
+
+def bce_logits(logits, target, loss_scale, loss, grad_scale=0.0, grad=None):
+    L.check(L.load().pai_bce_logits(_p(logits, torch.float32), logits.numel(), float(target), float(loss_scale),
+                                    _p(loss, torch.float64), float(grad_scale), _p(grad, torch.float32),
+                                    _stream()), "pai_bce_logits")
+
+
+def l1(pred, target, loss_scale, loss, grad_scale=0.0, grad=None):
+    L.check(L.load().pai_l1(_p(pred, torch.float32), _p(target, torch.float32), pred.numel(), float(loss_scale),
+                            _p(loss, torch.float64), float(grad_scale), _p(grad, torch.float32), _stream()),
+            "pai_l1")
+
+
+def mse(pred, target, loss_scale, loss, grad_scale=0.0, grad=None):
+    L.check(L.load().pai_mse(_p(pred, torch.float32), _p(target, torch.float32), pred.numel(), float(loss_scale),
+                             _p(loss, torch.float64), float(grad_scale), _p(grad, torch.float32), _stream()),
+            "pai_mse")
+
+
+def tanh_bwd(dtype, pred, g_a, g_b, dh):
+    L.check(L.load().pai_tanh_bwd(code_of(dtype), _p(pred, torch.float32), _p(g_a, torch.float32),
+                                  _p(g_b, torch.float32), pred.numel(), _p(dh), _stream()), "pai_tanh_bwd")
+
+
+def denormalize(x, grad_out, out):
+    L.check(L.load().pai_denormalize(_p(x, torch.float32), _p(grad_out, torch.float32), x.numel(),
+                                     _p(out, torch.float32), _stream()), "pai_denormalize")
+
+
+def ssim_sse(pred, target, NC, H, W, denorm, out2=None, per_image=None, full_map=None):
+    L.check(L.load().pai_ssim_sse(_p(pred, torch.float32), _p(target, torch.float32), NC, H, W, int(denorm),
+                                  _p(out2, torch.float64), _p(per_image, torch.float64),
+                                  _p(full_map, torch.float32), _stream()), "pai_ssim_sse")
+
+
+def ssim_bwd_workspace_floats(NC, H, W) -> int:
+    return L.load().pai_ssim_bwd_workspace_floats(NC, H, W)
+
+
+def ssim_psnr_bwd(pred, target, NC, H, W, denorm, w_ssim, w_psnr, sse, grad, workspace):
+    L.check(L.load().pai_ssim_psnr_bwd(_p(pred, torch.float32), _p(target, torch.float32), NC, H, W, int(denorm),
+                                       float(w_ssim), float(w_psnr), _p(sse, torch.float64),
+                                       _p(grad, torch.float32), _p(workspace, torch.float32), _stream()),
+            "pai_ssim_psnr_bwd")
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel()
+    L.check(L.load().pai_cast(code_of(src.dtype), _p(src), code_of(dst.dtype), _p(dst), src.numel(), _stream()),
+            "pai_cast")
+
+
+def reduce_rows(partial, rows, C_, out, accumulate=False):
+    L.check(L.load().pai_reduce_rows(_p(partial, torch.float32), rows, C_, _p(out, torch.float32),
+                                     int(accumulate), _stream()), "pai_reduce_rows")
+
+
+def adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    L.check(L.load().pai_adam(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
+                              _p(exp_avg_sq, torch.float32), param.numel(), lr, beta1, beta2, eps, step,
+                              _stream()), "pai_adam")
