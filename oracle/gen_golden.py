@@ -65,8 +65,51 @@ def build_reference_model(mults, loss_type, seed):
     return m
 
 
-def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors):
+class ActivationMargin:
+    """Smallest |input| / rms(input) seen by any ReLU / LeakyReLU of the reference model on tensors small
+    enough (< SMALL elements) that ONE sign flip would move a gradient by more than the 1e-4
+    parity bound.  ReLU'(0) is a discontinuity: a pre-activation of 1e-7 is rounding noise whose
+    sign differs between any two fp32 implementations, so fixtures are recorded only from seeds
+    that keep a margin there ("Parity tolerances")."""
+    SMALL = 200_000
+
+    def __init__(self, model):
+        self.min_abs = float("inf")
+        self.hooks = []
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.ReLU, torch.nn.LeakyReLU)):
+                self.hooks.append(mod.register_forward_pre_hook(self._hook))
+
+    def _hook(self, mod, args):
+        t = args[0].detach()
+        if t.numel() < self.SMALL:
+            rms = float(t.pow(2).mean().sqrt())
+            self.min_abs = min(self.min_abs, float(t.abs().min()) / max(rms, 1e-30))
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+
+
+def find_seed(mults, size, n, loss_type, seed0, steps, margin=2e-6, tries=400):
+    """First seed >= seed0 whose small-layer activations stay `margin` away from 0 for all steps."""
+    for seed in range(seed0, seed0 + tries):
+        m = build_reference_model(mults, loss_type, seed)
+        am = ActivationMargin(m)
+        x, t = synth_batch(seed + 100, n, size)
+        for s in range(steps):
+            m.training_step((x, t), s)
+        am.close()
+        if am.min_abs > margin:
+            print(f"  seed {seed}: min |pre-activation|/rms on small layers = {am.min_abs:.3g}")
+            return seed
+    raise RuntimeError("no seed with the requested activation margin")
+
+
+def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=True):
     from oracle.fingerprint import fingerprint
+    if search:
+        seed = find_seed(mults, size, n, loss_type, seed, steps)
     m = build_reference_model(mults, loss_type, seed)
     x, t = synth_batch(seed + 100, n, size)
     rec = OrderedDict()

@@ -48,7 +48,7 @@ static int check_desc(const pai_conv_desc* d) {
         if (d->stride == 2)
             PAI_CHECK((d->H % 2) == 0 && (d->W % 2) == 0, "stride-2 Conv2d needs even H, W");
         else
-            PAI_CHECK(d->H >= 3 && d->W >= 3, "k4 s1 p1 Conv2d needs H, W >= 3");
+            PAI_CHECK(d->H >= 2 && d->W >= 2, "k4 s1 p1 Conv2d needs H, W >= 2");
     }
     PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
     return 0;

@@ -210,6 +210,11 @@ class UnetEngine:
         self._plans = {}
         self._arena: Optional[GradArena] = None
         self.grad_ready_hook: Optional[Callable[[GradArena, int], None]] = None
+        self.debug_capture: Optional[dict] = None   # tests: name -> cloned intermediate tensor
+
+    def _dbg(self, name, t):
+        if self.debug_capture is not None:
+            self.debug_capture[name] = t.detach().clone()
 
     # ---- parameters -------------------------------------------------------------------
     def ordered_params(self):
@@ -459,6 +464,7 @@ class UnetEngine:
                               S["w"][j], M, C, st.mean, st.rstd, du, P["bwd_partials"], st.sums,
                               A.seg(bn.weight), A.seg(bn.bias))
             ops.bn_bwd_apply(dtype, du, S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
+            self._dbg(f"dec{j}.g", G["gr"][j]); self._dbg(f"dec{j}.du", du); self._dbg(f"dec{j}.dz", dz)
             d = P["dec_desc"][j]
             if j == 0:
                 x1, x2 = S["z"][L - 1], None
