@@ -1,0 +1,200 @@
+"""Headline benchmark: train images/s of the Pix2Pix GAN step (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = UnetWrapper.training_step on one synthetic batch already resident in HBM:
+D phase + G phase, both Adam updates and the per-step SSIM/PSNR/RMSE (reference
+models/wrapper.py:117-162), 256x256x1 pairs, 64 images per GPU (weak scaling), bf16 storage /
+fp32 accumulate.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel family (bf16 MFMA gather-GEMM, 128-wide tile) is timed per launch
+with HIP events recorded on the launch stream inside the timed region; achieved = algorithmic
+FLOPs of those launches / their summed duration, against the dense bf16 MFMA peak.
+cpu_baseline: the oracle's CPU restatement of the same step (same ATen ops the reference
+dispatches to), timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MULTS = (1, 2, 4, 8, 8, 8, 8, 8)
+SIZE = 256
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+# conv MACs per image: generator G, discriminator D, first layers G1, D1
+G_MAC, D_MAC, G1_MAC, D1_MAC = 5_947_523_072, 1_646_010_368, 16_777_216, 33_554_432
+
+
+def step_gflop_per_image(reuse_forward: bool) -> float:
+    g_passes = 3 if reuse_forward else 4
+    mac = g_passes * G_MAC - G1_MAC + 8 * D_MAC - 2 * D1_MAC
+    return 2 * mac / 1e9
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(batch=4, warmup=1, steps=36):
+    import oracle
+    torch.set_num_threads(host_cores())
+    g = oracle.init_state_portable(oracle.make_unet_state(1, 1, MULTS), 1)
+    d = oracle.init_state_portable(oracle.make_disc_state(1), 2)
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
+    t = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
+    og, od = oracle.AdamState(), oracle.AdamState()
+    for _ in range(warmup):
+        oracle.gan_training_step(g, d, og, od, x, t)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        oracle.gan_training_step(g, d, og, od, x, t)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} fp32 GAN steps at batch {batch} (BASELINE configs[0]), {warmup} warm-up, "
+                      f"oracle/step_ref.py on torch-CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--precision", default="bf16-mixed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reuse", action="store_true", help="literal two generator forwards per step")
+    args = ap.parse_args()
+
+    import pai_bootstrap
+    pai = pai_bootstrap.load()
+    from thesis_pai_reconstruction_amd import dist as pdist, ops
+
+    rank, local, world = pdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(0)
+    model = pai.Pix2Pix(1, 1, MULTS, 0.0, "gan")
+    model.to(dev)
+    model.set_precision(args.precision)
+    model.reuse_generator_forward = not args.no_reuse
+    model.train()
+    model.optimizers()
+    reducer = None
+    if world > 1:
+        pdist.broadcast_parameters(model)
+        reducer = pdist.GradReducer()
+        reducer.attach(model)
+
+        class _T:  # the hooks UnetWrapper needs from a trainer
+            pass
+        tr = _T()
+        tr.reducer = reducer
+        tr._log = lambda name, value: None
+        model.trainer = tr
+
+    rng = np.random.default_rng(1234 + rank)
+    x = torch.from_numpy(rng.random((args.batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1).to(dev)
+    t = torch.from_numpy(rng.random((args.batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1).to(dev)
+    batch = (x, t)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        model.training_step(batch, i)
+    torch.cuda.synchronize()
+    barrier()
+    ops.PROFILE = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.training_step(batch, i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax)
+
+    # ---- per-kernel roofline from the HIP-event brackets --------------------------------------
+    fam = {}
+    for kid, op, flops, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        f = fam.setdefault(kid, {"ms": 0.0, "flops": 0, "launches": 0})
+        f["ms"] += ms
+        f["flops"] += flops
+        f["launches"] += 1
+    dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
+    roofline = None
+    if dom is not None:
+        f = fam[dom]
+        achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "kernel": ops.KERNEL_NAMES.get(dom, str(dom)),
+                    "launches_per_step": f["launches"] / args.steps,
+                    "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
+                    "gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 3),
+                    "family_ms_per_step": {ops.KERNEL_NAMES.get(k, str(k)): round(v["ms"] / args.steps, 3)
+                                           for k, v in sorted(fam.items())}}
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+    reuse = model._can_reuse_forward()
+    gflop = step_gflop_per_image(reuse)
+    out = {
+        "metric": "train images/sec (256x256, bs=64) Pix2Pix step",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
+        "data": "synthetic",
+        "config": {"workload": "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
+                               "(BASELINE configs[1])",
+                   "global_batch": world * args.batch, "per_gpu_batch": args.batch,
+                   "channel_mults": list(MULTS), "loss_type": "gan",
+                   "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}"},
+        "step_conv_gflop_per_image": round(gflop, 2),
+        "step_mfma_frac": round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,12 @@ int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW);
 int pai_conv_fwd_stats_rows(const pai_conv_desc* d);
 int pai_bn_stats_buffer_rows(int rows);
 
+/* Kernel family a call with this descriptor runs (for profiling / roofline accounting):
+ * op 0 = forward, 1 = input gradient, 2 = weight gradient.
+ * returns 0 vector-ALU tile kernel, 1 row-dot kernel, 2 bf16 MFMA 128-wide tile, 3 bf16 MFMA
+ * 64-wide tile, < 0 on error. */
+int pai_conv_kernel_id(const pai_conv_desc* d, int op);
+
 /* y = conv(act(x1|x2), w) + bias.
  *   w_fwd   : fwd pack, storage dtype
  *   bias    : fp32 [Cout] or NULL

@@ -193,6 +193,31 @@ extern "C" int pai_conv_fwd_stats_rows(const pai_conv_desc* d) {
     return mt * g.nphase;
 }
 
+extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
+    GG g;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y1 = (void*)1;
+    if (op == 1) {
+        if (gg_build_dgrad(d, &g)) return -1;
+        a.y2 = (void*)1;
+    } else {
+        if (gg_build_fwd(d, &g)) return -1;
+    }
+    if (op == 2) {
+        if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+            int chunks = g.Cin / 8;
+            if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
+        }
+        if (wgrad_mfma_ok(d->dtype, g)) return (g.Cout % 128) == 0 ? 2 : 3;
+        return 0;
+    }
+    if (fwd_rowdot_ok(g, a)) return 1;
+    if (fwd_mfma_ok(d->dtype, g, a))
+        return ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 2 : 3;
+    return 0;
+}
+
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
     if (use_mfma(dtype, g, a)) return launch_fwd_mfma(g, a, s);

@@ -1,0 +1,134 @@
+"""Data-parallel gradient averaging: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference has no distributed code (it relies on Lightning's implicit DDP); this is the
+MI355X-native equivalent for its training step.  Parameter gradients of the HIP networks live
+in flat fp32 arenas ordered by backward-completion time (engine.GradArena).  While the
+backward pass is still running, every completed ``bucket_bytes`` range of an arena is handed to
+``torch.distributed.all_reduce(async_op=True)`` -- backend "nccl" is RCCL on ROCm -- which
+runs on the process group's own stream, so the collective of bucket k overlaps the kernels
+that produce bucket k+1.  ``finish()`` (called from ``manual_backward``) sends the tail, waits
+for everything and applies the 1/world_size average.  BatchNorm statistics stay local
+(non-synchronised), exactly like Lightning-DDP without ``sync_batchnorm``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True):
+        self.pg = process_group
+        self.bucket_elems = max(int(bucket_bytes) // 4, 1)
+        self.overlap = overlap
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._arenas = {}       # id(arena) -> state
+        self._engines = []
+        self._foreign_params: List[torch.nn.Parameter] = []
+        self.stats = {"buckets": 0, "bytes": 0}
+
+    # ---- wiring ---------------------------------------------------------------------------
+    def attach(self, model: torch.nn.Module):
+        """Hook every HIP engine found under ``model``; remember the parameters that are not
+        covered by an arena (plug-in ``unet`` modules) for a coalesced reduction in finish()."""
+        covered = set()
+        for m in model.modules():
+            eng = getattr(m, "engine", None) if hasattr(type(m), "engine") else None
+            if eng is not None and hasattr(eng, "arena"):
+                self.attach_engine(eng)
+                covered.update(id(p) for p, _ in eng.ordered_params())
+        self._foreign_params = [p for p in model.parameters() if id(p) not in covered]
+
+    def attach_engine(self, eng):
+        eng.grad_ready_hook = self._on_ready
+        self._engines.append(eng)
+
+    # ---- overlapped path ----------------------------------------------------------------------
+    def _state(self, arena):
+        st = self._arenas.get(id(arena))
+        if st is None:
+            st = {"arena": arena, "sent": 0, "works": [], "active": False}
+            self._arenas[id(arena)] = st
+        return st
+
+    def _launch(self, st, lo, hi):
+        if hi <= lo:
+            return
+        buf = st["arena"].flat[lo:hi]
+        if self.world > 1:
+            st["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.stats["buckets"] += 1
+        self.stats["bytes"] += (hi - lo) * 4
+
+    def _on_ready(self, arena, end: int):
+        """Engine callback: gradients in arena.flat[0:end] are final for this backward pass."""
+        st = self._state(arena)
+        if end < st["sent"]:
+            raise RuntimeError("GradReducer: a second backward pass touched an arena whose buckets were "
+                               "already reduced; use one backward per optimizer step")
+        st["active"] = True
+        if not self.overlap:
+            return
+        while end - st["sent"] >= self.bucket_elems:
+            self._launch(st, st["sent"], st["sent"] + self.bucket_elems)
+            st["sent"] += self.bucket_elems
+
+    # ---- completion ------------------------------------------------------------------------------
+    def finish(self):
+        """Reduce what is left, wait, average.  Called once after each backward pass."""
+        for st in self._arenas.values():
+            if not st["active"]:
+                continue
+            total = st["arena"].flat.numel()
+            self._launch(st, st["sent"], total)
+            for w in st["works"]:
+                w.wait()
+            if self.world > 1:
+                st["arena"].flat.mul_(1.0 / self.world)
+            st["sent"], st["works"], st["active"] = 0, [], False
+        grads = [p.grad for p in self._foreign_params if p.requires_grad and p.grad is not None]
+        if grads and self.world > 1:
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+            flat.mul_(1.0 / self.world)
+            off = 0
+            for g in grads:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
+
+
+def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=None):
+    """Make every rank start from rank ``src``'s parameters and buffers (what DDP does at wrap time)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.is_contiguous():
+                dist.broadcast(t, src=src, group=process_group)
+            else:
+                # parameters of the HIP networks are dense but permuted ("fwd pack"): ship them in
+                # storage order through a flat alias of the same memory
+                flat = t.detach().as_strided((t.numel(),), (1,), t.storage_offset())
+                dist.broadcast(flat, src=src, group=process_group)
+
+
+def init_from_env(backend: Optional[str] = None):
+    """torchrun-style environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pai_conv_out_hw": (_I, [_D, C.POINTER(_I), C.POINTER(_I)]),
     "pai_conv_fwd_stats_rows": (_I, [_D]),
     "pai_bn_stats_buffer_rows": (_I, [_I]),
+    "pai_conv_kernel_id": (_I, [_D, _I]),
     "pai_conv_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _I, _P]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),

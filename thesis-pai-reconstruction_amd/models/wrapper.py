@@ -100,8 +100,15 @@ class UnetWrapper(LightningModule):
             # Train discriminator.
             self.toggle_optimizer(opt_d)
             pred = pred_g.detach() if reuse else self.unet(x)
-            target_label = self.discriminator(x, target)
-            pred_label = self.discriminator(x, pred)
+            if getattr(self.discriminator, "supports_batched_pairs", False):
+                # the PatchGAN has no cross-sample coupling: D(x,target) and D(x,pred) are run as
+                # one batch of 2N (one backward pass, so gradient buckets can be reduced while it runs)
+                n = x.shape[0]
+                labels = self.discriminator(torch.cat([x, x], 0), torch.cat([target, pred], 0))
+                target_label, pred_label = labels[:n], labels[n:]
+            else:
+                target_label = self.discriminator(x, target)
+                pred_label = self.discriminator(x, pred)
             d_loss = self.discriminator_loss(pred_label, target_label)
             self.log("d_loss", d_loss, prog_bar=True)
             self.discriminator.zero_grad(set_to_none=True)
@@ -172,6 +179,7 @@ class Discriminator(nn.Module):
         super().__init__()
         self.in_channels = in_channels
         self.compute_dtype = torch.float32
+        self.supports_batched_pairs = True
         self.discriminator = nn.Sequential(
             DiscriminatorBlock(in_channels * 2, 64, norm=False),
             DiscriminatorBlock(64, 128),

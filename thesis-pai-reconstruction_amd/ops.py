@@ -62,20 +62,63 @@ def bn_stats_buffer_rows(rows: int) -> int:
     return L.load().pai_bn_stats_buffer_rows(rows)
 
 
+# ---- optional per-launch timing (bench.py roofline accounting) -------------------------------
+# When PROFILE is a list, every convolution-family call is bracketed by HIP events recorded on
+# the stream the kernel is launched on, and (kernel family, op, algorithmic FLOPs, events) is
+# appended.  Off (None) in normal operation.
+PROFILE = None
+KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64"}
+
+
+def conv_kernel_id(d: ConvDesc, op: int) -> int:
+    return L.load().pai_conv_kernel_id(C.byref(d), op)
+
+
+def conv_flops(d: ConvDesc) -> int:
+    """Algorithmic FLOPs (2 x MAC, padding taps included) of one fwd / dgrad / wgrad launch."""
+    if d.transposed:
+        return 2 * d.N * d.H * d.W * 16 * (d.C1 + d.C2) * d.Cout
+    oh = (d.H + 2 - 4) // d.stride + 1
+    ow = (d.W + 2 - 4) // d.stride + 1
+    return 2 * d.N * oh * ow * 16 * (d.C1 + d.C2) * d.Cout
+
+
+class _Timed:
+    def __init__(self, d, op):
+        self.on = PROFILE is not None
+        if self.on:
+            self.d, self.op = d, op
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE.append((conv_kernel_id(self.d, self.op), self.op, conv_flops(self.d), self.e0, self.e1))
+        return False
+
+
 def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None):
-    L.check(L.load().pai_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(w), _p(bias, torch.float32), _p(y_raw),
-                                  _p(y_act), _p(y_f32, torch.float32), _p(stats, torch.float32), _stream()),
-            "pai_conv_fwd")
+    with _Timed(d, 0):
+        L.check(L.load().pai_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(w), _p(bias, torch.float32), _p(y_raw),
+                                      _p(y_act), _p(y_f32, torch.float32), _p(stats, torch.float32),
+                                      _stream()), "pai_conv_fwd")
 
 
 def conv_dgrad(d, dy, w_dgrad, dx1, dx2=None, only_c2=False):
-    L.check(L.load().pai_conv_dgrad(C.byref(d), _p(dy), _p(w_dgrad), _p(dx1), _p(dx2), int(only_c2), _stream()),
-            "pai_conv_dgrad")
+    with _Timed(d, 1):
+        L.check(L.load().pai_conv_dgrad(C.byref(d), _p(dy), _p(w_dgrad), _p(dx1), _p(dx2), int(only_c2),
+                                        _stream()), "pai_conv_dgrad")
 
 
 def conv_wgrad(d, x1, x2, dy, dw, dbias=None):
-    L.check(L.load().pai_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw, torch.float32),
-                                    _p(dbias, torch.float32), _stream()), "pai_conv_wgrad")
+    with _Timed(d, 2):
+        L.check(L.load().pai_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw, torch.float32),
+                                        _p(dbias, torch.float32), _stream()), "pai_conv_wgrad")
 
 
 def pack_weights(dtype, w_master, Cout, taps, Cin, w_fwd=None, w_dgrad=None):
