@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads and exports exactly what include/pai_hip.h declares, and the ctypes
+table in lib.py covers the same set (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pai_hip.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(pai_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_lib_and_bindings_agree(pai):
+    decl = header_symbols()
+    assert len(decl) >= 25
+    table = set(pai.lib.SIGNATURES)
+    assert decl == table, (sorted(decl - table), sorted(table - decl))
+    lib = pai.lib.load()
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in pai_hip.h but not exported by libpai_hip.so"
+    assert lib.pai_version() >= 100
+
+
+def test_descriptor_layout_matches_header(pai):
+    # struct pai_conv_desc: 17 int32 fields, no padding
+    assert ctypes.sizeof(pai.lib.ConvDesc) == 17 * 4
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct pai_conv_desc {"):src.index("} pai_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"int32_t\s+([^;]+);", body):
+        for n in decl.split(","):
+            names.append(re.sub(r"\[.*\]", "", n).strip())
+    assert names == [f[0] for f in pai.lib.ConvDesc._fields_]
+
+
+def test_host_side_queries_work_without_gpu(pai):
+    """Shape / kernel-selection queries are pure host code and must work on a CPU-only box."""
+    from thesis_pai_reconstruction_amd import ops
+    import torch
+    d = ops.make_desc(torch.bfloat16, 0, 64, 128, 128, 64, 0, 128, 2)
+    assert ops.conv_out_hw(d) == (64, 64)
+    assert ops.conv_kernel_id(d, 0) == 2 and ops.conv_kernel_id(d, 1) in (2, 3) and ops.conv_kernel_id(d, 2) == 2
+    assert ops.conv_fwd_stats_rows(d) == 64 * 64 * 64 // 128
+    d32 = ops.make_desc(torch.float32, 0, 64, 128, 128, 64, 0, 128, 2)
+    assert ops.conv_kernel_id(d32, 0) == 0            # fp32 storage -> exact-fp32 vector-ALU kernel
+    dt = ops.make_desc(torch.bfloat16, 1, 4, 128, 128, 64, 64, 1, 2)
+    assert ops.conv_out_hw(dt) == (256, 256) and ops.conv_kernel_id(dt, 0) == 1   # Cout = 1 -> row-dot
+    assert ops.conv_flops(d) == 2 * 64 * 64 * 64 * 16 * 64 * 128
+    bad = ops.make_desc(torch.float32, 0, 1, 7, 8, 1, 0, 64, 2)
+    with pytest.raises(ops.PaiError, match="even"):
+        ops.conv_out_hw(bad)
+
+
+def test_product_path_refuses_cpu_tensors(pai):
+    """No CPU fallback: every product entry point raises on host tensors."""
+    import torch
+    from thesis_pai_reconstruction_amd import functional as PF
+    m = pai.Pix2Pix(1, 1, (1, 2), 0.0, "gan")
+    x = torch.zeros(1, 1, 32, 32)
+    with pytest.raises(pai.PaiError):
+        m.unet(x)
+    with pytest.raises(pai.PaiError):
+        m.discriminator(x, x)
+    with pytest.raises(pai.PaiError):
+        PF.ssim(x, x)
+    with pytest.raises(pai.PaiError):
+        PF.l1_loss(x.requires_grad_(True), x)
