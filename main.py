@@ -1,0 +1,100 @@
+"""Train CLI -- same flags, defaults and output tree as the reference's main.py:139-233
+(logs/<name>/version_k/{metrics.csv,checkpoints/best.ckpt}), running on the MI355X hot path.
+
+Added (build-only) flags: --synthetic N (train on N synthetic pairs instead of a YAML list),
+--image-size, --num-workers.  Multi-GPU: launch with
+``python -m torch.distributed.run --nproc-per-node N main.py ...`` (one process per GPU, RCCL).
+"""
+import argparse
+import pathlib
+from argparse import ArgumentParser
+
+import torch
+
+import pai_bootstrap
+
+pai = pai_bootstrap.load()
+from thesis_pai_reconstruction_amd import dist as pdist  # noqa: E402
+from thesis_pai_reconstruction_amd.dataset import ImageDataModule, SyntheticDataModule  # noqa: E402
+from thesis_pai_reconstruction_amd.lightning import CSVLogger, ModelCheckpoint, Trainer  # noqa: E402
+
+HIP_MODELS = ("pix2pix",)
+
+
+def main(hparams):
+    channel_mults = [int(x) for x in hparams.channel_mults.split(",")]
+    if hparams.model == "pix2pix":
+        model = pai.Pix2Pix(in_channels=1, out_channels=1, channel_mults=channel_mults,
+                            dropout=hparams.dropout, loss_type=hparams.loss_type)
+    elif hparams.model in ("attention_unet", "res18_unet", "res50_unet", "resv2_unet", "resnext_unet",
+                           "trans_unet", "palette"):
+        raise NotImplementedError(
+            f"model {hparams.model!r}: only the Pix2Pix hot path is built on the HIP kernels so far "
+            "(SURVEY.md section 8(f) lists the other families as next rows)")
+    else:
+        raise ValueError(f"Incorrect model name ({hparams.model})")
+
+    rank, local, world = pdist.init_from_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    if hparams.synthetic:
+        data_module = SyntheticDataModule(n_train=hparams.synthetic, n_val=max(hparams.batch_size, 8),
+                                          batch_size=hparams.batch_size, size=hparams.image_size,
+                                          seed=1234 + rank)
+    else:
+        data_module = ImageDataModule(hparams.data, hparams.val_data, batch_size=hparams.batch_size,
+                                      normalize=True, num_workers=hparams.num_workers)
+
+    checkpoint_callback = ModelCheckpoint(save_top_k=1, monitor="val_ssim", mode="max", filename="best",
+                                          save_last=False)
+    csv_logger = CSVLogger("logs", name=hparams.name)
+    reducer = None
+    if world > 1:
+        model.to(device)
+        pdist.broadcast_parameters(model)
+        reducer = pdist.GradReducer()
+    trainer = Trainer(max_epochs=hparams.epochs, max_steps=hparams.steps, log_every_n_steps=10,
+                      check_val_every_n_epoch=hparams.val_epochs, logger=[csv_logger],
+                      precision=hparams.precision, callbacks=[checkpoint_callback], benchmark=True,
+                      device=device, reducer=reducer)
+    if hparams.ema:
+        raise NotImplementedError("--ema: the EMA callback is a next-tier row (SURVEY.md 8(f) rank 3)")
+    trainer.fit(model, data_module)
+
+
+def build_parser():
+    parser = ArgumentParser()
+    parser.add_argument("name")
+    parser.add_argument("-d", "--data", type=pathlib.Path,
+                        help="YAML file containing filenames of images that make up the training data.")
+    parser.add_argument("-vd", "--val-data", type=pathlib.Path,
+                        help="YAML file containing filenames of images that make up the validation data.")
+    parser.add_argument("-e", "--epochs", default=200, type=int)
+    parser.add_argument("-s", "--steps", default=-1, type=int)
+    parser.add_argument("--batch-size", default=8, type=int)
+    parser.add_argument("--val-epochs", default=10, help="Validation run every n epochs.", type=int)
+    parser.add_argument("--precision", default="32", help="Floating-point precision")
+    parser.add_argument("--ema", default=False, action=argparse.BooleanOptionalAction,
+                        help="Whether to use EMA weight updating.")
+    parser.add_argument("--channel-mults", default="1,2,4,8,8,8,8,8",
+                        help="Defines the U-net architecture's depth and width. Should be comma-separated "
+                             "powers of 2.")
+    parser.add_argument("--attention-res", default="8,4,2",
+                        help="At what downsample multiples attention should be used, if the model supports it.")
+    parser.add_argument("--dropout", default=0.0, type=float)
+    parser.add_argument("--loss-type", default="gan", choices=["gan", "ssim", "psnr", "ssim+psnr", "mse"])
+    parser.add_argument("--schedule-type", default="linear", choices=["linear", "cosine"])
+    parser.add_argument("--learn-variance", default=False, action=argparse.BooleanOptionalAction)
+    parser.add_argument("-m", "--model", default="pix2pix",
+                        choices=["pix2pix", "attention_unet", "res18_unet", "res50_unet", "resv2_unet",
+                                 "resnext_unet", "trans_unet", "palette"])
+    # build-only additions
+    parser.add_argument("--synthetic", default=0, type=int, help="train on N synthetic pairs")
+    parser.add_argument("--image-size", default=256, type=int)
+    parser.add_argument("--num-workers", default=0, type=int)
+    return parser
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

@@ -1,0 +1,143 @@
+"""Data modules: the reference's YAML-listed image pairs (reference dataset.py:11-134) and the
+synthetic pairs used by the benchmark.
+
+Reference defect handled here: dataset.py:58 normalises 1-channel images with
+3-tuples, which cannot broadcast; this module normalises with (0.5,)/(0.5,), i.e. x*2-1.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from .lightning import LightningDataModule
+
+
+def load_gray_256(path: str, size: int = 256, normalize: bool = True) -> torch.Tensor:
+    """read_image(GRAY) -> Resize((256,256), antialias=True) on uint8 -> float32/255 -> [-1,1]
+    (reference dataset.py:51-59,129-132).  PIL's BILINEAR resize is the antialiased bilinear
+    filter torchvision's antialias=True reproduces."""
+    from PIL import Image
+    img = Image.open(path).convert("L")
+    if img.size != (size, size):
+        img = img.resize((size, size), Image.BILINEAR)
+    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(torch.float32).div_(255).unsqueeze(0)
+    return x * 2 - 1 if normalize else x
+
+
+class ImageDataset(Dataset):
+    """Pairs of (input, ground truth) image files (reference dataset.py:110-134)."""
+
+    def __init__(self, data_tuples, normalize=True, size=256):
+        super().__init__()
+        self.data_tuples, self.normalize, self.size = data_tuples, normalize, size
+
+    def __len__(self):
+        return len(self.data_tuples)
+
+    def __getitem__(self, idx):
+        inp, gt = self.data_tuples[idx]
+        return load_gray_256(inp, self.size, self.normalize), load_gray_256(gt, self.size, self.normalize)
+
+
+def _read_list(list_file):
+    import yaml
+    with open(list_file, "r") as f:
+        items = yaml.safe_load(f)
+    base = os.path.dirname(str(list_file))
+    return [(os.path.join(base, it["input"]), os.path.join(base, it["ground_truth"])) for it in items]
+
+
+class ImageDataModule(LightningDataModule):
+    """``ImageDataModule(data_list_file, val_list_file, batch_size, normalize)`` (reference
+    dataset.py:11-107).  ``num_workers`` / ``pin_memory`` are additions: the reference decodes on
+    the main process, which cannot feed a GPU at >2k images/s."""
+
+    def __init__(self, data_list_file: str, val_list_file: Optional[str] = None, batch_size: int = 1,
+                 normalize: bool = True, num_workers: int = 0, pin_memory: bool = True):
+        super().__init__()
+        self.data_tuples = _read_list(data_list_file)
+        self.val_tuples = _read_list(val_list_file) if val_list_file is not None else None
+        self.batch_size, self.normalize = batch_size, normalize
+        self.num_workers, self.pin_memory = num_workers, pin_memory
+
+    def setup(self, stage: str):
+        if stage == "fit":
+            self.train_split, self.val_split = self.data_tuples, self.val_tuples
+        if stage == "validate":
+            self.val_split = self.data_tuples
+        if stage == "test":
+            self.test_split = self.data_tuples
+        if stage == "predict":
+            self.pred_split = self.data_tuples
+
+    def _loader(self, split, shuffle):
+        return DataLoader(ImageDataset(split, self.normalize), batch_size=self.batch_size, shuffle=shuffle,
+                          drop_last=False, num_workers=self.num_workers,
+                          pin_memory=self.pin_memory and torch.cuda.is_available())
+
+    def train_dataloader(self):
+        return self._loader(self.train_split, True)
+
+    def val_dataloader(self):
+        return self._loader(self.val_split, False) if self.val_split else None
+
+    def test_dataloader(self):
+        return self._loader(self.test_split, False)
+
+    def predict_dataloader(self):
+        return self._loader(self.pred_split, False)
+
+
+def synthetic_pairs(n: int, size: int = 256, seed: int = 1234, kind: str = "uniform"):
+    """Canonical synthetic PAI pairs: numpy default_rng, fp32 in [-1, 1).
+    ``kind='blobs'`` makes depth-attenuated blob images so that training has something to learn."""
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        x = rng.random((n, 1, size, size), dtype=np.float32) * 2 - 1
+        t = rng.random((n, 1, size, size), dtype=np.float32) * 2 - 1
+        return torch.from_numpy(x), torch.from_numpy(t)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    t = np.zeros((n, 1, size, size), np.float32)
+    for i in range(n):
+        for _ in range(int(rng.integers(3, 9))):
+            cy, cx, r = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(3, 18)
+            t[i, 0] += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r)) * rng.uniform(0.4, 1.0)
+    t = np.clip(t, 0, 1)
+    depth = np.exp(-yy / size * 2.5)[None, None]
+    x = np.clip(t * depth + 0.05 * rng.standard_normal(t.shape).astype(np.float32), 0, 1)
+    return torch.from_numpy(x * 2 - 1), torch.from_numpy(t * 2 - 1)
+
+
+class _TensorPairs(Dataset):
+    def __init__(self, x, t):
+        self.x, self.t = x, t
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], self.t[i]
+
+
+class SyntheticDataModule(LightningDataModule):
+    def __init__(self, n_train=256, n_val=32, batch_size=8, size=256, seed=1234, kind="blobs"):
+        super().__init__()
+        self.n_train, self.n_val, self.batch_size, self.size, self.seed, self.kind = \
+            n_train, n_val, batch_size, size, seed, kind
+
+    def setup(self, stage: str):
+        self.train = _TensorPairs(*synthetic_pairs(self.n_train, self.size, self.seed, self.kind))
+        self.val = _TensorPairs(*synthetic_pairs(self.n_val, self.size, self.seed + 1, self.kind))
+
+    def train_dataloader(self):
+        return DataLoader(self.train, batch_size=self.batch_size, shuffle=True, drop_last=False)
+
+    def val_dataloader(self):
+        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False)
+
+    def predict_dataloader(self):
+        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False)
