@@ -85,6 +85,15 @@ int pai_bn_stats_buffer_rows(int rows);
  * 64-wide tile, < 0 on error. */
 int pai_conv_kernel_id(const pai_conv_desc* d, int op);
 
+/* Split-K scratch.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
+ * bottleneck: M <= 1024 rows, K up to 8192) are split over K; the fp32 partial sums meet in a
+ * caller-provided scratch buffer.  Register ONE buffer per process with pai_set_workspace; it must
+ * be zero-filled when registered and at least max(pai_conv_workspace_bytes(desc, op)) over the
+ * forward (op 0) and input-gradient (op 1) calls that will be made.  The library keeps it all-zero
+ * between calls.  Calls that would need more scratch than is registered run un-split. */
+int pai_set_workspace(void* zeroed_device_memory, int64_t bytes);
+int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op);
+
 /* y = conv(act(x1|x2), w) + bias.
  *   w_fwd   : fwd pack, storage dtype
  *   bias    : fp32 [Cout] or NULL

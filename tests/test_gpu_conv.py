@@ -62,6 +62,8 @@ def test_conv_family(pai, case, dtype):
 
     d = ops.make_desc(dtype, tr, N, H, W, C1, C2, Cout, s, r1, r2, ops.ACT_LRELU)
     assert ops.conv_out_hw(d) == (OH, OW)
+    # split-K scratch: small-M / long-K layers take the split path only when it is registered
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
     wm = fwd_pack(w, bool(tr))
     wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
     wd = torch.empty(wm.numel(), dtype=dtype, device=dev())

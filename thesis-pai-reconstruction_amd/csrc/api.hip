@@ -32,6 +32,8 @@ extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, i
     return 0;
 }
 
+static void finish_gg(GG* g);
+
 // ---------------------------------------------------------------------------------
 static int check_desc(const pai_conv_desc* d) {
     PAI_CHECK(d != nullptr, "null descriptor");
@@ -137,7 +139,7 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
         g->OHg = d->H; g->OWg = d->W;
         fill_phase_taps(g);
     }
-    g->M = g->N * g->OHg * g->OWg;
+    finish_gg(g);
     return 0;
 }
 
@@ -175,8 +177,37 @@ int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
         g->OHg = d->H; g->OWg = d->W;
         fill_conv_taps(g, 2, -d->pad);
     }
-    g->M = g->N * g->OHg * g->OWg;
+    finish_gg(g);
     return 0;
+}
+
+static void finish_gg(GG* g) {
+    g->M = g->N * g->OHg * g->OWg;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    g->lw = lg(g->OWg);
+    g->lh = lg(g->OHg);
+    if (g->lw < 0 || g->lh < 0) g->lw = g->lh = -1;
+}
+
+float* g_workspace = nullptr;
+int64_t g_workspace_bytes = 0;
+
+extern "C" int pai_set_workspace(void* zeroed_device_memory, int64_t bytes) {
+    g_workspace = (float*)zeroed_device_memory;
+    g_workspace_bytes = zeroed_device_memory ? bytes : 0;
+    return 0;
+}
+
+extern "C" int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op) {
+    GG g;
+    if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
+    if (op == 2) return 0;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y1 = (void*)1;
+    if (op == 1) a.y2 = (void*)1;
+    if (!fwd_mfma_ok(d->dtype, g, a)) return 0;
+    return fwd_mfma_workspace_bytes(g);
 }
 
 // ---------------------------------------------------------------------------------

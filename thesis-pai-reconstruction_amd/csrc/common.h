@@ -93,6 +93,7 @@ struct GG {
     int wtaps;
     int relu1, relu2;
     int M;  // rows per phase = N*OHg*OWg
+    int lw, lh;  // log2(OWg), log2(OHg) when both are powers of two, else -1
     signed char dy[4][16], dx[4][16], wt[4][16];
     signed char poy[4], pox[4];
 };
@@ -116,6 +117,11 @@ struct FwdArgs {
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s);
+int fwd_mfma_ksplit(const GG& g);
+int64_t fwd_mfma_workspace_bytes(const GG& g);
+// registered scratch for split-K partial sums (fp32, kept all-zero between calls)
+extern float* g_workspace;
+extern int64_t g_workspace_bytes;
 int fwd_simt_mtiles(const GG& g);
 int fwd_mfma_mtiles(const GG& g);
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);

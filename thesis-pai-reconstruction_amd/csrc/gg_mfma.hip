@@ -1,11 +1,18 @@
 // bf16 MFMA gather-GEMM kernels for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
 //
 // Forward / input-gradient:  out[m][co] = sum_{t,ci} A(m,t,ci) * Wp[co][wt][ci]
-//   128 x BN x 64 tile, 4 waves (2 x 2), register-staged double-buffered LDS, both operands
-//   K-contiguous so every fragment is one ds_read_b128 from an XOR-swizzled 128-B-row image.
+//   128 x BN x 64 tile, 4 waves (2 x 2).  Both operand tiles go HBM -> LDS directly
+//   (global_load_lds_dwordx4, no staging registers, no branches): one K-step = one tap x 64
+//   channels, so a tile row is one contiguous 128-B NHWC segment; out-of-image taps and rows
+//   beyond M fetch from a 128-B zero line instead.  The LDS image is lane-linear per load
+//   instruction and XOR-swizzled through the SOURCE address, every fragment is one conflict-free
+//   ds_read_b128.  One LDS buffer per workgroup (32-36 KB): latency is hidden by running 3-4
+//   workgroups per CU, not by a deep per-workgroup pipeline.  Layers with few output tiles and a
+//   long reduction (U-Net bottleneck) are split over K into an fp32 scratch buffer and finished
+//   by splitk_finish_k.
 // Weight gradient:           dW[co][wt][ci] += sum_m dY[m][co] * A(m,t,ci)
 //   both operands are pixel-major in HBM (NHWC), i.e. K-strided: they are staged row-major
-//   into LDS and the MFMA fragments are fetched with ds_read_b64_tr_b16 (hardware transpose).
+//   into LDS the same way and the MFMA fragments are fetched with ds_read_b64_tr_b16.
 //
 // Serves the dense layers of the reference's hot path: EncoderBlock / DecoderBlock convs
 // (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and their
@@ -16,9 +23,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
 typedef __attribute__((ext_vector_type(4))) float f4_t;
 typedef __attribute__((ext_vector_type(2))) short s2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 
 constexpr int MBM = 128;  // output rows per block
 constexpr int MBK = 64;   // K per iteration (one tap, 64 channels)
+
+__device__ uint4 g_zero_line[16];  // 256 B of zeros: source of padding / masked rows
+
+#define GLDS16(gptr, lptr)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),    \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 int fwd_mfma_mtiles(const GG& g) { return cdiv(g.M, MBM); }
 
@@ -30,108 +44,115 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (a.yf32) return false;
     if (a.skip_d1) return false;
     if ((a.y1 || a.y2) && a.yact) return false;  // one storage-dtype output per launch
+    if (a.yact && a.eact != PAI_ACT_NONE && a.eact != PAI_ACT_LRELU && a.eact != PAI_ACT_RELU) return false;
     return true;
 }
 
-__device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
+static bool fwd_bn128(const GG& g) { return (g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0); }
+
+int fwd_mfma_ksplit(const GG& g) {
+    const int bn = fwd_bn128(g) ? 128 : 64;
+    const int tiles = fwd_mfma_mtiles(g) * (g.Cout / bn) * g.nphase;
+    const int niter = g.ntaps * g.Cin / MBK;
+    if (tiles >= 192 || niter < 8) return 1;
+    int ks = 768 / tiles;
+    if (ks > niter / 2) ks = niter / 2;
+    if (ks < 1) ks = 1;
+    // every split gets the same number of iterations
+    while (ks > 1 && (niter % ks)) --ks;
+    return ks;
+}
+
+int64_t fwd_mfma_workspace_bytes(const GG& g) {
+    if (fwd_mfma_ksplit(g) <= 1) return 0;
+    return (int64_t)g.nphase * g.M * g.Cout * 4;
+}
+
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+
+__device__ __forceinline__ bf8_t relu_frag(bf8_t f) {
     // ReLU on packed bf16: as signed 16-bit integers every negative float is negative
-    s2_t z = {0, 0};
-    unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s2_t x = __builtin_bit_cast(s2_t, u[i]);
-        x = __builtin_elementwise_max(x, z);
-        u[i] = __builtin_bit_cast(unsigned, x);
-    }
-    return make_uint4(u[0], u[1], u[2], u[3]);
+    // (v_pk_max_i16 x4).  Done on one 8-lane vector: element-wise writes to a 4 x u32 vector in an
+    // unrolled loop were folded to a broadcast of element 0 by hipcc 7.2.
+    s8_t x = __builtin_bit_cast(s8_t, f);
+    const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    x = __builtin_elementwise_max(x, z);
+    return __builtin_bit_cast(bf8_t, x);
 }
 
 __device__ __forceinline__ void decode_row(const GG& g, int m, int& n, int& gy, int& gx) {
-    gx = m % g.OWg;
-    int r = m / g.OWg;
-    gy = r % g.OHg;
-    n = r / g.OHg;
+    if (g.lw >= 0) {
+        gx = m & (g.OWg - 1);
+        gy = (m >> g.lw) & (g.OHg - 1);
+        n = m >> (g.lw + g.lh);
+    } else {
+        gx = m % g.OWg;
+        int r = m / g.OWg;
+        gy = r % g.OHg;
+        n = r / g.OHg;
+    }
 }
 
-template <int BN>
-__global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles) {
-    constexpr int NT = BN / 32;          // 16-col MFMA tiles per wave along N
-    constexpr int BJ = BN / 32;          // staging passes for the B tile
-    constexpr int A_BYTES = MBM * 128;   // one A buffer
-    constexpr int B_BYTES = BN * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                 // 2 buffers
-    unsigned char* Bs = smem + 2 * A_BYTES;   // 2 buffers
+// XCD-aware tile order: consecutive logical tiles (same A rows, neighbouring image rows) land on
+// the same XCD / L2.  Bijective for any grid size (guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+template <int BN, bool SPLITK>
+__global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
+                                                     float* ws) {
+    constexpr int NT = BN / 32;  // 16-col MFMA tiles per wave along N
+    constexpr int BJ = BN / 32;  // load instructions per thread for the B tile
+    constexpr int A_BYTES = MBM * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bn = bid % ntiles;
     bid /= ntiles;
     const int bm = bid % mtiles;
-    const int ph = bid / mtiles;
+    bid /= mtiles;
+    const int ph = bid % g.nphase;
+    const int ks = bid / g.nphase;
     const int m0 = bm * MBM, n0 = bn * BN;
 
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
     const bf16_t* w = (const bf16_t*)a.w;
+    const bf16_t* zero = (const bf16_t*)g_zero_line;
 
-    // ---- staging map: 16-B chunk sc of row sr + 32*j ---------------------------
-    const int sc = tid & 7, sr = tid >> 3;
-    const int sswz = (sr >> 1) & 7;
-    const unsigned st_off = (unsigned)(sr * 128 + ((sc ^ sswz) << 4));
+    // ---- load map: lane-linear LDS image; position (row sr+32j, slot sc) holds global chunk sc^swz
+    const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
+    const int gch = (sc ^ ((sr >> 1) & 7)) * 8;  // element offset of the chunk this lane fetches
     int rnH[4], ry[4], rx[4];
-    bool rv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int m = m0 + sr + 32 * j;
-        rv[j] = m < g.M;
+        const int m = m0 + sr + 32 * j;
         int n, gy, gx;
-        decode_row(g, rv[j] ? m : 0, n, gy, gx);
+        decode_row(g, m < g.M ? m : 0, n, gy, gx);
         rnH[j] = n * g.H;
-        ry[j] = gy * g.S;
+        ry[j] = m < g.M ? gy * g.S : -100000;  // rows beyond M: permanently out of bounds -> zeros
         rx[j] = gx * g.S;
     }
-    size_t wrow[BJ];
+    const bf16_t* wrow[BJ];
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) wrow[j] = (size_t)(n0 + sr + 32 * j) * g.wtaps * g.Cin + sc * 8;
+    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + 32 * j) * g.wtaps * g.Cin + gch;
 
     const int cchunks = g.Cin / MBK;
-    const int niter = g.ntaps * cchunks;
+    const int niter_all = g.ntaps * cchunks;
+    const int niter = niter_all / ksplit;
+    int t = (ks * niter) / cchunks;
+    int c0 = ((ks * niter) - t * cchunks) * MBK;
 
-    uint4 pa[4], pb[BJ];
-    auto gload = [&](int it) {
-        const int t = it / cchunks;
-        const int c0 = (it - t * cchunks) * MBK;
-        const int ddy = g.dy[ph][t], ddx = g.dx[ph][t];
-        const bf16_t* src;
-        int cs, cc, relu;
-        if (c0 < g.C1) { src = x1; cs = g.C1; cc = c0; relu = g.relu1; }
-        else { src = x2; cs = g.C2; cc = c0 - g.C1; relu = g.relu2; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = ry[j] + ddy, ix = rx[j] + ddx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (rv[j] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-                v = *(const uint4*)(src + ((size_t)(rnH[j] + iy) * g.W + ix) * cs + cc + sc * 8);
-                if (relu) v = relu_bf16x8(v);
-            }
-            pa[j] = v;
-        }
-        const size_t woff = (size_t)g.wt[ph][t] * g.Cin + c0;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) pb[j] = *(const uint4*)(w + wrow[j] + woff);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(uint4*)(As + buf * A_BYTES + st_off + j * 32 * 128) = pa[j];
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) *(uint4*)(Bs + buf * B_BYTES + st_off + j * 32 * 128) = pb[j];
-    };
-
-    // ---- fragment read addresses -----------------------------------------------
+    // ---- fragment read addresses ----------------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
-    const int fswz = fr >> 1;  // (row>>1)&7 with row = 16*k + fr
+    const int fswz = fr >> 1;
     const unsigned a_base = (unsigned)((wm * 64 + fr) * 128);
     const unsigned b_base = (unsigned)((wn * (BN / 2) + fr) * 128);
 
@@ -141,36 +162,69 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
     for (int it = 0; it < niter; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < niter) gload(it + 1);
-        const unsigned char* Ab = As + buf * A_BYTES;
-        const unsigned char* Bb = Bs + buf * B_BYTES;
+        const int ddy = g.dy[ph][t], ddx = g.dx[ph][t];
+        const bf16_t* src;
+        int cs, cc, relu;
+        if (c0 < g.C1) { src = x1; cs = g.C1; cc = c0; relu = g.relu1; }
+        else { src = x2; cs = g.C2; cc = c0 - g.C1; relu = g.relu2; }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const unsigned coff = (unsigned)(((ks * 4 + fq) ^ fswz) << 4);
+        for (int j = 0; j < 4; ++j) {
+            const int iy = ry[j] + ddy, ix = rx[j] + ddx;
+            const bool inb = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const bf16_t* p = src + ((size_t)(rnH[j] + iy) * g.W + ix) * cs + cc + gch;
+            p = inb ? p : zero;
+            GLDS16(p, As + (j * 32 + wid * 8) * 128);
+        }
+        const size_t woff = (size_t)g.wt[ph][t] * g.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + (j * 32 + wid * 8) * 128);
+        c0 += MBK;
+        if (c0 == g.Cin) { c0 = 0; ++t; }
+        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned coff = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
             bf8_t af[4], bfr[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf8_t*)(Ab + a_base + mt * 16 * 128 + coff);
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf8_t*)(As + a_base + mt * 16 * 128 + coff);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(Bb + b_base + nt * 16 * 128 + coff);
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(Bs + b_base + nt * 16 * 128 + coff);
+            if (relu) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) af[mt] = relu_frag(af[mt]);
+            }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
-        if (it + 1 < niter) lstore(buf ^ 1);
-        __syncthreads();
+        __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
     }
 
-    // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --
+    if (SPLITK) {
+        // fp32 partial tile -> scratch [phase][m][Cout]; splitk_finish_k applies the epilogue
+        float* dst = ws + ((size_t)ph * g.M + m0) * g.Cout + n0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + mt * 16 + fq * 4 + r;
+                if (m0 + row < g.M) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        atomicAdd(dst + (size_t)row * g.Cout + wn * (BN / 2) + nt * 16 + fr, acc[mt][nt][r]);
+                }
+            }
+        return;
+    }
+
+    // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
     constexpr int CROW = BN * 2 + 16;  // padded bytes per staged output row
-    unsigned char* Cs = smem;          // reuse (all LDS reads of the main loop are done)
+    unsigned char* Cs = smem;
     float* sstat = (float*)(smem + MBM * CROW);  // [2 wm][2][BN]
+    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
     float csum[NT], csq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -184,7 +238,8 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
                 const int row = wm * 64 + mt * 16 + fq * 4 + r;
                 float v = acc[mt][nt][r] + b;
                 if (m0 + row < g.M) { s += v; q += v * v; }
-                if (a.yact) v = act_apply(v, a.eact);
+                if (eact == PAI_ACT_LRELU) v = fmaxf(v, 0.2f * v);
+                else if (eact == PAI_ACT_RELU) v = fmaxf(v, 0.f);
                 *(bf16_t*)(Cs + row * CROW + col * 2) = f2bf(v);
             }
         }
@@ -210,14 +265,13 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
         dst[0] = sstat[0 * BN + tid] + sstat[2 * BN + tid];
         dst[g.Cout] = sstat[1 * BN + tid] + sstat[3 * BN + tid];
     }
-    // destination tensor for this column tile
     bf16_t* dst;
     int dstride, dcol;
     if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
     else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
     else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
-    constexpr int CPR = BN / 8;          // 16-B chunks per row
-    constexpr int RPP = 256 / CPR;       // rows per pass
+    constexpr int CPR = BN / 8;     // 16-B chunks per row
+    constexpr int RPP = 256 / CPR;  // rows per pass
     const int oc = tid % CPR, orow0 = tid / CPR;
 #pragma unroll
     for (int p = 0; p < MBM / RPP; ++p) {
@@ -232,20 +286,81 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
     }
 }
 
+// Split-K epilogue: scratch [phase][M][Cout] fp32 -> bias, BN partial statistics per 128-row tile,
+// activation, bf16 store (two destinations), and the scratch is returned to all-zero.
+__global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* ws, int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) float sst[];  // [2][Cout]
+    const int tid = threadIdx.x;
+    const int bm = blockIdx.x, ph = blockIdx.y;
+    const int m0 = bm * MBM;
+    const int cgroups = g.Cout / 8;
+    for (int i = tid; i < 2 * g.Cout; i += 256) sst[i] = 0.f;
+    __syncthreads();
+    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const int rows = min(MBM, g.M - m0);
+    for (int idx = tid; idx < rows * cgroups; idx += 256) {
+        const int row = idx / cgroups, c0 = (idx - row * cgroups) * 8;
+        const int m = m0 + row;
+        float* src = ws + ((size_t)ph * g.M + m) * g.Cout + c0;
+        float4 v0 = *(float4*)src, v1 = *(float4*)(src + 4);
+        *(float4*)src = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(src + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        unsigned packed[4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] += a.bias ? a.bias[c0 + k] : 0.f;
+            if (a.stats) {
+                atomicAdd(&sst[c0 + k], v[k]);
+                atomicAdd(&sst[g.Cout + c0 + k], v[k] * v[k]);
+            }
+            if (eact == PAI_ACT_LRELU) v[k] = fmaxf(v[k], 0.2f * v[k]);
+            else if (eact == PAI_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) packed[k] = (unsigned)f2bf(v[2 * k]) | ((unsigned)f2bf(v[2 * k + 1]) << 16);
+        int n, gy, gx;
+        decode_row(g, m, n, gy, gx);
+        const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
+        bf16_t* dst;
+        if (a.yact) dst = (bf16_t*)a.yact + pix * g.Cout + c0;
+        else if (c0 < g.D1) dst = (bf16_t*)a.y1 + pix * g.D1 + c0;
+        else dst = (bf16_t*)a.y2 + pix * g.D2 + (c0 - g.D1);
+        *(uint4*)dst = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+    if (a.stats) {
+        __syncthreads();
+        float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout;
+        for (int i = tid; i < 2 * g.Cout; i += 256) dst[i] = sst[i];
+    }
+}
+
+template <int BN>
+static size_t fwd_lds_bytes() {
+    const size_t main_loop = MBM * 128 + BN * 128;
+    const size_t epilogue = MBM * (BN * 2 + 16) + 4 * BN * sizeof(float);
+    return main_loop > epilogue ? main_loop : epilogue;
+}
+
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int mtiles = fwd_mfma_mtiles(g);
-    bool bn128 = (g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0);
-    if (bn128) {
-        const int ntiles = g.Cout / 128;
-        const size_t lds = 2 * (MBM * 128 + 128 * 128);
-        hipLaunchKernelGGL(gg_fwd_mfma_k<128>, dim3(mtiles * ntiles * g.nphase), dim3(256), lds, s, g, a,
-                           mtiles, ntiles);
+    const bool bn128 = fwd_bn128(g);
+    const int ntiles = g.Cout / (bn128 ? 128 : 64);
+    int ksplit = fwd_mfma_ksplit(g);
+    if (ksplit > 1 && (g_workspace == nullptr || g_workspace_bytes < fwd_mfma_workspace_bytes(g))) ksplit = 1;
+    const dim3 grid(mtiles * ntiles * g.nphase * ksplit);
+#define FWD_LAUNCH(BN, SK)                                                                              \
+    hipLaunchKernelGGL((gg_fwd_mfma_k<BN, SK>), grid, dim3(256), fwd_lds_bytes<BN>(), s, g, a, mtiles, \
+                       ntiles, ksplit, g_workspace)
+    if (ksplit > 1) {
+        if (bn128) FWD_LAUNCH(128, true); else FWD_LAUNCH(64, true);
+        PAI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(splitk_finish_k, dim3(mtiles, g.nphase), dim3(256), 2 * g.Cout * sizeof(float), s, g,
+                           a, g_workspace, mtiles);
     } else {
-        const int ntiles = g.Cout / 64;
-        const size_t lds = 2 * (MBM * 128 + 64 * 128);
-        hipLaunchKernelGGL(gg_fwd_mfma_k<64>, dim3(mtiles * ntiles * g.nphase), dim3(256), lds, s, g, a,
-                           mtiles, ntiles);
+        if (bn128) FWD_LAUNCH(128, false); else FWD_LAUNCH(64, false);
     }
+#undef FWD_LAUNCH
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -261,24 +376,24 @@ bool wgrad_mfma_ok(int dtype, const GG& g) {
     return true;
 }
 
-// byte offset of 16-B chunk `ch` (0..15) of row `row` in a 256-B-row LDS image that is
-// conflict-free for both ds_write_b128 row stores and ds_read_b64_tr_b16 transposed reads
-__device__ __forceinline__ unsigned tr_off(int row, int ch) {
-    return (unsigned)(256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))));
-}
+// XOR applied to the 16-B chunk index of row `row` in a 256-B-row LDS image: conflict-free for
+// lane-linear row fills and for ds_read_b64_tr_b16 transposed reads (guide T10, layout (b))
+__device__ __forceinline__ int tr_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ unsigned tr_off(int row, int ch) { return (unsigned)(256 * row + 16 * (ch ^ tr_swz(row))); }
 
 template <int BMC>  // output-channel tile: 128 or 64
 __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int cotiles, int jtiles,
                                                        int splits, int rows_per_split) {
-    constexpr int MT = BMC / 32;           // 16-row MFMA tiles per wave along co
-    constexpr int BUF = 64 * 256;          // one staged operand tile: 64 pixel rows x 256 B
+    constexpr int MT = BMC / 32;   // 16-row MFMA tiles per wave along co
+    constexpr int BUF = 64 * 256;  // one staged operand tile: 64 pixel rows x 256 B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ys = smem;              // 2 buffers
-    unsigned char* Xs = smem + 2 * BUF;    // 2 buffers
+    unsigned char* Ys = smem;
+    unsigned char* Xs = smem + BUF;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int jt = bid % jtiles; bid /= jtiles;
     const int cot = bid % cotiles; bid /= cotiles;
     const int split = bid % splits;
@@ -288,11 +403,13 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
     const bf16_t* dy = (const bf16_t*)a.dy;
+    const bf16_t* zero = (const bf16_t*)g_zero_line;
 
-    // staging: chunk sc (0..15) of pixel row sr + 16*j
-    const int sc = tid & 15, sr = tid >> 4;
-    // this thread's gathered-column chunk -> (tap, source, channel)
-    const int jc = j0 + sc * 8;
+    // load map: position (row sr + 16j, slot sc) of the lane-linear image holds global chunk sc^swz(row)
+    const int sc = lane & 15, sr = wid * 4 + (lane >> 4);
+    const int gch = sc ^ tr_swz(sr);  // tr_swz(sr + 16j) == tr_swz(sr): only row bits 0..3 matter
+    // gathered-column chunk -> (tap, source, channel)
+    const int jc = j0 + gch * 8;
     const int xt = jc / g.Cin;
     const int xci = jc - xt * g.Cin;
     const int ddy = g.dy[ph][xt], ddx = g.dx[ph][xt];
@@ -300,46 +417,14 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     int xcs, xcc, xrelu;
     if (xci < g.C1) { xsrc = x1; xcs = g.C1; xcc = xci; xrelu = g.relu1; }
     else { xsrc = x2; xcs = g.C2; xcc = xci - g.C1; xrelu = g.relu2; }
-    const bool yv = (co0 + sc * 8) < g.Cout;  // BMC = 64 uses only chunks 0..7; Cout tail
+    const bool yvalid = gch < BMC / 8 && (co0 + gch * 8) < g.Cout;
+    // ReLU-on-load is per source tensor; a 128-wide column tile may straddle both sources
+    const bool relu_any = g.relu1 || g.relu2;
 
     const int mbeg = split * rows_per_split;
     const int mend = min(g.M, mbeg + rows_per_split);
     const int niter = (mend - mbeg + 63) / 64;
 
-    uint4 py[4], px[4];
-    auto gload = [&](int it) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = mbeg + it * 64 + sr + 16 * j;
-            uint4 vy = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-            if (m < mend) {
-                int n, gy, gx;
-                decode_row(g, m, n, gy, gx);
-                if (yv && sc < BMC / 8) {
-                    const size_t opix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-                    vy = *(const uint4*)(dy + opix * g.Cout + co0 + sc * 8);
-                }
-                const int iy = gy * g.S + ddy, ix = gx * g.S + ddx;
-                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
-                    vx = *(const uint4*)(xsrc + ((size_t)(n * g.H + iy) * g.W + ix) * xcs + xcc);
-                    if (xrelu) vx = relu_bf16x8(vx);
-                }
-            }
-            py[j] = vy;
-            px[j] = vx;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned o = tr_off(sr + 16 * j, sc);
-            *(uint4*)(Ys + buf * BUF + o) = py[j];
-            *(uint4*)(Xs + buf * BUF + o) = px[j];
-        }
-    };
-
-    // transposed-read lane geometry (guide T10): lane 4q+p of a 16-lane group addresses
-    // row r0+q, columns 4p..4p+3 of a 4 x 16 block and receives column (lane&15), rows r0..r0+3
     const int fi = lane & 15, fg = lane >> 4;
     const int tq = fi >> 2, tp = fi & 3;
 
@@ -349,27 +434,43 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
-    if (niter > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < niter; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < niter) gload(it + 1);
-        const unsigned char* Yb = Ys + buf * BUF;
-        const unsigned char* Xb = Xs + buf * BUF;
+    // which of this wave's four 16-column B tiles need ReLU (uniform per wave)
+    bool nt_relu[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    for (int nt = 0; nt < 4; ++nt) {
+        const int jcol = j0 + wn * 64 + nt * 16;
+        const int ci = jcol % g.Cin;
+        nt_relu[nt] = ci < g.C1 ? g.relu1 != 0 : g.relu2 != 0;
+    }
+
+    for (int it = 0; it < niter; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mbeg + it * 64 + sr + 16 * j;
+            int n, gy, gx;
+            decode_row(g, m < mend ? m : mbeg, n, gy, gx);
+            const size_t opix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
+            const bf16_t* py = dy + opix * g.Cout + co0 + gch * 8;
+            py = (m < mend && yvalid) ? py : zero;
+            GLDS16(py, Ys + (16 * j + wid * 4) * 256);
+            const int iy = gy * g.S + ddy, ix = gx * g.S + ddx;
+            const bool inb = m < mend && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const bf16_t* px = xsrc + ((size_t)(n * g.H + iy) * g.W + ix) * xcs + xcc;
+            px = inb ? px : zero;
+            GLDS16(px, Xs + (16 * j + wid * 4) * 256);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
             bf8_t af[MT], bfr[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int row = ks * 32 + fg * 8 + h * 4 + tq;
+                const int row = kk * 32 + fg * 8 + h * 4 + tq;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int ch = (wm * (BMC / 2) + mt * 16) / 8 + (tp >> 1);
                     bf4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf4_t __attribute__((address_space(3)))*)(Yb + tr_off(row, ch) + 8 * (tp & 1)));
+                        (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row, ch) + 8 * (tp & 1)));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) af[mt][h * 4 + e] = v[e];
                 }
@@ -377,10 +478,15 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
                 for (int nt = 0; nt < 4; ++nt) {
                     const int ch = (wn * 64 + nt * 16) / 8 + (tp >> 1);
                     bf4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf4_t __attribute__((address_space(3)))*)(Xb + tr_off(row, ch) + 8 * (tp & 1)));
+                        (bf4_t __attribute__((address_space(3)))*)(Xs + tr_off(row, ch) + 8 * (tp & 1)));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bfr[nt][h * 4 + e] = v[e];
                 }
+            }
+            if (relu_any) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (nt_relu[nt]) bfr[nt] = relu_frag(bfr[nt]);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -388,9 +494,9 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
-        if (it + 1 < niter) lstore(buf ^ 1);
         __syncthreads();
     }
+    (void)xrelu;
 
     // ---- accumulate into the fp32 gradient (fwd pack) ------------------------------
 #pragma unroll
@@ -423,7 +529,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     if (splits < 1) splits = 1;
     int rows = cdiv(cdiv(g.M, splits), 64) * 64;
     splits = cdiv(g.M, rows);
-    const size_t lds = 4 * 64 * 256;
+    const size_t lds = 2 * 64 * 256;
     dim3 grid(tiles * splits);
     if (big)
         hipLaunchKernelGGL(gg_wgrad_mfma_k<128>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);

@@ -102,6 +102,23 @@ class _Timed:
         return False
 
 
+_WORKSPACE = None
+
+
+def conv_workspace_bytes(d: ConvDesc, op: int) -> int:
+    return L.load().pai_conv_workspace_bytes(C.byref(d), op)
+
+
+def ensure_workspace(nbytes: int, device) -> None:
+    """Register (grow) the zero-filled split-K scratch buffer of libpai_hip.so (pai_set_workspace)."""
+    global _WORKSPACE
+    if nbytes <= 0:
+        return
+    if _WORKSPACE is None or _WORKSPACE.numel() * 4 < nbytes or _WORKSPACE.device != torch.device(device):
+        _WORKSPACE = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        L.check(L.load().pai_set_workspace(_WORKSPACE.data_ptr(), _WORKSPACE.numel() * 4), "pai_set_workspace")
+
+
 def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None):
     with _Timed(d, 0):
         L.check(L.load().pai_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(w), _p(bias, torch.float32), _p(y_raw),
