@@ -288,50 +288,74 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
 
 // Split-K epilogue: scratch [phase][M][Cout] fp32 -> bias, BN partial statistics per 128-row tile,
 // activation, bf16 store (two destinations), and the scratch is returned to all-zero.
+// thread = (8-channel group, row lane): statistics accumulate in registers over the lane's rows and
+// are combined across lanes through LDS (no atomics, deterministic).
 __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* ws, int mtiles) {
-    extern __shared__ __attribute__((aligned(16))) float sst[];  // [2][Cout]
+    __shared__ float red[2][256][8];
     const int tid = threadIdx.x;
     const int bm = blockIdx.x, ph = blockIdx.y;
     const int m0 = bm * MBM;
     const int cgroups = g.Cout / 8;
-    for (int i = tid; i < 2 * g.Cout; i += 256) sst[i] = 0.f;
-    __syncthreads();
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
     const int rows = min(MBM, g.M - m0);
-    for (int idx = tid; idx < rows * cgroups; idx += 256) {
-        const int row = idx / cgroups, c0 = (idx - row * cgroups) * 8;
-        const int m = m0 + row;
-        float* src = ws + ((size_t)ph * g.M + m) * g.Cout + c0;
-        float4 v0 = *(float4*)src, v1 = *(float4*)(src + 4);
-        *(float4*)src = make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)(src + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        unsigned packed[4];
+    for (int cg0 = 0; cg0 < cgroups; cg0 += 256) {
+        const int per_pass = min(cgroups - cg0, 256);
+        int lanes = 1;
+        while (lanes * 2 * per_pass <= 256) lanes *= 2;
+        const int cg = cg0 + tid % per_pass, rl = tid / per_pass;
+        const int c0 = cg * 8;
+        float sb[8], sq[8], bias[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] += a.bias ? a.bias[c0 + k] : 0.f;
-            if (a.stats) {
-                atomicAdd(&sst[c0 + k], v[k]);
-                atomicAdd(&sst[g.Cout + c0 + k], v[k] * v[k]);
+        for (int k = 0; k < 8; ++k) { sb[k] = sq[k] = 0.f; bias[k] = a.bias ? a.bias[c0 + k] : 0.f; }
+        if (rl < lanes) {
+            for (int row = rl; row < rows; row += lanes) {
+                const int m = m0 + row;
+                float* src = ws + ((size_t)ph * g.M + m) * g.Cout + c0;
+                const float4 v0 = *(float4*)src, v1 = *(float4*)(src + 4);
+                *(float4*)src = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(src + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                unsigned packed[4];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] += bias[k];
+                    sb[k] += v[k];
+                    sq[k] = fmaf(v[k], v[k], sq[k]);
+                    if (eact == PAI_ACT_LRELU) v[k] = fmaxf(v[k], 0.2f * v[k]);
+                    else if (eact == PAI_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    packed[k] = (unsigned)f2bf(v[2 * k]) | ((unsigned)f2bf(v[2 * k + 1]) << 16);
+                int n, gy, gx;
+                decode_row(g, m, n, gy, gx);
+                const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
+                bf16_t* dst;
+                if (a.yact) dst = (bf16_t*)a.yact + pix * g.Cout + c0;
+                else if (c0 < g.D1) dst = (bf16_t*)a.y1 + pix * g.D1 + c0;
+                else dst = (bf16_t*)a.y2 + pix * g.D2 + (c0 - g.D1);
+                *(uint4*)dst = make_uint4(packed[0], packed[1], packed[2], packed[3]);
             }
-            if (eact == PAI_ACT_LRELU) v[k] = fmaxf(v[k], 0.2f * v[k]);
-            else if (eact == PAI_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
         }
+        if (a.stats) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) packed[k] = (unsigned)f2bf(v[2 * k]) | ((unsigned)f2bf(v[2 * k + 1]) << 16);
-        int n, gy, gx;
-        decode_row(g, m, n, gy, gx);
-        const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-        bf16_t* dst;
-        if (a.yact) dst = (bf16_t*)a.yact + pix * g.Cout + c0;
-        else if (c0 < g.D1) dst = (bf16_t*)a.y1 + pix * g.D1 + c0;
-        else dst = (bf16_t*)a.y2 + pix * g.D2 + (c0 - g.D1);
-        *(uint4*)dst = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-    }
-    if (a.stats) {
-        __syncthreads();
-        float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout;
-        for (int i = tid; i < 2 * g.Cout; i += 256) dst[i] = sst[i];
+            for (int k = 0; k < 8; ++k) {
+                red[0][tid][k] = (rl < lanes) ? sb[k] : 0.f;
+                red[1][tid][k] = (rl < lanes) ? sq[k] : 0.f;
+            }
+            __syncthreads();
+            if (tid < per_pass) {
+                float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + c0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float t1 = 0.f, t2 = 0.f;
+                    for (int l = 0; l < lanes; ++l) { t1 += red[0][tid + l * per_pass][k]; t2 += red[1][tid + l * per_pass][k]; }
+                    dst[k] = t1;
+                    dst[g.Cout + k] = t2;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -355,8 +379,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     if (ksplit > 1) {
         if (bn128) FWD_LAUNCH(128, true); else FWD_LAUNCH(64, true);
         PAI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(splitk_finish_k, dim3(mtiles, g.nphase), dim3(256), 2 * g.Cout * sizeof(float), s, g,
-                           a, g_workspace, mtiles);
+        hipLaunchKernelGGL(splitk_finish_k, dim3(mtiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, mtiles);
     } else {
         if (bn128) FWD_LAUNCH(128, false); else FWD_LAUNCH(64, false);
     }

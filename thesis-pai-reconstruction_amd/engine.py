@@ -473,7 +473,9 @@ class UnetEngine:
             else:
                 skip = L - 1 - j
                 x1, x2 = S["r"][j - 1], (S["a"][skip] if skip > 0 else S["z"][0])
-            ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias))
+            # a conv bias in front of a BatchNorm has an identically zero gradient (BN subtracts the
+            # batch mean); the arena already holds zeros for it, no reduction pass is spent on it
+            ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), None)
             done(conv.bias)
             _, wd = self.dec_packs[j].get(dtype)
             if j == 0:
@@ -485,9 +487,10 @@ class UnetEngine:
         conv = self.enc_conv[i]
         n = S["z"][i].numel()
         dz = G["dz"][:n]
-        ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n, dz)
+        ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n // self.enc_c[i], self.enc_c[i],
+                    dz, A.seg(conv.bias))
         d = P["enc_desc"][i]
-        ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), A.seg(conv.bias))
+        ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), None)
         done(conv.bias)
         _, wd = self.enc_packs[i].get(dtype)
         ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
@@ -503,7 +506,7 @@ class UnetEngine:
                               A.seg(bn.bias))
             ops.bn_bwd_apply(dtype, du, S["z"][i], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
             d = P["enc_desc"][i]
-            ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), A.seg(conv.bias))
+            ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), None)   # bias grad == 0 (BN)
             done(conv.bias)
             _, wd = self.enc_packs[i].get(dtype)
             ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
@@ -511,8 +514,9 @@ class UnetEngine:
         conv = self.enc_conv[0]
         n = S["z"][0].numel()
         dz = G["dz"][:n]
-        ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n, dz)
-        ops.conv_wgrad(P["enc_desc"][0], S["x"], None, dz, A.seg(conv.weight), A.seg(conv.bias))
+        ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n // self.enc_c[0],
+                    self.enc_c[0], dz, A.seg(conv.bias))
+        ops.conv_wgrad(P["enc_desc"][0], S["x"], None, dz, A.seg(conv.weight), None)
         done(conv.bias)
 
 
@@ -633,14 +637,15 @@ class DiscEngine:
         ops.conv_dgrad(d, dl, wd, G["g"][3], None)
         for k in range(3, -1, -1):
             n = S["a"][k].numel()
-            ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n, G["du"][k])
-            d = P["desc"][k]
             conv = self.convs[k]
+            ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n // self.chans[k], self.chans[k],
+                        G["du"][k], A.seg(conv.bias) if need_params else None)
+            d = P["desc"][k]
             if need_params:
                 if k == 0:
-                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
+                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), None)
                 else:
-                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), None)
                 if hook is not None:
                     hook(A, A.end_of(conv.bias))
             if k > 0:
