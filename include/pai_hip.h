@@ -157,11 +157,10 @@ int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int a
 int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
                      const float* mean, const float* rstd, const float* gamma,
                      const float* sums, void* dz, void* stream);
-/* du = act1'(a)*g1 + act2'(a)*g2 over [M][C] without BatchNorm (last encoder, discriminator
- * blocks, encoder 0); g2 may be NULL.  dbias (fp32 [C], or NULL): dbias[c] += sum_rows du --
- * the bias gradient of the convolution that produced `a`, fused into this pass. */
+/* du = act1'(a)*g1 + act2'(a)*g2 without BatchNorm (last encoder, discriminator blocks,
+ * encoder 0); g2 may be NULL. */
 int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
-                int64_t M, int C, void* du, float* dbias, void* stream);
+                int64_t numel, void* du, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Losses.  Replace F.binary_cross_entropy_with_logits / F.l1_loss / F.mse_loss

@@ -357,77 +357,37 @@ extern "C" int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_
 }
 
 // ---- activation backward without a norm ------------------------------------------------------
-// du = act1'(a)*g1 + act2'(a)*g2; optionally dbias[c] += sum over rows of du (the bias gradient of
-// the convolution that produced `a`), fused here so that du is not re-read by a reduction pass.
-// thread = (8-channel group, row lane), block = slab of rows.
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_k(const T* g1, int act1, const T* g2, int act2, const T* a,
-                                                 int64_t M, int C, int64_t rows_per_block, T* du, float* dbias) {
-    __shared__ float red[256][8];
-    const int groups = C / 8;
-    const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int cg0 = 0; cg0 < groups; cg0 += 256) {
-        const int per_pass = min(groups - cg0, 256);
-        int lanes = 1;
-        while (lanes * 2 * per_pass <= 256) lanes *= 2;
-        const int cg = cg0 + tid % per_pass, rl = tid / per_pass;
-        float sb[8];
+                                                 int64_t nvec, T* du) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float gv[8], av[8], d[8];
+        V8<T>::ld(g1 + i * 8, gv);
+        V8<T>::ld(a + i * 8, av);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sb[k] = 0.f;
-        if (rl < lanes) {
-            for (int64_t r = r0 + rl; r < r1; r += lanes) {
-                const int64_t off = r * C + cg * 8;
-                float gv[8], av[8], d[8];
-                V8<T>::ld(g1 + off, gv);
-                V8<T>::ld(a + off, av);
+        for (int k = 0; k < 8; ++k) d[k] = gv[k] * act_grad(av[k], act1);
+        if (g2) {
+            float g2v[8];
+            V8<T>::ld(g2 + i * 8, g2v);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) d[k] = gv[k] * act_grad(av[k], act1);
-                if (g2) {
-                    float g2v[8];
-                    V8<T>::ld(g2 + off, g2v);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) d[k] = fmaf(g2v[k], act_grad(av[k], act2), d[k]);
-                }
-                V8<T>::st(du + off, d);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sb[k] += (sizeof(T) == 2) ? bf2f(f2bf(d[k])) : d[k];
-            }
+            for (int k = 0; k < 8; ++k) d[k] = fmaf(g2v[k], act_grad(av[k], act2), d[k]);
         }
-        if (dbias) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) red[tid][k] = (rl < lanes) ? sb[k] : 0.f;
-            __syncthreads();
-            if (tid < per_pass) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float t = 0.f;
-                    for (int l = 0; l < lanes; ++l) t += red[tid + l * per_pass][k];
-                    atomicAdd(dbias + cg * 8 + k, t);
-                }
-            }
-            __syncthreads();
-        }
+        V8<T>::st(du + i * 8, d);
     }
 }
 
 extern "C" int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
-                           int64_t M, int C, void* du, float* dbias, void* stream) {
+                           int64_t numel, void* du, void* stream) {
     PAI_CHECK(g1 && a && du, "pai_act_bwd: null pointer");
-    PAI_CHECK(C % 8 == 0, "pai_act_bwd: C=%d must be a multiple of 8", C);
+    PAI_CHECK(numel % 8 == 0, "pai_act_bwd: numel must be a multiple of 8");
+    const int64_t nvec = numel / 8;
     hipStream_t s = (hipStream_t)stream;
-    int64_t blocks = (M * C / 8 + 2047) / 2048;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks > M) blocks = M;
-    if (blocks < 1) blocks = 1;
-    const int64_t rpb = (M + blocks - 1) / blocks;
-    blocks = (M + rpb - 1) / rpb;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(act_bwd_k<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)g1, act1,
-                           (const float*)g2, act2, (const float*)a, M, C, rpb, (float*)du, dbias);
+        hipLaunchKernelGGL(act_bwd_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1, act1,
+                           (const float*)g2, act2, (const float*)a, nvec, (float*)du);
     else
-        hipLaunchKernelGGL(act_bwd_k<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)g1, act1,
-                           (const bf16_t*)g2, act2, (const bf16_t*)a, M, C, rpb, (bf16_t*)du, dbias);
+        hipLaunchKernelGGL(act_bwd_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1, act1,
+                           (const bf16_t*)g2, act2, (const bf16_t*)a, nvec, (bf16_t*)du);
     PAI_LAUNCH_CHECK();
     return 0;
 }

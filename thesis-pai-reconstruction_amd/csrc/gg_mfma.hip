@@ -466,6 +466,13 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
         nt_relu[nt] = ci < g.C1 ? g.relu1 != 0 : g.relu2 != 0;
     }
 
+    // bias gradient: the workgroups of the first column tile (and first tap of each phase) see every
+    // dY row of their channel tile exactly once -> column sums straight from the staged LDS tile
+    const bool do_bias = a.dbias != nullptr && jt == 0;
+    const int bc = tid % BMC, bh = tid / BMC;      // channel, row group (256/BMC groups)
+    constexpr int BROWS = 64 / (256 / BMC);        // rows per group
+    float bsum = 0.f;
+
     for (int it = 0; it < niter; ++it) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -517,9 +524,27 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < BROWS; ++r) {
+                const int row = bh * BROWS + r;
+                bsum += bf2f(*(const bf16_t*)(Ys + tr_off(row, bc >> 3) + (bc & 7) * 2));
+            }
+        }
         __syncthreads();
     }
     (void)xrelu;
+    if (do_bias) {
+        float* red = (float*)smem;   // all tile reads are behind the loop's final barrier
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < BMC && co0 + tid < g.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
+            atomicAdd(a.dbias + co0 + tid, t);
+        }
+    }
 
     // ---- accumulate into the fp32 gradient (fwd pack) ------------------------------
 #pragma unroll
@@ -559,9 +584,5 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     else
         hipLaunchKernelGGL(gg_wgrad_mfma_k<64>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
     PAI_LAUNCH_CHECK();
-    if (a.dbias) {
-        // destination pixels of all phases together tile the whole output: plain column sum
-        return launch_colsum(PAI_BF16, a.dy, (int64_t)g.N * g.OH * g.OW, g.Cout, a.dbias, s);
-    }
     return 0;
 }

@@ -487,10 +487,9 @@ class UnetEngine:
         conv = self.enc_conv[i]
         n = S["z"][i].numel()
         dz = G["dz"][:n]
-        ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n // self.enc_c[i], self.enc_c[i],
-                    dz, A.seg(conv.bias))
+        ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n, dz)
         d = P["enc_desc"][i]
-        ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), None)
+        ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), A.seg(conv.bias))
         done(conv.bias)
         _, wd = self.enc_packs[i].get(dtype)
         ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
@@ -514,9 +513,8 @@ class UnetEngine:
         conv = self.enc_conv[0]
         n = S["z"][0].numel()
         dz = G["dz"][:n]
-        ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n // self.enc_c[0],
-                    self.enc_c[0], dz, A.seg(conv.bias))
-        ops.conv_wgrad(P["enc_desc"][0], S["x"], None, dz, A.seg(conv.weight), None)
+        ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n, dz)
+        ops.conv_wgrad(P["enc_desc"][0], S["x"], None, dz, A.seg(conv.weight), A.seg(conv.bias))
         done(conv.bias)
 
 
@@ -638,14 +636,13 @@ class DiscEngine:
         for k in range(3, -1, -1):
             n = S["a"][k].numel()
             conv = self.convs[k]
-            ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n // self.chans[k], self.chans[k],
-                        G["du"][k], A.seg(conv.bias) if need_params else None)
+            ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n, G["du"][k])
             d = P["desc"][k]
             if need_params:
                 if k == 0:
-                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), None)
+                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
                 else:
-                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), None)
+                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
                 if hook is not None:
                     hook(A, A.end_of(conv.bias))
             if k > 0:

@@ -175,9 +175,9 @@ def bn_bwd_apply(dtype, du, z, M, C_, mean, rstd, gamma, sums, dz):
                                       _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply")
 
 
-def act_bwd(dtype, g1, act1, g2, act2, a, M, C_, du, dbias=None):
-    L.check(L.load().pai_act_bwd(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), M, C_, _p(du),
-                                 _p(dbias, torch.float32), _stream()), "pai_act_bwd")
+def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
+    L.check(L.load().pai_act_bwd(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), numel, _p(du), _stream()),
+            "pai_act_bwd")
 
 
 def bce_logits(logits, target, loss_scale, loss, grad_scale=0.0, grad=None):
