@@ -82,7 +82,7 @@ int pai_bn_stats_buffer_rows(int rows);
 /* Kernel family a call with this descriptor runs (for profiling / roofline accounting):
  * op 0 = forward, 1 = input gradient, 2 = weight gradient.
  * returns 0 vector-ALU tile kernel, 1 row-dot kernel, 2 bf16 MFMA 128-wide tile, 3 bf16 MFMA
- * 64-wide tile, < 0 on error. */
+ * 64-wide tile, 4 thin-layer MFMA kernels, < 0 on error. */
 int pai_conv_kernel_id(const pai_conv_desc* d, int op);
 
 /* Split-K scratch.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
@@ -93,6 +93,12 @@ int pai_conv_kernel_id(const pai_conv_desc* d, int op);
  * between calls.  Calls that would need more scratch than is registered run un-split. */
 int pai_set_workspace(void* zeroed_device_memory, int64_t bytes);
 int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op);
+/* General (dirty) scratch: the wide->thin layers (ConvTranspose2d(128,1) head, input gradient of
+ * the first discriminator conv) run as a skinny GEMM into fp32 scratch followed by a col2im pass.
+ * Register one buffer of at least max(pai_conv_scratch_bytes(desc, op)); without it those layers
+ * fall back to the slower row-dot kernel. */
+int pai_set_scratch(void* device_memory, int64_t bytes);
+int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op);
 
 /* y = conv(act(x1|x2), w) + bias.
  *   w_fwd   : fwd pack, storage dtype

@@ -210,6 +210,18 @@ extern "C" int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op) {
     return fwd_mfma_workspace_bytes(g);
 }
 
+extern "C" int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op) {
+    GG g;
+    if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
+    if (op == 2) return 0;
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    if (d->dtype == PAI_BF16 && g.nphase == 4 && g.ntaps == 4 && g.S == 1 && g.OS == 2 && g.Cout <= 2 &&
+        (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && g.Cin <= 256)
+        return thin_dgrad_scratch_bytes(g, a);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------
 static bool use_mfma(int dtype, const GG& g, const FwdArgs& a) { return fwd_mfma_ok(dtype, g, a); }
 
@@ -236,6 +248,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (gg_build_fwd(d, &g)) return -1;
     }
     if (op == 2) {
+        if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g)) return 4;
         if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
             int chunks = g.Cin / 8;
             if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
@@ -243,6 +256,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (wgrad_mfma_ok(d->dtype, g)) return (g.Cout % 128) == 0 ? 2 : 3;
         return 0;
     }
+    if (thin_fwd_ok(d->dtype, g, a) || thin_dgrad_ok(d->dtype, g, a)) return 4;
     if (fwd_rowdot_ok(g, a)) return 1;
     if (fwd_mfma_ok(d->dtype, g, a))
         return ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 2 : 3;
@@ -250,6 +264,8 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
 }
 
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (thin_fwd_ok(dtype, g, a)) return launch_thin_fwd(g, a, s);
+    if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);
     if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
     if (use_mfma(dtype, g, a)) return launch_fwd_mfma(g, a, s);
     return launch_fwd_simt(dtype, g, a, s);
@@ -295,6 +311,8 @@ extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void
     WgradArgs a;
     a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias;
     hipStream_t s = (hipStream_t)stream;
+    if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
+    if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
     if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
         int chunks = g.Cin / 8;
         if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);

@@ -127,6 +127,15 @@ int fwd_mfma_mtiles(const GG& g);
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);
 bool fwd_rowdot_ok(const GG& g, const FwdArgs& a);
 
+// thin layers on the matrix cores (gg_thin.hip)
+extern float* g_scratch;
+extern int64_t g_scratch_bytes;
+bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a);
+bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a);
+int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a);
+int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s);
+int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s);
+
 struct WgradArgs {
     const void *x1, *x2, *dy;
     float* dw;
@@ -136,3 +145,7 @@ int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s)
 int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s);
 bool wgrad_mfma_ok(int dtype, const GG& g);
+bool thin_wgrad_conv_ok(int dtype, const GG& g);
+bool thin_wgrad_convt_ok(int dtype, const GG& g);
+int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s);
+int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s);

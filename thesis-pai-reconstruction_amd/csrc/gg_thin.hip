@@ -1,0 +1,477 @@
+// "Thin" layers of the hot path on the matrix cores: convolutions with <= 2 channels on one
+// side and 64/128 on the other (bf16 storage):
+//   encoders[0]  Conv2d(1, 64)        models/pix2pix.py:141-147        (thin -> wide)
+//   D block 0    Conv2d(1|1, 64)      models/wrapper.py:229,237        (thin -> wide)
+//   decoders[7]  ConvTranspose2d(64|64, 1) + tanh  models/pix2pix.py:185-196   (wide -> thin)
+// and their gradients.  These layers are HBM-bound (they touch a 64/128-channel tensor once), but a
+// straightforward per-pixel dot product is issue-bound on the vector ALUs (1.5 ms for the head at
+// batch 64).  Here each one is a skinny GEMM on v_mfma_f32_16x16x32_bf16 with the wide tensor
+// streamed exactly once:
+//   TF  thin -> wide forward      D[co][pix]  = sum_k W[co][k] * patch[pix][k]        (K = 16*T <= 32)
+//   TD  wide -> thin, two steps   Y[pix][t,tap] = sum_c Wp[t,tap][c] * X[pix][c]      (N = 16*T)
+//                                 out[2a+ph][2b+pw][t] = bias + sum of 4 Y entries     (col2im)
+//   TW  thin weight gradient      D[k][wc]    = sum_pix patch[pix][k] * wide[pix][wc] (K = pixels)
+// patch[pix][k=(tap,t)] = thin_t[n][S*gy + dy[tap]][S*gx + dx[tap]] (zero outside the image).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
+
+__device__ uint4 g_zero_line_thin[16];  // 256 B of zeros (device symbols are per translation unit)
+
+float* g_scratch = nullptr;
+int64_t g_scratch_bytes = 0;
+
+extern "C" int pai_set_scratch(void* device_memory, int64_t bytes) {
+    g_scratch = (float*)device_memory;
+    g_scratch_bytes = device_memory ? bytes : 0;
+    return 0;
+}
+
+__device__ __forceinline__ bf8_t relu8(bf8_t f) {
+    s8_t x = __builtin_bit_cast(s8_t, f);
+    const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf8_t, __builtin_elementwise_max(x, z));
+}
+
+__device__ __forceinline__ void decode_row2(const GG& g, int m, int& n, int& gy, int& gx) {
+    if (g.lw >= 0) {
+        gx = m & (g.OWg - 1);
+        gy = (m >> g.lw) & (g.OHg - 1);
+        n = m >> (g.lw + g.lh);
+    } else {
+        gx = m % g.OWg;
+        int r = m / g.OWg;
+        gy = r % g.OHg;
+        n = r / g.OHg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TF: thin -> wide forward (conv form: one phase, 16 taps).  No LDS: the filter tile lives in
+// registers, the patch fragment is gathered from the (L1/L2-resident) 1-channel images.
+// ------------------------------------------------------------------------------------------------
+bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a) {
+    return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 16 && g.OS == 1 && g.C1 == 1 && g.C2 <= 1 &&
+           (g.Cout % 16) == 0 && g.Cout <= 128 && !a.stats && !a.yf32 && !a.skip_d1 &&
+           (g.D2 == 0 || (g.D1 % 4) == 0);
+}
+
+template <int T>  // thin channels (1 or 2, one per source tensor)
+__global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* x1 = (const bf16_t*)a.x1;
+    const bf16_t* x2 = (const bf16_t*)a.x2;
+    const bf16_t* w = (const bf16_t*)a.w;
+    const int mtiles = g.Cout / 16;
+    constexpr int KT = 16 * T;
+
+    // A operand: W[co][k], k = tap*T + t, zero beyond 16*T
+    bf8_t af[8];
+    float bias[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (mt < mtiles && 8 * fq < KT) z = *(const us8_t*)(w + (size_t)(16 * mt + fr) * KT + 8 * fq);
+        af[mt] = __builtin_bit_cast(bf8_t, z);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            bias[mt][r] = (a.bias && mt < mtiles) ? a.bias[16 * mt + 4 * fq + r] : 0.f;
+    }
+    // this lane's 8 patch elements: (tap, t) pairs
+    int pdy[8], pdx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fq + j;
+        const int tap = (k < KT) ? k / T : 0;
+        pdy[j] = g.dy[0][tap];
+        pdx[j] = (k < KT) ? g.dx[0][tap] : -100000;   // padding columns of K: always out of bounds
+    }
+
+    for (int p0 = (blockIdx.x * 4 + wid) * 16; p0 < g.M; p0 += gridDim.x * 64) {
+        const int m = p0 + fr;
+        int n, gy, gx;
+        decode_row2(g, m < g.M ? m : 0, n, gy, gx);
+        us8_t pv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int iy = gy * g.S + pdy[j], ix = gx * g.S + pdx[j];
+            const bool inb = m < g.M && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const size_t off = (size_t)(n * g.H + iy) * g.W + ix;
+            const bf16_t* src = (T == 2 && (j & 1)) ? x2 : x1;
+            unsigned short v = inb ? src[off] : (unsigned short)0;
+            if (inb && ((T == 2 && (j & 1)) ? g.relu2 : g.relu1) && (v & 0x8000)) v = 0;
+            pv[j] = v;
+        }
+        const bf8_t bfrag = __builtin_bit_cast(bf8_t, pv);
+        // rows beyond M carry an all-zero patch; the MFMAs run unconditionally (full wave), only the
+        // stores are predicated
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            if (mt >= mtiles) break;
+            f4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfrag, acc, 0, 0, 0);
+            if (m >= g.M) continue;
+            const int co = 16 * mt + 4 * fq;
+            float v[4], va[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[r] + bias[mt][r];
+                va[r] = v[r];
+                if (a.eact == PAI_ACT_LRELU) va[r] = fmaxf(v[r], 0.2f * v[r]);
+                else if (a.eact == PAI_ACT_RELU) va[r] = fmaxf(v[r], 0.f);
+            }
+            const size_t pix = (size_t)m;
+            if (a.y1 || a.y2) {
+                const uint2 pk = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                            (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                if (co < g.D1) *(uint2*)((bf16_t*)a.y1 + pix * g.D1 + co) = pk;
+                else *(uint2*)((bf16_t*)a.y2 + pix * g.D2 + (co - g.D1)) = pk;
+            }
+            if (a.yact) {
+                const uint2 pk = make_uint2((unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16),
+                                            (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16));
+                *(uint2*)((bf16_t*)a.yact + pix * g.Cout + co) = pk;
+            }
+        }
+    }
+}
+
+int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
+    int blocks = cdiv(g.M, 64);
+    if (blocks > 4096) blocks = 4096;
+    if (g.C2 == 0) hipLaunchKernelGGL(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a);
+    else hipLaunchKernelGGL(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TD: wide -> thin (4-phase transposed form, Cout <= 2): skinny GEMM into fp32 scratch, then col2im.
+// ------------------------------------------------------------------------------------------------
+static int thin_dgrad_T(const GG& g, const FwdArgs& a) { return (g.Cout == 2 && !a.skip_d1) ? 2 : 1; }
+
+int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a) {
+    return (int64_t)g.M * thin_dgrad_T(g, a) * 16 * 4;
+}
+
+bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a) {
+    if (!(dtype == PAI_BF16 && g.nphase == 4 && g.ntaps == 4 && g.S == 1 && g.OS == 2 && g.Cout <= 2 &&
+          (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && g.Cin <= 256 && !a.stats))
+        return false;
+    return g_scratch != nullptr && g_scratch_bytes >= thin_dgrad_scratch_bytes(g, a);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float* Y, int t0) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* x1 = (const bf16_t*)a.x1;
+    const bf16_t* x2 = (const bf16_t*)a.x2;
+    const bf16_t* w = (const bf16_t*)a.w;
+    const int ksteps = g.Cin / 32;   // <= 8
+    // A operand: Wp[(t, tap)][c]
+    bf8_t af[T][8];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (s < ksteps) z = *(const us8_t*)(w + (size_t)((t0 + tt) * 16 + fr) * g.Cin + 32 * s + 8 * fq);
+            af[tt][s] = __builtin_bit_cast(bf8_t, z);
+        }
+    for (int p0 = (blockIdx.x * 4 + wid) * 16; p0 < g.M; p0 += gridDim.x * 64) {
+        const int m = min(p0 + fr, g.M - 1);
+        f4_t acc[T];
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) acc[tt] = (f4_t){0.f, 0.f, 0.f, 0.f};
+        bf8_t bfr[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s >= ksteps) break;
+            const int c = 32 * s + 8 * fq;
+            if (c < g.C1) {
+                bfr[s] = *(const bf8_t*)(x1 + (size_t)m * g.C1 + c);
+                if (g.relu1) bfr[s] = relu8(bfr[s]);
+            } else {
+                bfr[s] = *(const bf8_t*)(x2 + (size_t)m * g.C2 + (c - g.C1));
+                if (g.relu2) bfr[s] = relu8(bfr[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s >= ksteps) break;
+#pragma unroll
+            for (int tt = 0; tt < T; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][s], bfr[s], acc[tt], 0, 0, 0);
+        }
+        if (p0 + fr < g.M) {
+#pragma unroll
+            for (int tt = 0; tt < T; ++tt)
+                *(float4*)(Y + ((size_t)(p0 + fr) * T + tt) * 16 + 4 * fq) =
+                    make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void thin_col2im_k(GG g, FwdArgs a, const float* Y, int T, int t0) {
+    const int64_t total = (int64_t)g.N * g.OH * g.OW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % g.OW);
+        const int64_t r = i / g.OW;
+        const int oy = (int)(r % g.OH), n = (int)(r / g.OH);
+        const int ph = (oy & 1) * 2 + (ox & 1), ay = oy >> 1, bx = ox >> 1;
+        for (int tt = 0; tt < T; ++tt) {
+            const int t = t0 + tt;
+            float v = a.bias ? a.bias[t] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int iy = ay + g.dy[ph][k], ix = bx + g.dx[ph][k];
+                if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                    v += Y[(((size_t)(n * g.H + iy) * g.W + ix) * T + tt) * 16 + g.wt[ph][k]];
+            }
+            if (t < g.D1) {
+                if (a.y1 && !a.skip_d1) ((bf16_t*)a.y1)[i * g.D1 + t] = f2bf(v);
+            } else if (a.y2) {
+                ((bf16_t*)a.y2)[i * g.D2 + (t - g.D1)] = f2bf(v);
+            }
+            if (a.yact || a.yf32) {
+                const float av = act_apply(v, a.eact);
+                if (a.yact) ((bf16_t*)a.yact)[i * g.Cout + t] = f2bf(av);
+                if (a.yf32) a.yf32[i * g.Cout + t] = av;
+            }
+        }
+    }
+}
+
+int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
+    const int T = thin_dgrad_T(g, a);
+    const int t0 = (g.Cout == 2 && a.skip_d1) ? 1 : 0;
+    int blocks = cdiv(g.M, 64);
+    if (blocks > 4096) blocks = 4096;
+    if (T == 1) hipLaunchKernelGGL(thin_dgrad_gemm_k<1>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
+    else hipLaunchKernelGGL(thin_dgrad_gemm_k<2>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
+    PAI_LAUNCH_CHECK();
+    int64_t b2 = ((int64_t)g.N * g.OH * g.OW + 255) / 256;
+    if (b2 > 8192) b2 = 8192;
+    hipLaunchKernelGGL(thin_col2im_k, dim3((int)b2), dim3(256), 0, s, g, a, (const float*)g_scratch, T, t0);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TW: thin weight gradient.  wide tile (64 pixels x <= 128 channels) staged by LDS-DMA into the
+// 256-B-row transposed-read image of the MFMA wgrad kernel; patch fragments gathered directly.
+// ------------------------------------------------------------------------------------------------
+struct ThinW {
+    const bf16_t *thin1, *thin2;  // [N][TH][TW] one channel each; thin2 may be null (T = 1)
+    const bf16_t *wide1, *wide2;  // [N][H][W][WC1] | [WC2]
+    int N, H, W, TH, TW, WC1, WC2;
+    int relu1, relu2;             // ReLU-on-load flags of the wide tensors
+    int lw, lh;                   // log2 W, log2 H or -1
+    float* dw;
+    int s_wc, s_tap, s_t;         // dw index = wc*s_wc + tap*s_tap + t*s_t
+    float* dbias;                 // per wide channel, or null
+    int M;                        // N*H*W
+};
+
+__device__ __forceinline__ int tw_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ unsigned tw_off(int row, int ch) { return (unsigned)(256 * row + 16 * (ch ^ tw_swz(row))); }
+
+template <int T>
+__global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 64 x 256 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+    const int WC = p.WC1 + p.WC2;
+    const int ntile = WC / 16;                 // column tiles of 16 wide channels (4 or 8)
+    const int ks = wid & 1;                    // this wave's 32-pixel K step of the 64-pixel chunk
+    const int nt0 = (wid >> 1) * (ntile / 2);  // and its half of the column tiles
+    const int ntn = ntile / 2;
+    const bf16_t* zero = (const bf16_t*)g_zero_line_thin;
+
+    // LDS-DMA map: position (row sr + 16j, slot sc) holds logical chunk sc ^ swz(row)
+    const int sc = lane & 15, sr = wid * 4 + (lane >> 4);
+    const int gch = sc ^ tw_swz(sr);
+    const bf16_t* wsrc;
+    int wstride, wcol;
+    bool wvalid = gch * 8 < WC;
+    if (gch * 8 < p.WC1) { wsrc = p.wide1; wstride = p.WC1; wcol = gch * 8; }
+    else { wsrc = p.wide2; wstride = p.WC2; wcol = gch * 8 - p.WC1; }
+
+    // patch row k = 16*tt + fr -> (tap, t)
+    int kdy[T], kdx[T];
+    const bf16_t* ksrc[T];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+        const int k = 16 * tt + fr;
+        const int tap = k / T, t = k - tap * T;
+        kdy[tt] = (tap >> 2) - 1;
+        kdx[tt] = (tap & 3) - 1;
+        ksrc[tt] = t ? p.thin2 : p.thin1;
+    }
+
+    f4_t acc[T][4];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tt][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    const int bc = tid & 127, bh = tid >> 7;
+    float bsum = 0.f;
+
+    for (int ci = 0; ci < chunks_per_block; ++ci) {
+        const int p0 = (blockIdx.x * chunks_per_block + ci) * 64;
+        if (p0 >= p.M) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = p0 + sr + 16 * j;
+            const bf16_t* src = (wvalid && m < p.M) ? wsrc + (size_t)m * wstride + wcol : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + (16 * j + wid * 4) * 256),
+                                             16, 0, 0);
+        }
+        // A operand: patch[pix = p0 + 32*ks + 8*fq + j][k]
+        bf8_t af[T];
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+            us8_t pv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = p0 + 32 * ks + 8 * fq + j;
+                int n, ay, bx;
+                if (p.lw >= 0) { bx = m & (p.W - 1); ay = (m >> p.lw) & (p.H - 1); n = m >> (p.lw + p.lh); }
+                else { bx = m % p.W; const int r = m / p.W; ay = r % p.H; n = r / p.H; }
+                const int iy = 2 * ay + kdy[tt], ix = 2 * bx + kdx[tt];
+                const bool inb = m < p.M && (unsigned)iy < (unsigned)p.TH && (unsigned)ix < (unsigned)p.TW;
+                pv[j] = inb ? ksrc[tt][(size_t)(n * p.TH + iy) * p.TW + ix] : (unsigned short)0;
+            }
+            af[tt] = __builtin_bit_cast(bf8_t, pv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt >= ntn) break;
+            const int col0 = (nt0 + nt) * 16;
+            bf8_t bfr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = ks * 32 + fq * 8 + h * 4 + tq;
+                const int ch = col0 / 8 + (tp >> 1);
+                bf4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(smem + tw_off(row, ch) + 8 * (tp & 1)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bfr[h * 4 + e] = v[e];
+            }
+            if ((col0 < p.WC1) ? p.relu1 : p.relu2) bfr = relu8(bfr);
+#pragma unroll
+            for (int tt = 0; tt < T; ++tt)
+                acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt], bfr, acc[tt][nt], 0, 0, 0);
+        }
+        if (p.dbias && bc < WC) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const int row = bh * 32 + r;
+                bsum += bf2f(*(const bf16_t*)(smem + tw_off(row, bc >> 3) + (bc & 7) * 2));
+            }
+        }
+        __syncthreads();
+    }
+    // D[k = 16*tt + 4*fq + r][wc = 16*(nt0+nt) + fr]
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt >= ntn) break;
+            const int wc = (nt0 + nt) * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * tt + 4 * fq + r;
+                const int tap = k / T, t = k - tap * T;
+                atomicAdd(p.dw + (size_t)wc * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
+            }
+        }
+    if (p.dbias) {
+        float* red = (float*)smem;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < WC) atomicAdd(p.dbias + tid, red[tid] + red[tid + 128]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sum1_k(const bf16_t* x, int64_t n, float* out) {
+    __shared__ float ws[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += bf2f(x[i]);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+static int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// conv-form thin wgrad (encoders[0], D block 0): thin = layer input, wide = dy
+bool thin_wgrad_conv_ok(int dtype, const GG& g) {
+    return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 16 && g.S == 2 && g.OS == 1 && g.C1 == 1 &&
+           g.C2 <= 1 && (g.Cout % 32) == 0 && g.Cout <= 128 && !g.relu1 && !g.relu2;
+}
+// transposed thin wgrad (decoders[7]): thin = dy (1 channel), wide = layer input x1|x2
+bool thin_wgrad_convt_ok(int dtype, const GG& g) {
+    return dtype == PAI_BF16 && g.nphase == 4 && g.ntaps == 4 && g.Cout == 1 && (g.C1 % 8) == 0 &&
+           (g.C2 % 8) == 0 && (g.Cin % 32) == 0 && g.Cin <= 128;
+}
+
+static int launch_tw(ThinW& p, int T, hipStream_t s) {
+    p.M = p.N * p.H * p.W;
+    p.lw = ilog2_exact(p.W);
+    p.lh = ilog2_exact(p.H);
+    if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
+    const int chunks = cdiv(p.M, 64);
+    int blocks = chunks < 512 ? chunks : 512;
+    const int cpb = cdiv(chunks, blocks);
+    blocks = cdiv(chunks, cpb);
+    if (T == 1) hipLaunchKernelGGL(thin_wgrad_k<1>, dim3(blocks), dim3(256), 64 * 256, s, p, cpb);
+    else hipLaunchKernelGGL(thin_wgrad_k<2>, dim3(blocks), dim3(256), 64 * 256, s, p, cpb);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s) {
+    ThinW p;
+    memset(&p, 0, sizeof(p));
+    const int T = g.C1 + g.C2;
+    p.thin1 = (const bf16_t*)a.x1; p.thin2 = (const bf16_t*)a.x2;
+    p.wide1 = (const bf16_t*)a.dy; p.wide2 = nullptr;
+    p.N = g.N; p.H = g.OHg; p.W = g.OWg; p.TH = g.H; p.TW = g.W;
+    p.WC1 = g.Cout; p.WC2 = 0;
+    p.dw = a.dw; p.s_wc = 16 * T; p.s_tap = T; p.s_t = 1;   // fwd pack [Cout][16][T]
+    p.dbias = a.dbias;
+    return launch_tw(p, T, s);
+}
+
+int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s) {
+    ThinW p;
+    memset(&p, 0, sizeof(p));
+    p.thin1 = (const bf16_t*)a.dy; p.thin2 = nullptr;
+    p.wide1 = (const bf16_t*)a.x1; p.wide2 = (const bf16_t*)a.x2;
+    p.N = g.N; p.H = g.H; p.W = g.W; p.TH = g.OH; p.TW = g.OW;
+    p.WC1 = g.C1; p.WC2 = g.C2; p.relu1 = g.relu1; p.relu2 = g.relu2;
+    p.dw = a.dw; p.s_wc = 1; p.s_tap = g.Cin; p.s_t = 0;     // fwd pack [1][16][Cin]
+    p.dbias = nullptr;
+    if (launch_tw(p, 1, s)) return 1;
+    if (a.dbias) {
+        const int64_t n = (int64_t)g.N * g.OH * g.OW;
+        hipLaunchKernelGGL(sum1_k, dim3(256), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -48,6 +48,8 @@ SIGNATURES = {
     "pai_conv_kernel_id": (_I, [_D, _I]),
     "pai_set_workspace": (_I, [_P, _L]),
     "pai_conv_workspace_bytes": (_L, [_D, _I]),
+    "pai_set_scratch": (_I, [_P, _L]),
+    "pai_conv_scratch_bytes": (_L, [_D, _I]),
     "pai_conv_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _I, _P]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),

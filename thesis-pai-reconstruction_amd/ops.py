@@ -67,7 +67,7 @@ def bn_stats_buffer_rows(rows: int) -> int:
 # the stream the kernel is launched on, and (kernel family, op, algorithmic FLOPs, events) is
 # appended.  Off (None) in normal operation.
 PROFILE = None
-KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64"}
+KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16"}
 
 
 def conv_kernel_id(d: ConvDesc, op: int) -> int:
@@ -117,6 +117,23 @@ def ensure_workspace(nbytes: int, device) -> None:
     if _WORKSPACE is None or _WORKSPACE.numel() * 4 < nbytes or _WORKSPACE.device != torch.device(device):
         _WORKSPACE = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
         L.check(L.load().pai_set_workspace(_WORKSPACE.data_ptr(), _WORKSPACE.numel() * 4), "pai_set_workspace")
+
+
+_SCRATCH = None
+
+
+def conv_scratch_bytes(d: ConvDesc, op: int) -> int:
+    return L.load().pai_conv_scratch_bytes(C.byref(d), op)
+
+
+def ensure_scratch(nbytes: int, device) -> None:
+    """Register (grow) the general scratch buffer of libpai_hip.so (pai_set_scratch)."""
+    global _SCRATCH
+    if nbytes <= 0:
+        return
+    if _SCRATCH is None or _SCRATCH.numel() * 4 < nbytes or _SCRATCH.device != torch.device(device):
+        _SCRATCH = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        L.check(L.load().pai_set_scratch(_SCRATCH.data_ptr(), _SCRATCH.numel() * 4), "pai_set_scratch")
 
 
 def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None):
