@@ -17,6 +17,8 @@
 // Serves the dense layers of the reference's hot path: EncoderBlock / DecoderBlock convs
 // (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and their
 // aten::convolution_backward calls.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
@@ -25,7 +27,6 @@ typedef __attribute__((ext_vector_type(4))) float f4_t;
 typedef __attribute__((ext_vector_type(2))) short s2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 
-constexpr int MBM = 128;  // output rows per block
 constexpr int MBK = 64;   // K per iteration (one tap, 64 channels)
 
 __device__ uint4 g_zero_line[16];  // 256 B of zeros: source of padding / masked rows
@@ -33,8 +34,6 @@ __device__ uint4 g_zero_line[16];  // 256 B of zeros: source of padding / masked
 #define GLDS16(gptr, lptr)                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),    \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-int fwd_mfma_mtiles(const GG& g) { return cdiv(g.M, MBM); }
 
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (dtype != PAI_BF16) return false;
@@ -48,23 +47,44 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
     return true;
 }
 
-static bool fwd_bn128(const GG& g) { return (g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0); }
+// Tile configuration of one launch.  L2 -> LDS fill bandwidth (~70 GB/s per CU) is what bounds this
+// kernel, so the tile is made as large as the problem allows: 256 x 128 (85 FLOP per staged byte,
+// double-buffered, one 512-thread workgroup per CU) when that still gives every CU a workgroup,
+// else 128 x 128 / 128 x 64 (single buffer, 3-4 workgroups per CU), split over K when even that
+// leaves CUs idle.
+struct FwdCfg { int bm, bn, ksplit; };
 
-int fwd_mfma_ksplit(const GG& g) {
-    const int bn = fwd_bn128(g) ? 128 : 64;
-    const int tiles = fwd_mfma_mtiles(g) * (g.Cout / bn) * g.nphase;
+static FwdCfg fwd_cfg(const GG& g) {
+    FwdCfg c;
+    c.bn = ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 128 : 64;
+    c.bm = 128;
+    c.ksplit = 1;
+    const int ntiles = g.Cout / c.bn;
     const int niter = g.ntaps * g.Cin / MBK;
-    if (tiles >= 192 || niter < 8) return 1;
+    static const int mode = getenv("PAI_FWD_MODE") ? atoi(getenv("PAI_FWD_MODE")) : 0;
+    if (mode == 1 && c.bn == 128 && (int64_t)cdiv(g.M, 256) * ntiles * g.nphase >= 256 && niter >= 4) {
+        c.bm = 256;
+        return c;
+    }
+    if (mode == 2 && c.bn == 128 && (int64_t)cdiv(g.M, 128) * ntiles * g.nphase >= 512 && niter >= 4) {
+        c.bm = -128;   // 128 x 128, double-buffered
+        return c;
+    }
+    const int tiles = cdiv(g.M, 128) * ntiles * g.nphase;
+    if (tiles >= 192 || niter < 8) return c;
     int ks = 768 / tiles;
     if (ks > niter / 2) ks = niter / 2;
     if (ks < 1) ks = 1;
-    // every split gets the same number of iterations
-    while (ks > 1 && (niter % ks)) --ks;
-    return ks;
+    while (ks > 1 && (niter % ks)) --ks;  // every split gets the same number of iterations
+    c.ksplit = ks;
+    return c;
 }
 
+int fwd_mfma_mtiles(const GG& g) { return cdiv(g.M, abs(fwd_cfg(g).bm)); }
+int fwd_mfma_ksplit(const GG& g) { return fwd_cfg(g).ksplit; }
+
 int64_t fwd_mfma_workspace_bytes(const GG& g) {
-    if (fwd_mfma_ksplit(g) <= 1) return 0;
+    if (fwd_cfg(g).ksplit <= 1) return 0;
     return (int64_t)g.nphase * g.M * g.Cout * 4;
 }
 
@@ -100,15 +120,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int BN, bool SPLITK>
-__global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
-                                                     float* ws) {
-    constexpr int NT = BN / 32;  // 16-col MFMA tiles per wave along N
-    constexpr int BJ = BN / 32;  // load instructions per thread for the B tile
-    constexpr int A_BYTES = MBM * 128;
+// BM x BN x 64 tile, BM/64 x 2 waves of 64 x (BN/2).  DB = double-buffered LDS: the LDS-DMA of tile
+// k+1 is issued before tile k is consumed and retired with a COUNTED s_waitcnt vmcnt + raw s_barrier
+// (a __syncthreads() would drain it: guide "Pipelining across barriers").
+template <int BM, int BN, bool SPLITK, bool DB>
+__global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
+                                                        float* ws) {
+    constexpr int NTHR = BM * 2;
+    constexpr int NT = BN / 32;              // 16-col MFMA tiles per wave along N
+    constexpr int RPP = NTHR / 8;            // tile rows covered by one load instruction of the block
+    constexpr int AJ = BM / RPP;             // = 4 load instructions per thread for the A tile
+    constexpr int BJ = BN / RPP;             // load instructions per thread for the B tile
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,33 +144,45 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
     bid /= mtiles;
     const int ph = bid % g.nphase;
     const int ks = bid / g.nphase;
-    const int m0 = bm * MBM, n0 = bn * BN;
+    const int m0 = bm * BM, n0 = bn * BN;
 
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
     const bf16_t* w = (const bf16_t*)a.w;
     const bf16_t* zero = (const bf16_t*)g_zero_line;
 
-    // ---- load map: lane-linear LDS image; position (row sr+32j, slot sc) holds global chunk sc^swz
+    // ---- load map: lane-linear LDS image; position (row sr+RPP*j, slot sc) holds global chunk sc^swz
+    // The steady state of the K loop is kept almost free of vector-ALU work (it competes with the
+    // MFMA issue slots): per tile row only a 32-bit element offset and two 5-bit validity masks are
+    // kept; pointers are rebuilt once per (tap, source tensor) segment and then just advanced by
+    // 64 channels per K-step.
     const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
     const int gch = (sc ^ ((sr >> 1) & 7)) * 8;  // element offset of the chunk this lane fetches
-    int rnH[4], ry[4], rx[4];
+    int pofs1[AJ], pofs2[AJ];
+    unsigned vym[AJ], vxm[AJ];  // bit (d+2): source row / column (grid*S + d) is inside the image
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + sr + 32 * j;
+    for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + sr + RPP * j;
         int n, gy, gx;
         decode_row(g, m < g.M ? m : 0, n, gy, gx);
-        rnH[j] = n * g.H;
-        ry[j] = m < g.M ? gy * g.S : -100000;  // rows beyond M: permanently out of bounds -> zeros
-        rx[j] = gx * g.S;
+        const int pix = (n * g.H + gy * g.S) * g.W + gx * g.S;
+        pofs1[j] = pix * g.C1 + gch;
+        pofs2[j] = pix * g.C2 + gch;
+        unsigned my = 0, mx = 0;
+#pragma unroll
+        for (int dd = -2; dd <= 2; ++dd) {
+            if (m < g.M && (unsigned)(gy * g.S + dd) < (unsigned)g.H) my |= 1u << (dd + 2);
+            if ((unsigned)(gx * g.S + dd) < (unsigned)g.W) mx |= 1u << (dd + 2);
+        }
+        vym[j] = my;
+        vxm[j] = mx;
     }
     const bf16_t* wrow[BJ];
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + 32 * j) * g.wtaps * g.Cin + gch;
+    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + RPP * j) * g.wtaps * g.Cin + gch;
 
     const int cchunks = g.Cin / MBK;
-    const int niter_all = g.ntaps * cchunks;
-    const int niter = niter_all / ksplit;
+    const int niter = g.ntaps * cchunks / ksplit;
     int t = (ks * niter) / cchunks;
     int c0 = ((ks * niter) - t * cchunks) * MBK;
 
@@ -154,7 +190,7 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
     const int fr = lane & 15, fq = lane >> 4;
     const int fswz = fr >> 1;
     const unsigned a_base = (unsigned)((wm * 64 + fr) * 128);
-    const unsigned b_base = (unsigned)((wn * (BN / 2) + fr) * 128);
+    const unsigned b_base = (unsigned)(A_BYTES + (wn * (BN / 2) + fr) * 128);
 
     f4_t acc[4][NT];
 #pragma unroll
@@ -162,34 +198,68 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int it = 0; it < niter; ++it) {
-        const int ddy = g.dy[ph][t], ddx = g.dx[ph][t];
-        const bf16_t* src;
-        int cs, cc, relu;
-        if (c0 < g.C1) { src = x1; cs = g.C1; cc = c0; relu = g.relu1; }
-        else { src = x2; cs = g.C2; cc = c0 - g.C1; relu = g.relu2; }
+    int relu_cur = 0;
+    const bf16_t* pa[AJ];
+    int astep[AJ];
+    const bf16_t* pb[BJ];
+    int seg_left = 0, seg_relu = 0;
+    // issue the LDS-DMA of the tile (t, c0) into stage `buf` and advance (t, c0)
+    auto issue = [&](int buf) -> int {
+        if (seg_left == 0) {  // wave-uniform: new tap or switch to the second source tensor
+            const int ddy = g.dy[ph][t], ddx = g.dx[ph][t];
+            const int dpix = ddy * g.W + ddx;
+            const unsigned sy = (unsigned)(ddy + 2), sx = (unsigned)(ddx + 2);
+            if (c0 < g.C1) {
+                const int sofs = dpix * g.C1 + c0;
+                seg_left = (g.C1 - c0) / MBK;
+                seg_relu = g.relu1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = ry[j] + ddy, ix = rx[j] + ddx;
-            const bool inb = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            const bf16_t* p = src + ((size_t)(rnH[j] + iy) * g.W + ix) * cs + cc + gch;
-            p = inb ? p : zero;
-            GLDS16(p, As + (j * 32 + wid * 8) * 128);
+                for (int j = 0; j < AJ; ++j) {
+                    const bool v = ((vym[j] >> sy) & (vxm[j] >> sx) & 1u) != 0;
+                    pa[j] = v ? x1 + (pofs1[j] + sofs) : zero;
+                    astep[j] = v ? MBK : 0;
+                }
+            } else {
+                const int sofs = dpix * g.C2 + (c0 - g.C1);
+                seg_left = (g.Cin - c0) / MBK;
+                seg_relu = g.relu2;
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) {
+                    const bool v = ((vym[j] >> sy) & (vxm[j] >> sx) & 1u) != 0;
+                    pa[j] = v ? x2 + (pofs2[j] + sofs) : zero;
+                    astep[j] = v ? MBK : 0;
+                }
+            }
+            const int woff = g.wt[ph][t] * g.Cin + c0;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) pb[j] = wrow[j] + woff;
         }
-        const size_t woff = (size_t)g.wt[ph][t] * g.Cin + c0;
+        unsigned char* As = smem + buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + (j * 32 + wid * 8) * 128);
+        for (int j = 0; j < AJ; ++j) {
+            GLDS16(pa[j], As + (j * RPP + wid * 8) * 128);
+            pa[j] += astep[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            GLDS16(pb[j], As + A_BYTES + (j * RPP + wid * 8) * 128);
+            pb[j] += MBK;
+        }
+        --seg_left;
         c0 += MBK;
         if (c0 == g.Cin) { c0 = 0; ++t; }
-        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+        return seg_relu;
+    };
+    auto compute = [&](int buf, int relu) {
+        const unsigned char* St = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const unsigned coff = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
             bf8_t af[4], bfr[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf8_t*)(As + a_base + mt * 16 * 128 + coff);
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf8_t*)(St + a_base + mt * 16 * 128 + coff);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(Bs + b_base + nt * 16 * 128 + coff);
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(St + b_base + nt * 16 * 128 + coff);
             if (relu) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) af[mt] = relu_frag(af[mt]);
@@ -200,7 +270,32 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
-        __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
+    };
+
+    if (DB) {
+        relu_cur = issue(0);
+        for (int it = 0; it < niter; ++it) {
+            int relu_next = 0;
+            if (it + 1 < niter) {
+                relu_next = issue((it + 1) & 1);
+                // all but the AJ+BJ loads just issued have landed -> tile `it` is complete
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            compute(it & 1, relu_cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage (it & 1) may be overwritten from the next iteration on
+            relu_cur = relu_next;
+        }
+    } else {
+        for (int it = 0; it < niter; ++it) {
+            relu_cur = issue(0);
+            __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+            compute(0, relu_cur);
+            __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
+        }
     }
 
     if (SPLITK) {
@@ -222,8 +317,9 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
 
     // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
     constexpr int CROW = BN * 2 + 16;  // padded bytes per staged output row
+    constexpr int WM = BM / 64;
     unsigned char* Cs = smem;
-    float* sstat = (float*)(smem + MBM * CROW);  // [2 wm][2][BN]
+    float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
     float csum[NT], csq[NT];
 #pragma unroll
@@ -262,20 +358,23 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
     __syncthreads();
     if (a.stats && tid < BN) {
         float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + n0 + tid;
-        dst[0] = sstat[0 * BN + tid] + sstat[2 * BN + tid];
-        dst[g.Cout] = sstat[1 * BN + tid] + sstat[3 * BN + tid];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) { s += sstat[(i * 2 + 0) * BN + tid]; q += sstat[(i * 2 + 1) * BN + tid]; }
+        dst[0] = s;
+        dst[g.Cout] = q;
     }
     bf16_t* dst;
     int dstride, dcol;
     if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
     else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
     else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
-    constexpr int CPR = BN / 8;     // 16-B chunks per row
-    constexpr int RPP = 256 / CPR;  // rows per pass
+    constexpr int CPR = BN / 8;        // 16-B chunks per row
+    constexpr int ORP = NTHR / CPR;    // rows per pass
     const int oc = tid % CPR, orow0 = tid / CPR;
 #pragma unroll
-    for (int p = 0; p < MBM / RPP; ++p) {
-        const int row = orow0 + p * RPP;
+    for (int p = 0; p < BM / ORP; ++p) {
+        const int row = orow0 + p * ORP;
         const int m = m0 + row;
         if (m < g.M) {
             int n, gy, gx;
@@ -291,6 +390,7 @@ __global__ __launch_bounds__(256) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles
 // thread = (8-channel group, row lane): statistics accumulate in registers over the lane's rows and
 // are combined across lanes through LDS (no atomics, deterministic).
 __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* ws, int mtiles) {
+    constexpr int MBM = 128;
     __shared__ float red[2][256][8];
     const int tid = threadIdx.x;
     const int bm = blockIdx.x, ph = blockIdx.y;
@@ -359,29 +459,40 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* w
     }
 }
 
-template <int BN>
+template <int BM, int BN, bool DB>
 static size_t fwd_lds_bytes() {
-    const size_t main_loop = MBM * 128 + BN * 128;
-    const size_t epilogue = MBM * (BN * 2 + 16) + 4 * BN * sizeof(float);
+    const size_t main_loop = (size_t)(DB ? 2 : 1) * (BM * 128 + BN * 128);
+    const size_t epilogue = BM * (BN * 2 + 16) + (BM / 64) * 2 * BN * sizeof(float);
     return main_loop > epilogue ? main_loop : epilogue;
 }
 
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
-    const int mtiles = fwd_mfma_mtiles(g);
-    const bool bn128 = fwd_bn128(g);
-    const int ntiles = g.Cout / (bn128 ? 128 : 64);
-    int ksplit = fwd_mfma_ksplit(g);
-    if (ksplit > 1 && (g_workspace == nullptr || g_workspace_bytes < fwd_mfma_workspace_bytes(g))) ksplit = 1;
-    const dim3 grid(mtiles * ntiles * g.nphase * ksplit);
-#define FWD_LAUNCH(BN, SK)                                                                              \
-    hipLaunchKernelGGL((gg_fwd_mfma_k<BN, SK>), grid, dim3(256), fwd_lds_bytes<BN>(), s, g, a, mtiles, \
-                       ntiles, ksplit, g_workspace)
-    if (ksplit > 1) {
-        if (bn128) FWD_LAUNCH(128, true); else FWD_LAUNCH(64, true);
+    FwdCfg c = fwd_cfg(g);
+    if (c.ksplit > 1 && (g_workspace == nullptr || g_workspace_bytes < fwd_mfma_workspace_bytes(g))) c.ksplit = 1;
+    const int mtiles = cdiv(g.M, abs(c.bm));
+    const int ntiles = g.Cout / c.bn;
+    const dim3 grid(mtiles * ntiles * g.nphase * c.ksplit);
+#define FWD_LAUNCH(BM, BN, SK, DB)                                                                  \
+    hipLaunchKernelGGL((gg_fwd_mfma_k<BM, BN, SK, DB>), grid, dim3(BM * 2), (fwd_lds_bytes<BM, BN, DB>()), s, g, \
+                       a, mtiles, ntiles, c.ksplit, g_workspace)
+    if (c.bm == 256) {
+        static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_mfma_k<256, 128, false, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)fwd_lds_bytes<256, 128, true>());
+            PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        FWD_LAUNCH(256, 128, false, true);
+    } else if (c.bm == -128) {
+        FWD_LAUNCH(128, 128, false, true);
+    } else if (c.ksplit > 1) {
+        if (c.bn == 128) FWD_LAUNCH(128, 128, true, false); else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
         hipLaunchKernelGGL(splitk_finish_k, dim3(mtiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, mtiles);
     } else {
-        if (bn128) FWD_LAUNCH(128, false); else FWD_LAUNCH(64, false);
+        if (c.bn == 128) FWD_LAUNCH(128, 128, false, false); else FWD_LAUNCH(128, 64, false, false);
     }
 #undef FWD_LAUNCH
     PAI_LAUNCH_CHECK();
