@@ -280,3 +280,32 @@ def test_baseline_config_properties(pai):
         first = first or vals
     assert vals["train_rmse"] < first["train_rmse"]
     assert int(m.unet.encoders[1].encode[2].num_batches_tracked) == 1 + 2 * 4  # manual forward + 2 per GAN step
+
+
+def test_arena_adam_equals_stock_adam(pai):
+    """The fused flat-arena optimizer step (pai_adam) and torch.optim.Adam produce the same
+    parameters; state_dict round-trips through the standard per-parameter layout."""
+    from thesis_pai_reconstruction_amd.optim import ArenaAdam
+    mults, seed = (1, 2, 2, 4), 32
+    x, t = synth_batch(seed + 100, 4, 32)
+    batch = (x.to(DEV), t.to(DEV))
+    ma, _, _ = build(pai, mults, "gan", seed)
+    mb, _, _ = build(pai, mults, "gan", seed)
+    assert all(isinstance(o, ArenaAdam) for o in ma.optimizers())
+    mb._pai_optimizers = [torch.optim.Adam(mb.unet.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7),
+                          torch.optim.Adam(mb.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7)]
+    for s in range(2):
+        ma.training_step(batch, s)
+        mb.training_step(batch, s)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        if sa[k].is_floating_point():
+            err = float((sa[k].double() - sb[k].double()).abs().max())
+            assert err <= 2e-5 * max(float(sb[k].abs().max()), 1e-3), (k, err)
+    osd = ma.optimizers()[0].state_dict()
+    assert len(osd["state"]) == len(list(ma.unet.parameters()))
+    st0 = osd["state"][0]
+    assert float(st0["step"]) == 2 and st0["exp_avg"].shape == next(iter(ma.unet.parameters())).shape
+    # the arena really is one flat buffer the parameters alias
+    arena = ma.unet.engine.arena()
+    assert arena.params_adopted()

@@ -123,9 +123,50 @@ class GradArena:
             if p.requires_grad:
                 p.grad = self.view(p)
 
+    # ---- flat parameter / Adam-moment arenas (same layout as the gradient arena) ----------------
+    def adopt_parameters(self) -> bool:
+        """Move the parameters into one flat fp32 buffer laid out like the gradient arena (each
+        ``p.data`` becomes a strided view of it) and allocate the two Adam moment buffers.  Returns
+        False when the parameters are not on this arena's device."""
+        dev = self.flat.device
+        if any(p.device != dev for p in self.params):
+            return False
+        if getattr(self, "pflat", None) is not None and self.params_adopted():
+            return True
+        pflat = torch.zeros_like(self.flat)
+        with torch.no_grad():
+            for p in self.params:
+                o, n = self.offsets[id(p)]
+                v = self.views[id(p)]
+                pv = pflat[o:o + n].as_strided(v.shape, v.stride(), o)
+                pv.copy_(p.data)
+                p.data = pv
+        self.pflat = pflat
+        if getattr(self, "mflat", None) is None:
+            self.mflat = torch.zeros_like(self.flat)
+            self.vflat = torch.zeros_like(self.flat)
+        return True
+
+    def params_adopted(self) -> bool:
+        pf = getattr(self, "pflat", None)
+        if pf is None:
+            return False
+        base = pf.data_ptr()
+        return all(p.data_ptr() == base + 4 * self.offsets[id(p)][0] for p in self.params)
+
+    def moment_views(self, p):
+        o, n = self.offsets[id(p)]
+        v = self.views[id(p)]
+        return (self.mflat[o:o + n].as_strided(v.shape, v.stride(), o),
+                self.vflat[o:o + n].as_strided(v.shape, v.stride(), o))
+
 
 class _Packs:
     """Compute-dtype filter packs of one conv layer, refreshed when the master weight changes."""
+
+    # bumped by optimizers that update the master weights through raw pointers (ArenaAdam), which
+    # torch's per-tensor version counter does not see
+    generation = 0
 
     def __init__(self, mod, need_dgrad: bool):
         self.mod = mod
@@ -137,7 +178,7 @@ class _Packs:
 
     def get(self, dtype):
         w = self.mod.weight
-        ver = (w._version, w.data_ptr())
+        ver = (w._version, w.data_ptr(), _Packs.generation)
         if self.version != ver or self.dtype != dtype:
             to_fwd_pack_(self.mod)
             w = self.mod.weight
@@ -156,7 +197,7 @@ class _Packs:
                 wd_out = self.wd
             if wf_out is not None or wd_out is not None:
                 ops.pack_weights(dtype, w, cout, 16, cin, wf_out, wd_out)
-            self.version = (w._version, w.data_ptr())
+            self.version = (w._version, w.data_ptr(), _Packs.generation)
             self.dtype = dtype
         return self.wf, self.wd
 

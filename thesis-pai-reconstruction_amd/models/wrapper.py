@@ -70,10 +70,14 @@ class UnetWrapper(LightningModule):
         return pred_loss + target_loss
 
     def configure_optimizers(self):
-        """Reference models/wrapper.py:97-115."""
-        opt_g = torch.optim.Adam(self.unet.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+        """Reference models/wrapper.py:97-115 (Adam lr 2e-4, betas (0.5, 0.999), eps 1e-7).  Networks
+        that run on the HIP engines get ``ArenaAdam`` -- a ``torch.optim.Adam`` subclass whose step is
+        ONE fused pass over the flat parameter / gradient / moment arenas; anything else gets the
+        stock optimizer."""
+        from ..optim import make_adam
+        opt_g = make_adam(self.unet, lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
         if self.discriminator is not None:
-            opt_d = torch.optim.Adam(self.discriminator.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+            opt_d = make_adam(self.discriminator, lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
             return opt_g, opt_d
         return opt_g
 

@@ -1,0 +1,85 @@
+"""``ArenaAdam``: torch.optim.Adam whose step is one fused kernel over flat arenas.
+
+The reference builds two stock ``torch.optim.Adam`` objects (models/wrapper.py:97-115).  For the
+networks that run on the HIP engines the parameters, their gradients and both Adam moments live in
+flat fp32 buffers with one common layout (engine.GradArena), so the whole update is a single
+HBM-bound pass (`pai_adam`, 28 B per parameter) instead of ~10 multi-tensor passes.  The object is
+still a ``torch.optim.Adam``: ``param_groups`` (used by toggle_optimizer), ``state_dict`` and the
+update rule (no weight decay / amsgrad) are unchanged, and whenever the arena preconditions do not
+hold (foreign gradients, parameters moved, CPU) it falls back to the stock implementation with the
+same moment tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class ArenaAdam(torch.optim.Adam):
+    def __init__(self, params, engine, lr=2e-4, betas=(0.5, 0.999), eps=1e-7):
+        super().__init__(list(params), lr=lr, betas=betas, eps=eps, foreach=True)
+        self._engine = engine
+        self._arena_steps = 0          # steps taken on the fused path and not yet mirrored into `state`
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _arena_ready(self):
+        group = self.param_groups[0]
+        if len(self.param_groups) != 1 or group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+            return None
+        params = group["params"]
+        if not params or not params[0].is_cuda:
+            return None
+        arena = self._engine.arena()
+        if len(params) != len(arena.params) or not arena.adopt_parameters():
+            return None
+        for p in params:
+            if p.grad is None or p.grad.data_ptr() != arena.view(p).data_ptr():
+                return None
+        return arena
+
+    def _mirror_state(self, arena):
+        """Expose the arena moments through the regular per-parameter optimizer state."""
+        for p in self.param_groups[0]["params"]:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                m, v = arena.moment_views(p)
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"], st["exp_avg_sq"] = m, v
+            st["step"] += self._arena_steps
+        self._arena_steps = 0
+
+    @property
+    def total_steps(self) -> int:
+        any_state = next(iter(self.state.values()), None)
+        done = int(any_state["step"]) if any_state and "step" in any_state else 0
+        return done + self._arena_steps
+
+    # ---- optimizer API ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        arena = self._arena_ready()
+        if arena is None:
+            if self._arena_steps:
+                self._mirror_state(self._engine.arena())
+            return super().step(closure)
+        group = self.param_groups[0]
+        step = self.total_steps + 1
+        ops.adam(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
+                 float(group["betas"][1]), float(group["eps"]), step)
+        self._arena_steps += 1
+        from .engine import _Packs
+        _Packs.generation += 1   # master weights changed behind torch's version counters
+        return None
+
+    def state_dict(self):
+        if self._arena_steps:
+            self._mirror_state(self._engine.arena())
+        return super().state_dict()
+
+
+def make_adam(module: torch.nn.Module, lr, betas, eps):
+    eng = getattr(module, "engine", None) if hasattr(type(module), "engine") else None
+    if eng is not None:
+        return ArenaAdam(module.parameters(), eng, lr=lr, betas=betas, eps=eps)
+    return torch.optim.Adam(module.parameters(), lr=lr, betas=betas, eps=eps)
