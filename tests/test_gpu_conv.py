@@ -27,6 +27,8 @@ CASES = [
     ("dec_skip_wide", 1, 2, 2, 8, 8, 128, 128, 128, 0, 1),
     ("head_cout1", 1, 2, 2, 16, 16, 64, 64, 1, 0, 0),
     ("patch_final", 0, 1, 2, 6, 6, 64, 0, 1, 0, 0),
+    ("patch_final_wide", 0, 1, 3, 16, 16, 256, 0, 1, 0, 0),
+    ("head_relu_skip", 1, 2, 2, 8, 8, 32, 32, 1, 1, 1),
     ("odd_batch_rgb", 0, 2, 3, 8, 8, 3, 3, 64, 0, 0),
 ]
 

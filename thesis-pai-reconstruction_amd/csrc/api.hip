@@ -216,9 +216,7 @@ extern "C" int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op) {
     if (op == 2) return 0;
     FwdArgs a;
     memset(&a, 0, sizeof(a));
-    if (d->dtype == PAI_BF16 && g.nphase == 4 && g.ntaps == 4 && g.S == 1 && g.OS == 2 && g.Cout <= 2 &&
-        (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && g.Cin <= 256)
-        return thin_dgrad_scratch_bytes(g, a);
+    if (thin_dgrad_shape_ok(d->dtype, g)) return thin_dgrad_scratch_bytes(g, a);
     return 0;
 }
 
@@ -248,7 +246,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (gg_build_fwd(d, &g)) return -1;
     }
     if (op == 2) {
-        if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g)) return 4;
+        if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g)) return 4;
         if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
             int chunks = g.Cin / 8;
             if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
@@ -313,6 +311,7 @@ extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void
     hipStream_t s = (hipStream_t)stream;
     if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
     if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
+    if (thin_wgrad_conv1_ok(d->dtype, g)) return launch_thin_wgrad_conv1(g, a, s);
     if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
         int chunks = g.Cin / 8;
         if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);

@@ -132,6 +132,7 @@ extern float* g_scratch;
 extern int64_t g_scratch_bytes;
 bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a);
 bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a);
+bool thin_dgrad_shape_ok(int dtype, const GG& g);
 int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a);
 int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s);
@@ -149,3 +150,5 @@ bool thin_wgrad_conv_ok(int dtype, const GG& g);
 bool thin_wgrad_convt_ok(int dtype, const GG& g);
 int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s);
+bool thin_wgrad_conv1_ok(int dtype, const GG& g);
+int launch_thin_wgrad_conv1(const GG& g, const WgradArgs& a, hipStream_t s);

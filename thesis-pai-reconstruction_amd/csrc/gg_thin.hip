@@ -156,13 +156,20 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
 static int thin_dgrad_T(const GG& g, const FwdArgs& a) { return (g.Cout == 2 && !a.skip_d1) ? 2 : 1; }
 
 int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a) {
-    return (int64_t)g.M * thin_dgrad_T(g, a) * 16 * 4;
+    return (int64_t)g.N * g.H * g.W * thin_dgrad_T(g, a) * 16 * 4;
+}
+
+// stride-1 gathers with <= 2 output channels: the 4-phase transposed form (decoders[7], input
+// gradient of D block 0) and the k4 s1 p1 PatchGAN head (models/wrapper.py:233)
+bool thin_dgrad_shape_ok(int dtype, const GG& g) {
+    const bool phases = g.nphase == 4 && g.ntaps == 4 && g.OS == 2;
+    const bool conv1 = g.nphase == 1 && g.ntaps == 16 && g.OS == 1;
+    return dtype == PAI_BF16 && g.S == 1 && (phases || conv1) && g.Cout <= 2 && (g.C1 % 32) == 0 &&
+           (g.C2 % 32) == 0 && g.Cin <= 512;
 }
 
 bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a) {
-    if (!(dtype == PAI_BF16 && g.nphase == 4 && g.ntaps == 4 && g.S == 1 && g.OS == 2 && g.Cout <= 2 &&
-          (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && g.Cin <= 256 && !a.stats))
-        return false;
+    if (!thin_dgrad_shape_ok(dtype, g) || a.stats) return false;
     return g_scratch != nullptr && g_scratch_bytes >= thin_dgrad_scratch_bytes(g, a);
 }
 
@@ -173,25 +180,27 @@ __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float*
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
     const bf16_t* w = (const bf16_t*)a.w;
-    const int ksteps = g.Cin / 32;   // <= 8
+    const int ksteps = g.Cin / 32;   // <= 16
+    const int Msrc = g.N * g.H * g.W; // one GEMM row per SOURCE pixel
+    constexpr int KS = 16;
     // A operand: Wp[(t, tap)][c]
-    bf8_t af[T][8];
+    bf8_t af[T][KS];
 #pragma unroll
     for (int tt = 0; tt < T; ++tt)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < KS; ++s) {
             us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
             if (s < ksteps) z = *(const us8_t*)(w + (size_t)((t0 + tt) * 16 + fr) * g.Cin + 32 * s + 8 * fq);
             af[tt][s] = __builtin_bit_cast(bf8_t, z);
         }
-    for (int p0 = (blockIdx.x * 4 + wid) * 16; p0 < g.M; p0 += gridDim.x * 64) {
-        const int m = min(p0 + fr, g.M - 1);
+    for (int p0 = (blockIdx.x * 4 + wid) * 16; p0 < Msrc; p0 += gridDim.x * 64) {
+        const int m = min(p0 + fr, Msrc - 1);
         f4_t acc[T];
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) acc[tt] = (f4_t){0.f, 0.f, 0.f, 0.f};
-        bf8_t bfr[8];
+        bf8_t bfr[KS];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < KS; ++s) {
             if (s >= ksteps) break;
             const int c = 32 * s + 8 * fq;
             if (c < g.C1) {
@@ -203,13 +212,13 @@ __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float*
             }
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < KS; ++s) {
             if (s >= ksteps) break;
 #pragma unroll
             for (int tt = 0; tt < T; ++tt)
                 acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][s], bfr[s], acc[tt], 0, 0, 0);
         }
-        if (p0 + fr < g.M) {
+        if (p0 + fr < Msrc) {
 #pragma unroll
             for (int tt = 0; tt < T; ++tt)
                 *(float4*)(Y + ((size_t)(p0 + fr) * T + tt) * 16 + 4 * fq) =
@@ -224,12 +233,13 @@ __global__ __launch_bounds__(256) void thin_col2im_k(GG g, FwdArgs a, const floa
         const int ox = (int)(i % g.OW);
         const int64_t r = i / g.OW;
         const int oy = (int)(r % g.OH), n = (int)(r / g.OH);
-        const int ph = (oy & 1) * 2 + (ox & 1), ay = oy >> 1, bx = ox >> 1;
+        const bool phases = g.nphase == 4;
+        const int ph = phases ? (oy & 1) * 2 + (ox & 1) : 0;
+        const int ay = phases ? oy >> 1 : oy, bx = phases ? ox >> 1 : ox;
         for (int tt = 0; tt < T; ++tt) {
             const int t = t0 + tt;
             float v = a.bias ? a.bias[t] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < g.ntaps; ++k) {
                 const int iy = ay + g.dy[ph][k], ix = bx + g.dx[ph][k];
                 if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
                     v += Y[(((size_t)(n * g.H + iy) * g.W + ix) * T + tt) * 16 + g.wt[ph][k]];
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(256) void thin_col2im_k(GG g, FwdArgs a, const floa
 int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int T = thin_dgrad_T(g, a);
     const int t0 = (g.Cout == 2 && a.skip_d1) ? 1 : 0;
-    int blocks = cdiv(g.M, 64);
+    int blocks = cdiv((int64_t)g.N * g.H * g.W, 64);
     if (blocks > 4096) blocks = 4096;
     if (T == 1) hipLaunchKernelGGL(thin_dgrad_gemm_k<1>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
     else hipLaunchKernelGGL(thin_dgrad_gemm_k<2>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
@@ -273,6 +283,7 @@ struct ThinW {
     int N, H, W, TH, TW, WC1, WC2;
     int relu1, relu2;             // ReLU-on-load flags of the wide tensors
     int lw, lh;                   // log2 W, log2 H or -1
+    int tmul, flip;               // thin pixel = tmul*wide + (flip ? 1 - k : k - 1)
     float* dw;
     int s_wc, s_tap, s_t;         // dw index = wc*s_wc + tap*s_tap + t*s_t
     float* dbias;                 // per wide channel, or null
@@ -288,7 +299,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
-    const int WC = p.WC1 + p.WC2;
+    const int wc0 = blockIdx.y * 128;          // channel group of this workgroup (WC > 128: single source)
+    const int WC = min(p.WC1 + p.WC2 - wc0, 128);
     const int ntile = WC / 16;                 // column tiles of 16 wide channels (4 or 8)
     const int ks = wid & 1;                    // this wave's 32-pixel K step of the 64-pixel chunk
     const int nt0 = (wid >> 1) * (ntile / 2);  // and its half of the column tiles
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     const bf16_t* wsrc;
     int wstride, wcol;
     bool wvalid = gch * 8 < WC;
-    if (gch * 8 < p.WC1) { wsrc = p.wide1; wstride = p.WC1; wcol = gch * 8; }
+    if (wc0 + gch * 8 < p.WC1) { wsrc = p.wide1; wstride = p.WC1; wcol = wc0 + gch * 8; }
     else { wsrc = p.wide2; wstride = p.WC2; wcol = gch * 8 - p.WC1; }
 
     // patch row k = 16*tt + fr -> (tap, t)
@@ -311,8 +323,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     for (int tt = 0; tt < T; ++tt) {
         const int k = 16 * tt + fr;
         const int tap = k / T, t = k - tap * T;
-        kdy[tt] = (tap >> 2) - 1;
-        kdx[tt] = (tap & 3) - 1;
+        kdy[tt] = p.flip ? 1 - (tap >> 2) : (tap >> 2) - 1;
+        kdx[tt] = p.flip ? 1 - (tap & 3) : (tap & 3) - 1;
         ksrc[tt] = t ? p.thin2 : p.thin1;
     }
 
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
                 int n, ay, bx;
                 if (p.lw >= 0) { bx = m & (p.W - 1); ay = (m >> p.lw) & (p.H - 1); n = m >> (p.lw + p.lh); }
                 else { bx = m % p.W; const int r = m / p.W; ay = r % p.H; n = r / p.H; }
-                const int iy = 2 * ay + kdy[tt], ix = 2 * bx + kdx[tt];
+                const int iy = p.tmul * ay + kdy[tt], ix = p.tmul * bx + kdx[tt];
                 const bool inb = m < p.M && (unsigned)iy < (unsigned)p.TH && (unsigned)ix < (unsigned)p.TW;
                 pv[j] = inb ? ksrc[tt][(size_t)(n * p.TH + iy) * p.TW + ix] : (unsigned short)0;
             }
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bfr[h * 4 + e] = v[e];
             }
-            if ((col0 < p.WC1) ? p.relu1 : p.relu2) bfr = relu8(bfr);
+            if ((wc0 + col0 < p.WC1) ? p.relu1 : p.relu2) bfr = relu8(bfr);
 #pragma unroll
             for (int tt = 0; tt < T; ++tt)
                 acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt], bfr, acc[tt][nt], 0, 0, 0);
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (nt >= ntn) break;
-            const int wc = (nt0 + nt) * 16 + fr;
+            const int wc = wc0 + (nt0 + nt) * 16 + fr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 16 * tt + 4 * fq + r;
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
         float* red = (float*)smem;
         red[tid] = bsum;
         __syncthreads();
-        if (tid < WC) atomicAdd(p.dbias + tid, red[tid] + red[tid + 128]);
+        if (tid < WC) atomicAdd(p.dbias + wc0 + tid, red[tid] + red[tid + 128]);
     }
 }
 
@@ -439,8 +451,9 @@ static int launch_tw(ThinW& p, int T, hipStream_t s) {
     int blocks = chunks < 512 ? chunks : 512;
     const int cpb = cdiv(chunks, blocks);
     blocks = cdiv(chunks, cpb);
-    if (T == 1) hipLaunchKernelGGL(thin_wgrad_k<1>, dim3(blocks), dim3(256), 64 * 256, s, p, cpb);
-    else hipLaunchKernelGGL(thin_wgrad_k<2>, dim3(blocks), dim3(256), 64 * 256, s, p, cpb);
+    const int groups = cdiv(p.WC1 + p.WC2, 128);
+    if (T == 1) hipLaunchKernelGGL(thin_wgrad_k<1>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
+    else hipLaunchKernelGGL(thin_wgrad_k<2>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -455,6 +468,7 @@ int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s) {
     p.WC1 = g.Cout; p.WC2 = 0;
     p.dw = a.dw; p.s_wc = 16 * T; p.s_tap = T; p.s_t = 1;   // fwd pack [Cout][16][T]
     p.dbias = a.dbias;
+    p.tmul = 2; p.flip = 0;
     return launch_tw(p, T, s);
 }
 
@@ -467,10 +481,37 @@ int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s) {
     p.WC1 = g.C1; p.WC2 = g.C2; p.relu1 = g.relu1; p.relu2 = g.relu2;
     p.dw = a.dw; p.s_wc = 1; p.s_tap = g.Cin; p.s_t = 0;     // fwd pack [1][16][Cin]
     p.dbias = nullptr;
+    p.tmul = 2; p.flip = 0;
     if (launch_tw(p, 1, s)) return 1;
     if (a.dbias) {
         const int64_t n = (int64_t)g.N * g.OH * g.OW;
         hipLaunchKernelGGL(sum1_k, dim3(256), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// k4 s1 p1 conv with one output channel (PatchGAN head): thin = dy, wide = layer input;
+// dW[kh][kw][c] = sum_pix x[a][b][c] * dy[a + 1 - kh][b + 1 - kw]
+bool thin_wgrad_conv1_ok(int dtype, const GG& g) {
+    return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 16 && g.S == 1 && g.OS == 1 && g.Cout == 1 &&
+           g.C2 == 0 && (g.C1 % 128) == 0;
+}
+
+int launch_thin_wgrad_conv1(const GG& g, const WgradArgs& a, hipStream_t s) {
+    ThinW p;
+    memset(&p, 0, sizeof(p));
+    p.thin1 = (const bf16_t*)a.dy; p.thin2 = nullptr;
+    p.wide1 = (const bf16_t*)a.x1; p.wide2 = nullptr;
+    p.N = g.N; p.H = g.H; p.W = g.W; p.TH = g.OH; p.TW = g.OW;
+    p.WC1 = g.C1; p.WC2 = 0; p.relu1 = g.relu1;
+    p.dw = a.dw; p.s_wc = 1; p.s_tap = g.Cin; p.s_t = 0;     // fwd pack [1][16][Cin]
+    p.dbias = nullptr;
+    p.tmul = 1; p.flip = 1;
+    if (launch_tw(p, 1, s)) return 1;
+    if (a.dbias) {
+        const int64_t n = (int64_t)g.N * g.OH * g.OW;
+        hipLaunchKernelGGL(sum1_k, dim3(64), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
         PAI_LAUNCH_CHECK();
     }
     return 0;

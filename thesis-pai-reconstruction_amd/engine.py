@@ -164,13 +164,12 @@ class GradArena:
 class _Packs:
     """Compute-dtype filter packs of one conv layer, refreshed when the master weight changes."""
 
-    # bumped by optimizers that update the master weights through raw pointers (ArenaAdam), which
-    # torch's per-tensor version counter does not see
-    generation = 0
-
-    def __init__(self, mod, need_dgrad: bool):
+    def __init__(self, mod, need_dgrad: bool, gen):
         self.mod = mod
         self.need_dgrad = need_dgrad
+        # gen[0] is bumped by optimizers that update the master weights through raw pointers
+        # (ArenaAdam), which torch's per-tensor version counter does not see
+        self.gen = gen
         self.version = None
         self.dtype = None
         self.wf = None
@@ -178,7 +177,7 @@ class _Packs:
 
     def get(self, dtype):
         w = self.mod.weight
-        ver = (w._version, w.data_ptr(), _Packs.generation)
+        ver = (w._version, w.data_ptr(), self.gen[0])
         if self.version != ver or self.dtype != dtype:
             to_fwd_pack_(self.mod)
             w = self.mod.weight
@@ -197,7 +196,7 @@ class _Packs:
                 wd_out = self.wd
             if wf_out is not None or wd_out is not None:
                 ops.pack_weights(dtype, w, cout, 16, cin, wf_out, wd_out)
-            self.version = (w._version, w.data_ptr(), _Packs.generation)
+            self.version = (w._version, w.data_ptr(), self.gen[0])
             self.dtype = dtype
         return self.wf, self.wd
 
@@ -246,8 +245,10 @@ class UnetEngine:
         self.out_ch = self.dec_conv[-1].weight.shape[1]
         self.enc_c = [c.weight.shape[0] for c in self.enc_conv]
         self.dec_c = [c.weight.shape[1] for c in self.dec_conv]
-        self.enc_packs = [_Packs(c, need_dgrad=(i > 0)) for i, c in enumerate(self.enc_conv)]
-        self.dec_packs = [_Packs(c, need_dgrad=True) for c in self.dec_conv]
+        self.weights_generation = [0]
+        self.enc_packs = [_Packs(c, need_dgrad=(i > 0), gen=self.weights_generation)
+                          for i, c in enumerate(self.enc_conv)]
+        self.dec_packs = [_Packs(c, need_dgrad=True, gen=self.weights_generation) for c in self.dec_conv]
         self._plans = {}
         self._arena: Optional[GradArena] = None
         self.grad_ready_hook: Optional[Callable[[GradArena, int], None]] = None
@@ -570,7 +571,8 @@ class DiscEngine:
         self.convs = [seq[i].block[0] for i in range(4)] + [seq[4]]
         self.in_ch = self.convs[0].weight.shape[1] // 2
         self.chans = [c.weight.shape[0] for c in self.convs]
-        self.packs = [_Packs(c, need_dgrad=True) for c in self.convs]
+        self.weights_generation = [0]
+        self.packs = [_Packs(c, need_dgrad=True, gen=self.weights_generation) for c in self.convs]
         self._plans = {}
         self._arena = None
         self.grad_ready_hook = None

@@ -68,8 +68,7 @@ class ArenaAdam(torch.optim.Adam):
         ops.adam(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
                  float(group["betas"][1]), float(group["eps"]), step)
         self._arena_steps += 1
-        from .engine import _Packs
-        _Packs.generation += 1   # master weights changed behind torch's version counters
+        self._engine.weights_generation[0] += 1   # master weights changed behind torch's version counters
         return None
 
     def state_dict(self):
