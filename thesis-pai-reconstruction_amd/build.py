@@ -15,8 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpai_hip.so")
 SOURCES = ["api.hip", "gg_simt.hip", "gg_mfma.hip", "gg_thin.hip", "bn.hip", "loss.hip", "ssim.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pai_hip.h")]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in the (unified) VGPR file.  Without it hipcc 7.2
+# put the wgrad accumulators in AGPRs with a different source/destination register per MFMA and
+# copied all 64 of them through VGPRs every K-step (192 -> 138 registers, +1 wave per SIMD).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():

@@ -187,6 +187,9 @@ static void finish_gg(GG* g) {
     g->lw = lg(g->OWg);
     g->lh = lg(g->OHg);
     if (g->lw < 0 || g->lh < 0) g->lw = g->lh = -1;
+    g->lsw = lg(g->W); g->lsh = lg(g->H); g->ldw = lg(g->OW); g->ldh = lg(g->OH);
+    if (g->lw < 0 || g->lsw < 0 || g->lsh < 0 || g->ldw < 0 || g->ldh < 0)
+        g->lsw = g->lsh = g->ldw = g->ldh = -1;
 }
 
 float* g_workspace = nullptr;

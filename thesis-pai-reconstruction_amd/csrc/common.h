@@ -94,6 +94,7 @@ struct GG {
     int relu1, relu2;
     int M;  // rows per phase = N*OHg*OWg
     int lw, lh;  // log2(OWg), log2(OHg) when both are powers of two, else -1
+    int lsw, lsh, ldw, ldh;  // log2 of source W, H and destination OW, OH (all -1 unless all are powers of two)
     signed char dy[4][16], dx[4][16], wt[4][16];
     signed char poy[4], pox[4];
 };

@@ -507,6 +507,7 @@ bool wgrad_mfma_ok(int dtype, const GG& g) {
     if (g.C1 % 64 || g.C2 % 64) return false;
     if (g.Cout % 64) return false;
     if ((g.ntaps * g.Cin) % 128) return false;
+    if (g.lsw < 0) return false;   // the K loop addresses pixels with shifts: power-of-two image sizes only
     return true;
 }
 
@@ -584,19 +585,26 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     constexpr int BROWS = 64 / (256 / BMC);        // rows per group
     float bsum = 0.f;
 
+    // power-of-two geometry: pixel <-> (n, y, x) by shifts (wgrad_mfma_ok guarantees it)
+    const int los = g.OS == 2 ? 1 : 0, lss = g.S == 2 ? 1 : 0;
+    const int poy = g.poy[ph], pox = g.pox[ph];
+    const int ycol = co0 + gch * 8;
     for (int it = 0; it < niter; ++it) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = mbeg + it * 64 + sr + 16 * j;
-            int n, gy, gx;
-            decode_row(g, m < mend ? m : mbeg, n, gy, gx);
-            const size_t opix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-            const bf16_t* py = dy + opix * g.Cout + co0 + gch * 8;
-            py = (m < mend && yvalid) ? py : zero;
+            const bool mv = m < mend;
+            const int gx = m & (g.OWg - 1);
+            const int gy = (m >> g.lw) & (g.OHg - 1);
+            const int n = m >> (g.lw + g.lh);
+            const int opix = ((((n << g.ldh) + (gy << los) + poy) << g.ldw) + (gx << los) + pox);
+            const bf16_t* py = dy + ((size_t)(unsigned)opix * (unsigned)g.Cout + ycol);
+            py = (mv && yvalid) ? py : zero;
             GLDS16(py, Ys + (16 * j + wid * 4) * 256);
-            const int iy = gy * g.S + ddy, ix = gx * g.S + ddx;
-            const bool inb = m < mend && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            const bf16_t* px = xsrc + ((size_t)(n * g.H + iy) * g.W + ix) * xcs + xcc;
+            const int iy = (gy << lss) + ddy, ix = (gx << lss) + ddx;
+            const bool inb = mv && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const int spix = (((n << g.lsh) + iy) << g.lsw) + ix;
+            const bf16_t* px = xsrc + ((size_t)(unsigned)spix * (unsigned)xcs + xcc);
             px = inb ? px : zero;
             GLDS16(px, Xs + (16 * j + wid * 4) * 256);
         }
@@ -604,25 +612,24 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf8_t af[MT], bfr[4];
+            const int row0 = kk * 32 + fg * 8 + tq;   // + 4 for the second half of the 8 k-values
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = kk * 32 + fg * 8 + h * 4 + tq;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ch = (wm * (BMC / 2) + mt * 16) / 8 + (tp >> 1);
+                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row0, ch) + 8 * (tp & 1)));
+                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row0 + 4, ch) + 8 * (tp & 1)));
+                af[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int ch = (wm * (BMC / 2) + mt * 16) / 8 + (tp >> 1);
-                    bf4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row, ch) + 8 * (tp & 1)));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) af[mt][h * 4 + e] = v[e];
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int ch = (wn * 64 + nt * 16) / 8 + (tp >> 1);
-                    bf4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf4_t __attribute__((address_space(3)))*)(Xs + tr_off(row, ch) + 8 * (tp & 1)));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bfr[nt][h * 4 + e] = v[e];
-                }
+            for (int nt = 0; nt < 4; ++nt) {
+                const int ch = (wn * 64 + nt * 16) / 8 + (tp >> 1);
+                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(Xs + tr_off(row0, ch) + 8 * (tp & 1)));
+                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(Xs + tr_off(row0 + 4, ch) + 8 * (tp & 1)));
+                bfr[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             if (relu_any) {
 #pragma unroll

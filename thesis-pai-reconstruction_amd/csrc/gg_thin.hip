@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void thin_col2im_k(GG g, FwdArgs a, const floa
 int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int T = thin_dgrad_T(g, a);
     const int t0 = (g.Cout == 2 && a.skip_d1) ? 1 : 0;
-    int blocks = cdiv((int64_t)g.N * g.H * g.W, 64);
+    // every wave keeps the whole filter in registers: give it >= 4 pixel groups to amortise that
+    int blocks = cdiv((int64_t)g.N * g.H * g.W, 256);
     if (blocks > 4096) blocks = 4096;
     if (T == 1) hipLaunchKernelGGL(thin_dgrad_gemm_k<1>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
     else hipLaunchKernelGGL(thin_dgrad_gemm_k<2>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
