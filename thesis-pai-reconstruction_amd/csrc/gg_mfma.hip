@@ -80,12 +80,25 @@ static FwdCfg fwd_cfg(const GG& g) {
     return c;
 }
 
-int fwd_mfma_mtiles(const GG& g) { return cdiv(g.M, abs(fwd_cfg(g).bm)); }
+constexpr int FIN_ROWS = 16;   // rows per split-K finish workgroup (= granularity of its BN partial statistics)
+
 int fwd_mfma_ksplit(const GG& g) { return fwd_cfg(g).ksplit; }
 
 int64_t fwd_mfma_workspace_bytes(const GG& g) {
     if (fwd_cfg(g).ksplit <= 1) return 0;
     return (int64_t)g.nphase * g.M * g.Cout * 4;
+}
+
+// the split actually used: only when the registered scratch is large enough
+static int fwd_effective_ksplit(const GG& g) {
+    const int ks = fwd_cfg(g).ksplit;
+    if (ks > 1 && (g_workspace == nullptr || g_workspace_bytes < fwd_mfma_workspace_bytes(g))) return 1;
+    return ks;
+}
+
+// number of BN partial-statistics rows per phase this launch configuration writes
+int fwd_mfma_mtiles(const GG& g) {
+    return fwd_effective_ksplit(g) > 1 ? cdiv(g.M, FIN_ROWS) : cdiv(g.M, abs(fwd_cfg(g).bm));
 }
 
 typedef __attribute__((ext_vector_type(8))) short s8_t;
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
 // thread = (8-channel group, row lane): statistics accumulate in registers over the lane's rows and
 // are combined across lanes through LDS (no atomics, deterministic).
 __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* ws, int mtiles) {
-    constexpr int MBM = 128;
+    constexpr int MBM = FIN_ROWS;
     __shared__ float red[2][256][8];
     const int tid = threadIdx.x;
     const int bm = blockIdx.x, ph = blockIdx.y;
@@ -468,7 +481,7 @@ static size_t fwd_lds_bytes() {
 
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     FwdCfg c = fwd_cfg(g);
-    if (c.ksplit > 1 && (g_workspace == nullptr || g_workspace_bytes < fwd_mfma_workspace_bytes(g))) c.ksplit = 1;
+    c.ksplit = fwd_effective_ksplit(g);
     const int mtiles = cdiv(g.M, abs(c.bm));
     const int ntiles = g.Cout / c.bn;
     const dim3 grid(mtiles * ntiles * g.nphase * c.ksplit);
@@ -490,7 +503,8 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     } else if (c.ksplit > 1) {
         if (c.bn == 128) FWD_LAUNCH(128, 128, true, false); else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(splitk_finish_k, dim3(mtiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, mtiles);
+        const int ftiles = cdiv(g.M, FIN_ROWS);
+        hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, ftiles);
     } else {
         if (c.bn == 128) FWD_LAUNCH(128, 128, false, false); else FWD_LAUNCH(128, 64, false, false);
     }
