@@ -132,6 +132,13 @@ def main():
     for i in range(args.warmup):
         model.training_step(batch, i)
     torch.cuda.synchronize()
+    # host-side cost of issuing one step (launches + autograd plumbing), measured without waiting
+    # for the GPU: if this approaches ms_per_step the run is launch-bound, not kernel-bound
+    tq = time.perf_counter()
+    for i in range(3):
+        model.training_step(batch, i)
+    host_issue_ms = (time.perf_counter() - tq) / 3 * 1e3
+    torch.cuda.synchronize()
     barrier()
     ops.PROFILE = []
     torch.cuda.synchronize()
@@ -185,6 +192,7 @@ def main():
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "channel_mults": list(MULTS), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}"},
+        "host_issue_ms_per_step": round(host_issue_ms, 3),
         "step_conv_gflop_per_image": round(gflop, 2),
         "step_mfma_frac": round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": roofline,

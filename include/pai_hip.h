@@ -77,6 +77,9 @@ int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW);
  * number of rows the caller must allocate for that buffer (the tail is scratch for
  * pai_bn_finalize's two-stage fp64 reduction). */
 int pai_conv_fwd_stats_rows(const pai_conv_desc* d);
+/* Upper bound of the above over every launch configuration (it depends on whether the split-K
+ * scratch is registered): allocate pai_bn_stats_buffer_rows(pai_conv_fwd_stats_rows_max(d)) rows. */
+int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d);
 int pai_bn_stats_buffer_rows(int rows);
 
 /* Kernel family a call with this descriptor runs (for profiling / roofline accounting):

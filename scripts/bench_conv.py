@@ -42,7 +42,7 @@ for name, tr, H, C1, C2, Cout in LAYERS:
     dy = torch.randn(n * OH * OW * Cout, device=dev).to(dt)
     dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
     dw = torch.zeros(Cout * 16 * Cin, device=dev)
-    stats = torch.empty(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows(d)) * 2 * Cout, device=dev)
+    stats = torch.empty(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, device=dev)
     fl = ops.conv_flops(d) / 1e6
     tf = timeit(lambda: ops.conv_fwd(d, x1, x2, wf, None, y_raw=y, stats=stats))
     tdg = timeit(lambda: ops.conv_dgrad(d, dy, wd, dx1, dx2))

@@ -80,7 +80,8 @@ def test_conv_family(pai, case, dtype):
     y_act = torch.empty_like(y_raw)
     want_f32 = Cout <= 2 or dtype == torch.float32
     rows = ops.conv_fwd_stats_rows(d)
-    stats = torch.zeros(ops.bn_stats_buffer_rows(rows) * 2 * Cout, dtype=torch.float32, device=dev())
+    stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, dtype=torch.float32,
+                        device=dev())
     use_stats = Cout > 2
     ops.conv_fwd(d, X1, X2, wf, B, y_raw=y_raw, stats=stats if use_stats else None)
     ops.conv_fwd(d, X1, X2, wf, B, y_act=y_act)

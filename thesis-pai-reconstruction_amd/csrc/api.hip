@@ -264,6 +264,14 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     return 0;
 }
 
+// upper bound of pai_conv_fwd_stats_rows over every launch configuration the library may pick
+// (the split-K path writes one row per 16 output rows); size the statistics buffer with this
+extern "C" int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return -1;
+    return cdiv(g.M, 16) * g.nphase;
+}
+
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     if (thin_fwd_ok(dtype, g, a)) return launch_thin_fwd(g, a, s);
     if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);

@@ -164,8 +164,9 @@ int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a) {
 bool thin_dgrad_shape_ok(int dtype, const GG& g) {
     const bool phases = g.nphase == 4 && g.ntaps == 4 && g.OS == 2;
     const bool conv1 = g.nphase == 1 && g.ntaps == 16 && g.OS == 1;
+    const int ks = g.Cin / 32;
     return dtype == PAI_BF16 && g.S == 1 && (phases || conv1) && g.Cout <= 2 && (g.C1 % 32) == 0 &&
-           (g.C2 % 32) == 0 && g.Cin <= 512;
+           (g.C2 % 32) == 0 && (ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16);
 }
 
 bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a) {
@@ -173,26 +174,23 @@ bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a) {
     return g_scratch != nullptr && g_scratch_bytes >= thin_dgrad_scratch_bytes(g, a);
 }
 
-template <int T>
+// KS = Cin / 32 is a template parameter: with a run-time trip count the fragment arrays are indexed
+// dynamically and hipcc places them in scratch memory (528 B/lane, 10x slower)
+template <int T, int KS>
 __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float* Y, int t0) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
     const bf16_t* w = (const bf16_t*)a.w;
-    const int ksteps = g.Cin / 32;   // <= 16
     const int Msrc = g.N * g.H * g.W; // one GEMM row per SOURCE pixel
-    constexpr int KS = 16;
     // A operand: Wp[(t, tap)][c]
     bf8_t af[T][KS];
 #pragma unroll
     for (int tt = 0; tt < T; ++tt)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (s < ksteps) z = *(const us8_t*)(w + (size_t)((t0 + tt) * 16 + fr) * g.Cin + 32 * s + 8 * fq);
-            af[tt][s] = __builtin_bit_cast(bf8_t, z);
-        }
+        for (int s = 0; s < KS; ++s)
+            af[tt][s] = *(const bf8_t*)(w + (size_t)((t0 + tt) * 16 + fr) * g.Cin + 32 * s + 8 * fq);
     for (int p0 = (blockIdx.x * 4 + wid) * 16; p0 < Msrc; p0 += gridDim.x * 64) {
         const int m = min(p0 + fr, Msrc - 1);
         f4_t acc[T];
@@ -201,7 +199,6 @@ __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float*
         bf8_t bfr[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if (s >= ksteps) break;
             const int c = 32 * s + 8 * fq;
             if (c < g.C1) {
                 bfr[s] = *(const bf8_t*)(x1 + (size_t)m * g.C1 + c);
@@ -213,7 +210,6 @@ __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float*
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if (s >= ksteps) break;
 #pragma unroll
             for (int tt = 0; tt < T; ++tt)
                 acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][s], bfr[s], acc[tt], 0, 0, 0);
@@ -264,8 +260,19 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     // every wave keeps the whole filter in registers: give it >= 4 pixel groups to amortise that
     int blocks = cdiv((int64_t)g.N * g.H * g.W, 256);
     if (blocks > 4096) blocks = 4096;
-    if (T == 1) hipLaunchKernelGGL(thin_dgrad_gemm_k<1>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
-    else hipLaunchKernelGGL(thin_dgrad_gemm_k<2>, dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0);
+#define TDG(TT, KK) hipLaunchKernelGGL((thin_dgrad_gemm_k<TT, KK>), dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0)
+#define TDG_K(TT)                                     \
+    switch (g.Cin / 32) {                             \
+        case 1: TDG(TT, 1); break;                    \
+        case 2: TDG(TT, 2); break;                    \
+        case 4: TDG(TT, 4); break;                    \
+        case 8: TDG(TT, 8); break;                    \
+        case 16: TDG(TT, 16); break;                  \
+        default: PAI_CHECK(false, "thin dgrad: unsupported Cin %d", g.Cin); \
+    }
+    if (T == 1) { TDG_K(1) } else { TDG_K(2) }
+#undef TDG_K
+#undef TDG
     PAI_LAUNCH_CHECK();
     int64_t b2 = ((int64_t)g.N * g.OH * g.OW + 255) / 256;
     if (b2 > 8192) b2 = 8192;

@@ -313,15 +313,15 @@ class UnetEngine:
             if j == L - 1:
                 r1, r2, act = 0, 0, ACT_TANH
             P["dec_desc"].append(ops.make_desc(dtype, 1, N, hin, win, c1, c2, self.dec_c[j], 2, r1, r2, act))
-        rows = 1
+        rows = 1   # floats: (partial rows + fp64 reduction scratch) x 2 x C, largest layer
         for i in range(L):
             if self.enc_bn[i] is not None:
-                rows = max(rows, ops.conv_fwd_stats_rows(P["enc_desc"][i]) * 2 * self.enc_c[i]
-                           + 2 * 64 * 2 * self.enc_c[i])
+                rows = max(rows, ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(P["enc_desc"][i]))
+                           * 2 * self.enc_c[i])
         for j in range(L):
             if self.dec_bn[j] is not None:
-                rows = max(rows, ops.conv_fwd_stats_rows(P["dec_desc"][j]) * 2 * self.dec_c[j]
-                           + 2 * 64 * 2 * self.dec_c[j])
+                rows = max(rows, ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(P["dec_desc"][j]))
+                           * 2 * self.dec_c[j])
         P["stats"] = torch.empty(rows, dtype=torch.float32, device=device)
         mx = 1
         for i in range(L):

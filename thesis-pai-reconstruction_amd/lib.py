@@ -44,6 +44,7 @@ SIGNATURES = {
     "pai_device_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     "pai_conv_out_hw": (_I, [_D, C.POINTER(_I), C.POINTER(_I)]),
     "pai_conv_fwd_stats_rows": (_I, [_D]),
+    "pai_conv_fwd_stats_rows_max": (_I, [_D]),
     "pai_bn_stats_buffer_rows": (_I, [_I]),
     "pai_conv_kernel_id": (_I, [_D, _I]),
     "pai_set_workspace": (_I, [_P, _L]),

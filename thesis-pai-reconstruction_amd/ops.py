@@ -58,6 +58,10 @@ def conv_fwd_stats_rows(d: ConvDesc) -> int:
     return r
 
 
+def conv_fwd_stats_rows_max(d: ConvDesc) -> int:
+    return L.load().pai_conv_fwd_stats_rows_max(C.byref(d))
+
+
 def bn_stats_buffer_rows(rows: int) -> int:
     return L.load().pai_bn_stats_buffer_rows(rows)
 
