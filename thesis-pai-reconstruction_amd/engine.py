@@ -224,6 +224,37 @@ def _bn_forward(bn: nn.BatchNorm2d, st: _BNState, stats, rows, count, training, 
                            st.scale, st.shift)
 
 
+class _SideStream:
+    """Weight gradients are off the critical path of the backward pass (only the input-gradient
+    chain is sequential), so they are issued on a second HIP stream and overlap the next layers'
+    dgrad / BatchNorm kernels.  ``fork`` orders the side stream after everything issued so far on
+    the main stream, ``join`` makes the main stream wait for the side stream."""
+
+    enabled = True   # PAI_NO_OVERLAP=1 turns it off (per-kernel timing without co-scheduling)
+
+    def __init__(self):
+        import os
+        self.stream = None
+        self.on = _SideStream.enabled and os.environ.get("PAI_NO_OVERLAP", "0") in ("", "0")
+        # optional cap (GFLOP per launch) on what goes to the side stream.  Measured at batch 64: the
+        # gain comes from co-scheduling the BIG layers (11.68 -> 11.15 ms/step); small layers alone
+        # gain nothing.  Each co-scheduled kernel runs longer (per-kernel TFLOP/s drop ~30 %) while
+        # the step gets shorter -- the kernels are latency-bound, not throughput-bound.
+        self.max_gflop = float(os.environ.get("PAI_OVERLAP_GFLOP", "1e9"))
+
+    def fork(self, d=None):
+        if not self.on or (d is not None and ops.conv_flops(d) > self.max_gflop * 1e9):
+            return torch.cuda.current_stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        return self.stream
+
+    def join(self):
+        if self.on and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 # --------------------------------------------------------------------------------------
 # generator
 # --------------------------------------------------------------------------------------
@@ -251,6 +282,7 @@ class UnetEngine:
         self.dec_packs = [_Packs(c, need_dgrad=True, gen=self.weights_generation) for c in self.dec_conv]
         self._plans = {}
         self._arena: Optional[GradArena] = None
+        self._side = _SideStream()
         self.grad_ready_hook: Optional[Callable[[GradArena, int], None]] = None
         self.debug_capture: Optional[dict] = None   # tests: name -> cloned intermediate tensor
 
@@ -374,7 +406,10 @@ class UnetEngine:
         biggest = max([S["z"][i].numel() for i in range(L)] + [S["w"][j].numel() for j in range(L - 1)]
                       + [S["pred"].numel()])
         G["du"] = torch.empty(biggest, dtype=dt, device=dev)
-        G["dz"] = torch.empty(biggest, dtype=dt, device=dev)
+        # dz is read by the side-stream weight gradient while the main stream moves on: one per layer
+        G["dz_head"] = torch.empty(S["pred"].numel(), dtype=dt, device=dev)
+        G["dz_dec"] = [torch.empty_like(S["w"][j]) if j < L - 1 else None for j in range(L)]
+        G["dz_enc"] = [torch.empty_like(S["z"][i]) for i in range(L)]
         S["grads"] = G
         return G
 
@@ -486,16 +521,22 @@ class UnetEngine:
             if hook is not None:
                 hook(A, A.end_of(p))
 
+        side = self._side
+
+        def wgrad(d, x1, x2, dz, conv, with_bias):
+            """Weight (and bias) gradient of one layer on the side stream."""
+            with torch.cuda.stream(side.fork(d)):
+                ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
+                done(conv.bias)
+
         # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
         j = L - 1
-        dh = G["dz"][:S["pred"].numel()]
+        dh = G["dz_head"]
         ops.tanh_bwd(dtype, S["pred"], gpred, None, dh)
         d = P["dec_desc"][j]
         x1 = S["r"][j - 1]
         x2 = S["z"][0]
-        conv = self.dec_conv[j]
-        ops.conv_wgrad(d, x1, x2, dh, A.seg(conv.weight), A.seg(conv.bias))
-        done(conv.bias)
+        wgrad(d, x1, x2, dh, self.dec_conv[j], True)
         _, wd = self.dec_packs[j].get(dtype)
         ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
         # BN decoders
@@ -505,7 +546,7 @@ class UnetEngine:
             C = self.dec_c[j]
             n = M * C
             act = ACT_RELU if j < L - 2 else ACT_NONE
-            du, dz = G["du"][:n], G["dz"][:n]
+            du, dz = G["du"][:n], G["dz_dec"][j]
             ops.bn_bwd_reduce(dtype, G["gr"][j], act, None, ACT_NONE, S["r"][j] if act != ACT_NONE else None,
                               S["w"][j], M, C, st.mean, st.rstd, du, P["bwd_partials"], st.sums,
                               A.seg(bn.weight), A.seg(bn.bias))
@@ -519,8 +560,7 @@ class UnetEngine:
                 x1, x2 = S["r"][j - 1], (S["a"][skip] if skip > 0 else S["z"][0])
             # a conv bias in front of a BatchNorm has an identically zero gradient (BN subtracts the
             # batch mean); the arena already holds zeros for it, no reduction pass is spent on it
-            ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), None)
-            done(conv.bias)
+            wgrad(d, x1, x2, dz, conv, False)
             _, wd = self.dec_packs[j].get(dtype)
             if j == 0:
                 ops.conv_dgrad(d, dz, wd, G["gz_last"], None)
@@ -530,11 +570,10 @@ class UnetEngine:
         i = L - 1
         conv = self.enc_conv[i]
         n = S["z"][i].numel()
-        dz = G["dz"][:n]
+        dz = G["dz_enc"][i]
         ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n, dz)
         d = P["enc_desc"][i]
-        ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), A.seg(conv.bias))
-        done(conv.bias)
+        wgrad(d, S["a"][i - 1], None, dz, conv, True)
         _, wd = self.enc_packs[i].get(dtype)
         ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
         # BN encoders
@@ -543,23 +582,22 @@ class UnetEngine:
             M = N * eh[i] * ew[i]
             C = self.enc_c[i]
             n = M * C
-            du, dz = G["du"][:n], G["dz"][:n]
+            du, dz = G["du"][:n], G["dz_enc"][i]
             ops.bn_bwd_reduce(dtype, G["ga"][i], ACT_LRELU, G["gskip"][i], ACT_RELU, S["a"][i], S["z"][i], M, C,
                               st.mean, st.rstd, du, P["bwd_partials"], st.sums, A.seg(bn.weight),
                               A.seg(bn.bias))
             ops.bn_bwd_apply(dtype, du, S["z"][i], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
             d = P["enc_desc"][i]
-            ops.conv_wgrad(d, S["a"][i - 1], None, dz, A.seg(conv.weight), None)   # bias grad == 0 (BN)
-            done(conv.bias)
+            wgrad(d, S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)
             ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
         # encoder 0: d z0 = lrelu'(z0) * g_enc + g_skip   (skip consumed raw by the last decoder)
         conv = self.enc_conv[0]
         n = S["z"][0].numel()
-        dz = G["dz"][:n]
+        dz = G["dz_enc"][0]
         ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n, dz)
-        ops.conv_wgrad(P["enc_desc"][0], S["x"], None, dz, A.seg(conv.weight), A.seg(conv.bias))
-        done(conv.bias)
+        wgrad(P["enc_desc"][0], S["x"], None, dz, conv, True)
+        side.join()
 
 
 # --------------------------------------------------------------------------------------
@@ -575,6 +613,7 @@ class DiscEngine:
         self.packs = [_Packs(c, need_dgrad=True, gen=self.weights_generation) for c in self.convs]
         self._plans = {}
         self._arena = None
+        self._side = _SideStream()
         self.grad_ready_hook = None
 
     def ordered_params(self):
@@ -673,10 +712,12 @@ class DiscEngine:
             ops.cast(glogits, G["dl"])
             dl = G["dl"]
         d = P["desc"][4]
+        side = self._side
         if need_params:
-            ops.conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
-            if hook is not None:
-                hook(A, A.end_of(self.convs[4].weight))
+            with torch.cuda.stream(side.fork(d)):
+                ops.conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
+                if hook is not None:
+                    hook(A, A.end_of(self.convs[4].weight))
         _, wd = self.packs[4].get(dtype)
         ops.conv_dgrad(d, dl, wd, G["g"][3], None)
         for k in range(3, -1, -1):
@@ -685,18 +726,20 @@ class DiscEngine:
             ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n, G["du"][k])
             d = P["desc"][k]
             if need_params:
-                if k == 0:
-                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
-                else:
-                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
-                if hook is not None:
-                    hook(A, A.end_of(conv.bias))
+                with torch.cuda.stream(side.fork(d)):
+                    if k == 0:
+                        ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
+                    else:
+                        ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                    if hook is not None:
+                        hook(A, A.end_of(conv.bias))
             if k > 0:
                 _, wd = self.packs[k].get(dtype)
                 ops.conv_dgrad(d, G["du"][k], wd, G["g"][k - 1], None)
             elif need_dy:
                 _, wd = self.packs[0].get(dtype)
                 ops.conv_dgrad(d, G["du"][0], wd, None, G["dy"], only_c2=True)
+        side.join()
         if not need_dy:
             return None
         gy = torch.empty(N * H * W * self.in_ch, dtype=torch.float32, device=dev)
