@@ -136,10 +136,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // BM x BN x 64 tile, BM/64 x 2 waves of 64 x (BN/2).  DB = double-buffered LDS: the LDS-DMA of tile
 // k+1 is issued before tile k is consumed and retired with a COUNTED s_waitcnt vmcnt + raw s_barrier
 // (a __syncthreads() would drain it: guide "Pipelining across barriers").
-template <int BM, int BN, bool SPLITK, bool DB>
-__global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
-                                                        float* ws) {
-    constexpr int NTHR = BM * 2;
+template <int BM, int BN, bool SPLITK, bool DB, int WR = 64>   // WR: output rows per wave (64 or 32)
+__global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
+                                                               float* ws) {
+    constexpr int NTHR = BM / WR * 128;
+    constexpr int MT = WR / 16;              // 16-row MFMA tiles per wave along M
     constexpr int NT = BN / 32;              // 16-col MFMA tiles per wave along N
     constexpr int RPP = NTHR / 8;            // tile rows covered by one load instruction of the block
     constexpr int AJ = BM / RPP;             // = 4 load instructions per thread for the A tile
@@ -150,13 +151,15 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
+    // tile order: column tile fastest, then the 4 output phases of the same source rows (they read
+    // the same input pixels), then the row tile -> neighbours in this order share A rows in L2
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bn = bid % ntiles;
     bid /= ntiles;
-    const int bm = bid % mtiles;
-    bid /= mtiles;
     const int ph = bid % g.nphase;
-    const int ks = bid / g.nphase;
+    bid /= g.nphase;
+    const int bm = bid % mtiles;
+    const int ks = bid / mtiles;
     const int m0 = bm * BM, n0 = bn * BN;
 
     const bf16_t* x1 = (const bf16_t*)a.x1;
@@ -202,12 +205,12 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
     // ---- fragment read addresses ----------------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
     const int fswz = fr >> 1;
-    const unsigned a_base = (unsigned)((wm * 64 + fr) * 128);
+    const unsigned a_base = (unsigned)((wm * WR + fr) * 128);
     const unsigned b_base = (unsigned)(A_BYTES + (wn * (BN / 2) + fr) * 128);
 
-    f4_t acc[4][NT];
+    f4_t acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -216,37 +219,41 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
     int astep[AJ];
     const bf16_t* pb[BJ];
     int seg_left = 0, seg_relu = 0;
-    // issue the LDS-DMA of the tile (t, c0) into stage `buf` and advance (t, c0)
-    auto issue = [&](int buf) -> int {
-        if (seg_left == 0) {  // wave-uniform: new tap or switch to the second source tensor
-            const int ddy = g.dy[ph][t], ddx = g.dx[ph][t];
-            const int dpix = ddy * g.W + ddx;
-            const unsigned sy = (unsigned)(ddy + 2), sx = (unsigned)(ddx + 2);
-            if (c0 < g.C1) {
-                const int sofs = dpix * g.C1 + c0;
-                seg_left = (g.C1 - c0) / MBK;
-                seg_relu = g.relu1;
+    // prepare(): (re)build the row pointers when the next tile starts a new (tap, source) segment.
+    // It is called right AFTER the loads of the current tile have been fired, so its scalar loads and
+    // vector-ALU work run while the LDS-DMA is in flight instead of delaying the next fire().
+    auto prepare = [&]() {
+        if (seg_left != 0) return;  // wave-uniform
+        const int ddy = g.dy[ph][t], ddx = g.dx[ph][t];
+        const int dpix = ddy * g.W + ddx;
+        const unsigned sy = (unsigned)(ddy + 2), sx = (unsigned)(ddx + 2);
+        if (c0 < g.C1) {
+            const int sofs = dpix * g.C1 + c0;
+            seg_left = (g.C1 - c0) / MBK;
+            seg_relu = g.relu1;
 #pragma unroll
-                for (int j = 0; j < AJ; ++j) {
-                    const bool v = ((vym[j] >> sy) & (vxm[j] >> sx) & 1u) != 0;
-                    pa[j] = v ? x1 + (pofs1[j] + sofs) : zero;
-                    astep[j] = v ? MBK : 0;
-                }
-            } else {
-                const int sofs = dpix * g.C2 + (c0 - g.C1);
-                seg_left = (g.Cin - c0) / MBK;
-                seg_relu = g.relu2;
-#pragma unroll
-                for (int j = 0; j < AJ; ++j) {
-                    const bool v = ((vym[j] >> sy) & (vxm[j] >> sx) & 1u) != 0;
-                    pa[j] = v ? x2 + (pofs2[j] + sofs) : zero;
-                    astep[j] = v ? MBK : 0;
-                }
+            for (int j = 0; j < AJ; ++j) {
+                const bool v = ((vym[j] >> sy) & (vxm[j] >> sx) & 1u) != 0;
+                pa[j] = v ? x1 + (pofs1[j] + sofs) : zero;
+                astep[j] = v ? MBK : 0;
             }
-            const int woff = g.wt[ph][t] * g.Cin + c0;
+        } else {
+            const int sofs = dpix * g.C2 + (c0 - g.C1);
+            seg_left = (g.Cin - c0) / MBK;
+            seg_relu = g.relu2;
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) pb[j] = wrow[j] + woff;
+            for (int j = 0; j < AJ; ++j) {
+                const bool v = ((vym[j] >> sy) & (vxm[j] >> sx) & 1u) != 0;
+                pa[j] = v ? x2 + (pofs2[j] + sofs) : zero;
+                astep[j] = v ? MBK : 0;
+            }
         }
+        const int woff = g.wt[ph][t] * g.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pb[j] = wrow[j] + woff;
+    };
+    // fire(): issue the LDS-DMA of the prepared tile into stage `buf`, advance to the next tile
+    auto fire = [&](int buf) -> int {
         unsigned char* As = smem + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -258,39 +265,42 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
             GLDS16(pb[j], As + A_BYTES + (j * RPP + wid * 8) * 128);
             pb[j] += MBK;
         }
+        const int relu = seg_relu;
         --seg_left;
         c0 += MBK;
         if (c0 == g.Cin) { c0 = 0; ++t; }
-        return seg_relu;
+        return relu;
     };
     auto compute = [&](int buf, int relu) {
         const unsigned char* St = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const unsigned coff = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
-            bf8_t af[4], bfr[NT];
+            bf8_t af[MT], bfr[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const bf8_t*)(St + a_base + mt * 16 * 128 + coff);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(St + a_base + mt * 16 * 128 + coff);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(St + b_base + nt * 16 * 128 + coff);
             if (relu) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) af[mt] = relu_frag(af[mt]);
+                for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
     };
 
+    prepare();
     if (DB) {
-        relu_cur = issue(0);
+        relu_cur = fire(0);
         for (int it = 0; it < niter; ++it) {
             int relu_next = 0;
             if (it + 1 < niter) {
-                relu_next = issue((it + 1) & 1);
+                prepare();
+                relu_next = fire((it + 1) & 1);
                 // all but the AJ+BJ loads just issued have landed -> tile `it` is complete
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
             } else {
@@ -304,7 +314,8 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
         }
     } else {
         for (int it = 0; it < niter; ++it) {
-            relu_cur = issue(0);
+            relu_cur = fire(0);
+            if (it + 1 < niter) prepare();  // overlaps the DMA latency
             __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
             compute(0, relu_cur);
             __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
@@ -315,10 +326,10 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
         // fp32 partial tile -> scratch [phase][m][Cout]; splitk_finish_k applies the epilogue
         float* dst = ws + ((size_t)ph * g.M + m0) * g.Cout + n0;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + mt * 16 + fq * 4 + r;
+                const int row = wm * WR + mt * 16 + fq * 4 + r;
                 if (m0 + row < g.M) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
 
     // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
     constexpr int CROW = BN * 2 + 16;  // padded bytes per staged output row
-    constexpr int WM = BM / 64;
+    constexpr int WM = BM / WR;
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
@@ -341,10 +352,10 @@ __global__ __launch_bounds__(BM * 2) void gg_fwd_mfma_k(GG g, FwdArgs a, int mti
         const float b = a.bias ? a.bias[n0 + col] : 0.f;
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + mt * 16 + fq * 4 + r;
+                const int row = wm * WR + mt * 16 + fq * 4 + r;
                 float v = acc[mt][nt][r] + b;
                 if (m0 + row < g.M) { s += v; q += v * v; }
                 if (eact == PAI_ACT_LRELU) v = fmaxf(v, 0.2f * v);
@@ -472,10 +483,10 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* w
     }
 }
 
-template <int BM, int BN, bool DB>
+template <int BM, int BN, bool DB, int WR = 64>
 static size_t fwd_lds_bytes() {
     const size_t main_loop = (size_t)(DB ? 2 : 1) * (BM * 128 + BN * 128);
-    const size_t epilogue = BM * (BN * 2 + 16) + (BM / 64) * 2 * BN * sizeof(float);
+    const size_t epilogue = BM * (BN * 2 + 16) + (BM / WR) * 2 * BN * sizeof(float);
     return main_loop > epilogue ? main_loop : epilogue;
 }
 
@@ -500,6 +511,9 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         FWD_LAUNCH(256, 128, false, true);
     } else if (c.bm == -128) {
         FWD_LAUNCH(128, 128, false, true);
+    } else if (c.bm == 128 && c.bn == 128 && c.ksplit == 1 && getenv("PAI_FWD_MODE") && atoi(getenv("PAI_FWD_MODE")) == 3) {
+        hipLaunchKernelGGL((gg_fwd_mfma_k<128, 128, false, false, 32>), grid, dim3(512),
+                           (fwd_lds_bytes<128, 128, false, 32>()), s, g, a, mtiles, ntiles, c.ksplit, g_workspace);
     } else if (c.ksplit > 1) {
         if (c.bn == 128) FWD_LAUNCH(128, 128, true, false); else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
@@ -603,7 +617,10 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     const int los = g.OS == 2 ? 1 : 0, lss = g.S == 2 ? 1 : 0;
     const int poy = g.poy[ph], pox = g.pox[ph];
     const int ycol = co0 + gch * 8;
-    for (int it = 0; it < niter; ++it) {
+    // row pointers of the next 64-pixel step are computed while the current step's LDS-DMA is in flight
+    const bf16_t* py[4];
+    const bf16_t* px[4];
+    auto prepare = [&](int it) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = mbeg + it * 64 + sr + 16 * j;
@@ -612,16 +629,23 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
             const int gy = (m >> g.lw) & (g.OHg - 1);
             const int n = m >> (g.lw + g.lh);
             const int opix = ((((n << g.ldh) + (gy << los) + poy) << g.ldw) + (gx << los) + pox);
-            const bf16_t* py = dy + ((size_t)(unsigned)opix * (unsigned)g.Cout + ycol);
-            py = (mv && yvalid) ? py : zero;
-            GLDS16(py, Ys + (16 * j + wid * 4) * 256);
+            const bf16_t* p = dy + ((size_t)(unsigned)opix * (unsigned)g.Cout + ycol);
+            py[j] = (mv && yvalid) ? p : zero;
             const int iy = (gy << lss) + ddy, ix = (gx << lss) + ddx;
             const bool inb = mv && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             const int spix = (((n << g.lsh) + iy) << g.lsw) + ix;
-            const bf16_t* px = xsrc + ((size_t)(unsigned)spix * (unsigned)xcs + xcc);
-            px = inb ? px : zero;
-            GLDS16(px, Xs + (16 * j + wid * 4) * 256);
+            const bf16_t* q = xsrc + ((size_t)(unsigned)spix * (unsigned)xcs + xcc);
+            px[j] = inb ? q : zero;
         }
+    };
+    if (niter > 0) prepare(0);
+    for (int it = 0; it < niter; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            GLDS16(py[j], Ys + (16 * j + wid * 4) * 256);
+            GLDS16(px[j], Xs + (16 * j + wid * 4) * 256);
+        }
+        if (it + 1 < niter) prepare(it + 1);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
