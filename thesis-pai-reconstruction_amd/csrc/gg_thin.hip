@@ -56,8 +56,8 @@ __device__ __forceinline__ void decode_row2(const GG& g, int m, int& n, int& gy,
 // ------------------------------------------------------------------------------------------------
 bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a) {
     return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 16 && g.OS == 1 && g.C1 == 1 && g.C2 <= 1 &&
-           (g.Cout % 16) == 0 && g.Cout <= 128 && !a.stats && !a.yf32 && !a.skip_d1 &&
-           (g.D2 == 0 || (g.D1 % 4) == 0);
+           (g.Cout % 64) == 0 && g.Cout <= 128 && !a.stats && !a.yf32 && !a.skip_d1 &&
+           (g.D2 == 0 || (g.D1 % 16) == 0);
 }
 
 template <int T>  // thin channels (1 or 2, one per source tensor)
@@ -70,18 +70,25 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
     const int mtiles = g.Cout / 16;
     constexpr int KT = 16 * T;
 
-    // A operand: W[co][k], k = tap*T + t, zero beyond 16*T
+    // A operand: W[co][k], k = tap*T + t, zero beyond 16*T.  MFMA row i of tile mt computes output
+    // channel co(mt, i) = 64*(mt>>2) + 16*(i>>2) + 4*(mt&3) + (i&3): after the four tiles of a group a
+    // lane (fq = i>>2 of its D rows) holds 16 CONSECUTIVE channels of its pixel -> two 16-B stores
+    // per pixel and group instead of four scattered 8-B ones.
     bf8_t af[8];
-    float bias[8][4];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (mt < mtiles && 8 * fq < KT) z = *(const us8_t*)(w + (size_t)(16 * mt + fr) * KT + 8 * fq);
+        const int co = 64 * (mt >> 2) + 16 * (fr >> 2) + 4 * (mt & 3) + (fr & 3);
+        if (mt < mtiles && 8 * fq < KT) z = *(const us8_t*)(w + (size_t)co * KT + 8 * fq);
         af[mt] = __builtin_bit_cast(bf8_t, z);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            bias[mt][r] = (a.bias && mt < mtiles) ? a.bias[16 * mt + 4 * fq + r] : 0.f;
     }
+    // bias of this lane's 16 channels per group: co = 64*grp + 16*fq + e
+    float bias[2][16];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            bias[gq][e] = (a.bias && gq * 4 < mtiles) ? a.bias[64 * gq + 16 * fq + e] : 0.f;
     // this lane's 8 patch elements: (tap, t) pairs
     int pdy[8], pdx[8];
 #pragma unroll
@@ -111,31 +118,39 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
         // rows beyond M carry an all-zero patch; the MFMAs run unconditionally (full wave), only the
         // stores are predicated
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            if (mt >= mtiles) break;
-            f4_t acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfrag, acc, 0, 0, 0);
-            if (m >= g.M) continue;
-            const int co = 16 * mt + 4 * fq;
-            float v[4], va[4];
+        for (int gq = 0; gq < 2; ++gq) {
+            if (gq * 4 >= mtiles) break;
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[r] + bias[mt][r];
-                va[r] = v[r];
-                if (a.eact == PAI_ACT_LRELU) va[r] = fmaxf(v[r], 0.2f * v[r]);
-                else if (a.eact == PAI_ACT_RELU) va[r] = fmaxf(v[r], 0.f);
+            for (int q = 0; q < 4; ++q) {
+                f4_t acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gq * 4 + q], bfrag, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * q + r] = acc[r] + bias[gq][4 * q + r];
             }
+            if (m >= g.M) continue;
+            const int co = 64 * gq + 16 * fq;   // first of this lane's 16 channels
             const size_t pix = (size_t)m;
             if (a.y1 || a.y2) {
-                const uint2 pk = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                            (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-                if (co < g.D1) *(uint2*)((bf16_t*)a.y1 + pix * g.D1 + co) = pk;
-                else *(uint2*)((bf16_t*)a.y2 + pix * g.D2 + (co - g.D1)) = pk;
+                unsigned pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+                bf16_t* dst = (co < g.D1) ? (bf16_t*)a.y1 + pix * g.D1 + co : (bf16_t*)a.y2 + pix * g.D2 + (co - g.D1);
+                *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
             if (a.yact) {
-                const uint2 pk = make_uint2((unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16),
-                                            (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16));
-                *(uint2*)((bf16_t*)a.yact + pix * g.Cout + co) = pk;
+                unsigned pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v0 = v[2 * e], v1 = v[2 * e + 1];
+                    if (a.eact == PAI_ACT_LRELU) { v0 = fmaxf(v0, 0.2f * v0); v1 = fmaxf(v1, 0.2f * v1); }
+                    else if (a.eact == PAI_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    pk[e] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                }
+                bf16_t* dst = (bf16_t*)a.yact + pix * g.Cout + co;
+                *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
         }
     }
