@@ -16,6 +16,7 @@ import pai_bootstrap
 pai = pai_bootstrap.load()
 from thesis_pai_reconstruction_amd import dist as pdist  # noqa: E402
 from thesis_pai_reconstruction_amd.dataset import ImageDataModule, SyntheticDataModule  # noqa: E402
+from thesis_pai_reconstruction_amd.callbacks import EMACallback  # noqa: E402
 from thesis_pai_reconstruction_amd.lightning import CSVLogger, ModelCheckpoint, Trainer  # noqa: E402
 
 HIP_MODELS = ("pix2pix",)
@@ -54,12 +55,11 @@ def main(hparams):
         model.to(device)
         pdist.broadcast_parameters(model)
         reducer = pdist.GradReducer()
+    callbacks = [EMACallback(0.9999), checkpoint_callback] if hparams.ema else [checkpoint_callback]
     trainer = Trainer(max_epochs=hparams.epochs, max_steps=hparams.steps, log_every_n_steps=10,
                       check_val_every_n_epoch=hparams.val_epochs, logger=[csv_logger],
-                      precision=hparams.precision, callbacks=[checkpoint_callback], benchmark=True,
+                      precision=hparams.precision, callbacks=callbacks, benchmark=True,
                       device=device, reducer=reducer)
-    if hparams.ema:
-        raise NotImplementedError("--ema: the EMA callback is a next-tier row (SURVEY.md 8(f) rank 3)")
     trainer.fit(model, data_module)
 
 

@@ -164,3 +164,31 @@ def test_precision_strings(pai):
     m = pai.Pix2Pix(1, 1, (1, 2), 0.0, "gan")
     m.set_precision("bf16-mixed")
     assert m.unet.compute_dtype == torch.bfloat16 and m.discriminator.compute_dtype == torch.bfloat16
+
+
+def test_ema_callback_matches_torch_ema_semantics(pai):
+    """torch_ema 0.3 update rule with warm-up decay, swap-in / restore around validation
+    (reference callbacks/ema.py:24-52)."""
+    from thesis_pai_reconstruction_amd.callbacks import EMACallback
+    torch.manual_seed(0)
+    net = nn.Linear(3, 2)
+    cb = EMACallback(decay=0.9)
+    cb.on_fit_start(None, net)
+    ref = [p.detach().clone() for p in net.parameters()]
+    for n in range(1, 6):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        cb.on_train_batch_end(None, net)
+        d = min(0.9, (1 + n) / (10 + n))
+        ref = [r - (1 - d) * (r - p.detach()) for r, p in zip(ref, net.parameters())]
+    for s, r in zip(cb.shadow, ref):
+        assert torch.allclose(s, r, atol=1e-6)
+    live = [p.detach().clone() for p in net.parameters()]
+    cb.on_validation_start(None, net)
+    for p, r in zip(net.parameters(), ref):
+        assert torch.allclose(p, r, atol=1e-6)
+    cb.on_validation_end(None, net)
+    for p, l in zip(net.parameters(), live):
+        assert torch.equal(p, l)
+    assert cb.state_dict()["num_updates"] == 5
