@@ -169,14 +169,18 @@ def main():
             dom = max(fam, key=lambda k: fam[k]["ms"])
         f = fam[dom]
         achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))[dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         return dom, {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                     "kernel": ops.KERNEL_NAMES.get(dom, str(dom)),
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                     "kernel": dom,
                      "launches_per_step": f["launches"] / nsteps,
                      "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                      "gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 3),
-                     "family_ms_per_step": {ops.KERNEL_NAMES.get(k, str(k)): round(v["ms"] / nsteps, 3)
-                                            for k, v in sorted(fam.items())}}
+                     "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())}}
 
     dom, roofline = roofline_of(prof, args.steps)
     # The timed region co-schedules weight-gradient kernels with the input-gradient chain on a second

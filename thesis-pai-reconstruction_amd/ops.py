@@ -102,7 +102,11 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            PROFILE.append((conv_kernel_id(self.d, self.op), self.op, conv_flops(self.d), self.e0, self.e1))
+            kid = conv_kernel_id(self.d, self.op)
+            name = KERNEL_NAMES.get(kid, str(kid))
+            if kid in (2, 3):
+                name += "_wgrad" if self.op == 2 else "_fwd"   # forward and input-gradient share a kernel
+            PROFILE.append((name, self.op, conv_flops(self.d), self.e0, self.e1))
         return False
 
 
