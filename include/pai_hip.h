@@ -122,6 +122,15 @@ int pai_conv_fwd(const pai_conv_desc* d, const void* x1, const void* x2, const v
 int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* dx1,
                    void* dx2, int only_c2, void* stream);
 
+/* pai_conv_dgrad followed by the activation backward of the layer that produced x1, in one pass:
+ *   dx1 = act1'(a1) * conv_backward_input(dy, w)[:, :C1],  dx2 as pai_conv_dgrad
+ * a1: storage dtype, shaped like dx1 (the stored activation whose sign carries the derivative:
+ * nn.LeakyReLU(0.2) / nn.ReLU in front of the next block, models/wrapper.py:205,
+ * models/pix2pix.py:62,98).  Bit-identical to pai_conv_dgrad + pai_act_bwd(dx1, act1, a1); the
+ * matrix-core kernels apply it in their store, the others run the second pass themselves. */
+int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* dx1,
+                       void* dx2, const void* a1, int act1, void* stream);
+
 /* dw += conv_backward_weight(act(x1|x2), dy)   (fp32, fwd pack; caller zeroes it first)
  * dbias += sum over N,OH,OW of dy              (fp32 [Cout], or NULL) */
 int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,

@@ -114,6 +114,21 @@ def test_conv_family(pai, case, dtype):
         ops.conv_dgrad(d, DY, wd, None, dx2b, only_c2=True)
         assert rel_err(from_nhwc(dx2b, N, H, W, C2), gx[:, C1:]) < TOL[dtype], name
 
+    # fused activation backward in the dgrad store == dgrad, then pai_act_bwd (bit-identical)
+    A1 = nhwc(q(rnd((N, C1, H, W), 6), dtype), dtype)
+    two = torch.empty_like(dx1)
+    ops.act_bwd(dtype, dx1, ops.ACT_LRELU, None, ops.ACT_NONE, A1, dx1.numel(), two)
+    one = torch.zeros_like(dx1)
+    dx2c = torch.zeros_like(dx2) if C2 else None
+    ops.conv_dgrad_act(d, DY, wd, one, dx2c, A1, ops.ACT_LRELU)
+    torch.cuda.synchronize()
+    if ops.conv_workspace_bytes(d, 1) == 0:
+        assert torch.equal(one, two), name
+        if C2:
+            assert torch.equal(dx2c, dx2), name
+    else:   # split-K sums its partial products with fp32 atomics: the order, and so the last bit, varies per launch
+        assert rel_err(one.float().cpu(), two.float().cpu()) < 2.0 ** -7, name
+
     # ---- weight / bias gradient -----------------------------------------------------------------------
     dw = torch.zeros(wm.numel(), dtype=torch.float32, device=dev())
     db = torch.zeros(Cout, dtype=torch.float32, device=dev())

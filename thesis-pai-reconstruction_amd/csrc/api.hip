@@ -311,6 +311,27 @@ extern "C" int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void
     return run_fwd(d->dtype, g, a, (hipStream_t)stream);
 }
 
+extern "C" int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const void* w_dgrad,
+                                  void* dx1, void* dx2, const void* a1, int act1, void* stream) {
+    GG g;
+    if (gg_build_dgrad(d, &g)) return 1;
+    PAI_CHECK(dy && w_dgrad && dx1 && a1, "pai_conv_dgrad_act: null pointer");
+    PAI_CHECK(d->C2 == 0 || dx2, "pai_conv_dgrad_act: C2 > 0 but dx2 is null");
+    PAI_CHECK(act1 == PAI_ACT_LRELU || act1 == PAI_ACT_RELU || act1 == PAI_ACT_NONE, "pai_conv_dgrad_act: act1=%d", act1);
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = dy; a.w = w_dgrad;
+    a.y1 = dx1; a.y2 = dx2;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = !thin_fwd_ok(d->dtype, g, a) && !thin_dgrad_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) &&
+                       use_mfma(d->dtype, g, a);
+    if (fused) { a.mask = a1; a.mask_act = act1; }
+    int rc = run_fwd(d->dtype, g, a, s);
+    if (rc || fused || act1 == PAI_ACT_NONE) return rc;
+    // kernels without the fused store: the same product as a second pass, in place
+    return pai_act_bwd(d->dtype, dx1, act1, nullptr, PAI_ACT_NONE, a1, (int64_t)g.N * g.OH * g.OW * g.D1, dx1, stream);
+}
+
 extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2,
                               const void* dy, float* dw, float* dbias, void* stream) {
     GG g;

@@ -174,7 +174,7 @@ extern "C" int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const fl
 }
 
 // ---- backward -------------------------------------------------------------------------------
-constexpr int BWD_MAX_PARTIAL = 256;
+constexpr int BWD_MAX_PARTIAL = 2048;
 
 extern "C" int pai_bn_bwd_partial_rows(int64_t M) {
     int64_t r = (M + 63) / 64;
@@ -208,41 +208,54 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
 #pragma unroll
         for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
         if (rl < lanes) {
-            for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            struct Row { float gv[8], zv[8], av[8], g2v[8]; };
+            auto load = [&](int64_t r, Row& q) {
                 const int64_t off = r * C + cg * 8;
-                float gv[8], zv[8], d[8];
-                V8<T>::ld(g1 + off, gv);
-                V8<T>::ld(z + off, zv);
+                V8<T>::ld(g1 + off, q.gv);
+                V8<T>::ld(z + off, q.zv);
+                if (a) V8<T>::ld(a + off, q.av);
+                if (g2) V8<T>::ld(g2 + off, q.g2v);
+            };
+            auto consume = [&](int64_t r, const Row& q) {
+                float d[8];
                 if (a) {
-                    float av[8];
-                    V8<T>::ld(a + off, av);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) d[k] = gv[k] * act_grad(av[k], act1);
+                    for (int k = 0; k < 8; ++k) d[k] = q.gv[k] * act_grad(q.av[k], act1);
                     if (g2) {
-                        float g2v[8];
-                        V8<T>::ld(g2 + off, g2v);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) d[k] = fmaf(g2v[k], act_grad(av[k], act2), d[k]);
+                        for (int k = 0; k < 8; ++k) d[k] = fmaf(q.g2v[k], act_grad(q.av[k], act2), d[k]);
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) d[k] = gv[k];
+                    for (int k = 0; k < 8; ++k) d[k] = q.gv[k];
                     if (g2) {
-                        float g2v[8];
-                        V8<T>::ld(g2 + off, g2v);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) d[k] += g2v[k];
+                        for (int k = 0; k < 8; ++k) d[k] += q.g2v[k];
                     }
                 }
-                V8<T>::st(du + off, d);
+                V8<T>::st(du + r * C + cg * 8, d);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // statistics from the value as stored (what pass 2 will read back)
                     float dd = d[k];
                     if (sizeof(T) == 2) dd = bf2f(f2bf(dd));
                     s1[k] += dd;
-                    s2[k] = fmaf(dd, (zv[k] - mu[k]) * rs[k], s2[k]);
+                    s2[k] = fmaf(dd, (q.zv[k] - mu[k]) * rs[k], s2[k]);
                 }
+            };
+            // two rows in flight per thread; row order (and so the summation order) is unchanged
+            int64_t r = r0 + rl;
+            for (; r + lanes < r1; r += 2 * lanes) {
+                Row q0, q1;
+                load(r, q0);
+                load(r + lanes, q1);
+                consume(r, q0);
+                consume(r + lanes, q1);
+            }
+            if (r < r1) {
+                Row q0;
+                load(r, q0);
+                consume(r, q0);
             }
         }
 #pragma unroll
@@ -262,15 +275,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
     }
 }
 
-// 32 channels x 8 row lanes per block: the <= 256 partial rows are summed in fp64 by 8 lanes in parallel
+// 8 channels x 32 row lanes per block: the <= 2048 partial rows are summed in fp64 by 32 lanes in parallel
 __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* partials, int rows, int C, float* sums,
                                                          float* dgamma, float* dbeta) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[2][32][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int r = rl; r < rows; r += 8) {
+        for (int r = rl; r < rows; r += 32) {
             s1 += (double)partials[((size_t)r * 2 + 0) * C + c];
             s2 += (double)partials[((size_t)r * 2 + 1) * C + c];
         }
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* partials, 
     if (rl == 0 && c < C) {
         s1 = s2 = 0.0;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
+        for (int l = 0; l < 32; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
         sums[c] = (float)s1;
         sums[C + c] = (float)s2;
         if (dbeta) dbeta[c] += (float)s1;
@@ -308,7 +321,7 @@ extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void
                            (const bf16_t*)g2, act2, (const bf16_t*)a, (const bf16_t*)z, M, C, rpb, mean, rstd,
                            (bf16_t*)du, partials);
     PAI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 32)), dim3(256), 0, s, partials, rows, C, sums, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, s, partials, rows, C, sums, dgamma,
                        dbeta);
     PAI_LAUNCH_CHECK();
     return 0;

@@ -114,6 +114,8 @@ struct FwdArgs {
     float* stats;   // [nphase*mtiles][2][Cout]
     int eact;
     int skip_d1;    // only write the D2 part (pai_conv_dgrad only_c2)
+    const void* mask;  // D1-shaped activations: the D1 output is multiplied by mask_act'(mask) (pai_conv_dgrad_act)
+    int mask_act;
 };
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);

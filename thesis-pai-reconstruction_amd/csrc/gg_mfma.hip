@@ -136,6 +136,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // BM x BN x 64 tile, BM/64 x 2 waves of 64 x (BN/2).  DB = double-buffered LDS: the LDS-DMA of tile
 // k+1 is issued before tile k is consumed and retired with a COUNTED s_waitcnt vmcnt + raw s_barrier
 // (a __syncthreads() would drain it: guide "Pipelining across barriers").
+// 8 bf16 gradients times act'(8 bf16 activations), rounded back to bf16
+__device__ __forceinline__ uint4 mask_frag(uint4 gq, uint4 aq, int act) {
+    const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w}, aw[4] = {aq.x, aq.y, aq.z, aq.w};
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
+        const float a0 = __uint_as_float(aw[k] << 16), a1 = __uint_as_float(aw[k] & 0xffff0000u);
+        o[k] = (unsigned)f2bf(g0 * act_grad(a0, act)) | ((unsigned)f2bf(g1 * act_grad(a1, act)) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 template <int BM, int BN, bool SPLITK, bool DB, int WR = 64>   // WR: output rows per wave (64 or 32)
 __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
                                                                float* ws) {
@@ -393,6 +406,9 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
     if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
     else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
     else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
+    // activation backward of the producer fused into the store: same values as storing bf16 and running
+    // pai_act_bwd over it (the product is formed from the bf16-rounded gradient)
+    const bf16_t* mask = (a.mask && !a.yact && n0 < g.D1) ? (const bf16_t*)a.mask : nullptr;
     constexpr int CPR = BN / 8;        // 16-B chunks per row
     constexpr int ORP = NTHR / CPR;    // rows per pass
     const int oc = tid % CPR, orow0 = tid / CPR;
@@ -404,7 +420,10 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
             int n, gy, gx;
             decode_row(g, m, n, gy, gx);
             const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-            *(uint4*)(dst + pix * dstride + dcol + oc * 8) = *(const uint4*)(Cs + row * CROW + oc * 16);
+            uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
+            const size_t off = pix * dstride + dcol + oc * 8;
+            if (mask) o = mask_frag(o, *(const uint4*)(mask + off), a.mask_act);
+            *(uint4*)(dst + off) = o;
         }
     }
 }
@@ -458,7 +477,10 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* w
                 if (a.yact) dst = (bf16_t*)a.yact + pix * g.Cout + c0;
                 else if (c0 < g.D1) dst = (bf16_t*)a.y1 + pix * g.D1 + c0;
                 else dst = (bf16_t*)a.y2 + pix * g.D2 + (c0 - g.D1);
-                *(uint4*)dst = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                uint4 o = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                if (a.mask && !a.yact && c0 < g.D1)
+                    o = mask_frag(o, *(const uint4*)((const bf16_t*)a.mask + pix * g.D1 + c0), a.mask_act);
+                *(uint4*)dst = o;
             }
         }
         if (a.stats) {

@@ -697,8 +697,7 @@ class DiscEngine:
         P = S["P"]
         N, H, W, dtype, dev = P["N"], P["H"], P["W"], P["dtype"], P["device"]
         if S["grads"] is None:
-            G = {"g": [torch.empty_like(a) for a in S["a"]],
-                 "du": [torch.empty_like(a) for a in S["a"]],
+            G = {"du": [torch.empty_like(a) for a in S["a"]],
                  "dl": torch.empty(S["logits"].numel(), dtype=dtype, device=dev),
                  "dy": torch.empty(N * H * W * self.in_ch, dtype=dtype, device=dev)}
             S["grads"] = G
@@ -719,11 +718,10 @@ class DiscEngine:
                 if hook is not None:
                     hook(A, A.end_of(self.convs[4].weight))
         _, wd = self.packs[4].get(dtype)
-        ops.conv_dgrad(d, dl, wd, G["g"][3], None)
+        # du[k] = LeakyReLU'(a[k]) * dgrad of block k+1: the activation backward rides on the dgrad store
+        ops.conv_dgrad_act(d, dl, wd, G["du"][3], None, S["a"][3], ACT_LRELU)
         for k in range(3, -1, -1):
-            n = S["a"][k].numel()
             conv = self.convs[k]
-            ops.act_bwd(dtype, G["g"][k], ACT_LRELU, None, ACT_NONE, S["a"][k], n, G["du"][k])
             d = P["desc"][k]
             if need_params:
                 with torch.cuda.stream(side.fork(d)):
@@ -735,7 +733,7 @@ class DiscEngine:
                         hook(A, A.end_of(conv.bias))
             if k > 0:
                 _, wd = self.packs[k].get(dtype)
-                ops.conv_dgrad(d, G["du"][k], wd, G["g"][k - 1], None)
+                ops.conv_dgrad_act(d, G["du"][k], wd, G["du"][k - 1], None, S["a"][k - 1], ACT_LRELU)
             elif need_dy:
                 _, wd = self.packs[0].get(dtype)
                 ops.conv_dgrad(d, G["du"][0], wd, None, G["dy"], only_c2=True)

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpai_hip.so")
+# PAI_HIP_LIB: another build of the same library (A/B timing of kernel changes on one box)
+LIB_PATH = os.environ.get("PAI_HIP_LIB") or os.path.join(HERE, "libpai_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
@@ -53,6 +54,7 @@ SIGNATURES = {
     "pai_conv_scratch_bytes": (_L, [_D, _I]),
     "pai_conv_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _I, _P]),
+    "pai_conv_dgrad_act": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

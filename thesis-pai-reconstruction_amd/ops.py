@@ -157,6 +157,13 @@ def conv_dgrad(d, dy, w_dgrad, dx1, dx2=None, only_c2=False):
                                         _stream()), "pai_conv_dgrad")
 
 
+def conv_dgrad_act(d, dy, w_dgrad, dx1, dx2, a1, act1):
+    """dx1 = act1'(a1) * dgrad[:, :C1]  (pai_conv_dgrad + pai_act_bwd in one pass)."""
+    with _Timed(d, 1):
+        L.check(L.load().pai_conv_dgrad_act(C.byref(d), _p(dy), _p(w_dgrad), _p(dx1), _p(dx2), _p(a1), int(act1),
+                                            _stream()), "pai_conv_dgrad_act")
+
+
 def conv_wgrad(d, x1, x2, dy, dw, dbias=None):
     with _Timed(d, 2):
         L.check(L.load().pai_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw, torch.float32),
