@@ -30,6 +30,10 @@ CASES = [
     ("patch_final_wide", 0, 1, 3, 16, 16, 256, 0, 1, 0, 0),
     ("head_relu_skip", 1, 2, 2, 8, 8, 32, 32, 1, 1, 1),
     ("odd_batch_rgb", 0, 2, 3, 8, 8, 3, 3, 64, 0, 0),
+    # enough 8 x 16 output tiles for the patch-resident MFMA kernel (no split-K): stride-2 windows forward,
+    # per-phase windows in the input gradient (64-wide tile), and the transposed pair with two sources
+    ("enc_patch", 0, 2, 4, 128, 128, 64, 0, 256, 0, 0),
+    ("dec_patch", 1, 2, 4, 64, 64, 64, 64, 128, 1, 1),
 ]
 
 

@@ -505,6 +505,270 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* w
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Patch-resident forward / input-gradient kernel
+// ------------------------------------------------------------------------------------
+// Measured on the kernel above (profiles/README.md, "LDS budget"): the LDS port, not the matrix
+// pipe, bounds it.  Per 128 x 128 x 64 step a workgroup needs 512 MFMA cycles per SIMD but asks
+// the LDS for 32 KB of LDS-DMA fill (64 B/clk/CU measured -> 512 cycles) plus 64 KB of fragment
+// reads (256 B/clk -> 256 cycles).  The fill is the expensive half, and three quarters of the A
+// fill is redundant: the 4 taps of a 2 x 2 window read the same source pixels shifted by one.
+// Here a workgroup owns an 8 x 16 block of output pixels of one image and keeps the 9 x 17 source
+// pixels its 2 x 2 window touches (64 channels) in LDS: one 20 KB patch fill serves 4 taps, only
+// the 16 KB weight tile changes per tap (21 KB of fill per step instead of 32 KB).
+//   ConvTranspose2d forward and Conv2d input gradient: each output phase has exactly one 2 x 2 window.
+//   Conv2d k4 s2 forward and ConvTranspose2d input gradient: the 16 taps are 4 windows, one per
+//   parity plane of the source (patch pixel stride 2).
+// LDS image of the patch: pixel p = py * 17 + px at byte 128 p, 16-B chunk c of the pixel stored at
+// slot c ^ (p & 6).  With that swizzle the 16 lanes of a ds_read_b128 group -- 16 consecutive p,
+// starting anywhere -- hit 16 different bank quads for every tap shift (the XOR only touches chunk
+// bits 1-2, the lane's own k-quarter keeps bit 0).
+struct PatchGeo {
+    int groups;                    // windows per phase: 1 or 4
+    int TY, TX;                    // 8 x 16 tiles per image
+    signed char by[4][4], bx[4][4];  // [phase][window] source offset of patch pixel (0,0) from (gy0*S, gx0*S)
+    unsigned toff4[4][4];          // 4 x 8 bit: patch offset ty*17+tx of the window's taps
+    unsigned wt4[4][4];            // 4 x 8 bit: weight tap slot of the window's taps
+};
+constexpr int PATCH_W = 17, PATCH_PIX = 9 * 17, PATCH_BYTES = 160 * 128;
+
+static bool patch_geo(const GG& g, PatchGeo* pg) {
+    if ((g.OWg % 16) || (g.OHg % 8)) return false;
+    memset(pg, 0, sizeof(*pg));
+    pg->TY = g.OHg / 8;
+    pg->TX = g.OWg / 16;
+    if (g.S == 1 && g.ntaps == 4) {
+        pg->groups = 1;
+        for (int ph = 0; ph < g.nphase; ++ph) {
+            int by = 127, bx = 127;
+            for (int t = 0; t < 4; ++t) { by = g.dy[ph][t] < by ? g.dy[ph][t] : by; bx = g.dx[ph][t] < bx ? g.dx[ph][t] : bx; }
+            unsigned seen = 0;
+            for (int t = 0; t < 4; ++t) {
+                const int ty = g.dy[ph][t] - by, tx = g.dx[ph][t] - bx;
+                if (ty > 1 || tx > 1) return false;
+                seen |= 1u << (ty * 2 + tx);
+                pg->toff4[ph][0] |= (unsigned)(ty * PATCH_W + tx) << (8 * t);
+                pg->wt4[ph][0] |= (unsigned)g.wt[ph][t] << (8 * t);
+            }
+            if (seen != 15u) return false;
+            pg->by[ph][0] = (signed char)by;
+            pg->bx[ph][0] = (signed char)bx;
+        }
+        return true;
+    }
+    if (g.S == 2 && g.ntaps == 16 && g.nphase == 1) {
+        pg->groups = 4;
+        int ymin = 127, xmin = 127;
+        for (int t = 0; t < 16; ++t) { ymin = g.dy[0][t] < ymin ? g.dy[0][t] : ymin; xmin = g.dx[0][t] < xmin ? g.dx[0][t] : xmin; }
+        for (int q = 0; q < 4; ++q) {
+            const int by = ymin + (q >> 1), bx = xmin + (q & 1);
+            int k = 0;
+            unsigned seen = 0;
+            for (int t = 0; t < 16; ++t) {
+                const int ry = g.dy[0][t] - by, rx = g.dx[0][t] - bx;
+                if (ry < 0 || rx < 0 || (ry & 1) || (rx & 1)) continue;
+                const int ty = ry / 2, tx = rx / 2;
+                if (ty > 1 || tx > 1 || k == 4) return false;
+                seen |= 1u << (ty * 2 + tx);
+                pg->toff4[0][q] |= (unsigned)(ty * PATCH_W + tx) << (8 * k);
+                pg->wt4[0][q] |= (unsigned)g.wt[0][t] << (8 * k);
+                ++k;
+            }
+            if (k != 4 || seen != 15u) return false;
+            pg->by[0][q] = (signed char)by;
+            pg->bx[0][q] = (signed char)bx;
+        }
+        return true;
+    }
+    return false;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+    constexpr int BM = 128, NTHR = 256, MT = 4, NT = BN / 32;
+    constexpr int PJ = 5;                    // patch fill instructions per thread (32 pixels each)
+    constexpr int BJ = BN / 32;              // weight tile fill instructions per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Bs = smem + PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % ntiles;
+    bid /= ntiles;
+    const int ph = bid % g.nphase;
+    const int bm = bid / g.nphase;
+    const int n0 = bn * BN;
+    const int tpi = pg.TY * pg.TX;
+    const int img = bm / tpi, trem = bm - img * tpi;
+    const int gy0 = (trem / pg.TX) * 8, gx0 = (trem % pg.TX) * 16;
+
+    const bf16_t* w = (const bf16_t*)a.w;
+    const bf16_t* zero = (const bf16_t*)g_zero_line;
+
+    // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
+    const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
+    const int gchA = (sc ^ (sr & 6)) * 8;    // p & 6 == sr & 6 (32 j does not touch bits 1-2)
+    int pixb[PJ];                            // source pixel index of the patch pixel for window offset (0,0)
+    unsigned vmask[PJ];                      // bit q: inside the image for window q of this phase
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int p = j * 32 + sr;
+        const int py = p / PATCH_W, px = p - py * PATCH_W;
+        const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
+        pixb[j] = (img * g.H + y) * g.W + x;
+        unsigned m = 0;
+        for (int q = 0; q < pg.groups; ++q) {
+            const int yy = y + pg.by[ph][q], xx = x + pg.bx[ph][q];
+            if (p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
+        }
+        vmask[j] = m;
+    }
+    const int gchB = (sc ^ ((sr >> 1) & 7)) * 8;
+    const bf16_t* wrow[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + 32 * j) * g.wtaps * g.Cin + gchB;
+
+    // ---- fragment read addresses -----------------------------------------------------------------
+    const int fr = lane & 15, fq = lane >> 4;
+    int pbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) pbase[mt] = (wm * 4 + mt) * PATCH_W + fr;
+    const unsigned b_base = (unsigned)(PATCH_BYTES + (wn * (BN / 2) + fr) * 128);
+    const int fswz = fr >> 1;
+
+    f4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int cchunks = g.Cin / MBK;
+    for (int cc = 0; cc < cchunks; ++cc) {
+        const int c0 = cc * MBK;
+        const bool second = c0 >= g.C1;
+        const bf16_t* src = second ? (const bf16_t*)a.x2 : (const bf16_t*)a.x1;
+        const int C = second ? g.C2 : g.C1;
+        const int cofs = (second ? c0 - g.C1 : c0) + gchA;
+        const int relu = second ? g.relu2 : g.relu1;
+        for (int q = 0; q < pg.groups; ++q) {
+            const int dpix = pg.by[ph][q] * g.W + pg.bx[ph][q];
+            const unsigned toff4 = pg.toff4[ph][q], wt4 = pg.wt4[ph][q];
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) {
+                const bf16_t* pa = ((vmask[j] >> q) & 1u) ? src + ((pixb[j] + dpix) * C + cofs) : zero;
+                GLDS16(pa, smem + (j * 32 + wid * 8) * 128);
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int woff = (int)((wt4 >> (8 * k)) & 0xffu) * g.Cin + c0;
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + (j * 32 + wid * 8) * 128);
+                const int toff = (int)((toff4 >> (8 * k)) & 0xffu);
+                unsigned abase[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const unsigned pp = (unsigned)(pbase[mt] + toff);
+                    abase[mt] = (pp << 7) ^ ((pp & 6u) << 4);
+                }
+                __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes patch + weight tile
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
+                    const unsigned cb = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
+                    bf8_t af[MT], bfr[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + b_base + nt * 16 * 128 + cb);
+                    if (relu) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                }
+                __syncthreads();  // every wave is done reading before the next fill overwrites
+            }
+        }
+    }
+
+    // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
+    constexpr int CROW = BN * 2 + 16;
+    constexpr int WM = 2;
+    unsigned char* Cs = smem;
+    float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
+    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = wn * (BN / 2) + nt * 16 + fr;
+        const float b = a.bias ? a.bias[n0 + col] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + mt * 16 + fq * 4 + r;
+                float v = acc[mt][nt][r] + b;
+                s += v;
+                q += v * v;
+                if (eact == PAI_ACT_LRELU) v = fmaxf(v, 0.2f * v);
+                else if (eact == PAI_ACT_RELU) v = fmaxf(v, 0.f);
+                *(bf16_t*)(Cs + row * CROW + col * 2) = f2bf(v);
+            }
+        }
+        csum[nt] = s;
+        csq[nt] = q;
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s = csum[nt], q = csq[nt];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (fq == 0) {
+                const int col = wn * (BN / 2) + nt * 16 + fr;
+                sstat[(wm * 2 + 0) * BN + col] = s;
+                sstat[(wm * 2 + 1) * BN + col] = q;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.stats && tid < BN) {
+        float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + n0 + tid;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) { s += sstat[(i * 2 + 0) * BN + tid]; q += sstat[(i * 2 + 1) * BN + tid]; }
+        dst[0] = s;
+        dst[g.Cout] = q;
+    }
+    bf16_t* dst;
+    int dstride, dcol;
+    if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
+    else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
+    else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
+    const bf16_t* mask = (a.mask && !a.yact && n0 < g.D1) ? (const bf16_t*)a.mask : nullptr;
+    constexpr int CPR = BN / 8;        // 16-B chunks per row
+    constexpr int ORP = NTHR / CPR;    // rows per pass
+    const int oc = tid % CPR, orow0 = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < BM / ORP; ++p) {
+        const int row = orow0 + p * ORP;
+        const int gy = gy0 + (row >> 4), gx = gx0 + (row & 15);
+        const size_t pix = (size_t)(img * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
+        uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
+        const size_t off = pix * dstride + dcol + oc * 8;
+        if (mask) o = mask_frag(o, *(const uint4*)(mask + off), a.mask_act);
+        *(uint4*)(dst + off) = o;
+    }
+}
+
 template <int BM, int BN, bool DB, int WR = 64>
 static size_t fwd_lds_bytes() {
     const size_t main_loop = (size_t)(DB ? 2 : 1) * (BM * 128 + BN * 128);
@@ -542,7 +806,16 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         const int ftiles = cdiv(g.M, FIN_ROWS);
         hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, ftiles);
     } else {
-        if (c.bn == 128) FWD_LAUNCH(128, 128, false, false); else FWD_LAUNCH(128, 64, false, false);
+        static const bool no_patch = getenv("PAI_NO_PATCH") && atoi(getenv("PAI_NO_PATCH")) != 0;
+        PatchGeo pg;
+        if (!no_patch && patch_geo(g, &pg)) {
+            const size_t lds = PATCH_BYTES + (size_t)c.bn * 128;
+            const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 2 * 2 * c.bn * sizeof(float);
+            if (c.bn == 128)
+                hipLaunchKernelGGL(gg_fwd_patch_k<128>, grid, dim3(256), lds > epi ? lds : epi, s, g, a, pg, mtiles, ntiles);
+            else
+                hipLaunchKernelGGL(gg_fwd_patch_k<64>, grid, dim3(256), lds > epi ? lds : epi, s, g, a, pg, mtiles, ntiles);
+        } else if (c.bn == 128) FWD_LAUNCH(128, 128, false, false); else FWD_LAUNCH(128, 64, false, false);
     }
 #undef FWD_LAUNCH
     PAI_LAUNCH_CHECK();
