@@ -34,6 +34,9 @@ CASES = [
     # per-phase windows in the input gradient (64-wide tile), and the transposed pair with two sources
     ("enc_patch", 0, 2, 4, 128, 128, 64, 0, 256, 0, 0),
     ("dec_patch", 1, 2, 4, 64, 64, 64, 64, 128, 1, 1),
+    # >= 512 tiles of 16 x 16 output pixels: the 8-wave variant of the patch kernel (forward of both)
+    ("enc_patch256", 0, 2, 8, 256, 256, 64, 0, 128, 0, 0),
+    ("dec_patch256", 1, 2, 8, 64, 64, 128, 0, 128, 1, 0),
 ]
 
 

@@ -97,8 +97,13 @@ static int fwd_effective_ksplit(const GG& g) {
 }
 
 // number of BN partial-statistics rows per phase this launch configuration writes
+// rows per workgroup of the patch-resident kernel for this problem: 0 (not applicable), 128 or 256
+static int patch_rows(const GG& g, const FwdCfg& c);
+
 int fwd_mfma_mtiles(const GG& g) {
-    return fwd_effective_ksplit(g) > 1 ? cdiv(g.M, FIN_ROWS) : cdiv(g.M, abs(fwd_cfg(g).bm));
+    if (fwd_effective_ksplit(g) > 1) return cdiv(g.M, FIN_ROWS);
+    const FwdCfg c = fwd_cfg(g);
+    return patch_rows(g, c) == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
 }
 
 typedef __attribute__((ext_vector_type(8))) short s8_t;
@@ -531,12 +536,22 @@ struct PatchGeo {
     unsigned toff4[4][4];          // 4 x 8 bit: patch offset ty*17+tx of the window's taps
     unsigned wt4[4][4];            // 4 x 8 bit: weight tap slot of the window's taps
 };
-constexpr int PATCH_W = 17, PATCH_PIX = 9 * 17, PATCH_BYTES = 160 * 128;
+constexpr int PATCH_W = 17;
+// BM = 128: 8 x 16 output pixels, 4 waves;  BM = 256: 16 x 16 output pixels, 8 waves (4 x 2) -- the weight
+// tile fill is then shared by twice the rows: 25 KB of fill and 128 KB of fragment reads per 2 x 512
+// MFMA cycles, the first configuration whose LDS time (916 cycles) is below its matrix time (1024).
+template <int BM> struct PatchDims {
+    static constexpr int TH = BM / 16;
+    static constexpr int PIX = (TH + 1) * PATCH_W;
+    static constexpr int RPP = BM / 4;                       // pixels per block-wide fill instruction
+    static constexpr int PJ = (PIX + RPP - 1) / RPP;
+    static constexpr int BYTES = PJ * RPP * 128;
+};
 
-static bool patch_geo(const GG& g, PatchGeo* pg) {
-    if ((g.OWg % 16) || (g.OHg % 8)) return false;
+static bool patch_geo(const GG& g, int th, PatchGeo* pg) {
+    if ((g.OWg % 16) || (g.OHg % th)) return false;
     memset(pg, 0, sizeof(*pg));
-    pg->TY = g.OHg / 8;
+    pg->TY = g.OHg / th;
     pg->TX = g.OWg / 16;
     if (g.S == 1 && g.ntaps == 4) {
         pg->groups = 1;
@@ -584,11 +599,22 @@ static bool patch_geo(const GG& g, PatchGeo* pg) {
     return false;
 }
 
-template <int BN>
-__global__ __launch_bounds__(256) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
-    constexpr int BM = 128, NTHR = 256, MT = 4, NT = BN / 32;
-    constexpr int PJ = 5;                    // patch fill instructions per thread (32 pixels each)
-    constexpr int BJ = BN / 32;              // weight tile fill instructions per thread
+static int patch_rows(const GG& g, const FwdCfg& c) {
+    static const bool no_patch = getenv("PAI_NO_PATCH") && atoi(getenv("PAI_NO_PATCH")) != 0;
+    static const bool no_256 = getenv("PAI_NO_PATCH256") && atoi(getenv("PAI_NO_PATCH256")) != 0;
+    if (no_patch || c.ksplit > 1 || c.bm != 128) return 0;
+    PatchGeo pg;
+    // 16 x 16 tiles when the layer still fills the chip with them (two 8-wave workgroups per CU)
+    if (!no_256 && c.bn == 128 && (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= 512 && patch_geo(g, 16, &pg)) return 256;
+    return patch_geo(g, 8, &pg) ? 128 : 0;
+}
+
+template <int BM, int BN, bool DBB>   // DBB: two weight-tile buffers
+__global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : 4) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+    typedef PatchDims<BM> PD;
+    constexpr int NTHR = BM * 2, MT = 4, NT = BN / 32;
+    constexpr int RPP = PD::RPP, PJ = PD::PJ, PATCH_PIX = PD::PIX, PATCH_BYTES = PD::BYTES;
+    constexpr int BJ = BN / RPP;             // weight tile fill instructions per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Bs = smem + PATCH_BYTES;
 
@@ -603,19 +629,19 @@ __global__ __launch_bounds__(256) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo 
     const int n0 = bn * BN;
     const int tpi = pg.TY * pg.TX;
     const int img = bm / tpi, trem = bm - img * tpi;
-    const int gy0 = (trem / pg.TX) * 8, gx0 = (trem % pg.TX) * 16;
+    const int gy0 = (trem / pg.TX) * PD::TH, gx0 = (trem % pg.TX) * 16;
 
     const bf16_t* w = (const bf16_t*)a.w;
     const bf16_t* zero = (const bf16_t*)g_zero_line;
 
     // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
     const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
-    const int gchA = (sc ^ (sr & 6)) * 8;    // p & 6 == sr & 6 (32 j does not touch bits 1-2)
+    const int gchA = (sc ^ (sr & 6)) * 8;    // p & 6 == sr & 6 (RPP j does not touch bits 1-2)
     int pixb[PJ];                            // source pixel index of the patch pixel for window offset (0,0)
     unsigned vmask[PJ];                      // bit q: inside the image for window q of this phase
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
-        const int p = j * 32 + sr;
+        const int p = j * RPP + sr;
         const int py = p / PATCH_W, px = p - py * PATCH_W;
         const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
         pixb[j] = (img * g.H + y) * g.W + x;
@@ -629,7 +655,7 @@ __global__ __launch_bounds__(256) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo 
     const int gchB = (sc ^ ((sr >> 1) & 7)) * 8;
     const bf16_t* wrow[BJ];
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + 32 * j) * g.wtaps * g.Cin + gchB;
+    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + RPP * j) * g.wtaps * g.Cin + gchB;
 
     // ---- fragment read addresses -----------------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
@@ -645,62 +671,95 @@ __global__ __launch_bounds__(256) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
+    // One step = one tap of one window: 64 channels of the patch against one weight tile.  The weight tile
+    // of step i+1 is in flight (second buffer) while step i is multiplied; the patch is replaced every 4
+    // steps, behind a barrier of its own.
     const int cchunks = g.Cin / MBK;
-    for (int cc = 0; cc < cchunks; ++cc) {
-        const int c0 = cc * MBK;
+    const int ngroups = cchunks * pg.groups;
+    const int gsh = pg.groups == 4 ? 2 : 0;
+    auto fire_patch = [&](int gi) {
+        const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
         const bool second = c0 >= g.C1;
         const bf16_t* src = second ? (const bf16_t*)a.x2 : (const bf16_t*)a.x1;
         const int C = second ? g.C2 : g.C1;
         const int cofs = (second ? c0 - g.C1 : c0) + gchA;
-        const int relu = second ? g.relu2 : g.relu1;
-        for (int q = 0; q < pg.groups; ++q) {
-            const int dpix = pg.by[ph][q] * g.W + pg.bx[ph][q];
-            const unsigned toff4 = pg.toff4[ph][q], wt4 = pg.wt4[ph][q];
+        const int dpix = pg.by[ph][q] * g.W + pg.bx[ph][q];
 #pragma unroll
-            for (int j = 0; j < PJ; ++j) {
-                const bf16_t* pa = ((vmask[j] >> q) & 1u) ? src + ((pixb[j] + dpix) * C + cofs) : zero;
-                GLDS16(pa, smem + (j * 32 + wid * 8) * 128);
-            }
+        for (int j = 0; j < PJ; ++j) {
+            const bf16_t* pa = ((vmask[j] >> q) & 1u) ? src + ((pixb[j] + dpix) * C + cofs) : zero;
+            GLDS16(pa, smem + (j * RPP + wid * 8) * 128);
+        }
+    };
+    auto fire_b = [&](int gi, int k, int buf) {
+        const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
+        const int woff = (int)((pg.wt4[ph][q] >> (8 * k)) & 0xffu) * g.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + buf * (BN * 128) + (j * RPP + wid * 8) * 128);
+    };
+    fire_patch(0);
+    fire_b(0, 0, 0);
+    int buf = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int c0g = (gi >> gsh) * MBK;
+        const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
+        const unsigned toff4 = pg.toff4[ph][gi & (pg.groups - 1)];
+        const bool more = gi + 1 < ngroups;
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) {
-                const int woff = (int)((wt4 >> (8 * k)) & 0xffu) * g.Cin + c0;
+        for (int k = 0; k < 4; ++k) {
+            const int toff = (int)((toff4 >> (8 * k)) & 0xffu);
+            unsigned abase[MT];
 #pragma unroll
-                for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + (j * 32 + wid * 8) * 128);
-                const int toff = (int)((toff4 >> (8 * k)) & 0xffu);
-                unsigned abase[MT];
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned pp = (unsigned)(pbase[mt] + toff);
+                abase[mt] = (pp << 7) ^ ((pp & 6u) << 4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // this step's tiles have landed; everyone is done with the other weight buffer
+            if (DBB) {
+                if (k < 3) fire_b(gi, k + 1, buf ^ 1);
+                else if (more) fire_b(gi + 1, 0, buf ^ 1);
+            }
+            const unsigned bb = b_base + (DBB ? buf * (BN * 128) : 0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const unsigned pp = (unsigned)(pbase[mt] + toff);
-                    abase[mt] = (pp << 7) ^ ((pp & 6u) << 4);
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
+                const unsigned cb = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
+                bf8_t af[MT], bfr[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + bb + nt * 16 * 128 + cb);
+                if (relu) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
                 }
-                __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes patch + weight tile
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
-                    const unsigned cb = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
-                    bf8_t af[MT], bfr[NT];
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + b_base + nt * 16 * 128 + cb);
-                    if (relu) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+            }
+            if (DBB) {
+                buf ^= 1;
+                if (k == 3 && more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // every wave is done reading the patch
+                    fire_patch(gi + 1);
                 }
-                __syncthreads();  // every wave is done reading before the next fill overwrites
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();       // every wave is done reading before the next fill overwrites
+                if (k < 3) fire_b(gi, k + 1, 0);
+                else if (more) { fire_patch(gi + 1); fire_b(gi + 1, 0, 0); }
             }
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the epilogue reuses the tile memory
 
     // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
     constexpr int CROW = BN * 2 + 16;
-    constexpr int WM = 2;
+    constexpr int WM = BM / 64;
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
@@ -806,15 +865,44 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         const int ftiles = cdiv(g.M, FIN_ROWS);
         hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, ftiles);
     } else {
-        static const bool no_patch = getenv("PAI_NO_PATCH") && atoi(getenv("PAI_NO_PATCH")) != 0;
         PatchGeo pg;
-        if (!no_patch && patch_geo(g, &pg)) {
-            const size_t lds = PATCH_BYTES + (size_t)c.bn * 128;
+        const int prow = patch_rows(g, c);
+        // second weight-tile buffer: pays on the 128-wide tiles (bit 0: 256-row, bit 1: 128-row), not on the
+        // 64-wide ones (bit 2), whose 8 KB weight tile is cheap to wait for and which lose a workgroup per CU to it
+        static const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
+        if (prow == 256 && patch_geo(g, 16, &pg)) {
+            typedef PatchDims<256> PD;
+            const bool db = (dbb & 1) != 0;
+            const size_t lds = PD::BYTES + (size_t)128 * 128 * (db ? 2 : 1);
+            const size_t epi = 256 * ((size_t)128 * 2 + 16) + 4 * 2 * 128 * sizeof(float);
+            const size_t need = lds > epi ? lds : epi;
+            static bool attr = false;
+            if (!attr) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patch_k<256, 128, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patch_k<256, 128, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+                attr = true;
+            }
+            const int mt256 = g.M / 256;
+            const dim3 grid256(mt256 * ntiles * g.nphase);
+            if (db) hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+            else hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, false>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+        } else if (prow == 128 && patch_geo(g, 8, &pg)) {
+            typedef PatchDims<128> PD;
+            const bool db = (dbb & (c.bn == 128 ? 2 : 4)) != 0;
+            const size_t lds = PD::BYTES + (size_t)c.bn * 128 * (db ? 2 : 1);
             const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 2 * 2 * c.bn * sizeof(float);
-            if (c.bn == 128)
-                hipLaunchKernelGGL(gg_fwd_patch_k<128>, grid, dim3(256), lds > epi ? lds : epi, s, g, a, pg, mtiles, ntiles);
-            else
-                hipLaunchKernelGGL(gg_fwd_patch_k<64>, grid, dim3(256), lds > epi ? lds : epi, s, g, a, pg, mtiles, ntiles);
+            const size_t need = lds > epi ? lds : epi;
+            if (c.bn == 128) {
+                if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                else hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+            } else {
+                if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 64, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                else hipLaunchKernelGGL((gg_fwd_patch_k<128, 64, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+            }
         } else if (c.bn == 128) FWD_LAUNCH(128, 128, false, false); else FWD_LAUNCH(128, 64, false, false);
     }
 #undef FWD_LAUNCH
