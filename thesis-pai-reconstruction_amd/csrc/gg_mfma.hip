@@ -1103,6 +1103,184 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     }
 }
 
+
+// Patch-resident weight gradient.  Same LDS arithmetic as the forward kernel: per 64-pixel step the kernel
+// above fills 32 KB (dY tile + gathered X tile) for 512 MFMA cycles.  Here the column tile is one 2 x 2
+// tap window x 32 input channels, and the K step is a 4 x 16 block of output pixels: the four taps read
+// the same 5 x 17 source pixels (64 B each), so the X fill drops from 16 KB to 5.4 KB per step.
+//   X patch image: pixel p = py * 17 + px at byte 64 p; its two 32-B halves are swapped when bit 3 of p is
+//   set, which keeps the two 8-row groups of a ds_read_b64_tr_b16 on different banks for every tap shift.
+template <int BMC>
+__global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
+                                                        int splits, int blocks_per_split) {
+    constexpr int MT = BMC / 32;
+    constexpr int YBUF = 64 * 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ys = smem;
+    unsigned char* Xs = smem + YBUF;   // 128 pixels x 64 B (85 used)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = bid % jtiles; bid /= jtiles;
+    const int cot = bid % cotiles; bid /= cotiles;
+    const int split = bid % splits;
+    const int ph = bid / splits;
+    const int co0 = cot * BMC;
+    const int q = jt & (pg.groups - 1);
+    const int ci0 = (jt >> (pg.groups == 4 ? 2 : 0)) * 32;
+
+    const bf16_t* dy = (const bf16_t*)a.dy;
+    const bf16_t* zero = (const bf16_t*)g_zero_line;
+    const bool second = ci0 >= g.C1;
+    const bf16_t* xsrc = second ? (const bf16_t*)a.x2 : (const bf16_t*)a.x1;
+    const int xcs = second ? g.C2 : g.C1;
+    const int xrelu = second ? g.relu2 : g.relu1;
+
+    // dY tile fill map (as gg_wgrad_mfma_k): row sr + 16 j = pixel (gy0 + j, gx0 + sr) of the step's block
+    const int sc = lane & 15, sr = wid * 4 + (lane >> 4);
+    const int gch = sc ^ tr_swz(sr);
+    const bool yvalid = gch < BMC / 8 && (co0 + gch * 8) < g.Cout;
+    const int ycol = co0 + gch * 8;
+    const int los = g.OS == 2 ? 1 : 0;
+    const int poy = g.poy[ph], pox = g.pox[ph];
+    // X patch fill map: thread -> (pixel 64 jj + tid / 4, 16-B slot tid % 4)
+    const int xs = tid & 3;
+    int xpy[2], xpx[2], xch[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int p = jj * 64 + (tid >> 2);
+        xpy[jj] = p / PATCH_W;
+        xpx[jj] = p - xpy[jj] * PATCH_W;
+        if (p >= 5 * PATCH_W) xpy[jj] = -1000;   // beyond the patch: never inside the image
+        xch[jj] = (second ? ci0 - g.C1 : ci0) + ((xs ^ (((p >> 3) & 1) << 1)) * 8);
+    }
+    const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
+
+    const int lbx = g.lw - 4, lby = g.lh - 2;
+    const int kb0 = split * blocks_per_split;
+    const int kb1 = min(g.M >> 6, kb0 + blocks_per_split);
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const int tq = fi >> 2, tp = fi & 3;
+    // X fragment addresses: row r = kk * 32 + fg * 8 + tq (+ 4) of the step -> patch pixel (r >> 4) * 17 + (r & 15)
+    unsigned xrow[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = kk * 32 + fg * 8 + tq + 4 * h;
+            xrow[kk][h] = (unsigned)((r >> 4) * PATCH_W + (r & 15));
+        }
+    const unsigned toff4 = pg.toff4[ph][q];
+
+    f4_t acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    const bool do_bias = a.dbias != nullptr && jt == 0;
+    const int bc = tid % BMC, bh = tid / BMC;
+    constexpr int BROWS = 64 / (256 / BMC);
+    float bsum = 0.f;
+
+    const bf16_t* py[4];
+    const bf16_t* px[2];
+    auto prepare = [&](int kb) {
+        const int gx0 = (kb & ((1 << lbx) - 1)) << 4;
+        const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << 2;
+        const int n = kb >> (lbx + lby);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int opix = ((((n << g.ldh) + ((gy0 + j) << los) + poy) << g.ldw) + ((gx0 + sr) << los) + pox);
+            py[j] = yvalid ? dy + ((size_t)(unsigned)opix * (unsigned)g.Cout + ycol) : zero;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int iy = (gy0 + xpy[jj]) * g.S + wby, ix = (gx0 + xpx[jj]) * g.S + wbx;
+            const bool inb = xpy[jj] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const int spix = (((n << g.lsh) + iy) << g.lsw) + ix;
+            px[jj] = inb ? xsrc + ((size_t)(unsigned)spix * (unsigned)xcs + xch[jj]) : zero;
+        }
+    };
+    if (kb0 < kb1) prepare(kb0);
+    for (int kb = kb0; kb < kb1; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) GLDS16(py[j], Ys + (16 * j + wid * 4) * 256);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) GLDS16(px[jj], Xs + (jj * 64 + wid * 16) * 64);
+        if (kb + 1 < kb1) prepare(kb + 1);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf8_t af[MT], bfr[4];
+            const int row0 = kk * 32 + fg * 8 + tq;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ch = (wm * (BMC / 2) + mt * 16) / 8 + (tp >> 1);
+                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row0, ch) + 8 * (tp & 1)));
+                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row0 + 4, ch) + 8 * (tp & 1)));
+                af[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned toff = (toff4 >> (8 * (wn * 2 + (nt >> 1)))) & 0xffu;
+                const unsigned p0 = xrow[kk][0] + toff, p1 = xrow[kk][1] + toff;
+                const unsigned o0 = p0 * 64 + ((((unsigned)(nt & 1)) ^ ((p0 >> 3) & 1u)) << 5) + tp * 8;
+                const unsigned o1 = p1 * 64 + ((((unsigned)(nt & 1)) ^ ((p1 >> 3) & 1u)) << 5) + tp * 8;
+                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(Xs + o0));
+                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(Xs + o1));
+                bfr[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if (xrelu) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bfr[nt] = relu_frag(bfr[nt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < BROWS; ++r) {
+                const int row = bh * BROWS + r;
+                bsum += bf2f(*(const bf16_t*)(Ys + tr_off(row, bc >> 3) + (bc & 7) * 2));
+            }
+        }
+        __syncthreads();
+    }
+    if (do_bias) {
+        float* red = (float*)smem;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < BMC && co0 + tid < g.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
+            atomicAdd(a.dbias + co0 + tid, t);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int wt = (int)((pg.wt4[ph][q] >> (8 * (wn * 2 + (nt >> 1)))) & 0xffu);
+        const size_t cbase = (size_t)wt * g.Cin + ci0 + (nt & 1) * 16 + fi;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (BMC / 2) + mt * 16 + fg * 4 + r;
+                if (co < g.Cout) atomicAdd(a.dw + (size_t)co * g.wtaps * g.Cin + cbase, acc[mt][nt][r]);
+            }
+        }
+    }
+}
+
 int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hipStream_t s);
 
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
@@ -1110,12 +1288,33 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     const int cotiles = big ? g.Cout / 128 : g.Cout / 64;
     const int jtiles = g.ntaps * g.Cin / 128;
     const int tiles = cotiles * jtiles * g.nphase;
-    int splits = cdiv(1024, tiles);
-    const int max_splits = cdiv(g.M, 256);
+    // Split of the pixel range: enough workgroups to fill the chip (3 per CU for the 128-wide tile, 4 for the
+    // lighter 64-wide one), but every split adds one fp32 atomic pass over dW -- for the small-image layers
+    // that pass, not the MFMA loop, is the cost, so a split never gets fewer than 512 pixels.
+    static const int target_env = getenv("PAI_WGRAD_TARGET") ? atoi(getenv("PAI_WGRAD_TARGET")) : 0;
+    const int target = target_env ? target_env : (big ? 768 : 1024);
+    int splits = cdiv(target, tiles);
+    static const int min_rows = getenv("PAI_WGRAD_MINROWS") ? atoi(getenv("PAI_WGRAD_MINROWS")) : 512;
+    const int max_splits = cdiv(g.M, min_rows);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rows = cdiv(cdiv(g.M, splits), 64) * 64;
     splits = cdiv(g.M, rows);
+    static const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
+    PatchGeo pg;
+    if (!no_patch && g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && patch_geo(g, 4, &pg)) {
+        const int kblocks = g.M / 64;
+        const int per = rows / 64;
+        const int psplits = cdiv(kblocks, per);
+        const size_t plds = 64 * 256 + 128 * 64;
+        dim3 pgrid(tiles * psplits);
+        if (big)
+            hipLaunchKernelGGL(gg_wgrad_patch_k<128>, pgrid, dim3(256), plds, s, g, a, pg, cotiles, jtiles, psplits, per);
+        else
+            hipLaunchKernelGGL(gg_wgrad_patch_k<64>, pgrid, dim3(256), plds, s, g, a, pg, cotiles, jtiles, psplits, per);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = 2 * 64 * 256;
     dim3 grid(tiles * splits);
     if (big)
