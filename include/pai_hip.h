@@ -98,8 +98,11 @@ int pai_set_workspace(void* zeroed_device_memory, int64_t bytes);
 int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op);
 /* General (dirty) scratch: the wide->thin layers (ConvTranspose2d(128,1) head, input gradient of
  * the first discriminator conv) run as a skinny GEMM into fp32 scratch followed by a col2im pass.
- * Register one buffer of at least max(pai_conv_scratch_bytes(desc, op)); without it those layers
- * fall back to the slower row-dot kernel. */
+ * Their weight gradients (op 2) collect one partial tile per workgroup there and add them in a second
+ * pass.  Forward / input-gradient calls use the HEAD of the buffer, weight-gradient calls its TAIL, so
+ * that the two may run on different streams: register at least
+ *   max over op 0,1 of pai_conv_scratch_bytes(desc, op)  +  max of pai_conv_scratch_bytes(desc, 2).
+ * Without it those layers fall back to the slower row-dot kernel / to fp32 atomics. */
 int pai_set_scratch(void* device_memory, int64_t bytes);
 int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op);
 

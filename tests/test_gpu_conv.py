@@ -73,7 +73,7 @@ def test_conv_family(pai, case, dtype):
     assert ops.conv_out_hw(d) == (OH, OW)
     # split-K scratch: small-M / long-K layers take the split path only when it is registered
     ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
-    ops.ensure_scratch(max(ops.conv_scratch_bytes(d, 0), ops.conv_scratch_bytes(d, 1)), dev())
+    ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
     wm = fwd_pack(w, bool(tr))
     wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
     wd = torch.empty(wm.numel(), dtype=dtype, device=dev())

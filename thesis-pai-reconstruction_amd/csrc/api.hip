@@ -216,7 +216,12 @@ extern "C" int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op) {
 extern "C" int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op) {
     GG g;
     if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
-    if (op == 2) return 0;
+    if (op == 2) {
+        if (thin_wgrad_conv_ok(d->dtype, g)) return thin_wgrad_scratch_bytes((int64_t)g.N * g.OHg * g.OWg, g.C1 + g.C2, g.Cout);
+        if (thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g))
+            return thin_wgrad_scratch_bytes((int64_t)g.N * g.H * g.W, 1, g.Cin);
+        return 0;
+    }
     FwdArgs a;
     memset(&a, 0, sizeof(a));
     if (thin_dgrad_shape_ok(d->dtype, g)) return thin_dgrad_scratch_bytes(g, a);

@@ -12,6 +12,8 @@
 //                                 out[2a+ph][2b+pw][t] = bias + sum of 4 Y entries     (col2im)
 //   TW  thin weight gradient      D[k][wc]    = sum_pix patch[pix][k] * wide[pix][wc] (K = pixels)
 // patch[pix][k=(tap,t)] = thin_t[n][S*gy + dy[tap]][S*gx + dx[tap]] (zero outside the image).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
@@ -311,6 +313,7 @@ struct ThinW {
     int s_wc, s_tap, s_t;         // dw index = wc*s_wc + tap*s_tap + t*s_t
     float* dbias;                 // per wide channel, or null
     int M;                        // N*H*W
+    float* partial;               // per-workgroup partial sums [grid.x][grid.y][16 T + 1][128] or null (atomics)
 };
 
 __device__ __forceinline__ int tw_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -417,24 +420,69 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
         __syncthreads();
     }
     // D[k = 16*tt + 4*fq + r][wc = 16*(nt0+nt) + fr]
+    // two partial tiles per workgroup: the two 32-pixel halves (ks) of a chunk are separate waves
+    float* part0 = p.partial ? p.partial + (((size_t)blockIdx.x * 2) * gridDim.y + blockIdx.y) * ((16 * T + 1) * 128) : nullptr;
+    float* part = part0 ? part0 + (size_t)ks * gridDim.y * ((16 * T + 1) * 128) : nullptr;
 #pragma unroll
     for (int tt = 0; tt < T; ++tt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (nt >= ntn) break;
-            const int wc = wc0 + (nt0 + nt) * 16 + fr;
+            const int wcl = (nt0 + nt) * 16 + fr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 16 * tt + 4 * fq + r;
-                const int tap = k / T, t = k - tap * T;
-                atomicAdd(p.dw + (size_t)wc * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
+                if (part) {
+                    part[k * 128 + wcl] = acc[tt][nt][r];
+                } else {
+                    const int tap = k / T, t = k - tap * T;
+                    atomicAdd(p.dw + (size_t)(wc0 + wcl) * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
+                }
             }
         }
     if (p.dbias) {
         float* red = (float*)smem;
         red[tid] = bsum;
         __syncthreads();
-        if (tid < WC) atomicAdd(p.dbias + wc0 + tid, red[tid] + red[tid + 128]);
+        if (tid < WC) {
+            if (part0) {
+                part0[16 * T * 128 + tid] = red[tid] + red[tid + 128];
+                part0[(size_t)gridDim.y * ((16 * T + 1) * 128) + 16 * T * 128 + tid] = 0.f;
+            } else {
+                atomicAdd(p.dbias + wc0 + tid, red[tid] + red[tid + 128]);
+            }
+        }
+    }
+}
+
+// Second stage of the weight gradient: dw += sum over workgroups of their partial tiles (16 atomics per
+// element instead of one per workgroup and element -- 512 workgroups x 1024 atomics on 1024 addresses
+// cost ~100 us).  grid.y = 16 ranges of tiles; thread = (element, 1 of 4 slices of the range).
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_k(ThinW p, int T, int ntiles, int groups) {
+    __shared__ float red[4][64];
+    const int pst = (16 * T + 1) * 128;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    const int gy = e / pst, le = e - gy * pst;
+    const int per = (ntiles + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(ntiles, b0 + per);
+    float sum = 0.f;
+    if (gy < groups) {
+        const float* src = p.partial + (size_t)gy * pst + le;
+        for (int b = b0 + slice; b < b1; b += 4) sum += src[(size_t)b * groups * pst];
+    }
+    red[slice][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (slice == 0 && gy < groups) {
+        sum = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const int k = le >> 7, wc = gy * 128 + (le & 127);
+        if (wc < p.WC1 + p.WC2) {
+            if (k < 16 * T) {
+                const int tap = k / T, t = k - tap * T;
+                atomicAdd(p.dw + (size_t)wc * p.s_wc + tap * p.s_tap + t * p.s_t, sum);
+            } else if (p.dbias) {
+                atomicAdd(p.dbias + wc, sum);
+            }
+        }
     }
 }
 
@@ -465,19 +513,44 @@ bool thin_wgrad_convt_ok(int dtype, const GG& g) {
            (g.C2 % 8) == 0 && (g.Cin % 32) == 0 && g.Cin <= 128;
 }
 
+// workgroups along the pixel range; with the two-stage reduction more of them cost nothing
+static int tw_blocks(int64_t M, int groups, bool two_stage) {
+    static const int cap_env = getenv("PAI_TW_BLOCKS") ? atoi(getenv("PAI_TW_BLOCKS")) : 0;
+    int cap = cap_env ? cap_env : (two_stage ? 1024 / groups : 512);   // ~4 workgroups per CU over all channel groups
+    if (cap < 64) cap = 64;
+    const int chunks = cdiv(M, 64);
+    int blocks = chunks < cap ? chunks : cap;
+    const int cpb = cdiv(chunks, blocks);
+    return cdiv(chunks, cpb);
+}
+
+// bytes of registered scratch the two-stage path of a thin weight gradient wants (its TAIL is used, so that
+// a thin input gradient running on another stream can use the head at the same time)
+int64_t thin_wgrad_scratch_bytes(int64_t M, int T, int WC) {
+    return (int64_t)tw_blocks(M, cdiv(WC, 128), true) * 2 * cdiv(WC, 128) * (16 * T + 1) * 128 * sizeof(float);
+}
+
 static int launch_tw(ThinW& p, int T, hipStream_t s) {
     p.M = p.N * p.H * p.W;
     p.lw = ilog2_exact(p.W);
     p.lh = ilog2_exact(p.H);
     if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
     const int chunks = cdiv(p.M, 64);
-    int blocks = chunks < 512 ? chunks : 512;
-    const int cpb = cdiv(chunks, blocks);
-    blocks = cdiv(chunks, cpb);
     const int groups = cdiv(p.WC1 + p.WC2, 128);
+    const int64_t need = thin_wgrad_scratch_bytes(p.M, T, p.WC1 + p.WC2);
+    static const bool no_two = getenv("PAI_TW_ATOMIC") && atoi(getenv("PAI_TW_ATOMIC")) != 0;
+    const bool two_stage = !no_two && g_scratch != nullptr && g_scratch_bytes >= need;
+    int blocks = tw_blocks(p.M, groups, two_stage);
+    const int cpb = cdiv(chunks, blocks);
+    p.partial = two_stage ? (float*)((char*)g_scratch + (g_scratch_bytes - need)) : nullptr;
     if (T == 1) hipLaunchKernelGGL(thin_wgrad_k<1>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
     else hipLaunchKernelGGL(thin_wgrad_k<2>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
     PAI_LAUNCH_CHECK();
+    if (two_stage) {
+        const int elems = groups * (16 * T + 1) * 128;
+        hipLaunchKernelGGL(thin_wgrad_reduce_k, dim3(cdiv(elems, 64), 16), dim3(256), 0, s, p, T, blocks * 2, groups);
+        PAI_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -365,8 +365,7 @@ class UnetEngine:
         P["bwd_partials"] = torch.empty(mx, dtype=torch.float32, device=device)
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["enc_desc"] + P["dec_desc"]
                                  for op in (0, 1)), device)
-        ops.ensure_scratch(max(ops.conv_scratch_bytes(d, op) for d in P["enc_desc"] + P["dec_desc"]
-                               for op in (0, 1)), device)
+        ops.ensure_scratch(ops.scratch_bytes_for(P["enc_desc"] + P["dec_desc"]), device)
         self._plans[key] = P
         return P
 
@@ -645,7 +644,7 @@ class DiscEngine:
         P["desc"].append(ops.make_desc(dtype, 0, N, H >> 4, W >> 4, self.chans[3], 0, 1, 1, 0, 0, ACT_NONE))
         P["oh"], P["ow"] = (H >> 4) - 1, (W >> 4) - 1
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["desc"] for op in (0, 1)), device)
-        ops.ensure_scratch(max(ops.conv_scratch_bytes(d, op) for d in P["desc"] for op in (0, 1)), device)
+        ops.ensure_scratch(ops.scratch_bytes_for(P["desc"]), device)
         self._plans[key] = P
         return P
 

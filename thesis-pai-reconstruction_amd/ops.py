@@ -134,6 +134,14 @@ def conv_scratch_bytes(d: ConvDesc, op: int) -> int:
     return L.load().pai_conv_scratch_bytes(C.byref(d), op)
 
 
+def scratch_bytes_for(descs) -> int:
+    """Scratch to register for a set of layers: forward / input-gradient calls use the head of the buffer, the
+    weight-gradient calls (which run on a second stream) its tail -- see pai_set_scratch in include/pai_hip.h."""
+    head = max((conv_scratch_bytes(d, op) for d in descs for op in (0, 1)), default=0)
+    tail = max((conv_scratch_bytes(d, 2) for d in descs), default=0)
+    return head + tail
+
+
 def ensure_scratch(nbytes: int, device) -> None:
     """Register (grow) the general scratch buffer of libpai_hip.so (pai_set_scratch)."""
     global _SCRATCH
