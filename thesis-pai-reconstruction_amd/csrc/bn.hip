@@ -129,7 +129,7 @@ template <> struct V8<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
         unsigned u[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) u[i] = pk2bf(v[2 * i], v[2 * i + 1]);
         *(uint4*)p = make_uint4(u[0], u[1], u[2], u[3]);
     }
 };

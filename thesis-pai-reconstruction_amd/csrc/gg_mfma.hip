@@ -149,7 +149,7 @@ __device__ __forceinline__ uint4 mask_frag(uint4 gq, uint4 aq, int act) {
     for (int k = 0; k < 4; ++k) {
         const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
         const float a0 = __uint_as_float(aw[k] << 16), a1 = __uint_as_float(aw[k] & 0xffff0000u);
-        o[k] = (unsigned)f2bf(g0 * act_grad(a0, act)) | ((unsigned)f2bf(g1 * act_grad(a1, act)) << 16);
+        o[k] = pk2bf(g0 * act_grad(a0, act), g1 * act_grad(a1, act));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* w
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    packed[k] = (unsigned)f2bf(v[2 * k]) | ((unsigned)f2bf(v[2 * k + 1]) << 16);
+                    packed[k] = pk2bf(v[2 * k], v[2 * k + 1]);
                 int n, gy, gx;
                 decode_row(g, m, n, gy, gx);
                 const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];

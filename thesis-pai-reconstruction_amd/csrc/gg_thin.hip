@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
             if (a.y1 || a.y2) {
                 unsigned pk[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pk[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+                for (int e = 0; e < 8; ++e) pk[e] = pk2bf(v[2 * e], v[2 * e + 1]);
                 bf16_t* dst = (co < g.D1) ? (bf16_t*)a.y1 + pix * g.D1 + co : (bf16_t*)a.y2 + pix * g.D2 + (co - g.D1);
                 *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
                     float v0 = v[2 * e], v1 = v[2 * e + 1];
                     if (a.eact == PAI_ACT_LRELU) { v0 = fmaxf(v0, 0.2f * v0); v1 = fmaxf(v1, 0.2f * v1); }
                     else if (a.eact == PAI_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                    pk[e] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                    pk[e] = pk2bf(v0, v1);
                 }
                 bf16_t* dst = (bf16_t*)a.yact + pix * g.Cout + co;
                 *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
