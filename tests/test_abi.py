@@ -47,7 +47,9 @@ def test_host_side_queries_work_without_gpu(pai):
     d = ops.make_desc(torch.bfloat16, 0, 64, 128, 128, 64, 0, 128, 2)
     assert ops.conv_out_hw(d) == (64, 64)
     assert ops.conv_kernel_id(d, 0) == 2 and ops.conv_kernel_id(d, 1) in (2, 3) and ops.conv_kernel_id(d, 2) == 2
-    assert ops.conv_fwd_stats_rows(d) == 64 * 64 * 64 // 128
+    # one partial row per output tile: 128-row GEMM tiles or 256-pixel (16x16) patch tiles
+    assert ops.conv_fwd_stats_rows(d) in (64 * 64 * 64 // 128, 64 * 64 * 64 // 256)
+    assert ops.conv_fwd_stats_rows(d) <= ops.conv_fwd_stats_rows_max(d)
     d32 = ops.make_desc(torch.float32, 0, 64, 128, 128, 64, 0, 128, 2)
     assert ops.conv_kernel_id(d32, 0) == 0            # fp32 storage -> exact-fp32 vector-ALU kernel
     dt = ops.make_desc(torch.bfloat16, 1, 4, 128, 128, 64, 64, 1, 2)
