@@ -8,9 +8,10 @@ D phase + G phase, both Adam updates and the per-step SSIM/PSNR/RMSE (reference
 models/wrapper.py:117-162), 256x256x1 pairs, 64 images per GPU (weak scaling), bf16 storage /
 fp32 accumulate.  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel family (bf16 MFMA gather-GEMM, 128-wide tile) is timed per launch
-with HIP events recorded on the launch stream inside the timed region; achieved = algorithmic
-FLOPs of those launches / their summed duration, against the dense bf16 MFMA peak.
+roofline: every convolution launch is timed with HIP events recorded on the stream it is launched
+on and keyed by the kernel symbol rocprofv3 reports (pai_conv_kernel_name); the kernel with the
+largest summed time is the dominant one: achieved = algorithmic FLOPs of its launches / their
+summed duration, against the dense bf16 MFMA peak.
 cpu_baseline: the oracle's CPU restatement of the same step (same ATen ops the reference
 dispatches to), timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -215,7 +216,7 @@ def main():
                      "launches_per_step": f["launches"] / nsteps,
                      "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                      "gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 3),
-                     "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())}}
+                     "kernel_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())}}
 
     dom, roofline = roofline_of(prof or [], args.steps)
     # The timed region co-schedules weight-gradient kernels with the input-gradient chain on a second

@@ -87,6 +87,11 @@ int pai_bn_stats_buffer_rows(int rows);
  * returns 0 vector-ALU tile kernel, 1 row-dot kernel, 2 bf16 MFMA 128-wide tile, 3 bf16 MFMA
  * 64-wide tile, 4 thin-layer MFMA kernels, < 0 on error. */
 int pai_conv_kernel_id(const pai_conv_desc* d, int op);
+/* Symbol (as rocprofv3 --kernel-trace prints it, without "void " and the argument list) of the main
+ * kernel such a call launches, e.g. "gg_fwd_patch_k<256, 128, true>"; bench.py keys its per-kernel
+ * roofline on it so that the figure can be checked against profiles/ *_kernel_stats.csv.
+ * Families without a single dominant kernel report their family name.  Returns 0, < 0 on error. */
+int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len);
 
 /* Split-K scratch.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
  * bottleneck: M <= 1024 rows, K up to 8192) are split over K; the fp32 partial sums meet in a

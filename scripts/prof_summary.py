@@ -2,13 +2,15 @@
 per-launch timeline of the last step."""
 import csv, glob, sys
 d = sys.argv[1]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 13
+steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0
 stats = glob.glob(d + "/*/*_kernel_stats.csv")[0]
 trace = glob.glob(d + "/*/*_kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(stats)))
+if not steps:   # one ssim_k launch per training step (clock-ramp and warm-up steps included)
+    steps = max(int(r['Calls']) for r in rows if 'ssim_k' in r['Name'])
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f"kernel time per step: {tot/1e6/steps:.2f} ms")
-for r in rows[:22]:
+for r in rows[:30]:
     print(f"{float(r['TotalDurationNs'])/1e6/steps:7.3f} ms/step {float(r['Percentage']):5.1f}% calls/step {int(r['Calls'])/steps:5.1f} avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:80]}")
 if "--timeline" in sys.argv:
     rows = list(csv.DictReader(open(trace)))

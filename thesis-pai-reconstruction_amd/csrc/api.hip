@@ -269,6 +269,21 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     return 0;
 }
 
+extern "C" int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len) {
+    static const char* fam[5] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16"};
+    const int id = pai_conv_kernel_id(d, op);
+    if (id < 0 || !name || name_len <= 0) return -1;
+    const char* n = fam[id];
+    if (id == 2 || id == 3) {
+        GG g;
+        if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
+        n = op == 2 ? wgrad_mfma_kernel_name(g) : fwd_mfma_kernel_name(g);
+    }
+    strncpy(name, n, name_len - 1);
+    name[name_len - 1] = 0;
+    return 0;
+}
+
 // upper bound of pai_conv_fwd_stats_rows over every launch configuration the library may pick
 // (the split-K path writes one row per 16 output rows); size the statistics buffer with this
 extern "C" int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d) {

@@ -124,6 +124,8 @@ int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s);
 int fwd_mfma_ksplit(const GG& g);
+const char* fwd_mfma_kernel_name(const GG& g);
+const char* wgrad_mfma_kernel_name(const GG& g);
 int64_t fwd_mfma_workspace_bytes(const GG& g);
 // registered scratch for split-K partial sums (fp32, kept all-zero between calls)
 extern float* g_workspace;

@@ -910,6 +910,25 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     return 0;
 }
 
+// rocprofv3-visible symbol of the main kernel launch_fwd_mfma picks for this problem (same decisions, no launch)
+const char* fwd_mfma_kernel_name(const GG& g) {
+    FwdCfg c = fwd_cfg(g);
+    c.ksplit = fwd_effective_ksplit(g);
+    const int mode = getenv("PAI_FWD_MODE") ? atoi(getenv("PAI_FWD_MODE")) : 0;
+    if (c.bm == 256) return "gg_fwd_mfma_k<256, 128, false, true, 64>";
+    if (c.bm == -128) return "gg_fwd_mfma_k<128, 128, false, true, 64>";
+    if (c.bm == 128 && c.bn == 128 && c.ksplit == 1 && mode == 3) return "gg_fwd_mfma_k<128, 128, false, false, 32>";
+    if (c.ksplit > 1) return c.bn == 128 ? "gg_fwd_mfma_k<128, 128, true, false, 64>" : "gg_fwd_mfma_k<128, 64, true, false, 64>";
+    const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
+    const int prow = patch_rows(g, c);
+    if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";
+    if (prow == 128) {
+        if (c.bn == 128) return (dbb & 2) ? "gg_fwd_patch_k<128, 128, true>" : "gg_fwd_patch_k<128, 128, false>";
+        return (dbb & 4) ? "gg_fwd_patch_k<128, 64, true>" : "gg_fwd_patch_k<128, 64, false>";
+    }
+    return c.bn == 128 ? "gg_fwd_mfma_k<128, 128, false, false, 64>" : "gg_fwd_mfma_k<128, 64, false, false, 64>";
+}
+
 // ------------------------------------------------------------------------------------
 // Weight gradient
 // ------------------------------------------------------------------------------------
@@ -1323,4 +1342,13 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(gg_wgrad_mfma_k<64>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
     PAI_LAUNCH_CHECK();
     return 0;
+}
+
+const char* wgrad_mfma_kernel_name(const GG& g) {
+    const bool big = (g.Cout % 128) == 0;
+    const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
+    PatchGeo pg;
+    if (!no_patch && g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && patch_geo(g, 4, &pg))
+        return big ? "gg_wgrad_patch_k<128>" : "gg_wgrad_patch_k<64>";
+    return big ? "gg_wgrad_mfma_k<128>" : "gg_wgrad_mfma_k<64>";
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pai_conv_fwd_stats_rows_max": (_I, [_D]),
     "pai_bn_stats_buffer_rows": (_I, [_I]),
     "pai_conv_kernel_id": (_I, [_D, _I]),
+    "pai_conv_kernel_name": (_I, [_D, _I, C.c_char_p, _I]),
     "pai_set_workspace": (_I, [_P, _L]),
     "pai_conv_workspace_bytes": (_L, [_D, _I]),
     "pai_set_scratch": (_I, [_P, _L]),

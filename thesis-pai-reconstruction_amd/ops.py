@@ -78,6 +78,14 @@ def conv_kernel_id(d: ConvDesc, op: int) -> int:
     return L.load().pai_conv_kernel_id(C.byref(d), op)
 
 
+def conv_kernel_name(d: ConvDesc, op: int) -> str:
+    """rocprofv3 symbol of the main kernel the call launches (family name for the non-MFMA families)."""
+    buf = C.create_string_buffer(96)
+    if L.load().pai_conv_kernel_name(C.byref(d), op, buf, 96) != 0:
+        L.check(1, "pai_conv_kernel_name")
+    return buf.value.decode()
+
+
 def conv_flops(d: ConvDesc) -> int:
     """Algorithmic FLOPs (2 x MAC, padding taps included) of one fwd / dgrad / wgrad launch."""
     if d.transposed:
@@ -102,11 +110,8 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            kid = conv_kernel_id(self.d, self.op)
-            name = KERNEL_NAMES.get(kid, str(kid))
-            if kid in (2, 3):
-                name += "_wgrad" if self.op == 2 else "_fwd"   # forward and input-gradient share a kernel
-            PROFILE.append((name, self.op, conv_flops(self.d), self.e0, self.e1))
+            # forward and input-gradient share kernels; keyed by the symbol rocprofv3 reports
+            PROFILE.append((conv_kernel_name(self.d, self.op), self.op, conv_flops(self.d), self.e0, self.e1))
         return False
 
 
