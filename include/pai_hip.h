@@ -94,11 +94,13 @@ int pai_conv_kernel_id(const pai_conv_desc* d, int op);
 int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len);
 
 /* Split-K scratch.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
- * bottleneck: M <= 1024 rows, K up to 8192) are split over K; the fp32 partial sums meet in a
- * caller-provided scratch buffer.  Register ONE buffer per process with pai_set_workspace; it must
- * be zero-filled when registered and at least max(pai_conv_workspace_bytes(desc, op)) over the
- * forward (op 0) and input-gradient (op 1) calls that will be made.  The library keeps it all-zero
- * between calls.  Calls that would need more scratch than is registered run un-split. */
+ * bottleneck: M <= 1024 rows, K up to 8192) are split over K; every split writes its fp32 partial
+ * tile into its own slab of a caller-provided scratch buffer (plain stores, no atomics) and a
+ * finish kernel sums the slabs in a fixed order.  Register ONE buffer per process with
+ * pai_set_workspace, at least max(pai_conv_workspace_bytes(desc, op)) over the forward (op 0) and
+ * input-gradient (op 1) calls that will be made; its contents need not be preserved between
+ * calls, but calls that use it must be issued on one stream.  Calls that would need more scratch
+ * than is registered run un-split. */
 int pai_set_workspace(void* zeroed_device_memory, int64_t bytes);
 int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op);
 /* General (dirty) scratch: the wide->thin layers (ConvTranspose2d(128,1) head, input gradient of

@@ -233,8 +233,9 @@ def test_bf16_mode_tracks_fp32_oracle(pai, golden_dir):
 
 def test_baseline_config_properties(pai):
     """BASELINE.json configs[1]: 256x256, batch 64, bf16.  Size-independent properties:
-    (1) the PatchGAN has no cross-sample coupling -> D on a half batch is bit-identical to the
-        matching half of D on the full batch (tile decomposition must not change any dot product);
+    (1) the PatchGAN has no cross-sample coupling -> changing the other samples of a batch leaves a
+        sample's logits bit-identical, and D on a half batch equals the matching half of D on the full
+        batch up to bf16 rounding (the K split, i.e. the summation order, may depend on the batch size);
     (2) training-mode BatchNorm output of every BN layer has ~zero mean / unit variance per channel
         (checked on the normalised tensors the engine keeps);
     (3) accumulating the weight gradient twice doubles it; (4) a few GAN steps stay finite and the
@@ -250,7 +251,13 @@ def test_baseline_config_properties(pai):
     with torch.no_grad():
         full = m.discriminator(x, t)
         half = m.discriminator(x[:32].contiguous(), t[:32].contiguous())
-    assert torch.equal(full[:32], half)
+        t2 = t.clone()
+        t2[32:] = -t2[32:]
+        other = m.discriminator(x, t2)
+    # same launch configuration, different neighbours: bit-identical
+    assert torch.equal(full[:32], other[:32]) and not torch.equal(full[32:], other[32:])
+    # a different batch size may pick another K split (summation order): equal up to bf16 rounding
+    assert torch.allclose(full[:32], half, rtol=2e-2, atol=2e-2)
     assert full.shape == (64, 1, 15, 15)
 
     eng = m.unet.engine

@@ -331,6 +331,11 @@ extern "C" int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void
     return run_fwd(d->dtype, g, a, (hipStream_t)stream);
 }
 
+static bool dgrad_store_fusable(const pai_conv_desc* d, const GG& g, const FwdArgs& a) {
+    return !thin_fwd_ok(d->dtype, g, a) && !thin_dgrad_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) &&
+           use_mfma(d->dtype, g, a);
+}
+
 extern "C" int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const void* w_dgrad,
                                   void* dx1, void* dx2, const void* a1, int act1, void* stream) {
     GG g;
@@ -343,13 +348,61 @@ extern "C" int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const 
     a.x1 = dy; a.w = w_dgrad;
     a.y1 = dx1; a.y2 = dx2;
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = !thin_fwd_ok(d->dtype, g, a) && !thin_dgrad_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) &&
-                       use_mfma(d->dtype, g, a);
-    if (fused) { a.mask = a1; a.mask_act = act1; }
+    const bool fused = dgrad_store_fusable(d, g, a);
+    if (fused) { a.bz = a1; a.bact1 = act1; }
     int rc = run_fwd(d->dtype, g, a, s);
     if (rc || fused || act1 == PAI_ACT_NONE) return rc;
     // kernels without the fused store: the same product as a second pass, in place
     return pai_act_bwd(d->dtype, dx1, act1, nullptr, PAI_ACT_NONE, a1, (int64_t)g.N * g.OH * g.OW * g.D1, dx1, stream);
+}
+
+extern "C" int pai_conv_dgrad_bn_rows_max(const pai_conv_desc* d) {
+    GG g;
+    if (gg_build_dgrad(d, &g)) return -1;
+    const int fused = cdiv(g.M, 16) * g.nphase;
+    const int twopass = pai_bn_bwd_partial_rows((int64_t)g.N * g.OH * g.OW);
+    return fused > twopass ? fused : twopass;
+}
+
+int bn_bwd_reduce_affine(int dtype, void* g1_du, int act1, const void* g2, int act2, const void* z, int64_t M, int C,
+                         const float* scale, const float* shift, const float* mean, const float* rstd,
+                         float* partials, hipStream_t s);
+
+extern "C" int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* dx1,
+                                 void* dx2, const pai_bwd_epilogue* e, int* partial_rows, void* stream) {
+    GG g;
+    if (gg_build_dgrad(d, &g)) return 1;
+    PAI_CHECK(dy && w_dgrad && dx1 && e && e->z, "pai_conv_dgrad_bn: null pointer");
+    PAI_CHECK(d->C2 == 0 || dx2, "pai_conv_dgrad_bn: C2 > 0 but dx2 is null");
+    PAI_CHECK((e->scale == nullptr) == (e->shift == nullptr), "pai_conv_dgrad_bn: scale and shift go together");
+    PAI_CHECK(!e->partials || (e->mean && e->rstd && partial_rows), "pai_conv_dgrad_bn: partials need mean, rstd and partial_rows");
+    for (int act : {e->act1, e->act2})
+        PAI_CHECK(act == PAI_ACT_LRELU || act == PAI_ACT_RELU || act == PAI_ACT_NONE, "pai_conv_dgrad_bn: act=%d", act);
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = dy; a.w = w_dgrad;
+    a.y1 = dx1; a.y2 = dx2;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)g.N * g.OH * g.OW;
+    if (dgrad_store_fusable(d, g, a)) {
+        a.bz = e->z; a.badd = e->add;
+        a.bscale = e->scale; a.bshift = e->shift; a.bmean = e->mean; a.brstd = e->rstd;
+        a.bact1 = e->act1; a.bact2 = e->act2;
+        a.bpart = e->partials;
+        if (partial_rows) *partial_rows = e->partials ? fwd_mfma_mtiles(g) * g.nphase : 0;
+        return run_fwd(d->dtype, g, a, s);
+    }
+    // other kernel families: plain input gradient, then the same arithmetic as a second pass in place
+    int rc = run_fwd(d->dtype, g, a, s);
+    if (rc) return rc;
+    if (e->partials) {
+        *partial_rows = pai_bn_bwd_partial_rows(M);
+        return bn_bwd_reduce_affine(d->dtype, dx1, e->act1, e->add, e->act2, e->z, M, g.D1, e->scale, e->shift,
+                                    e->mean, e->rstd, e->partials, s);
+    }
+    if (partial_rows) *partial_rows = 0;
+    PAI_CHECK(e->scale == nullptr, "pai_conv_dgrad_bn: affine pre-activation without partial sums is only built for the matrix-core kernels");
+    return pai_act_bwd(d->dtype, dx1, e->act1, e->add, e->act2, e->z, M * g.D1, dx1, stream);
 }
 
 extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2,

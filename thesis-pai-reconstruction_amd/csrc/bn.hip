@@ -188,7 +188,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, const T* g2, int act2,
                                                        const T* a, const T* z, int64_t M, int C,
                                                        int64_t rows_per_block, const float* mean,
-                                                       const float* rstd, T* du, float* partials) {
+                                                       const float* rstd, T* du, float* partials,
+                                                       const float* scale = nullptr, const float* shift = nullptr) {
     __shared__ float red[2][256][8];
     const int groups = C / 8;
     const int tid = threadIdx.x;
@@ -202,9 +203,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
         const int per_pass = min(groups - cg0, 256);
         const int lanes = 256 / per_pass;  // per_pass is a power of two <= 256
         const int cg = cg0 + tid % per_pass, rl = tid / per_pass;
-        float mu[8], rs[8];
+        float mu[8], rs[8], sc[8], sh[8];
         V8<float>::ld(mean + cg * 8, mu);
         V8<float>::ld(rstd + cg * 8, rs);
+        if (scale) { V8<float>::ld(scale + cg * 8, sc); V8<float>::ld(shift + cg * 8, sh); }
 #pragma unroll
         for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
         if (rl < lanes) {
@@ -215,10 +217,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
                 V8<T>::ld(z + off, q.zv);
                 if (a) V8<T>::ld(a + off, q.av);
                 if (g2) V8<T>::ld(g2 + off, q.g2v);
+                if (scale) {   // sign source: the pre-activation rebuilt from z (pai_conv_dgrad_bn's two-pass form)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) q.av[k] = fmaf(q.zv[k], sc[k], sh[k]);
+                }
             };
             auto consume = [&](int64_t r, const Row& q) {
                 float d[8];
-                if (a) {
+                if (a || scale) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) d[k] = q.gv[k] * act_grad(q.av[k], act1);
                     if (g2) {
@@ -300,6 +306,36 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* partials, 
         if (dbeta) dbeta[c] += (float)s1;
         if (dgamma) dgamma[c] += (float)s2;
     }
+}
+
+// pai_conv_dgrad_bn for the kernel families without the fused store: in place over the plain input gradient
+int bn_bwd_reduce_affine(int dtype, void* g1_du, int act1, const void* g2, int act2, const void* z, int64_t M, int C,
+                         const float* scale, const float* shift, const float* mean, const float* rstd,
+                         float* partials, hipStream_t s) {
+    PAI_CHECK(C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "pai_conv_dgrad_bn: C1=%d must be 8 * 2^k", C);
+    const int rows = pai_bn_bwd_partial_rows(M);
+    const int64_t rpb = (M + rows - 1) / rows;
+    // without an affine map the stored tensor itself carries the sign
+    const void* a = scale ? nullptr : z;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1_du, act1,
+                           (const float*)g2, act2, (const float*)a, (const float*)z, M, C, rpb, mean, rstd,
+                           (float*)g1_du, partials, scale, shift);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1_du, act1,
+                           (const bf16_t*)g2, act2, (const bf16_t*)a, (const bf16_t*)z, M, C, rpb, mean, rstd,
+                           (bf16_t*)g1_du, partials, scale, shift);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pai_bn_bwd_finalize(const float* partials, int rows, int C, float* sums, float* dgamma,
+                                   float* dbeta, void* stream) {
+    PAI_CHECK(partials && sums && rows > 0 && C > 0, "pai_bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials, rows, C,
+                       sums, dgamma, dbeta);
+    PAI_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int act2,

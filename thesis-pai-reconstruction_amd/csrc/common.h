@@ -117,8 +117,15 @@ struct FwdArgs {
     float* stats;   // [nphase*mtiles][2][Cout]
     int eact;
     int skip_d1;    // only write the D2 part (pai_conv_dgrad only_c2)
-    const void* mask;  // D1-shaped activations: the D1 output is multiplied by mask_act'(mask) (pai_conv_dgrad_act)
-    int mask_act;
+    // Backward of the layer that produced x1, fused into the store of the D1 output (pai_conv_dgrad_act,
+    // pai_conv_dgrad_bn):  dx1 = bact1'(pre) * dgrad + bact2'(pre) * badd,  pre = bz * bscale + bshift
+    // (bscale == NULL: pre = bz, the stored activation).  With bpart the BatchNorm-backward partial sums
+    // [rows][2][D1] = (sum dx1, sum dx1 * (bz - bmean) * brstd) are written, one row per output tile.
+    const void* bz;
+    const void* badd;
+    const float *bscale, *bshift, *bmean, *brstd;
+    int bact1, bact2;
+    float* bpart;
 };
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);

@@ -71,12 +71,35 @@ static FwdCfg fwd_cfg(const GG& g) {
         return c;
     }
     const int tiles = cdiv(g.M, 128) * ntiles * g.nphase;
-    if (tiles >= 192 || niter < 8) return c;
-    int ks = 768 / tiles;
-    if (ks > niter / 2) ks = niter / 2;
-    if (ks < 1) ks = 1;
-    while (ks > 1 && (niter % ks)) --ks;  // every split gets the same number of iterations
-    c.ksplit = ks;
+    if (tiles >= 768 || niter < 8) return c;
+    static const int fixed = getenv("PAI_FWD_KSPLIT") ? atoi(getenv("PAI_FWD_KSPLIT")) : 0;
+    if (fixed > 0) {
+        int ks = fixed > niter / 2 ? niter / 2 : fixed;
+        while (ks > 1 && (niter % ks)) --ks;
+        c.ksplit = ks;
+        return c;
+    }
+    // Split count by a small cost model (us), fitted to the per-layer timings of scripts/bench_conv.py:
+    // a K iteration of one workgroup takes ~1.0 us alone on its CU and ~1.3 us with three resident
+    // (which then progress together); a split adds one fp32 slab written and read back at ~5 TB/s plus
+    // the finish launch.  Every split gets the same number of iterations (ks divides niter).
+    const double out_bytes = (double)g.nphase * g.M * g.Cout * 4.0;
+    double best = 1e30;
+    int best_ks = 1;
+    for (int ks = 1; ks <= niter / 2; ++ks) {
+        if (niter % ks) continue;
+        const double wgs = (double)tiles * ks;
+        double t;
+        if (wgs <= 768.0) {
+            const double occ = wgs <= 256.0 ? 1.0 : wgs / 256.0;
+            t = (niter / ks) * (0.85 + 0.15 * occ);
+        } else {
+            t = cdiv((int64_t)wgs, 768) * (niter / ks) * 1.3;
+        }
+        if (ks > 1) t += 3.0 + 2.0 * ks * out_bytes / 5e6;
+        if (t < best) { best = t; best_ks = ks; }
+    }
+    c.ksplit = best_ks;
     return c;
 }
 
@@ -85,8 +108,9 @@ constexpr int FIN_ROWS = 16;   // rows per split-K finish workgroup (= granulari
 int fwd_mfma_ksplit(const GG& g) { return fwd_cfg(g).ksplit; }
 
 int64_t fwd_mfma_workspace_bytes(const GG& g) {
-    if (fwd_cfg(g).ksplit <= 1) return 0;
-    return (int64_t)g.nphase * g.M * g.Cout * 4;
+    const int ks = fwd_cfg(g).ksplit;
+    if (ks <= 1) return 0;
+    return (int64_t)ks * g.nphase * g.M * g.Cout * 4;   // one fp32 slab per K split
 }
 
 // the split actually used: only when the registered scratch is large enough
@@ -141,17 +165,72 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // BM x BN x 64 tile, BM/64 x 2 waves of 64 x (BN/2).  DB = double-buffered LDS: the LDS-DMA of tile
 // k+1 is issued before tile k is consumed and retired with a COUNTED s_waitcnt vmcnt + raw s_barrier
 // (a __syncthreads() would drain it: guide "Pipelining across barriers").
-// 8 bf16 gradients times act'(8 bf16 activations), rounded back to bf16
-__device__ __forceinline__ uint4 mask_frag(uint4 gq, uint4 aq, int act) {
-    const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w}, aw[4] = {aq.x, aq.y, aq.z, aq.w};
+// Producer backward on one 16-B chunk (8 channels) of the staged bf16 gradient tile:
+//   du = act1'(pre) * g + act2'(pre) * add,  pre = z * sc + sh per channel (affine) or z itself,
+// rounded to bf16; with `sums` the BatchNorm-backward sums are accumulated from the value as stored
+// (what pai_bn_bwd_apply reads back): s1 += du, s2 += du * (z - mu) * rs.  Same arithmetic as
+// bn_bwd_reduce_k / act_bwd_k on the bf16-rounded gradient.
+struct BwdParams { float sc[8], sh[8], mu[8], rs[8]; };
+__device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdParams& P) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        P.sc[k] = a.bscale ? a.bscale[c + k] : 1.f;
+        P.sh[k] = a.bscale ? a.bshift[c + k] : 0.f;
+        P.mu[k] = a.bpart ? a.bmean[c + k] : 0.f;
+        P.rs[k] = a.bpart ? a.brstd[c + k] : 0.f;
+    }
+}
+__device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool has_add, bool affine, bool sums,
+                                           int act1, int act2, const BwdParams& P, float* s1, float* s2) {
+    const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w}, zw[4] = {zq.x, zq.y, zq.z, zq.w}, aw[4] = {aq.x, aq.y, aq.z, aq.w};
     unsigned o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
-        const float a0 = __uint_as_float(aw[k] << 16), a1 = __uint_as_float(aw[k] & 0xffff0000u);
-        o[k] = pk2bf(g0 * act_grad(a0, act), g1 * act_grad(a1, act));
+        const float z0 = __uint_as_float(zw[k] << 16), z1 = __uint_as_float(zw[k] & 0xffff0000u);
+        const float p0 = affine ? fmaf(z0, P.sc[2 * k], P.sh[2 * k]) : z0;
+        const float p1 = affine ? fmaf(z1, P.sc[2 * k + 1], P.sh[2 * k + 1]) : z1;
+        float d0 = g0 * act_grad(p0, act1), d1 = g1 * act_grad(p1, act1);
+        if (has_add) {
+            const float a0 = __uint_as_float(aw[k] << 16), a1 = __uint_as_float(aw[k] & 0xffff0000u);
+            d0 = fmaf(a0, act_grad(p0, act2), d0);
+            d1 = fmaf(a1, act_grad(p1, act2), d1);
+        }
+        o[k] = pk2bf(d0, d1);
+        if (sums) {
+            const float r0 = __uint_as_float(o[k] << 16), r1 = __uint_as_float(o[k] & 0xffff0000u);
+            s1[2 * k] += r0;
+            s1[2 * k + 1] += r1;
+            s2[2 * k] = fmaf(r0, (z0 - P.mu[2 * k]) * P.rs[2 * k], s2[2 * k]);
+            s2[2 * k + 1] = fmaf(r1, (z1 - P.mu[2 * k + 1]) * P.rs[2 * k + 1], s2[2 * k + 1]);
+        }
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// Per-tile reduction of the chunk sums: lanes of a wave that own the same chunk (lane % CPR) first, then the
+// waves through `sred` [NW][2][BN]; thread c < BN writes column c of the tile's partial row.
+template <int BN, int CPR, int NW>
+__device__ __forceinline__ void bwd_write_partials(float* sred, const float* s1, const float* s2, int tid,
+                                                   float* row_dst, int D1) {
+    const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float a = s1[k], b = s2[k];
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (lane < CPR) {
+            sred[(wid * 2 + 0) * BN + lane * 8 + k] = a;
+            sred[(wid * 2 + 1) * BN + lane * 8 + k] = b;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { a += sred[(w * 2 + 0) * BN + tid]; b += sred[(w * 2 + 1) * BN + tid]; }
+        row_dst[tid] = a;
+        row_dst[D1 + tid] = b;
+    }
 }
 
 template <int BM, int BN, bool SPLITK, bool DB, int WR = 64>   // WR: output rows per wave (64 or 32)
@@ -341,8 +420,11 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
     }
 
     if (SPLITK) {
-        // fp32 partial tile -> scratch [phase][m][Cout]; splitk_finish_k applies the epilogue
-        float* dst = ws + ((size_t)ph * g.M + m0) * g.Cout + n0;
+        // fp32 partial tile -> this split's own slab [split][phase][m][Cout], plain stores: float atomics
+        // run at ~1.3 TB/s chip-wide against ~6 TB/s for stores, and at 16-64 splits the added bytes
+        // (splits x output) were the whole cost of the bottleneck layers.  splitk_finish_k sums the slabs
+        // in a fixed order (deterministic) and applies the epilogue.
+        float* dst = ws + ((size_t)(ks * g.nphase + ph) * g.M + m0) * g.Cout + n0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -351,7 +433,7 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
                 if (m0 + row < g.M) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        atomicAdd(dst + (size_t)row * g.Cout + wn * (BN / 2) + nt * 16 + fr, acc[mt][nt][r]);
+                        dst[(size_t)row * g.Cout + wn * (BN / 2) + nt * 16 + fr] = acc[mt][nt][r];
                 }
             }
         return;
@@ -411,12 +493,20 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
     if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
     else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
     else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
-    // activation backward of the producer fused into the store: same values as storing bf16 and running
-    // pai_act_bwd over it (the product is formed from the bf16-rounded gradient)
-    const bf16_t* mask = (a.mask && !a.yact && n0 < g.D1) ? (const bf16_t*)a.mask : nullptr;
+    // backward of the producer fused into the store: same values as storing bf16 and running
+    // pai_act_bwd / pai_bn_bwd_reduce over it (the product is formed from the bf16-rounded gradient)
+    const bool bwd = a.bz && !a.yact && n0 < g.D1;   // uniform per workgroup
+    const bf16_t* bzp = (const bf16_t*)a.bz;
+    const bf16_t* bap = (const bf16_t*)a.badd;
+    const bool bsum = bwd && a.bpart;
     constexpr int CPR = BN / 8;        // 16-B chunks per row
     constexpr int ORP = NTHR / CPR;    // rows per pass
     const int oc = tid % CPR, orow0 = tid / CPR;
+    BwdParams BP;
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+    if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
 #pragma unroll
     for (int p = 0; p < BM / ORP; ++p) {
         const int row = orow0 + p * ORP;
@@ -427,85 +517,111 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
             const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
             uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
             const size_t off = pix * dstride + dcol + oc * 8;
-            if (mask) o = mask_frag(o, *(const uint4*)(mask + off), a.mask_act);
+            if (bwd)
+                o = bwd_chunk(o, *(const uint4*)(bzp + off), bap ? *(const uint4*)(bap + off) : make_uint4(0, 0, 0, 0),
+                              bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
             *(uint4*)(dst + off) = o;
         }
     }
+    if (bsum)
+        bwd_write_partials<BN, CPR, NTHR / 64>(sstat, bs1, bs2, tid,
+                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1);
 }
 
-// Split-K epilogue: scratch [phase][M][Cout] fp32 -> bias, BN partial statistics per 128-row tile,
-// activation, bf16 store (two destinations), and the scratch is returned to all-zero.
-// thread = (8-channel group, row lane): statistics accumulate in registers over the lane's rows and
-// are combined across lanes through LDS (no atomics, deterministic).
-__global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, float* ws, int mtiles) {
-    constexpr int MBM = FIN_ROWS;
-    __shared__ float red[2][256][8];
+// Split-K epilogue: sums the fp32 slabs [split][phase][M][Cout] in split order, then bias, BN partial
+// statistics per 16-row tile, activation, bf16 store (two destinations, optional activation-backward
+// mask).  block = 16 rows x 128 channels, thread = (row, 8-channel group): the `ksplit` 32-B loads of a
+// thread are independent, statistics meet through LDS (no atomics, deterministic).
+constexpr int FIN_COLS = 128;
+__global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, const float* ws, int mtiles, int ksplit) {
+    __shared__ float red[2][FIN_ROWS][FIN_COLS + 8];
     const int tid = threadIdx.x;
-    const int bm = blockIdx.x, ph = blockIdx.y;
-    const int m0 = bm * MBM;
-    const int cgroups = g.Cout / 8;
+    const int bm = blockIdx.x, ph = blockIdx.y, cb = blockIdx.z;
+    const int row = tid >> 4, cgl = tid & 15;
+    const int m = bm * FIN_ROWS + row;
+    const int c0 = cb * FIN_COLS + cgl * 8;
+    const bool valid = m < g.M && c0 < g.Cout;
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
-    const int rows = min(MBM, g.M - m0);
-    for (int cg0 = 0; cg0 < cgroups; cg0 += 256) {
-        const int per_pass = min(cgroups - cg0, 256);
-        int lanes = 1;
-        while (lanes * 2 * per_pass <= 256) lanes *= 2;
-        const int cg = cg0 + tid % per_pass, rl = tid / per_pass;
-        const int c0 = cg * 8;
-        float sb[8], sq[8], bias[8];
+    float v[8], bs1[8], bs2[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { sb[k] = sq[k] = 0.f; bias[k] = a.bias ? a.bias[c0 + k] : 0.f; }
-        if (rl < lanes) {
-            for (int row = rl; row < rows; row += lanes) {
-                const int m = m0 + row;
-                float* src = ws + ((size_t)ph * g.M + m) * g.Cout + c0;
-                const float4 v0 = *(float4*)src, v1 = *(float4*)(src + 4);
-                *(float4*)src = make_float4(0.f, 0.f, 0.f, 0.f);
-                *(float4*)(src + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                unsigned packed[4];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k] += bias[k];
-                    sb[k] += v[k];
-                    sq[k] = fmaf(v[k], v[k], sq[k]);
-                    if (eact == PAI_ACT_LRELU) v[k] = fmaxf(v[k], 0.2f * v[k]);
-                    else if (eact == PAI_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    packed[k] = pk2bf(v[2 * k], v[2 * k + 1]);
-                int n, gy, gx;
-                decode_row(g, m, n, gy, gx);
-                const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-                bf16_t* dst;
-                if (a.yact) dst = (bf16_t*)a.yact + pix * g.Cout + c0;
-                else if (c0 < g.D1) dst = (bf16_t*)a.y1 + pix * g.D1 + c0;
-                else dst = (bf16_t*)a.y2 + pix * g.D2 + (c0 - g.D1);
-                uint4 o = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-                if (a.mask && !a.yact && c0 < g.D1)
-                    o = mask_frag(o, *(const uint4*)((const bf16_t*)a.mask + pix * g.D1 + c0), a.mask_act);
-                *(uint4*)dst = o;
-            }
+    for (int k = 0; k < 8; ++k) v[k] = bs1[k] = bs2[k] = 0.f;
+    if (valid) {
+        const size_t slab = (size_t)g.nphase * g.M * g.Cout;
+        const float* src = ws + ((size_t)ph * g.M + m) * g.Cout + c0;
+#pragma unroll 4
+        for (int s = 0; s < ksplit; ++s) {
+            const float4 v0 = *(const float4*)(src + s * slab), v1 = *(const float4*)(src + s * slab + 4);
+            v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w;
+            v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
         }
-        if (a.stats) {
+        if (a.bias) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                red[0][tid][k] = (rl < lanes) ? sb[k] : 0.f;
-                red[1][tid][k] = (rl < lanes) ? sq[k] : 0.f;
-            }
-            __syncthreads();
-            if (tid < per_pass) {
-                float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + c0;
+            for (int k = 0; k < 8; ++k) v[k] += a.bias[c0 + k];
+        }
+    }
+    if (a.stats) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float t1 = 0.f, t2 = 0.f;
-                    for (int l = 0; l < lanes; ++l) { t1 += red[0][tid + l * per_pass][k]; t2 += red[1][tid + l * per_pass][k]; }
-                    dst[k] = t1;
-                    dst[g.Cout + k] = t2;
-                }
-            }
-            __syncthreads();
+        for (int k = 0; k < 8; ++k) {
+            red[0][row][cgl * 8 + k] = v[k];          // rows beyond M contribute 0
+            red[1][row][cgl * 8 + k] = v[k] * v[k];
+        }
+    }
+    if (valid) {
+        unsigned packed[4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (eact == PAI_ACT_LRELU) v[k] = fmaxf(v[k], 0.2f * v[k]);
+            else if (eact == PAI_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) packed[k] = pk2bf(v[2 * k], v[2 * k + 1]);
+        int n, gy, gx;
+        decode_row(g, m, n, gy, gx);
+        const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
+        bf16_t* dst;
+        if (a.yact) dst = (bf16_t*)a.yact + pix * g.Cout + c0;
+        else if (c0 < g.D1) dst = (bf16_t*)a.y1 + pix * g.D1 + c0;
+        else dst = (bf16_t*)a.y2 + pix * g.D2 + (c0 - g.D1);
+        uint4 o = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        if (a.bz && !a.yact && c0 < g.D1) {
+            BwdParams BP;
+            bwd_load_params(a, c0, BP);
+            const size_t off = pix * g.D1 + c0;
+            const bf16_t* bap = (const bf16_t*)a.badd;
+            o = bwd_chunk(o, *(const uint4*)((const bf16_t*)a.bz + off),
+                          bap ? *(const uint4*)(bap + off) : make_uint4(0, 0, 0, 0), bap != nullptr,
+                          a.bscale != nullptr, a.bpart != nullptr, a.bact1, a.bact2, BP, bs1, bs2);
+        }
+        *(uint4*)dst = o;
+    }
+    if (a.stats) {
+        __syncthreads();
+        const int c = cb * FIN_COLS + tid;
+        if (tid < FIN_COLS && c < g.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < FIN_ROWS; ++r) { t1 += red[0][r][tid]; t2 += red[1][r][tid]; }
+            float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + c;
+            dst[0] = t1;
+            dst[g.Cout] = t2;
+        }
+    } else if (a.bpart && a.bz) {
+        // BatchNorm-backward partial sums of the D1 channels, one row per 16-row tile (rows beyond M and
+        // channels of the D2 part contribute zeros and are not written)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[0][row][cgl * 8 + k] = bs1[k];
+            red[1][row][cgl * 8 + k] = bs2[k];
+        }
+        __syncthreads();
+        const int c = cb * FIN_COLS + tid;
+        if (tid < FIN_COLS && c < g.D1) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < FIN_ROWS; ++r) { t1 += red[0][r][tid]; t2 += red[1][r][tid]; }
+            float* dst = a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + c;
+            dst[0] = t1;
+            dst[g.D1] = t2;
         }
     }
 }
@@ -812,10 +928,18 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : 4) void gg_fwd_pat
     if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
     else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
     else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
-    const bf16_t* mask = (a.mask && !a.yact && n0 < g.D1) ? (const bf16_t*)a.mask : nullptr;
+    const bool bwd = a.bz && !a.yact && n0 < g.D1;   // uniform per workgroup
+    const bf16_t* bzp = (const bf16_t*)a.bz;
+    const bf16_t* bap = (const bf16_t*)a.badd;
+    const bool bsum = bwd && a.bpart;
     constexpr int CPR = BN / 8;        // 16-B chunks per row
     constexpr int ORP = NTHR / CPR;    // rows per pass
     const int oc = tid % CPR, orow0 = tid / CPR;
+    BwdParams BP;
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+    if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
 #pragma unroll
     for (int p = 0; p < BM / ORP; ++p) {
         const int row = orow0 + p * ORP;
@@ -823,15 +947,20 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : 4) void gg_fwd_pat
         const size_t pix = (size_t)(img * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
         uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
         const size_t off = pix * dstride + dcol + oc * 8;
-        if (mask) o = mask_frag(o, *(const uint4*)(mask + off), a.mask_act);
+        if (bwd)
+            o = bwd_chunk(o, *(const uint4*)(bzp + off), bap ? *(const uint4*)(bap + off) : make_uint4(0, 0, 0, 0),
+                          bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
         *(uint4*)(dst + off) = o;
     }
+    if (bsum)
+        bwd_write_partials<BN, CPR, NTHR / 64>(sstat, bs1, bs2, tid,
+                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1);
 }
 
 template <int BM, int BN, bool DB, int WR = 64>
 static size_t fwd_lds_bytes() {
     const size_t main_loop = (size_t)(DB ? 2 : 1) * (BM * 128 + BN * 128);
-    const size_t epilogue = BM * (BN * 2 + 16) + (BM / WR) * 2 * BN * sizeof(float);
+    const size_t epilogue = BM * (BN * 2 + 16) + (BM / WR * 2) * 2 * BN * sizeof(float);   // staged tile + [waves][2][BN]
     return main_loop > epilogue ? main_loop : epilogue;
 }
 
@@ -863,7 +992,8 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         if (c.bn == 128) FWD_LAUNCH(128, 128, true, false); else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
         const int ftiles = cdiv(g.M, FIN_ROWS);
-        hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase), dim3(256), 0, s, g, a, g_workspace, ftiles);
+        hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
+                           g_workspace, ftiles, c.ksplit);
     } else {
         PatchGeo pg;
         const int prow = patch_rows(g, c);
@@ -874,7 +1004,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             typedef PatchDims<256> PD;
             const bool db = (dbb & 1) != 0;
             const size_t lds = PD::BYTES + (size_t)128 * 128 * (db ? 2 : 1);
-            const size_t epi = 256 * ((size_t)128 * 2 + 16) + 4 * 2 * 128 * sizeof(float);
+            const size_t epi = 256 * ((size_t)128 * 2 + 16) + 8 * 2 * 128 * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
             static bool attr = false;
             if (!attr) {
@@ -894,7 +1024,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             typedef PatchDims<128> PD;
             const bool db = (dbb & (c.bn == 128 ? 2 : 4)) != 0;
             const size_t lds = PD::BYTES + (size_t)c.bn * 128 * (db ? 2 : 1);
-            const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 2 * 2 * c.bn * sizeof(float);
+            const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 4 * 2 * c.bn * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
             if (c.bn == 128) {
                 if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
@@ -1100,7 +1230,8 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
             float t = 0.f;
 #pragma unroll
             for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
-            atomicAdd(a.dbias + co0 + tid, t);
+            if (splits == 1 && g.nphase == 1) a.dbias[co0 + tid] += t;
+            else atomicAdd(a.dbias + co0 + tid, t);
         }
     }
 
@@ -1116,7 +1247,13 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wm * (BMC / 2) + mt * 16 + fg * 4 + r;
-                if (co < g.Cout) atomicAdd(a.dw + (size_t)co * g.wtaps * g.Cin + cbase, acc[mt][nt][r]);
+                if (co < g.Cout) {
+                    float* pw = a.dw + (size_t)co * g.wtaps * g.Cin + cbase;
+                    // un-split: this workgroup is the only writer of the element (taps of different phases are
+                    // disjoint) -> plain read-modify-write at store bandwidth instead of the ~1.3 TB/s atomic rate
+                    if (splits == 1) *pw += acc[mt][nt][r];
+                    else atomicAdd(pw, acc[mt][nt][r]);
+                }
             }
         }
     }
@@ -1282,7 +1419,8 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
             float t = 0.f;
 #pragma unroll
             for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
-            atomicAdd(a.dbias + co0 + tid, t);
+            if (splits == 1 && g.nphase == 1) a.dbias[co0 + tid] += t;
+            else atomicAdd(a.dbias + co0 + tid, t);
         }
     }
 #pragma unroll
@@ -1294,7 +1432,13 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wm * (BMC / 2) + mt * 16 + fg * 4 + r;
-                if (co < g.Cout) atomicAdd(a.dw + (size_t)co * g.wtaps * g.Cin + cbase, acc[mt][nt][r]);
+                if (co < g.Cout) {
+                    float* pw = a.dw + (size_t)co * g.wtaps * g.Cin + cbase;
+                    // un-split: this workgroup is the only writer of the element (taps of different phases are
+                    // disjoint) -> plain read-modify-write at store bandwidth instead of the ~1.3 TB/s atomic rate
+                    if (splits == 1) *pw += acc[mt][nt][r];
+                    else atomicAdd(pw, acc[mt][nt][r]);
+                }
             }
         }
     }
@@ -1317,6 +1461,11 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     const int max_splits = cdiv(g.M, min_rows);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    // An un-split launch owns every dW element in exactly one workgroup and updates it with a plain
+    // read-modify-write; a split one adds splits x |dW| bytes of float atomics (~1.3 TB/s chip-wide).  For the
+    // bottleneck layers (<= 2048 pixels, 4-8 M weights) those atomics were the whole cost.
+    static const int unsplit_rows = getenv("PAI_WGRAD_UNSPLIT_ROWS") ? atoi(getenv("PAI_WGRAD_UNSPLIT_ROWS")) : 2048;
+    if ((tiles >= 256 && g.M <= unsplit_rows) || (tiles >= 512 && g.M <= 2 * unsplit_rows)) splits = 1;
     int rows = cdiv(cdiv(g.M, splits), 64) * 64;
     splits = cdiv(g.M, rows);
     static const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;

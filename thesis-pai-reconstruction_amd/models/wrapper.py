@@ -85,11 +85,30 @@ class UnetWrapper(LightningModule):
         return (self.reuse_generator_forward and getattr(self.unet, "supports_forward_reuse", False)
                 and self.unet.training)
 
+    def _metrics_async(self, pred, target):
+        if not pred.is_cuda:
+            return None
+        side = getattr(self, "_metrics_stream", None)
+        if side is None:
+            side = torch.cuda.Stream(device=pred.device)
+            object.__setattr__(self, "_metrics_stream", side)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            return PF.metrics_of_normalized(pred, target)
+
+    def _metrics_join(self, vals):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._metrics_stream)
+        for v in vals:
+            v.record_stream(cur)   # allocated on the side stream's pool, consumed on this one
+        return vals
+
     def training_step(self, batch, batch_idx):
         """Reference models/wrapper.py:117-162 (manual optimisation, D step then G step)."""
         x, target = batch
         reuse = self.loss_type == "gan" and self._can_reuse_forward()
         pred_g = None
+        metrics_early = None
 
         if self.loss_type == "gan":
             opt_d = self.optimizers()[1]
@@ -100,6 +119,11 @@ class UnetWrapper(LightningModule):
                     pred_g = self.unet(x)
                 finally:
                     self.unet.bn_updates_per_forward = 1
+
+                # The per-step SSIM / PSNR / RMSE (reference models/wrapper.py:150-156) depend only on
+                # (pred, target): they are issued now on a side stream, where their kernels fill the tail
+                # of the discriminator backward instead of extending the generator phase; same values.
+                metrics_early = self._metrics_async(pred_g, target)
 
             # Train discriminator.
             self.toggle_optimizer(opt_d)
@@ -130,7 +154,9 @@ class UnetWrapper(LightningModule):
         loss = self.loss(x, pred, target)
 
         self.log("loss", loss, prog_bar=True)
-        if pred.is_cuda:
+        if metrics_early is not None:
+            s, p, r = self._metrics_join(metrics_early)
+        elif pred.is_cuda:
             s, p, r = PF.metrics_of_normalized(pred, target)
         else:
             den_pred, den_target = denormalize(pred), denormalize(target)
