@@ -141,6 +141,33 @@ int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void* w_dgrad, 
 int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* dx1,
                        void* dx2, const void* a1, int act1, void* stream);
 
+/* pai_conv_dgrad with the backward of the layer that PRODUCED x1 fused into the store of dx1 --
+ * the activation in front of this convolution and, optionally, the first pass of the BatchNorm
+ * backward of that layer (nn.BatchNorm2d of EncoderBlock / DecoderBlock, models/pix2pix.py:70,106;
+ * nn.LeakyReLU / nn.ReLU at :62,98; replaces the threshold_backward + native_batch_norm_backward
+ * reductions autograd would run on the materialised gradient):
+ *   pre  = z * scale + shift            (scale == NULL: pre = z, e.g. a stored activation)
+ *   dx1  = act1'(pre) * conv_backward_input(dy, w)[:, :C1] + act2'(pre) * add
+ *   partials[row] = (sum dx1, sum dx1 * (z - mean) * rstd) per channel over the rows of one output
+ *                   tile, from the value as stored; *partial_rows rows are written.
+ * dx2 as pai_conv_dgrad.  Continue with pai_bn_bwd_finalize(partials, *partial_rows, C1, ...) and
+ * pai_bn_bwd_apply(dx1, z, ...).  The matrix-core kernels do this in their store (no extra pass
+ * over dx1); the other kernel families run the same arithmetic as a second pass in place.
+ * z, add: storage dtype, shaped like dx1.  scale/shift/mean/rstd: fp32 [C1]. */
+typedef struct pai_bwd_epilogue {
+    const void* z;
+    const void* add;       /* or NULL */
+    const float* scale;    /* or NULL (then shift is NULL too) */
+    const float* shift;
+    const float* mean;     /* needed with partials */
+    const float* rstd;
+    float* partials;       /* fp32 [pai_conv_dgrad_bn_rows_max(d)][2][C1], or NULL: no sums */
+    int32_t act1, act2;    /* PAI_ACT_NONE | PAI_ACT_RELU | PAI_ACT_LRELU */
+} pai_bwd_epilogue;
+int pai_conv_dgrad_bn_rows_max(const pai_conv_desc* d);
+int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* dx1,
+                      void* dx2, const pai_bwd_epilogue* e, int* partial_rows, void* stream);
+
 /* dw += conv_backward_weight(act(x1|x2), dy)   (fp32, fwd pack; caller zeroes it first)
  * dbias += sum over N,OH,OW of dy              (fp32 [Cout], or NULL) */
 int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
@@ -181,6 +208,10 @@ int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int a
                       const void* z, int64_t M, int C, const float* mean, const float* rstd,
                       void* du, float* partials, float* sums, float* dgamma, float* dbeta,
                       void* stream);
+/* Second half of pai_bn_bwd_reduce on its own: reduces `rows` partial rows [2][C] (from
+ * pai_conv_dgrad_bn) in fp64 into sums [2][C] and accumulates dbeta += sums[0], dgamma += sums[1]. */
+int pai_bn_bwd_finalize(const float* partials, int rows, int C, float* sums, float* dgamma,
+                        float* dbeta, void* stream);
 /* Backward, pass 2:  dz = gamma*rstd * (du - sums[0]/M - xhat*sums[1]/M). */
 int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
                      const float* mean, const float* rstd, const float* gamma,

@@ -37,6 +37,11 @@ CASES = [
     # >= 512 tiles of 16 x 16 output pixels: the 8-wave variant of the patch kernel (forward of both)
     ("enc_patch256", 0, 2, 8, 256, 256, 64, 0, 128, 0, 0),
     ("dec_patch256", 1, 2, 8, 64, 64, 128, 0, 128, 1, 0),
+    # input gradient on the 16 x 16 patch kernel (dgrad of a stride-2 conv = 4 phases x 128 tiles)
+    ("enc_dgrad256", 0, 2, 8, 128, 128, 128, 0, 128, 0, 0),
+    # long reduction, few output rows: split-K slabs + finish kernel in forward and input gradient
+    ("enc_splitk", 0, 2, 4, 8, 8, 256, 0, 256, 0, 0),
+    ("dec_splitk", 1, 2, 4, 4, 4, 256, 256, 256, 1, 1),
 ]
 
 
@@ -129,12 +134,56 @@ def test_conv_family(pai, case, dtype):
     dx2c = torch.zeros_like(dx2) if C2 else None
     ops.conv_dgrad_act(d, DY, wd, one, dx2c, A1, ops.ACT_LRELU)
     torch.cuda.synchronize()
-    if ops.conv_workspace_bytes(d, 1) == 0:
-        assert torch.equal(one, two), name
+    # (split-K included: the per-split slabs are summed in a fixed order)
+    assert torch.equal(one, two), name
+    if C2:
+        assert torch.equal(dx2c, dx2), name
+
+    # producer backward in the dgrad store (pai_conv_dgrad_bn) == dgrad, then pai_act_bwd / pai_bn_bwd_reduce
+    if C1 % 8 == 0 and ((C1 // 8) & (C1 // 8 - 1)) == 0:
+        M = N * H * W
+        Z = nhwc(q(rnd((N, C1, H, W), 7), dtype), dtype)
+        ADD = nhwc(q(rnd((N, C1, H, W), 8), dtype), dtype)
+        # (a) no norm: du = lrelu'(z) * g + add
+        two = torch.empty_like(dx1)
+        ops.act_bwd(dtype, dx1, ops.ACT_LRELU, ADD, ops.ACT_NONE, Z, dx1.numel(), two)
+        one = torch.zeros_like(dx1)
+        dx2c = torch.zeros_like(dx2) if C2 else None
+        rows = ops.conv_dgrad_bn(d, DY, wd, one, dx2c, Z, ops.ACT_LRELU, ADD, ops.ACT_NONE)
+        torch.cuda.synchronize()
+        assert rows == 0 and torch.equal(one, two), name
         if C2:
             assert torch.equal(dx2c, dx2), name
-    else:   # split-K sums its partial products with fp32 atomics: the order, and so the last bit, varies per launch
-        assert rel_err(one.float().cpu(), two.float().cpu()) < 2.0 ** -7, name
+        # (b) BatchNorm producer read through LeakyReLU by this layer and through ReLU by a skip consumer
+        mean = rnd((C1,), 9, 0.3).to(dev())
+        rstd = (rnd((C1,), 10, 0.2).abs() + 0.5).to(dev())
+        gamma = (rnd((C1,), 11, 0.5) + 1.0).to(dev())
+        beta = rnd((C1,), 12, 0.3).to(dev())
+        scale = gamma * rstd
+        shift = beta - mean * scale
+        Aact = torch.empty_like(Z)
+        ops.bn_apply(dtype, Z, M, C1, scale, shift, ops.ACT_LRELU, Aact)
+        du2 = torch.empty_like(dx1)
+        part2 = torch.zeros(ops.bn_bwd_partial_rows(M) * 2 * C1, dtype=torch.float32, device=dev())
+        sums2 = torch.zeros(2 * C1, dtype=torch.float32, device=dev())
+        dg2, db2 = torch.zeros(C1, device=dev()), torch.zeros(C1, device=dev())
+        ops.bn_bwd_reduce(dtype, dx1, ops.ACT_LRELU, ADD, ops.ACT_RELU, Aact, Z, M, C1, mean, rstd, du2, part2, sums2,
+                          dg2, db2)
+        du1 = torch.zeros_like(dx1)
+        part1 = torch.zeros(ops.conv_dgrad_bn_rows_max(d) * 2 * C1, dtype=torch.float32, device=dev())
+        sums1 = torch.zeros(2 * C1, dtype=torch.float32, device=dev())
+        dg1, db1 = torch.zeros(C1, device=dev()), torch.zeros(C1, device=dev())
+        rows = ops.conv_dgrad_bn(d, DY, wd, du1, dx2c, Z, ops.ACT_LRELU, ADD, ops.ACT_RELU, scale, shift, mean, rstd,
+                                 part1)
+        assert 0 < rows <= ops.conv_dgrad_bn_rows_max(d)
+        ops.bn_bwd_finalize(part1, rows, C1, sums1, dg1, db1)
+        torch.cuda.synchronize()
+        assert torch.equal(du1, du2), name
+        if C2:
+            assert torch.equal(dx2c, dx2), name
+        scl = float(sums2.abs().max()) + 1e-6
+        assert float((sums1 - sums2).abs().max()) / scl < 1e-4, name
+        assert torch.allclose(dg1, sums1[C1:]) and torch.allclose(db1, sums1[:C1])
 
     # ---- weight / bias gradient -----------------------------------------------------------------------
     dw = torch.zeros(wm.numel(), dtype=torch.float32, device=dev())

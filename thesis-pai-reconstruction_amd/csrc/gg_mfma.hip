@@ -168,18 +168,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Producer backward on one 16-B chunk (8 channels) of the staged bf16 gradient tile:
 //   du = act1'(pre) * g + act2'(pre) * add,  pre = z * sc + sh per channel (affine) or z itself,
 // rounded to bf16; with `sums` the BatchNorm-backward sums are accumulated from the value as stored
-// (what pai_bn_bwd_apply reads back): s1 += du, s2 += du * (z - mu) * rs.  Same arithmetic as
-// bn_bwd_reduce_k / act_bwd_k on the bf16-rounded gradient.
-struct BwdParams { float sc[8], sh[8], mu[8], rs[8]; };
+// (what pai_bn_bwd_apply reads back).  Same du as bn_bwd_reduce_k / act_bwd_k on the bf16-rounded gradient.
+struct BwdParams { float sc[8], sh[8]; };
 __device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdParams& P) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         P.sc[k] = a.bscale ? a.bscale[c + k] : 1.f;
         P.sh[k] = a.bscale ? a.bshift[c + k] : 0.f;
-        P.mu[k] = a.bpart ? a.bmean[c + k] : 0.f;
-        P.rs[k] = a.bpart ? a.brstd[c + k] : 0.f;
     }
 }
+__device__ __forceinline__ float bwd_sel(float g, bool pos, int act) {   // act'(pre) * g
+    return act == PAI_ACT_RELU ? (pos ? g : 0.f) : (act == PAI_ACT_LRELU ? (pos ? g : 0.2f * g) : g);
+}
+// s2 accumulates du * z; the tile's sum of du * xhat is rstd * (s2 - mean * s1), formed once per channel in
+// bwd_write_partials (3 vector-ALU operations per element fewer in a store that runs behind every MFMA loop)
 __device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool has_add, bool affine, bool sums,
                                            int act1, int act2, const BwdParams& P, float* s1, float* s2) {
     const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w}, zw[4] = {zq.x, zq.y, zq.z, zq.w}, aw[4] = {aq.x, aq.y, aq.z, aq.w};
@@ -188,21 +190,20 @@ __device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool ha
     for (int k = 0; k < 4; ++k) {
         const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
         const float z0 = __uint_as_float(zw[k] << 16), z1 = __uint_as_float(zw[k] & 0xffff0000u);
-        const float p0 = affine ? fmaf(z0, P.sc[2 * k], P.sh[2 * k]) : z0;
-        const float p1 = affine ? fmaf(z1, P.sc[2 * k + 1], P.sh[2 * k + 1]) : z1;
-        float d0 = g0 * act_grad(p0, act1), d1 = g1 * act_grad(p1, act1);
+        const bool q0 = (affine ? fmaf(z0, P.sc[2 * k], P.sh[2 * k]) : z0) > 0.f;
+        const bool q1 = (affine ? fmaf(z1, P.sc[2 * k + 1], P.sh[2 * k + 1]) : z1) > 0.f;
+        float d0 = bwd_sel(g0, q0, act1), d1 = bwd_sel(g1, q1, act1);
         if (has_add) {
-            const float a0 = __uint_as_float(aw[k] << 16), a1 = __uint_as_float(aw[k] & 0xffff0000u);
-            d0 = fmaf(a0, act_grad(p0, act2), d0);
-            d1 = fmaf(a1, act_grad(p1, act2), d1);
+            d0 += bwd_sel(__uint_as_float(aw[k] << 16), q0, act2);
+            d1 += bwd_sel(__uint_as_float(aw[k] & 0xffff0000u), q1, act2);
         }
         o[k] = pk2bf(d0, d1);
         if (sums) {
             const float r0 = __uint_as_float(o[k] << 16), r1 = __uint_as_float(o[k] & 0xffff0000u);
             s1[2 * k] += r0;
             s1[2 * k + 1] += r1;
-            s2[2 * k] = fmaf(r0, (z0 - P.mu[2 * k]) * P.rs[2 * k], s2[2 * k]);
-            s2[2 * k + 1] = fmaf(r1, (z1 - P.mu[2 * k + 1]) * P.rs[2 * k + 1], s2[2 * k + 1]);
+            s2[2 * k] = fmaf(r0, z0, s2[2 * k]);
+            s2[2 * k + 1] = fmaf(r1, z1, s2[2 * k + 1]);
         }
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
@@ -211,7 +212,7 @@ __device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool ha
 // waves through `sred` [NW][2][BN]; thread c < BN writes column c of the tile's partial row.
 template <int BN, int CPR, int NW>
 __device__ __forceinline__ void bwd_write_partials(float* sred, const float* s1, const float* s2, int tid,
-                                                   float* row_dst, int D1) {
+                                                   float* row_dst, int D1, const float* mean, const float* rstd) {
     const int lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -229,7 +230,7 @@ __device__ __forceinline__ void bwd_write_partials(float* sred, const float* s1,
 #pragma unroll
         for (int w = 0; w < NW; ++w) { a += sred[(w * 2 + 0) * BN + tid]; b += sred[(w * 2 + 1) * BN + tid]; }
         row_dst[tid] = a;
-        row_dst[D1 + tid] = b;
+        row_dst[D1 + tid] = rstd[tid] * (b - mean[tid] * a);   // sum du * xhat from sum du * z
     }
 }
 
@@ -506,26 +507,42 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
     float bs1[8], bs2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+    // The chunks of the producer's tensors are requested four passes at a time, ahead of that batch's
+    // stores: the stores may alias them as far as the compiler knows, and one load -> store round trip per
+    // pass serialised 8 HBM latencies at the tail of every workgroup.
+    constexpr int NP = BM / ORP, NB = NP < 4 ? NP : 4;
     if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
 #pragma unroll
-    for (int p = 0; p < BM / ORP; ++p) {
-        const int row = orow0 + p * ORP;
-        const int m = m0 + row;
-        if (m < g.M) {
+    for (int p0 = 0; p0 < NP; p0 += NB) {
+        size_t offs[NB];
+        uint4 zq[NB], aq[NB];
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int m = m0 + orow0 + (p0 + p) * ORP;
             int n, gy, gx;
-            decode_row(g, m, n, gy, gx);
+            decode_row(g, m < g.M ? m : 0, n, gy, gx);
             const size_t pix = (size_t)(n * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-            uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
-            const size_t off = pix * dstride + dcol + oc * 8;
-            if (bwd)
-                o = bwd_chunk(o, *(const uint4*)(bzp + off), bap ? *(const uint4*)(bap + off) : make_uint4(0, 0, 0, 0),
-                              bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
-            *(uint4*)(dst + off) = o;
+            offs[p] = pix * dstride + dcol + oc * 8;
+            if (bwd) {
+                zq[p] = *(const uint4*)(bzp + offs[p]);
+                aq[p] = bap ? *(const uint4*)(bap + offs[p]) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int row = orow0 + (p0 + p) * ORP;
+            if (m0 + row < g.M) {
+                uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
+                if (bwd)
+                    o = bwd_chunk(o, zq[p], aq[p], bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
+                *(uint4*)(dst + offs[p]) = o;
+            }
         }
     }
     if (bsum)
         bwd_write_partials<BN, CPR, NTHR / 64>(sstat, bs1, bs2, tid,
-                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1);
+                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1,
+                                               a.bmean + n0, a.brstd + n0);
 }
 
 // Split-K epilogue: sums the fp32 slabs [split][phase][M][Cout] in split order, then bias, BN partial
@@ -621,7 +638,7 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, const fl
             for (int r = 0; r < FIN_ROWS; ++r) { t1 += red[0][r][tid]; t2 += red[1][r][tid]; }
             float* dst = a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + c;
             dst[0] = t1;
-            dst[g.D1] = t2;
+            dst[g.D1] = a.brstd[c] * (t2 - a.bmean[c] * t1);
         }
     }
 }
@@ -726,7 +743,7 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 }
 
 template <int BM, int BN, bool DBB>   // DBB: two weight-tile buffers
-__global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : 4) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+__global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
     typedef PatchDims<BM> PD;
     constexpr int NTHR = BM * 2, MT = 4, NT = BN / 32;
     constexpr int RPP = PD::RPP, PJ = PD::PJ, PATCH_PIX = PD::PIX, PATCH_BYTES = PD::BYTES;
@@ -939,22 +956,37 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : 4) void gg_fwd_pat
     float bs1[8], bs2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+    // producer chunks requested four passes at a time, ahead of that batch's stores (see gg_fwd_mfma_k)
+    constexpr int NP = BM / ORP, NB = NP < 4 ? NP : 4;
     if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
 #pragma unroll
-    for (int p = 0; p < BM / ORP; ++p) {
-        const int row = orow0 + p * ORP;
-        const int gy = gy0 + (row >> 4), gx = gx0 + (row & 15);
-        const size_t pix = (size_t)(img * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-        uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
-        const size_t off = pix * dstride + dcol + oc * 8;
-        if (bwd)
-            o = bwd_chunk(o, *(const uint4*)(bzp + off), bap ? *(const uint4*)(bap + off) : make_uint4(0, 0, 0, 0),
-                          bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
-        *(uint4*)(dst + off) = o;
+    for (int p0 = 0; p0 < NP; p0 += NB) {
+        size_t offs[NB];
+        uint4 zq[NB], aq[NB];
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int row = orow0 + (p0 + p) * ORP;
+            const int gy = gy0 + (row >> 4), gx = gx0 + (row & 15);
+            const size_t pix = (size_t)(img * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
+            offs[p] = pix * dstride + dcol + oc * 8;
+            if (bwd) {
+                zq[p] = *(const uint4*)(bzp + offs[p]);
+                aq[p] = bap ? *(const uint4*)(bap + offs[p]) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int row = orow0 + (p0 + p) * ORP;
+            uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
+            if (bwd)
+                o = bwd_chunk(o, zq[p], aq[p], bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
+            *(uint4*)(dst + offs[p]) = o;
+        }
     }
     if (bsum)
         bwd_write_partials<BN, CPR, NTHR / 64>(sstat, bs1, bs2, tid,
-                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1);
+                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1,
+                                               a.bmean + n0, a.brstd + n0);
 }
 
 template <int BM, int BN, bool DB, int WR = 64>

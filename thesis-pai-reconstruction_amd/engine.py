@@ -362,6 +362,12 @@ class UnetEngine:
         for j in range(L):
             if self.dec_bn[j] is not None:
                 mx = max(mx, ops.bn_bwd_partial_rows(N * 4 * eh[L - 1 - j] * ew[L - 1 - j]) * 2 * self.dec_c[j])
+        for i in range(2, L):      # fused first pass of encoder i-1's BatchNorm backward in encoder i's dgrad
+            if self.enc_bn[i - 1] is not None:
+                mx = max(mx, ops.conv_dgrad_bn_rows_max(P["enc_desc"][i]) * 2 * self.enc_c[i - 1])
+        for j in range(1, L - 1):  # ... of decoder j-1's in decoder j's dgrad
+            if self.dec_bn[j - 1] is not None:
+                mx = max(mx, ops.conv_dgrad_bn_rows_max(P["dec_desc"][j]) * 2 * self.dec_c[j - 1])
         P["bwd_partials"] = torch.empty(mx, dtype=torch.float32, device=device)
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["enc_desc"] + P["dec_desc"]
                                  for op in (0, 1)), device)
@@ -538,6 +544,12 @@ class UnetEngine:
         wgrad(d, x1, x2, dh, self.dec_conv[j], True)
         _, wd = self.dec_packs[j].get(dtype)
         ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
+        # From here on every input-gradient launch also runs the first half of the backward of the layer
+        # that PRODUCED its input (activation derivative, the encoder/skip sum, BatchNorm-backward partial
+        # sums) in its store (pai_conv_dgrad_bn): the gradient tensor it writes is already `du`, and
+        # `fused_rows` partial rows wait in P["bwd_partials"] for pai_bn_bwd_finalize.
+        fused_rows = None   # None: the head's thin kernel wrote a plain gradient for decoder L-2
+        part = P["bwd_partials"]
         # BN decoders
         for j in range(L - 2, -1, -1):
             bn, st, conv = self.dec_bn[j], S["dbn"][j], self.dec_conv[j]
@@ -545,12 +557,17 @@ class UnetEngine:
             C = self.dec_c[j]
             n = M * C
             act = ACT_RELU if j < L - 2 else ACT_NONE
-            du, dz = G["du"][:n], G["dz_dec"][j]
-            ops.bn_bwd_reduce(dtype, G["gr"][j], act, None, ACT_NONE, S["r"][j] if act != ACT_NONE else None,
-                              S["w"][j], M, C, st.mean, st.rstd, du, P["bwd_partials"], st.sums,
-                              A.seg(bn.weight), A.seg(bn.bias))
+            dz = G["dz_dec"][j]
+            if fused_rows is None:
+                du = G["du"][:n]
+                ops.bn_bwd_reduce(dtype, G["gr"][j], act, None, ACT_NONE, S["r"][j] if act != ACT_NONE else None,
+                                  S["w"][j], M, C, st.mean, st.rstd, du, part, st.sums,
+                                  A.seg(bn.weight), A.seg(bn.bias))
+            else:
+                du = G["gr"][j]
+                ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
             ops.bn_bwd_apply(dtype, du, S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
-            self._dbg(f"dec{j}.g", G["gr"][j]); self._dbg(f"dec{j}.du", du); self._dbg(f"dec{j}.dz", dz)
+            self._dbg(f"dec{j}.du", du); self._dbg(f"dec{j}.dz", dz)
             d = P["dec_desc"][j]
             if j == 0:
                 x1, x2 = S["z"][L - 1], None
@@ -562,40 +579,46 @@ class UnetEngine:
             wgrad(d, x1, x2, dz, conv, False)
             _, wd = self.dec_packs[j].get(dtype)
             if j == 0:
-                ops.conv_dgrad(d, dz, wd, G["gz_last"], None)
+                # producer: the norm-free last encoder, consumed through ReLU -> dz_last = relu'(z_last) * g
+                fused_rows = ops.conv_dgrad_bn(d, dz, wd, G["dz_enc"][L - 1], None, S["z"][L - 1], ACT_RELU)
             else:
-                ops.conv_dgrad(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j])
-        # last encoder (no norm): d relu(z_last) -> dz_last
+                pst = S["dbn"][j - 1]   # producer: decoder j-1 (BatchNorm, read through ReLU)
+                fused_rows = ops.conv_dgrad_bn(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j], S["w"][j - 1],
+                                               ACT_RELU, None, ACT_NONE, pst.scale, pst.shift, pst.mean, pst.rstd,
+                                               part)
+        # last encoder (no norm)
         i = L - 1
         conv = self.enc_conv[i]
-        n = S["z"][i].numel()
         dz = G["dz_enc"][i]
-        ops.act_bwd(dtype, G["gz_last"], ACT_RELU, None, ACT_NONE, S["z"][i], n, dz)
         d = P["enc_desc"][i]
         wgrad(d, S["a"][i - 1], None, dz, conv, True)
         _, wd = self.enc_packs[i].get(dtype)
-        ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
+
+        def enc_dgrad(i, dz, wd):
+            """Input gradient of encoder i; producer = encoder i-1, read through LeakyReLU here and through
+            ReLU (raw for encoder 0) by its skip decoder: du = lrelu'(pre) * g + relu'(pre) * g_skip."""
+            d = P["enc_desc"][i]
+            if i - 1 == 0:   # bare Conv2d: no norm; the gradient written IS dz of encoder 0
+                return ops.conv_dgrad_bn(d, dz, wd, G["dz_enc"][0], None, S["z"][0], ACT_LRELU, G["gskip"][0], ACT_NONE)
+            pst = S["ebn"][i - 1]
+            return ops.conv_dgrad_bn(d, dz, wd, G["ga"][i - 1], None, S["z"][i - 1], ACT_LRELU, G["gskip"][i - 1],
+                                     ACT_RELU, pst.scale, pst.shift, pst.mean, pst.rstd, part)
+
+        fused_rows = enc_dgrad(i, dz, wd)
         # BN encoders
         for i in range(L - 2, 0, -1):
             bn, st, conv = self.enc_bn[i], S["ebn"][i], self.enc_conv[i]
             M = N * eh[i] * ew[i]
             C = self.enc_c[i]
-            n = M * C
-            du, dz = G["du"][:n], G["dz_enc"][i]
-            ops.bn_bwd_reduce(dtype, G["ga"][i], ACT_LRELU, G["gskip"][i], ACT_RELU, S["a"][i], S["z"][i], M, C,
-                              st.mean, st.rstd, du, P["bwd_partials"], st.sums, A.seg(bn.weight),
-                              A.seg(bn.bias))
+            du, dz = G["ga"][i], G["dz_enc"][i]
+            ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
             ops.bn_bwd_apply(dtype, du, S["z"][i], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
             d = P["enc_desc"][i]
             wgrad(d, S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)
-            ops.conv_dgrad(d, dz, wd, G["ga"][i - 1], None)
-        # encoder 0: d z0 = lrelu'(z0) * g_enc + g_skip   (skip consumed raw by the last decoder)
-        conv = self.enc_conv[0]
-        n = S["z"][0].numel()
-        dz = G["dz_enc"][0]
-        ops.act_bwd(dtype, G["ga"][0], ACT_LRELU, G["gskip"][0], ACT_NONE, S["z"][0], n, dz)
-        wgrad(P["enc_desc"][0], S["x"], None, dz, conv, True)
+            fused_rows = enc_dgrad(i, dz, wd)
+        # encoder 0 (its dz came out of encoder 1's input gradient)
+        wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], self.enc_conv[0], True)
         side.join()
 
 

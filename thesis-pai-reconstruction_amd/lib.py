@@ -31,6 +31,13 @@ class ConvDesc(C.Structure):
                 ("reserved", C.c_int32 * 3)]
 
 
+class BwdEpilogue(C.Structure):
+    """struct pai_bwd_epilogue (include/pai_hip.h)."""
+    _fields_ = [("z", C.c_void_p), ("add", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("partials", C.c_void_p),
+                ("act1", C.c_int32), ("act2", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -56,6 +63,9 @@ SIGNATURES = {
     "pai_conv_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _I, _P]),
     "pai_conv_dgrad_act": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
+    "pai_conv_dgrad_bn_rows_max": (_I, [_D]),
+    "pai_conv_dgrad_bn": (_I, [_D, _P, _P, _P, _P, C.POINTER(BwdEpilogue), C.POINTER(_I), _P]),
+    "pai_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

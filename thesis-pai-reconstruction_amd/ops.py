@@ -177,6 +177,29 @@ def conv_dgrad_act(d, dy, w_dgrad, dx1, dx2, a1, act1):
                                             _stream()), "pai_conv_dgrad_act")
 
 
+def conv_dgrad_bn_rows_max(d) -> int:
+    return L.load().pai_conv_dgrad_bn_rows_max(C.byref(d))
+
+
+def conv_dgrad_bn(d, dy, w_dgrad, dx1, dx2, z, act1, add=None, act2=ACT_NONE, scale=None, shift=None,
+                  mean=None, rstd=None, partials=None) -> int:
+    """Input gradient with the producer's activation / BatchNorm backward (first pass) in its store
+    (pai_conv_dgrad_bn).  Returns the number of partial rows written (0 without `partials`)."""
+    e = L.BwdEpilogue(_p(z), _p(add), _p(scale, torch.float32), _p(shift, torch.float32), _p(mean, torch.float32),
+                      _p(rstd, torch.float32), _p(partials, torch.float32), int(act1), int(act2))
+    rows = C.c_int(0)
+    with _Timed(d, 1):
+        L.check(L.load().pai_conv_dgrad_bn(C.byref(d), _p(dy), _p(w_dgrad), _p(dx1), _p(dx2), C.byref(e),
+                                           C.byref(rows), _stream()), "pai_conv_dgrad_bn")
+    return rows.value
+
+
+def bn_bwd_finalize(partials, rows, C_, sums, dgamma, dbeta):
+    L.check(L.load().pai_bn_bwd_finalize(_p(partials, torch.float32), rows, C_, _p(sums, torch.float32),
+                                         _p(dgamma, torch.float32), _p(dbeta, torch.float32), _stream()),
+            "pai_bn_bwd_finalize")
+
+
 def conv_wgrad(d, x1, x2, dy, dw, dbias=None):
     with _Timed(d, 2):
         L.check(L.load().pai_conv_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw, torch.float32),
