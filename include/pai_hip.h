@@ -62,9 +62,10 @@ typedef struct pai_conv_desc {
     int32_t N, H, W;      /* input batch / height / width */
     int32_t C1, C2;       /* input channels taken from x1 and x2 (C2 = 0: x2 unused) */
     int32_t Cout;         /* output channels */
-    int32_t kernel;       /* 4 */
+    int32_t kernel;       /* 4, or 1: pointwise Conv2d of the attention gates
+                             (models/attention_unet.py:72-84; stride 1, pad 0, one weight tap) */
     int32_t stride;       /* 2 (or 1 for Conv2d) */
-    int32_t pad;          /* 1 */
+    int32_t pad;          /* 1 (0 with kernel 1) */
     int32_t relu1, relu2; /* apply ReLU to x1 / x2 while loading (fused nn.ReLU of the
                              decoder block, models/pix2pix.py:98) */
     int32_t epilogue_act; /* PAI_ACT_* applied to y_act / y_f32 */
@@ -220,6 +221,41 @@ int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
  * encoder 0); g2 may be NULL. */
 int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
                 int64_t numel, void* du, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Attention gate of the Attention U-Net skip connections.  Replaces the ATen ops behind
+ * AttentionBlock.forward (models/attention_unet.py:88-96) that are not convolutions:
+ *   h = ReLU(BN_s(sg) + BN_i(ig)),  logit = conv1x1(h; w_a, b_a)  (K -> 1),
+ *   att = Sigmoid(BN_a(logit)),  out = x * att
+ * and their autograd.  ig / sg are the raw outputs of the two C -> K pointwise convolutions
+ * (pai_conv_fwd with kernel = 1), K = C / 2; BatchNorm statistics are finalised by
+ * pai_bn_finalize (C = K for BN_i / BN_s, C = 1 for BN_a) from the partial rows written here.
+ * Tensors are NHWC [M][channels] in the storage dtype; logit / att / dl are fp32 [M].
+ * `partials`: fp32 [pai_gate_partial_rows(M)][2][1] (forward: sum, sum of squares of logit;
+ * backward: sum dl, sum dl * xhat_a), sized through pai_bn_stats_buffer_rows for pai_bn_finalize.
+ * ------------------------------------------------------------------------- */
+int pai_gate_partial_rows(int64_t M);
+int pai_gate_hidden(int dtype, const void* ig, const void* sg, int64_t M, int K, const float* scale_i,
+                    const float* shift_i, const float* scale_s, const float* shift_s, const float* w_a,
+                    const float* b_a, void* h, float* logit, float* partials, void* stream);
+int pai_gate_apply(int dtype, const void* x, const float* logit, int64_t M, int C, const float* scale_a,
+                   const float* shift_a, void* out, float* att, void* stream);
+/* dx_skip = dout * att;  dl = <dout, x> * att * (1 - att)  (gradient w.r.t. BN_a's output);
+ * partials rows = (sum dl, sum dl * (logit - mean_a) * rstd_a).  relu_out != 0: dout is the gradient
+ * w.r.t. ReLU(out) (the nn.ReLU in front of the consuming DecoderBlock, models/pix2pix.py:98) and is
+ * masked with out > 0 first. */
+int pai_gate_apply_bwd(int dtype, const void* dout, const void* x, const float* att, const float* logit,
+                       int64_t M, int C, const float* mean_a, const float* rstd_a, void* dx_skip, float* dl,
+                       float* partials, int relu_out, void* stream);
+/* BN_a backward (sums_a from pai_bn_bwd_finalize), then through w_a and the ReLU:
+ *   dsum = 1[h > 0] * dlogit * w_a  (gradient w.r.t. both BN_i's and BN_s's output),
+ *   dw_a += sum dlogit * h,  db_a += sum dlogit,
+ *   partials_i / partials_s rows = (sum dsum, sum dsum * xhat_i|s)  [pai_gate_partial_rows(M)][2][K]. */
+int pai_gate_hidden_bwd(int dtype, const float* dl, const float* logit, const void* h, const void* ig,
+                        const void* sg, int64_t M, int K, const float* mean_a, const float* rstd_a,
+                        const float* gamma_a, const float* sums_a, const float* w_a, const float* mean_i,
+                        const float* rstd_i, const float* mean_s, const float* rstd_s, void* dsum,
+                        float* partials_i, float* partials_s, float* dw_a, float* db_a, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Losses.  Replace F.binary_cross_entropy_with_logits / F.l1_loss / F.mse_loss

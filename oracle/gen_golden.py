@@ -38,6 +38,9 @@ def _import_reference():
     from models.pix2pix import Pix2Pix            # noqa
     from models.wrapper import Discriminator     # noqa
     from models.utils import init_weights        # noqa
+    from models.attention_unet import AttentionUnetGAN   # noqa
+    global _ATT
+    _ATT = AttentionUnetGAN
     return Pix2Pix, Discriminator, init_weights
 
 
@@ -49,12 +52,14 @@ def synth_batch(seed, n, size):
     return torch.from_numpy(x), torch.from_numpy(t)
 
 
-def build_reference_model(mults, loss_type, seed):
+def build_reference_model(mults, loss_type, seed, family="pix2pix"):
     from oracle.pix2pix_ref import make_unet_state, make_disc_state, init_state_portable
+    from oracle.attention_ref import make_attention_unet_state
     Pix2Pix, Discriminator, init_weights = _REF
-    m = Pix2Pix(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=0.0,
-                loss_type=loss_type)
-    g_st = init_state_portable(make_unet_state(1, 1, mults), seed, perturb_bn=True)
+    cls = _ATT if family == "attention" else Pix2Pix
+    make = make_attention_unet_state if family == "attention" else make_unet_state
+    m = cls(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=0.0, loss_type=loss_type)
+    g_st = init_state_portable(make(1, 1, mults), seed, perturb_bn=True)
     missing = m.unet.load_state_dict(g_st, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     if loss_type == "gan":
@@ -91,10 +96,10 @@ class ActivationMargin:
             h.remove()
 
 
-def find_seed(mults, size, n, loss_type, seed0, steps, margin=2e-6, tries=400):
+def find_seed(mults, size, n, loss_type, seed0, steps, margin=2e-6, tries=400, family="pix2pix"):
     """First seed >= seed0 whose small-layer activations stay `margin` away from 0 for all steps."""
     for seed in range(seed0, seed0 + tries):
-        m = build_reference_model(mults, loss_type, seed)
+        m = build_reference_model(mults, loss_type, seed, family)
         am = ActivationMargin(m)
         x, t = synth_batch(seed + 100, n, size)
         for s in range(steps):
@@ -106,11 +111,11 @@ def find_seed(mults, size, n, loss_type, seed0, steps, margin=2e-6, tries=400):
     raise RuntimeError("no seed with the requested activation margin")
 
 
-def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=True):
+def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=True, family="pix2pix"):
     from oracle.fingerprint import fingerprint
     if search:
-        seed = find_seed(mults, size, n, loss_type, seed, steps)
-    m = build_reference_model(mults, loss_type, seed)
+        seed = find_seed(mults, size, n, loss_type, seed, steps, family=family)
+    m = build_reference_model(mults, loss_type, seed, family)
     x, t = synth_batch(seed + 100, n, size)
     rec = OrderedDict()
     rec["meta.mults"] = np.array(mults)
@@ -119,6 +124,7 @@ def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=
     rec["meta.seed"] = np.array(seed)
     rec["meta.steps"] = np.array(steps)
     rec["meta.loss_type"] = np.array(loss_type)
+    rec["meta.family"] = np.array(family)
     for s in range(steps):
         m.logged = {}
         m.training_step((x, t), s)
@@ -152,19 +158,22 @@ def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=
     print("wrote", name, {k: float(v) for k, v in rec.items() if ".log." in k})
 
 
-def run_forward_case(name, mults, size, n, seed):
+def run_forward_case(name, mults, size, n, seed, family="pix2pix"):
     """Train-mode forward only: per-level activations of the reference Unet and
     the PatchGAN logits, recorded with forward hooks on the reference modules."""
     from oracle.fingerprint import fingerprint
-    m = build_reference_model(mults, "gan", seed)
+    m = build_reference_model(mults, "gan", seed, family)
     x, t = synth_batch(seed + 100, n, size)
     rec = OrderedDict()
     rec["meta.mults"] = np.array(mults)
     rec["meta.size"] = np.array(size)
     rec["meta.n"] = np.array(n)
     rec["meta.seed"] = np.array(seed)
+    rec["meta.family"] = np.array(family)
     acts = {}
     hooks = []
+    for k, blk in enumerate(getattr(m.unet, "attention_blocks", [])):
+        hooks.append(blk.register_forward_hook(lambda mod, a, out, k=k: acts.__setitem__(f"gate{k + 1}", out.detach())))
     for i, enc in enumerate(m.unet.encoders):
         hooks.append(enc.register_forward_hook(lambda mod, a, out, i=i: acts.__setitem__(f"enc{i}", out.detach())))
     for j, dec in enumerate(m.unet.decoders):
@@ -207,6 +216,16 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _REF = _import_reference()
+    if "--attention" in sys.argv:     # Attention U-Net fixtures only
+        run_forward_case("ref_att_forward_tiny", (1, 2, 2, 4), 32, 4, seed=61, family="attention")
+        run_case("ref_att_gan_tiny", (1, 2, 2, 4), 32, 4, "gan", seed=71, steps=3, full_tensors=True,
+                 family="attention")
+        run_case("ref_att_ssim_tiny", (1, 2, 2, 4), 32, 4, "ssim", seed=81, steps=2, full_tensors=False,
+                 family="attention")
+        run_forward_case("ref_att_forward_full", (1, 2, 4, 8, 8, 8, 8, 8), 256, 2, seed=91, family="attention")
+        run_case("ref_att_gan_full", (1, 2, 4, 8, 8, 8, 8, 8), 256, 4, "gan", seed=95, steps=1,
+                 full_tensors=False, family="attention")
+        sys.exit(0)
     run_metric_kats()
     run_forward_case("ref_forward_tiny", (1, 2, 2, 4), 32, 4, seed=11)
     run_case("ref_gan_tiny", (1, 2, 2, 4), 32, 4, "gan", seed=21, steps=3, full_tensors=True)

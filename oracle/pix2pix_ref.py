@@ -106,7 +106,7 @@ def init_state_portable(st: OrderedDict, seed: int, perturb_bn: bool = False) ->
             v.fill_(1.0)
             if perturb_bn:
                 v.copy_(torch.from_numpy((1.0 + 0.2 * rng.random(v.shape)).astype(np.float32)))
-        elif ".encode.2." in k or ".decode.2." in k:
+        elif (k.rsplit(".", 1)[0] + ".running_mean") in st:   # affine parameters of a BatchNorm
             if k.endswith("weight"):
                 v.fill_(1.0)
                 if perturb_bn:
@@ -151,7 +151,7 @@ def unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True,
     Skip concat puts the decoder output first (:212).  dropout must be 0.
     """
     L = 1 + sum(1 for k in st if k.startswith("encoders.") and k.endswith("encode.1.weight"))
-    h = x.to(torch.float32)                                        # :199
+    h = x if x.dtype == torch.float64 else x.to(torch.float32)    # :199 (fp64 only for noise-floor studies)
     feats = []
     acts = {}
     h = F.conv2d(h, st["encoders.0.weight"], st["encoders.0.bias"], stride=2, padding=1)

@@ -17,7 +17,17 @@ import torch
 import torch.nn.functional as F
 
 from .metrics_ref import denormalize, psnr, rmse, ssim
-from .pix2pix_ref import disc_forward, unet_forward
+from .attention_ref import attention_unet_forward
+from .pix2pix_ref import disc_forward
+from .pix2pix_ref import unet_forward as _pix2pix_forward
+
+
+def unet_forward(st, x, training=True):
+    """Generator forward selected by the state's keys: Attention U-Net when it carries
+    ``attention_blocks.*`` (models/attention_unet.py), the Pix2Pix U-Net otherwise."""
+    if "attention_blocks.0.input_gate.0.weight" in st:
+        return attention_unet_forward(st, x, training=training)
+    return _pix2pix_forward(st, x, training=training)
 
 LR = 2e-4
 BETAS = (0.5, 0.999)

@@ -8,8 +8,9 @@ include/pai_hip.h); this package holds the host-side mirror of the reference int
 from . import lib  # noqa: F401
 from .lib import PaiError  # noqa: F401
 from .models.pix2pix import Pix2Pix, Unet, EncoderBlock, DecoderBlock  # noqa: F401
+from .models.attention_unet import AttentionUnetGAN, AttentionUnet, AttentionBlock  # noqa: F401
 from .models.wrapper import UnetWrapper, Discriminator, DiscriminatorBlock  # noqa: F401
 from .lightning import Trainer, CSVLogger, ModelCheckpoint, LightningModule  # noqa: F401
 
-__all__ = ["Pix2Pix", "Unet", "UnetWrapper", "Discriminator", "Trainer", "CSVLogger", "ModelCheckpoint",
+__all__ = ["Pix2Pix", "Unet", "AttentionUnetGAN", "AttentionUnet", "UnetWrapper", "Discriminator", "Trainer", "CSVLogger", "ModelCheckpoint",
            "PaiError", "lib"]

@@ -38,8 +38,12 @@ static void finish_gg(GG* g);
 static int check_desc(const pai_conv_desc* d) {
     PAI_CHECK(d != nullptr, "null descriptor");
     PAI_CHECK(d->dtype == PAI_F32 || d->dtype == PAI_BF16, "bad dtype %d", d->dtype);
-    PAI_CHECK(d->kernel == 4 && d->pad == 1, "only kernel=4 pad=1 supported (got k=%d p=%d)",
-              d->kernel, d->pad);
+    if (d->kernel == 1) {   // pointwise conv of the attention gates (models/attention_unet.py:72-84)
+        PAI_CHECK(d->pad == 0 && d->stride == 1 && !d->transposed, "kernel=1 needs pad=0 stride=1 Conv2d");
+    } else {
+        PAI_CHECK(d->kernel == 4 && d->pad == 1, "only kernel=4 pad=1 or kernel=1 pad=0 supported (got k=%d p=%d)",
+                  d->kernel, d->pad);
+    }
     PAI_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0,
               "bad shape N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2,
               d->Cout);
@@ -49,7 +53,7 @@ static int check_desc(const pai_conv_desc* d) {
         PAI_CHECK(d->stride == 1 || d->stride == 2, "Conv2d stride must be 1 or 2");
         if (d->stride == 2)
             PAI_CHECK((d->H % 2) == 0 && (d->W % 2) == 0, "stride-2 Conv2d needs even H, W");
-        else
+        else if (d->kernel == 4)
             PAI_CHECK(d->H >= 2 && d->W >= 2, "k4 s1 p1 Conv2d needs H, W >= 2");
     }
     PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
@@ -96,6 +100,12 @@ static void fill_conv_taps(GG* g, int S, int off0) {
         }
 }
 
+static void fill_pointwise(GG* g) {
+    g->S = 1; g->nphase = 1; g->ntaps = 1; g->OS = 1; g->wtaps = 1;
+    g->poy[0] = g->pox[0] = 0;
+    g->dy[0][0] = g->dx[0][0] = g->wt[0][0] = 0;
+}
+
 static void fill_phase_taps(GG* g) {
     g->S = 1;
     g->nphase = 4;
@@ -131,7 +141,10 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
     int OH, OW;
     pai_conv_out_hw(d, &OH, &OW);
     g->OH = OH; g->OW = OW;
-    if (!d->transposed) {
+    if (d->kernel == 1) {
+        g->OHg = OH; g->OWg = OW;
+        fill_pointwise(g);
+    } else if (!d->transposed) {
         g->OHg = OH; g->OWg = OW;
         fill_conv_taps(g, d->stride, -d->pad);
     } else {
@@ -155,7 +168,10 @@ int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
     g->D1 = d->C1; g->D2 = d->C2;
     g->wtaps = 16;
     g->OH = d->H; g->OW = d->W;
-    if (!d->transposed) {
+    if (d->kernel == 1) {
+        g->OHg = d->H; g->OWg = d->W;
+        fill_pointwise(g);    // dx = dy x W^T, pixel by pixel
+    } else if (!d->transposed) {
         if (d->stride == 2) {
             // dx[2a+ph] = sum_kh dy[a + off] w[kh]  -- same phase structure as ConvTranspose2d
             g->OHg = d->H / 2; g->OWg = d->W / 2;
@@ -255,7 +271,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     }
     if (op == 2) {
         if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g)) return 4;
-        if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+        if (g.Cout <= 2 && g.ntaps != 1 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
             int chunks = g.Cin / 8;
             if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
         }
@@ -417,7 +433,7 @@ extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void
     if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
     if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
     if (thin_wgrad_conv1_ok(d->dtype, g)) return launch_thin_wgrad_conv1(g, a, s);
-    if (g.Cout <= 2 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+    if (g.Cout <= 2 && g.ntaps != 1 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
         int chunks = g.Cin / 8;
         if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);
     }

@@ -52,6 +52,36 @@ template <> struct Conv<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// ---- 8-wide vector access ----------------------------------------------------------------
+template <typename T> struct V8;
+template <> struct V8<float> {
+    static __device__ __forceinline__ void ld(const float* p, float* o) {
+        float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* v) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct V8<bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* o) {
+        uint4 v = *(const uint4*)p;
+        unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(u[i] << 16);
+            o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = pk2bf(v[2 * i], v[2 * i + 1]);
+        *(uint4*)p = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case PAI_ACT_LRELU: return v > 0.f ? v : 0.2f * v;

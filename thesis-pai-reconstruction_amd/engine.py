@@ -195,7 +195,7 @@ class _Packs:
                     self.wd = torch.empty(w.numel(), dtype=dtype, device=w.device)
                 wd_out = self.wd
             if wf_out is not None or wd_out is not None:
-                ops.pack_weights(dtype, w, cout, 16, cin, wf_out, wd_out)
+                ops.pack_weights(dtype, w, cout, w.shape[2] * w.shape[3], cin, wf_out, wd_out)
             self.version = (w._version, w.data_ptr(), self.gen[0])
             self.dtype = dtype
         return self.wf, self.wd

@@ -35,12 +35,13 @@ def _p(t, dtype=None):
     return t.data_ptr()
 
 
-def make_desc(dtype, transposed, N, H, W, C1, C2, Cout, stride=2, relu1=0, relu2=0, act=ACT_NONE) -> ConvDesc:
+def make_desc(dtype, transposed, N, H, W, C1, C2, Cout, stride=2, relu1=0, relu2=0, act=ACT_NONE,
+              kernel=4) -> ConvDesc:
     d = ConvDesc()
     d.dtype = code_of(dtype)
     d.transposed = int(transposed)
     d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
-    d.kernel, d.stride, d.pad = 4, stride, 1
+    d.kernel, d.stride, d.pad = (4, stride, 1) if kernel == 4 else (1, 1, 0)
     d.relu1, d.relu2, d.epilogue_act = int(relu1), int(relu2), int(act)
     return d
 
@@ -90,9 +91,9 @@ def conv_flops(d: ConvDesc) -> int:
     """Algorithmic FLOPs (2 x MAC, padding taps included) of one fwd / dgrad / wgrad launch."""
     if d.transposed:
         return 2 * d.N * d.H * d.W * 16 * (d.C1 + d.C2) * d.Cout
-    oh = (d.H + 2 - 4) // d.stride + 1
-    ow = (d.W + 2 - 4) // d.stride + 1
-    return 2 * d.N * oh * ow * 16 * (d.C1 + d.C2) * d.Cout
+    oh = (d.H + 2 * d.pad - d.kernel) // d.stride + 1
+    ow = (d.W + 2 * d.pad - d.kernel) // d.stride + 1
+    return 2 * d.N * oh * ow * d.kernel * d.kernel * (d.C1 + d.C2) * d.Cout
 
 
 class _Timed:
@@ -246,6 +247,40 @@ def bn_bwd_apply(dtype, du, z, M, C_, mean, rstd, gamma, sums, dz):
 def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
     L.check(L.load().pai_act_bwd(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), numel, _p(du), _stream()),
             "pai_act_bwd")
+
+
+# ---- attention gate (models/attention_unet.py:88-96) -------------------------------------------
+def gate_partial_rows(M) -> int:
+    return L.load().pai_gate_partial_rows(M)
+
+
+def gate_hidden(dtype, ig, sg, M, K, scale_i, shift_i, scale_s, shift_s, w_a, b_a, h, logit, partials):
+    L.check(L.load().pai_gate_hidden(code_of(dtype), _p(ig), _p(sg), M, K, _p(scale_i), _p(shift_i), _p(scale_s),
+                                     _p(shift_s), _p(w_a, torch.float32), _p(b_a, torch.float32), _p(h),
+                                     _p(logit, torch.float32), _p(partials, torch.float32), _stream()),
+            "pai_gate_hidden")
+
+
+def gate_apply(dtype, x, logit, M, C_, scale_a, shift_a, out, att):
+    L.check(L.load().pai_gate_apply(code_of(dtype), _p(x), _p(logit, torch.float32), M, C_, _p(scale_a), _p(shift_a),
+                                    _p(out), _p(att, torch.float32), _stream()), "pai_gate_apply")
+
+
+def gate_apply_bwd(dtype, dout, x, att, logit, M, C_, mean_a, rstd_a, dx_skip, dl, partials, relu_out=False):
+    L.check(L.load().pai_gate_apply_bwd(code_of(dtype), _p(dout), _p(x), _p(att, torch.float32),
+                                        _p(logit, torch.float32), M, C_, _p(mean_a), _p(rstd_a), _p(dx_skip),
+                                        _p(dl, torch.float32), _p(partials, torch.float32), int(relu_out), _stream()),
+            "pai_gate_apply_bwd")
+
+
+def gate_hidden_bwd(dtype, dl, logit, h, ig, sg, M, K, mean_a, rstd_a, gamma_a, sums_a, w_a, mean_i, rstd_i,
+                    mean_s, rstd_s, dsum, partials_i, partials_s, dw_a, db_a):
+    L.check(L.load().pai_gate_hidden_bwd(code_of(dtype), _p(dl, torch.float32), _p(logit, torch.float32), _p(h),
+                                         _p(ig), _p(sg), M, K, _p(mean_a), _p(rstd_a), _p(gamma_a), _p(sums_a),
+                                         _p(w_a, torch.float32), _p(mean_i), _p(rstd_i), _p(mean_s), _p(rstd_s),
+                                         _p(dsum), _p(partials_i, torch.float32), _p(partials_s, torch.float32),
+                                         _p(dw_a, torch.float32), _p(db_a, torch.float32), _stream()),
+            "pai_gate_hidden_bwd")
 
 
 def bce_logits(logits, target, loss_scale, loss, grad_scale=0.0, grad=None):
