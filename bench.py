@@ -35,9 +35,20 @@ PEAK_HBM_GBS = 8000.0
 G_MAC, D_MAC, G1_MAC, D1_MAC = 5_947_523_072, 1_646_010_368, 16_777_216, 33_554_432
 
 
-def step_gflop_per_image(reuse_forward: bool) -> float:
+def gate_mac_per_image() -> int:
+    """Forward MACs of the 7 attention gates of BASELINE configs[2]: two C -> C/2
+    pointwise convolutions and the C/2 -> 1 head per gated level."""
+    total = 0
+    for lvl, mult in enumerate(MULTS[:-1]):
+        c, sp = mult * 64, SIZE >> (lvl + 1)
+        total += sp * sp * (2 * c * (c // 2) + c // 2)
+    return total
+
+
+def step_gflop_per_image(reuse_forward: bool, attention: bool = False) -> float:
     g_passes = 3 if reuse_forward else 4
-    mac = g_passes * G_MAC - G1_MAC + 8 * D_MAC - 2 * D1_MAC
+    g_mac = G_MAC + (gate_mac_per_image() if attention else 0)
+    mac = g_passes * g_mac - G1_MAC + 8 * D_MAC - 2 * D1_MAC
     return 2 * mac / 1e9
 
 
@@ -59,10 +70,11 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(batch=4, warmup=1, steps=36):
+def cpu_baseline(batch=4, warmup=1, steps=36, attention=False):
     import oracle
     torch.set_num_threads(host_cores())
-    g = oracle.init_state_portable(oracle.make_unet_state(1, 1, MULTS), 1)
+    make = oracle.make_attention_unet_state if attention else oracle.make_unet_state
+    g = oracle.init_state_portable(make(1, 1, MULTS), 1)
     d = oracle.init_state_portable(oracle.make_disc_state(1), 2)
     rng = np.random.default_rng(1234)
     x = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
@@ -91,6 +103,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the convolution launches with HIP events in the timed region (no roofline)")
     ap.add_argument("--no-reuse", action="store_true", help="literal two generator forwards per step")
+    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "attention_unet"],
+                    help="pix2pix = BASELINE configs[1] (the headline metric); attention_unet = configs[2]")
     args = ap.parse_args()
 
     import pai_bootstrap
@@ -104,7 +118,7 @@ def main():
     dev = torch.device("cuda", local)
 
     torch.manual_seed(0)
-    model = pai.Pix2Pix(1, 1, MULTS, 0.0, "gan")
+    model = (pai.AttentionUnetGAN if args.model == "attention_unet" else pai.Pix2Pix)(1, 1, MULTS, 0.0, "gan")
     model.to(dev)
     model.set_precision(args.precision)
     model.reuse_generator_forward = not args.no_reuse
@@ -246,15 +260,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
     reuse = model._can_reuse_forward()
-    gflop = step_gflop_per_image(reuse)
+    gflop = step_gflop_per_image(reuse, args.model == "attention_unet")
     out = {
         "metric": "train images/sec (256x256, bs=64) Pix2Pix step",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
         "data": "synthetic",
-        "config": {"workload": "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
-                               "(BASELINE configs[1])",
+        "config": {"workload": ("Attention U-Net generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
+                                "(BASELINE configs[2])" if args.model == "attention_unet" else
+                                "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
+                                "(BASELINE configs[1])"),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "channel_mults": list(MULTS), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}"},
@@ -266,7 +282,7 @@ def main():
         "roofline_isolated": roofline_isolated,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(attention=args.model == "attention_unet")
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)

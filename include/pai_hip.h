@@ -222,6 +222,13 @@ int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
 int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
                 int64_t numel, void* du, void* stream);
 
+/* nn.Dropout2d of the three widest DecoderBlocks (models/pix2pix.py:108,176-179), forward and
+ * backward: out[n][p][c] = x[n][p][c] * mask[n][c] on an NHWC tensor [N][HW][C] (may run in place).
+ * mask: fp32 [N][C] holding 0 or 1 / (1 - p); drawing it (a Bernoulli sample per sample and channel)
+ * is the caller's RNG plumbing. */
+int pai_dropout2d(int dtype, const void* x, const float* mask, int N, int64_t HW, int C, void* out,
+                  void* stream);
+
 /* ---------------------------------------------------------------------------
  * Attention gate of the Attention U-Net skip connections.  Replaces the ATen ops behind
  * AttentionBlock.forward (models/attention_unet.py:88-96) that are not convolutions:

@@ -19,7 +19,7 @@ from thesis_pai_reconstruction_amd.dataset import ImageDataModule, SyntheticData
 from thesis_pai_reconstruction_amd.callbacks import EMACallback  # noqa: E402
 from thesis_pai_reconstruction_amd.lightning import CSVLogger, ModelCheckpoint, Trainer  # noqa: E402
 
-HIP_MODELS = ("pix2pix",)
+HIP_MODELS = ("pix2pix", "attention_unet")
 
 
 def main(hparams):
@@ -27,10 +27,12 @@ def main(hparams):
     if hparams.model == "pix2pix":
         model = pai.Pix2Pix(in_channels=1, out_channels=1, channel_mults=channel_mults,
                             dropout=hparams.dropout, loss_type=hparams.loss_type)
-    elif hparams.model in ("attention_unet", "res18_unet", "res50_unet", "resv2_unet", "resnext_unet",
-                           "trans_unet", "palette"):
+    elif hparams.model == "attention_unet":
+        model = pai.AttentionUnetGAN(in_channels=1, out_channels=1, channel_mults=channel_mults,
+                                     dropout=hparams.dropout, loss_type=hparams.loss_type)
+    elif hparams.model in ("res18_unet", "res50_unet", "resv2_unet", "resnext_unet", "trans_unet", "palette"):
         raise NotImplementedError(
-            f"model {hparams.model!r}: only the Pix2Pix hot path is built on the HIP kernels so far "
+            f"model {hparams.model!r}: the Pix2Pix and Attention U-Net paths are built on the HIP kernels so far "
             "(SURVEY.md section 8(f) lists the other families as next rows)")
     else:
         raise ValueError(f"Incorrect model name ({hparams.model})")

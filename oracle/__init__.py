@@ -21,7 +21,7 @@ Pinning status (see DESIGN.md "Oracle"):
 
 from .pix2pix_ref import (  # noqa: F401
     make_unet_state, make_disc_state, unet_forward, disc_forward,
-    init_state_portable,
+    init_state_portable, dropout_rates,
 )
 from .attention_ref import make_attention_unet_state, attention_unet_forward, attention_block  # noqa: F401
 from .metrics_ref import denormalize, ssim, ssim_full, psnr, rmse, mse  # noqa: F401

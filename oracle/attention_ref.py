@@ -12,7 +12,7 @@ from typing import Sequence
 import torch
 import torch.nn.functional as F
 
-from .pix2pix_ref import _bn, _bn_entries, make_unet_state
+from .pix2pix_ref import _bn, _bn_entries, apply_dropout2d, dropout_rates, make_unet_state
 
 
 def make_attention_unet_state(in_channels: int = 1, out_channels: int = 1,
@@ -53,7 +53,8 @@ def attention_block(st, p: str, x, signal, training: bool):
     return x * torch.sigmoid(a)
 
 
-def attention_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True, return_feats: bool = False):
+def attention_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True, return_feats: bool = False,
+                           dropout: float = 0.0, mask_log=None, masks=None):
     """``AttentionUnet.forward`` (attention_unet.py:194-221): the Pix2Pix encoder (skips are the
     un-activated block outputs), then for every decoder but the first
     ``h = cat([h, attention_blocks[index-1](feats.pop(), h)])`` (:200-203), tanh at the end."""
@@ -73,6 +74,7 @@ def attention_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = Tr
         feats.append(h)
         acts[f"enc{i}"] = h
     feats.pop()
+    drops = dropout_rates(st, dropout)
     for j in range(L):
         if j != 0:
             s = attention_block(st, f"attention_blocks.{j - 1}", feats.pop(), h, training)
@@ -83,6 +85,8 @@ def attention_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = Tr
             h = F.relu(h)
             h = F.conv_transpose2d(h, st[p + ".1.weight"], st[p + ".1.bias"], stride=2, padding=1)
             h = _bn(st, p + ".2", h, training)
+            if training and drops[j] > 0:
+                h = apply_dropout2d(h, drops[j], j, mask_log, masks)
             acts[f"dec{j}"] = h
         else:
             h = F.conv_transpose2d(h, st[f"decoders.{j}.weight"], st[f"decoders.{j}.bias"], stride=2, padding=1)

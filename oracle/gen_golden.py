@@ -52,13 +52,13 @@ def synth_batch(seed, n, size):
     return torch.from_numpy(x), torch.from_numpy(t)
 
 
-def build_reference_model(mults, loss_type, seed, family="pix2pix"):
+def build_reference_model(mults, loss_type, seed, family="pix2pix", dropout=0.0):
     from oracle.pix2pix_ref import make_unet_state, make_disc_state, init_state_portable
     from oracle.attention_ref import make_attention_unet_state
     Pix2Pix, Discriminator, init_weights = _REF
     cls = _ATT if family == "attention" else Pix2Pix
     make = make_attention_unet_state if family == "attention" else make_unet_state
-    m = cls(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=0.0, loss_type=loss_type)
+    m = cls(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=dropout, loss_type=loss_type)
     g_st = init_state_portable(make(1, 1, mults), seed, perturb_bn=True)
     missing = m.unet.load_state_dict(g_st, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -111,11 +111,12 @@ def find_seed(mults, size, n, loss_type, seed0, steps, margin=2e-6, tries=400, f
     raise RuntimeError("no seed with the requested activation margin")
 
 
-def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=True, family="pix2pix"):
+def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=True, family="pix2pix",
+             dropout=0.0):
     from oracle.fingerprint import fingerprint
     if search:
         seed = find_seed(mults, size, n, loss_type, seed, steps, family=family)
-    m = build_reference_model(mults, loss_type, seed, family)
+    m = build_reference_model(mults, loss_type, seed, family, dropout)
     x, t = synth_batch(seed + 100, n, size)
     rec = OrderedDict()
     rec["meta.mults"] = np.array(mults)
@@ -125,8 +126,10 @@ def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=
     rec["meta.steps"] = np.array(steps)
     rec["meta.loss_type"] = np.array(loss_type)
     rec["meta.family"] = np.array(family)
+    rec["meta.dropout"] = np.array(dropout)
     for s in range(steps):
         m.logged = {}
+        torch.manual_seed(1000 + s)      # the Dropout2d masks of this step come from the global CPU generator
         m.training_step((x, t), s)
         for k, v in m.logged.items():
             rec[f"step{s}.log.{k}"] = np.array(float(v), dtype=np.float64)
@@ -216,6 +219,12 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _REF = _import_reference()
+    if "--dropout" in sys.argv:       # Dropout2d(0.5) in the widest decoders (the class default of the reference)
+        run_case("ref_gan_dropout_tiny", (1, 4, 4, 4), 32, 4, "gan", seed=111, steps=2, full_tensors=False,
+                 search=False, dropout=0.5)
+        run_case("ref_att_gan_dropout_tiny", (1, 4, 4, 4), 32, 4, "gan", seed=121, steps=2, full_tensors=False,
+                 search=False, family="attention", dropout=0.5)
+        sys.exit(0)
     if "--attention" in sys.argv:     # Attention U-Net fixtures only
         run_forward_case("ref_att_forward_tiny", (1, 2, 2, 4), 32, 4, seed=61, family="attention")
         run_case("ref_att_gan_tiny", (1, 2, 2, 4), 32, 4, "gan", seed=71, steps=3, full_tensors=True,

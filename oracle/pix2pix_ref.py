@@ -140,8 +140,33 @@ def _bn(st, prefix, h, training: bool):
         training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
 
 
+def dropout_rates(st: OrderedDict, dropout: float):
+    """Dropout2d rate of every DecoderBlock: `dropout` for the blocks at the widest channel multiple and
+    level > L - 5, else 0 (models/pix2pix.py:176-179, models/attention_unet.py:166-171)."""
+    L = 1 + sum(1 for k in st if k.startswith("encoders.") and k.endswith("encode.1.weight"))
+    mults = [st["encoders.0.weight"].shape[0] // 64] + \
+            [st[f"encoders.{i}.encode.1.weight"].shape[0] // 64 for i in range(1, L)]
+    out = []
+    for j, level in enumerate(reversed(range(L - 1))):
+        out.append(dropout if (mults[level] == max(mults) and level > L - 5) else 0.0)
+    return out
+
+
+def apply_dropout2d(h, p, j, mask_log=None, masks=None):
+    """nn.Dropout2d(p) in training mode (models/pix2pix.py:108).  The mask is drawn exactly as torch's
+    feature dropout draws it (a Bernoulli(1-p) sample per (n, c), scaled by 1/(1-p), from the global CPU
+    generator), so a run seeded like the reference sees the reference's masks; `masks` replays given ones."""
+    if masks is not None:
+        m = masks.pop(0)
+    else:
+        m = F.dropout2d(torch.ones(h.shape[0], h.shape[1], 1, 1, dtype=h.dtype), p, training=True)
+    if mask_log is not None:
+        mask_log.append((j, m.clone()))
+    return h * m
+
+
 def unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True,
-                 return_feats: bool = False):
+                 return_feats: bool = False, dropout: float = 0.0, mask_log=None, masks=None):
     """``Unet.forward`` (models/pix2pix.py:198-216).
 
     Encoder i>=1 = LeakyReLU(0.2) -> Conv2d(k4,s2,p1) -> BN (pix2pix.py:61-71);
@@ -166,6 +191,7 @@ def unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True,
         feats.append(h)
         acts[f"enc{i}"] = h
     feats.pop()                                                    # :208
+    drops = dropout_rates(st, dropout)
     for j in range(L - 1):
         p = f"decoders.{j}.decode"
         if j != 0:
@@ -173,6 +199,8 @@ def unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True,
         h = F.relu(h)
         h = F.conv_transpose2d(h, st[p + ".1.weight"], st[p + ".1.bias"], stride=2, padding=1)
         h = _bn(st, p + ".2", h, training)
+        if training and drops[j] > 0:
+            h = apply_dropout2d(h, drops[j], j, mask_log, masks)
         acts[f"dec{j}"] = h
     j = L - 1
     if j != 0:

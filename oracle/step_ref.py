@@ -22,12 +22,12 @@ from .pix2pix_ref import disc_forward
 from .pix2pix_ref import unet_forward as _pix2pix_forward
 
 
-def unet_forward(st, x, training=True):
+def unet_forward(st, x, training=True, **kw):
     """Generator forward selected by the state's keys: Attention U-Net when it carries
     ``attention_blocks.*`` (models/attention_unet.py), the Pix2Pix U-Net otherwise."""
     if "attention_blocks.0.input_gate.0.weight" in st:
-        return attention_unet_forward(st, x, training=training)
-    return _pix2pix_forward(st, x, training=training)
+        return attention_unet_forward(st, x, training=training, **kw)
+    return _pix2pix_forward(st, x, training=training, **kw)
 
 LR = 2e-4
 BETAS = (0.5, 0.999)
@@ -106,9 +106,14 @@ def _with_grad(st, keys):
 
 
 def gan_training_step(g_st, d_st, opt_g: AdamState, opt_d: AdamState, x, target,
-                      loss_type: str = "gan", return_grads: bool = False):
+                      loss_type: str = "gan", return_grads: bool = False, dropout: float = 0.0,
+                      mask_log=None, masks=None):
     """One ``training_step`` (models/wrapper.py:117-162).  Mutates g_st/d_st/opt_*
     in place; returns the logged scalars (and optionally the gradients).
+
+    ``dropout``: the generator's Dropout2d rate (two forwards = two independent mask draws from the global
+    CPU generator, as in the reference); ``mask_log`` collects (decoder, mask) in draw order, ``masks``
+    replays a list of masks instead of drawing.
 
     D phase (:120-138): G forward with G frozen (no graph, but BN running stats
     ARE updated -- SURVEY Q5/Q6), D(x,target), D(x,pred), d_loss, Adam(D).
@@ -119,7 +124,7 @@ def gan_training_step(g_st, d_st, opt_g: AdamState, opt_d: AdamState, x, target,
     grads_out = {}
     if loss_type == "gan":
         with torch.no_grad():
-            pred = unet_forward(g_st, x, training=True)
+            pred = unet_forward(g_st, x, training=True, dropout=dropout, mask_log=mask_log, masks=masks)
         dview, dleaves = _with_grad(d_st, param_keys(d_st))
         target_label = disc_forward(dview, x, target)
         pred_label = disc_forward(dview, x, pred)
@@ -132,7 +137,7 @@ def gan_training_step(g_st, d_st, opt_g: AdamState, opt_d: AdamState, x, target,
             grads_out["d"] = dgrads
 
     gview, gleaves = _with_grad(g_st, param_keys(g_st))
-    pred = unet_forward(gview, x, training=True)
+    pred = unet_forward(gview, x, training=True, dropout=dropout, mask_log=mask_log, masks=masks)
     loss = generator_loss(loss_type, d_st, x, pred, target)
     with torch.no_grad():
         dp, dt = denormalize(pred), denormalize(target)

@@ -57,6 +57,9 @@ def count_macs(model) -> int:
         hin = size >> (eng.L - j)
         k = eng.enc_c[-1] if j == 0 else eng.dec_c[j - 1] + eng.enc_c[eng.L - 1 - j]
         total += hin * hin * 16 * k * c
+    for j, g in enumerate(getattr(eng, "gates", []), 1):      # attention gates: two C -> K pointwise convs, K -> 1
+        sp = size >> (eng.L - j)
+        total += sp * sp * (2 * g.C * g.K + g.K)
     return total
 
 
@@ -64,6 +67,9 @@ def main(hparams):
     dev = torch.device("cuda", 0)
     if hparams.model == "pix2pix":
         model = pai.Pix2Pix.load_from_checkpoint(hparams.checkpoint, map_location=dev)
+        model.freeze()
+    elif hparams.model == "attention_unet":
+        model = pai.AttentionUnetGAN.load_from_checkpoint(hparams.checkpoint, map_location=dev)
         model.freeze()
     elif hparams.model == "identity":
         def model(x):

@@ -39,11 +39,13 @@ def test_train_and_report_flags_match_reference():
 
 
 @pytest.mark.gpu
-def test_train_then_report_roundtrip(tmp_path):
+@pytest.mark.parametrize("model", ["pix2pix", "attention_unet"])
+def test_train_then_report_roundtrip(tmp_path, model):
     env = dict(os.environ, PYTHONPATH=ROOT)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "cli_run", "--synthetic", "24",
                           "--batch-size", "8", "-e", "2", "--val-epochs", "1", "--channel-mults", "1,2,2,4",
-                          "--image-size", "64"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+                          "--image-size", "64", "-m", model], cwd=tmp_path, env=env, capture_output=True, text=True,
+                         timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     vdir = tmp_path / "logs" / "cli_run" / "version_0"
     assert (vdir / "metrics.csv").exists()
@@ -51,7 +53,8 @@ def test_train_then_report_roundtrip(tmp_path):
     assert "val_ssim" in header and "val_psnr" in header and "val_rmse" in header
     ckpt = vdir / "checkpoints" / "best.ckpt"
     assert ckpt.exists()
-    rep = subprocess.run([sys.executable, os.path.join(ROOT, "report.py"), "cli_rep", "-c", str(ckpt), "-bs", "4"],
+    rep = subprocess.run([sys.executable, os.path.join(ROOT, "report.py"), "cli_rep", "-c", str(ckpt), "-bs", "4",
+                          "-m", model],
                          cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert rep.returncode == 0, rep.stdout[-2000:] + rep.stderr[-2000:]
     rdir = tmp_path / "reports" / "cli_rep"

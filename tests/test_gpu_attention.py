@@ -32,8 +32,8 @@ def _zero_grad_bias(k, keys):
     return False
 
 
-def build(pai, mults, loss_type, seed, dtype=torch.float32):
-    m = pai.AttentionUnetGAN(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=0.0,
+def build(pai, mults, loss_type, seed, dtype=torch.float32, dropout=0.0):
+    m = pai.AttentionUnetGAN(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=dropout,
                              loss_type=loss_type)
     g = oracle.init_state_portable(oracle.make_attention_unet_state(1, 1, tuple(mults)), seed, perturb_bn=True)
     m.unet.load_state_dict(g, strict=True)
@@ -237,3 +237,56 @@ def test_bf16_mode_tracks_fp32(pai, golden_dir):
     m.training_step(batch, 1)
     for k, p in m.unet.named_parameters():
         assert torch.isfinite(p).all(), k
+
+
+def test_dropout2d_step_matches_reference_fixture(pai, golden_dir):
+    """Dropout2d(0.5) in the widest decoder blocks (the reference's class default, models/pix2pix.py:108,
+    176-179): two generator forwards per GAN step, each with its own masks.  The masks the reference drew are
+    recovered by the oracle (same torch generator, same draw order -- tests/test_oracle_golden.py pins that) and
+    injected into the HIP engine; everything else must match the recorded step."""
+    z = _load(golden_dir, "ref_att_gan_dropout_tiny")
+    seed, n, size, steps = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), int(z["meta.steps"])
+    mults, p = [int(v) for v in z["meta.mults"]], float(z["meta.dropout"])
+    m, g, d = build(pai, mults, "gan", seed, dropout=p)
+    assert not m.unet.supports_forward_reuse and sum(r > 0 for r in m.unet.engine.dec_drop) == 2
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    og, od = oracle.AdamState(), oracle.AdamState()
+    gkeys = set(g.keys())
+    for s in range(steps):
+        torch.manual_seed(1000 + s)
+        mask_log = []
+        oracle.gan_training_step(g, d, og, od, x, t, dropout=p, mask_log=mask_log)
+        queue = list(mask_log)
+
+        def replay(j, N, C, rate, device):
+            jj, mk = queue.pop(0)
+            assert jj == j and rate == p and mk.shape[:2] == (N, C)
+            return mk.reshape(N, C).to(device)
+
+        m.unet.engine.dropout_mask_fn = replay
+        m.logged = {}
+        m.training_step(batch, s)
+        torch.cuda.synchronize()
+        assert not queue
+        for k, v in m.logged.items():
+            want = float(z[f"step{s}.log.{k}"])
+            assert abs(float(v) - want) <= 1e-4 * max(1.0, abs(want)), (s, k, float(v), want)
+        for k, pp in m.unet.named_parameters():
+            if _zero_grad_bias(k, gkeys):
+                continue
+            tol = (2e-4 if pp.numel() > 1 else 2e-2) if s == 0 else 0.15 * s
+            _fp_ok(pp.grad, z[f"step{s}.ggrad.{k}"], tol, f"step{s} ggrad {k}")
+    # eval mode: Dropout2d is the identity
+    m.unet.engine.dropout_mask_fn = None
+    m.eval()
+    m.logged = {}
+    with torch.no_grad():
+        m.validation_step(batch, 0)
+    for k, v in m.logged.items():
+        want = float(z[f"val.log.{k}"])
+        assert abs(float(v) - want) <= 2e-3 * max(1.0, abs(want)), (k, float(v), want)
+    # the engine's own draw: channels of a sample are either dropped or scaled by 1 / (1 - p)
+    m.train()
+    with torch.no_grad():
+        m.unet(batch[0])

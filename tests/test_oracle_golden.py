@@ -64,7 +64,8 @@ def test_forward_matches_reference(golden_dir, name):
 
 @pytest.mark.parametrize("name", ["ref_gan_tiny", "ref_ssim_tiny", "ref_psnr_tiny",
                                   "ref_ssim_psnr_tiny", "ref_mse_tiny", "ref_gan_full",
-                                  "ref_att_gan_tiny", "ref_att_ssim_tiny", "ref_att_gan_full"])
+                                  "ref_att_gan_tiny", "ref_att_ssim_tiny", "ref_att_gan_full",
+                                  "ref_gan_dropout_tiny", "ref_att_gan_dropout_tiny"])
 def test_training_step_matches_reference(golden_dir, name):
     z = _load(golden_dir, name)
     seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
@@ -72,9 +73,14 @@ def test_training_step_matches_reference(golden_dir, name):
     g, d = _states(z["meta.mults"], seed, gan=(loss_type == "gan"), family=_family(z))
     x, t = synth_batch(seed + 100, n, size)
     og, od = oracle.AdamState(), oracle.AdamState()
+    dropout = float(z["meta.dropout"]) if "meta.dropout" in z.files else 0.0
     for s in range(steps):
+        torch.manual_seed(1000 + s)      # Dropout2d masks: same generator state as the recording run
+        mask_log = []
         logs, grads = oracle.gan_training_step(g, d, og, od, x, t, loss_type=loss_type,
-                                               return_grads=True)
+                                               return_grads=True, dropout=dropout, mask_log=mask_log)
+        if dropout > 0:
+            assert len(mask_log) == 2 * sum(r > 0 for r in oracle.dropout_rates(g, dropout)) > 0
         for k, v in logs.items():
             want = float(z[f"step{s}.log.{k}"])
             assert abs(float(v) - want) <= 5e-5 * max(1.0, abs(want)), (s, k, float(v), want)

@@ -181,6 +181,7 @@ class AttentionUnetEngine(UnetEngine):
             raise ops.PaiError("Unet needs at least two levels")
         S = self.acquire(N, H, W, dtype, x.device)
         P = S["P"]
+        S["drop"] = {}
         xs = x.to(torch.float32)
         xs = xs.contiguous() if Ci == 1 else xs.permute(0, 2, 3, 1).contiguous()
         if dtype == torch.float32:
@@ -230,6 +231,8 @@ class AttentionUnetEngine(UnetEngine):
                 # stored un-activated: the next decoder applies ReLU on load, the gate reads it raw
                 ops.bn_apply(dtype, S["w"][j], M, self.dec_c[j], S["dbn"][j].scale, S["dbn"][j].shift, ACT_NONE,
                              S["r"][j])
+                if training and self.dec_drop[j] > 0:
+                    self._dropout(S, j, M, self.dec_c[j], dtype)
             else:
                 ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_f32=S["pred"])
         pred = S["pred"]
@@ -291,6 +294,14 @@ class AttentionUnetEngine(UnetEngine):
             ops.conv_dgrad_bn(d, G["dig"][j], wd_i, G["gx"][j], None, x, ACT_NONE, G["dxs"][j], ACT_NONE)
             # d r_{j-1} = W_s^T dsg + act'(r) * (gradient from decoder j), plus decoder j-1's BatchNorm sums
             pst = S["dbn"][j - 1]
+            if (j - 1) in S["drop"]:
+                # decoder j-1 carries Dropout2d: sum the two parts (sign from the stored r), mask, and leave the
+                # BatchNorm backward to the two-pass form
+                ops.conv_dgrad_bn(d, G["dsg"][j], wd_s, G["gr"][j - 1], None, S["r"][j - 1], ACT_NONE,
+                                  G["gr_raw"][j - 1], ACT_RELU if relu_out else ACT_NONE)
+                ops.dropout2d(dtype, G["gr"][j - 1], S["drop"][j - 1], N, S["dh"][j - 1] * S["dw"][j - 1],
+                              self.dec_c[j - 1], G["gr"][j - 1])
+                return None
             return ops.conv_dgrad_bn(d, G["dsg"][j], wd_s, G["gr"][j - 1], None, S["w"][j - 1], ACT_NONE,
                                      G["gr_raw"][j - 1], ACT_RELU if relu_out else ACT_NONE, pst.scale, pst.shift,
                                      pst.mean, pst.rstd, part)
@@ -309,8 +320,14 @@ class AttentionUnetEngine(UnetEngine):
             M = N * S["dh"][j] * S["dw"][j]
             C = self.dec_c[j]
             dz = G["dz_dec"][j]
-            ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
-            ops.bn_bwd_apply(dtype, G["gr"][j], S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
+            du = G["gr"][j]
+            if fused_rows is None:      # Dropout2d layer: G['gr'][j] is the masked gradient w.r.t. BN's output
+                du = G["du"][:M * C]
+                ops.bn_bwd_reduce(dtype, G["gr"][j], ACT_NONE, None, ACT_NONE, None, S["w"][j], M, C, st.mean, st.rstd,
+                                  du, part, st.sums, A.seg(bn.weight), A.seg(bn.bias))
+            else:
+                ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
+            ops.bn_bwd_apply(dtype, du, S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
             d = P["dec_desc"][j]
             _, wd = self.dec_packs[j].get(dtype)
             if j == 0:

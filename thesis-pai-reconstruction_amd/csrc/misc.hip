@@ -29,6 +29,40 @@ extern "C" int pai_cast(int src_dtype, const void* src, int dst_dtype, void* dst
     return 0;
 }
 
+// nn.Dropout2d on an NHWC tensor: out[n][p][c] = x[n][p][c] * mask[n][c]; the gradient is the same product
+template <typename T>
+__global__ __launch_bounds__(256) void dropout2d_k(const T* x, const float* mask, int64_t nvec, int64_t vec_per_image,
+                                                   int C, T* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / vec_per_image;
+        const int c0 = (int)((i * 8) % C);
+        float v[8], m[8];
+        V8<T>::ld(x + i * 8, v);
+        V8<float>::ld(mask + n * C + c0, m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= m[k];
+        V8<T>::st(out + i * 8, v);
+    }
+}
+
+extern "C" int pai_dropout2d(int dtype, const void* x, const float* mask, int N, int64_t HW, int C, void* out,
+                             void* stream) {
+    PAI_CHECK(x && mask && out, "pai_dropout2d: null pointer");
+    PAI_CHECK(C % 8 == 0 && N > 0 && HW > 0, "pai_dropout2d: bad shape N=%d HW=%lld C=%d", N, (long long)HW, C);
+    const int64_t vpi = HW * C / 8, nvec = vpi * N;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(dropout2d_k<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, mask, nvec, vpi, C,
+                           (float*)out);
+    else
+        hipLaunchKernelGGL(dropout2d_k<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, mask, nvec, vpi,
+                           C, (bf16_t*)out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
 // master [Cout][taps][Cin] fp32 -> fwd pack (same order) and dgrad pack [Cin][taps][Cout]
 template <typename D>
 __global__ __launch_bounds__(256) void pack_k(const float* w, int Cout, int taps, int Cin, D* wf, D* wd) {

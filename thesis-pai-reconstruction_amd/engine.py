@@ -269,9 +269,11 @@ class UnetEngine:
                                 for e in encs[1:]]
         self.dec_conv = [d.decode[1] for d in decs[:-1]] + [decs[-1]]
         self.dec_bn = [d.decode[2] for d in decs[:-1]] + [None]
-        for d in decs[:-1]:
-            if isinstance(d.decode[3], nn.Dropout2d) and d.decode[3].p > 0:
-                raise ops.PaiError("Dropout2d > 0 is not supported by the HIP generator path yet")
+        # nn.Dropout2d of the widest decoder blocks (reference models/pix2pix.py:108,176-179); 0 = Identity
+        self.dec_drop = [float(d.decode[3].p) if isinstance(d.decode[3], nn.Dropout2d) else 0.0
+                         for d in decs[:-1]] + [0.0]
+        # tests inject masks here: fn(j, N, C, p, device) -> fp32 [N, C] of {0, 1 / (1 - p)}
+        self.dropout_mask_fn: Optional[Callable] = None
         self.in_ch = self.enc_conv[0].weight.shape[1]
         self.out_ch = self.dec_conv[-1].weight.shape[1]
         self.enc_c = [c.weight.shape[0] for c in self.enc_conv]
@@ -289,6 +291,19 @@ class UnetEngine:
     def _dbg(self, name, t):
         if self.debug_capture is not None:
             self.debug_capture[name] = t.detach().clone()
+
+    def _dropout(self, S, j, M, C, dtype):
+        """Training-mode Dropout2d behind decoder j's BatchNorm: S['r'][j] *= mask[n][c] in place; the mask
+        is kept in the slot for the backward pass.  The Bernoulli draw uses torch's device generator."""
+        p = self.dec_drop[j]
+        N = S["P"]["N"]
+        if self.dropout_mask_fn is not None:
+            mask = self.dropout_mask_fn(j, N, C, p, S["r"][j].device).to(torch.float32).contiguous()
+        else:
+            keep = torch.full((N, C), 1.0 - p, dtype=torch.float32, device=S["r"][j].device)
+            mask = torch.bernoulli(keep) / (1.0 - p)
+        S["drop"][j] = mask
+        ops.dropout2d(dtype, S["r"][j], mask, N, M // N, C, S["r"][j])
 
     # ---- parameters -------------------------------------------------------------------
     def ordered_params(self):
@@ -440,6 +455,7 @@ class UnetEngine:
         L = self.L
         S = self.acquire(N, H, W, dtype, x.device)
         P = S["P"]
+        S["drop"] = {}
         xs = x.to(torch.float32)
         xs = xs.contiguous() if Ci == 1 else xs.permute(0, 2, 3, 1).contiguous()
         if dtype == torch.float32:
@@ -498,6 +514,9 @@ class UnetEngine:
                 act = ACT_RELU if j < L - 2 else ACT_NONE
                 ops.bn_apply(dtype, S["w"][j], M, self.dec_c[j], S["dbn"][j].scale, S["dbn"][j].shift, act,
                              S["r"][j])
+                if training and self.dec_drop[j] > 0:
+                    # ReLU(Dropout2d(y)) == Dropout2d(ReLU(y)) (mask >= 0): applied to the stored activation
+                    self._dropout(S, j, M, self.dec_c[j], dtype)
             else:
                 ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_f32=S["pred"])
         if L == 1:
@@ -544,6 +563,9 @@ class UnetEngine:
         wgrad(d, x1, x2, dh, self.dec_conv[j], True)
         _, wd = self.dec_packs[j].get(dtype)
         ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
+        if (j - 1) in S["drop"]:
+            ops.dropout2d(dtype, G["gr"][j - 1], S["drop"][j - 1], N, S["dh"][j - 1] * S["dw"][j - 1], self.dec_c[j - 1],
+                          G["gr"][j - 1])
         # From here on every input-gradient launch also runs the first half of the backward of the layer
         # that PRODUCED its input (activation derivative, the encoder/skip sum, BatchNorm-backward partial
         # sums) in its store (pai_conv_dgrad_bn): the gradient tensor it writes is already `du`, and
@@ -581,6 +603,12 @@ class UnetEngine:
             if j == 0:
                 # producer: the norm-free last encoder, consumed through ReLU -> dz_last = relu'(z_last) * g
                 fused_rows = ops.conv_dgrad_bn(d, dz, wd, G["dz_enc"][L - 1], None, S["z"][L - 1], ACT_RELU)
+            elif (j - 1) in S["drop"]:
+                # producer carries Dropout2d: plain gradient, mask, then the two-pass BatchNorm backward
+                ops.conv_dgrad(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j])
+                ops.dropout2d(dtype, G["gr"][j - 1], S["drop"][j - 1], N, S["dh"][j - 1] * S["dw"][j - 1],
+                              self.dec_c[j - 1], G["gr"][j - 1])
+                fused_rows = None
             else:
                 pst = S["dbn"][j - 1]   # producer: decoder j-1 (BatchNorm, read through ReLU)
                 fused_rows = ops.conv_dgrad_bn(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j], S["w"][j - 1],

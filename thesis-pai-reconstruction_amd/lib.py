@@ -75,6 +75,7 @@ SIGNATURES = {
     "pai_bn_bwd_reduce": (_I, [_I, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_bwd_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pai_act_bwd": (_I, [_I, _P, _I, _P, _I, _P, _L, _P, _P]),
+    "pai_dropout2d": (_I, [_I, _P, _P, _I, _L, _I, _P, _P]),
     "pai_gate_partial_rows": (_I, [_L]),
     "pai_gate_hidden": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_gate_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P]),

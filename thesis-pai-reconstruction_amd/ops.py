@@ -249,6 +249,12 @@ def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
             "pai_act_bwd")
 
 
+def dropout2d(dtype, x, mask, N, HW, C_, out):
+    """out = x * mask[n][c] over an NHWC tensor (nn.Dropout2d forward, and its backward on gradients)."""
+    L.check(L.load().pai_dropout2d(code_of(dtype), _p(x), _p(mask, torch.float32), N, HW, C_, _p(out), _stream()),
+            "pai_dropout2d")
+
+
 # ---- attention gate (models/attention_unet.py:88-96) -------------------------------------------
 def gate_partial_rows(M) -> int:
     return L.load().pai_gate_partial_rows(M)
