@@ -742,8 +742,17 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
     return patch_geo(g, 8, &pg) ? 128 : 0;
 }
 
+// Compile-time timing ablations of gg_fwd_patch_k (results are WRONG; scripts/abl.sh builds the variants):
+// 1 no weight-tile fill, 2 no patch fill, 4 no MFMA, 8 no fragment reads, 16 no epilogue
+#ifndef PATCH_ABL
+#define PATCH_ABL 0
+#endif
+#ifndef PATCH_SETPRIO
+#define PATCH_SETPRIO 0   // 1: raise the wave's issue priority over its MFMA cluster (guide T5)
+#endif
 template <int BM, int BN, bool DBB>   // DBB: two weight-tile buffers
 __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+    constexpr int abl = PATCH_ABL;
     typedef PatchDims<BM> PD;
     constexpr int NTHR = BM * 2, MT = 4, NT = BN / 32;
     constexpr int RPP = PD::RPP, PJ = PD::PJ, PATCH_PIX = PD::PIX, PATCH_BYTES = PD::BYTES;
@@ -786,9 +795,16 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
         vmask[j] = m;
     }
     const int gchB = (sc ^ ((sr >> 1) & 7)) * 8;
+    // LDS row rho = 16 nt + i of a wave's half of the weight tile holds output channel
+    // (4 NT) (i >> 2) + 4 nt + (i & 3) of that half: with the weights as the MFMA's A operand a lane then ends
+    // up with 4 NT CONSECUTIVE channels of one pixel, and the epilogue stages 16-B pieces instead of 2-B ones
     const bf16_t* wrow[BJ];
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) wrow[j] = w + (size_t)(n0 + sr + RPP * j) * g.wtaps * g.Cin + gchB;
+    for (int j = 0; j < BJ; ++j) {
+        const int lr = sr + RPP * j, half = lr / (BN / 2), rho = lr % (BN / 2);
+        const int ch = half * (BN / 2) + (4 * NT) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+        wrow[j] = w + (size_t)(n0 + ch) * g.wtaps * g.Cin + gchB;
+    }
 
     // ---- fragment read addresses -----------------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
@@ -817,6 +833,7 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
         const int C = second ? g.C2 : g.C1;
         const int cofs = (second ? c0 - g.C1 : c0) + gchA;
         const int dpix = pg.by[ph][q] * g.W + pg.bx[ph][q];
+        if (abl & 2) return;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
             const bf16_t* pa = ((vmask[j] >> q) & 1u) ? src + ((pixb[j] + dpix) * C + cofs) : zero;
@@ -826,6 +843,7 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     auto fire_b = [&](int gi, int k, int buf) {
         const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
         const int woff = (int)((pg.wt4[ph][q] >> (8 * k)) & 0xffu) * g.Cin + c0;
+        if (abl & 1) return;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + buf * (BN * 128) + (j * RPP + wid * 8) * 128);
     };
@@ -858,19 +876,33 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
                 const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
                 const unsigned cb = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
                 bf8_t af[MT], bfr[NT];
+                if (!(abl & 8)) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + bb + nt * 16 * 128 + cb);
+                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + bb + nt * 16 * 128 + cb);
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(bf8_t, make_uint4(ca, cb, mt, kk));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(cb, ca, nt, kk));
+                }
                 if (relu) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
                 }
+                if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                if (!(abl & 4)) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                } else {
+                    acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];
+                }
+                if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
             }
             if (DBB) {
                 buf ^= 1;
@@ -889,6 +921,15 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the epilogue reuses the tile memory
+    if (abl & 16) {   // every accumulator stays live, nothing of the epilogue runs
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) *(float*)a.y1 = t;
+        return;
+    }
 
     // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
     constexpr int CROW = BN * 2 + 16;
@@ -896,38 +937,51 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
-    float csum[NT], csq[NT];
+    // lane (fq, fr) holds, for each of its 4 pixel rows mt*16 + fr, the 4 NT consecutive channels
+    // wn*(BN/2) + 4 NT fq + (4 nt + r): bias, statistics, activation, then one or two 16-B LDS stores per row
+    constexpr int CL = 4 * NT;               // channels per lane
+    const int col0 = wn * (BN / 2) + CL * fq;
+    float bias_v[CL], csum[CL], csq[CL];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = wn * (BN / 2) + nt * 16 + fr;
-        const float b = a.bias ? a.bias[n0 + col] : 0.f;
-        float s = 0.f, q = 0.f;
+    for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + mt * 16 + fq * 4 + r;
-                float v = acc[mt][nt][r] + b;
-                s += v;
-                q += v * v;
-                if (eact == PAI_ACT_LRELU) v = fmaxf(v, 0.2f * v);
-                else if (eact == PAI_ACT_RELU) v = fmaxf(v, 0.f);
-                *(bf16_t*)(Cs + row * CROW + col * 2) = f2bf(v);
-            }
-        }
-        csum[nt] = s;
-        csq[nt] = q;
-    }
-    if (a.stats) {
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = wm * 64 + mt * 16 + fr;
+        unsigned pk[CL / 2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float s = csum[nt], q = csq[nt];
-            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-            if (fq == 0) {
-                const int col = wn * (BN / 2) + nt * 16 + fr;
-                sstat[(wm * 2 + 0) * BN + col] = s;
-                sstat[(wm * 2 + 1) * BN + col] = q;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[mt][nt][r] + bias_v[4 * nt + r];
+                csum[4 * nt + r] += v[r];
+                csq[4 * nt + r] = fmaf(v[r], v[r], csq[4 * nt + r]);
+                if (eact == PAI_ACT_LRELU) v[r] = fmaxf(v[r], 0.2f * v[r]);
+                else if (eact == PAI_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            pk[2 * nt] = pk2bf(v[0], v[1]);
+            pk[2 * nt + 1] = pk2bf(v[2], v[3]);
+        }
+#pragma unroll
+        for (int h = 0; h < CL / 8; ++h)
+            *(uint4*)(Cs + row * CROW + (col0 + 8 * h) * 2) = make_uint4(pk[4 * h], pk[4 * h + 1], pk[4 * h + 2], pk[4 * h + 3]);
+    }
+    if (a.stats) {
+        // sum over the 16 pixels (lanes fr) of every row of 16 lanes: quad_perm, row_half_mirror, row_mirror
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+            float s = csum[c], q = csq[c];
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, false));
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x141, 0xF, 0xF, false));
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x140, 0xF, 0xF, false));
+            if (fr == 0) {
+                sstat[(wm * 2 + 0) * BN + col0 + c] = s;
+                sstat[(wm * 2 + 1) * BN + col0 + c] = q;
             }
         }
     }
