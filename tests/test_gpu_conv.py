@@ -37,6 +37,8 @@ CASES = [
     # >= 512 tiles of 16 x 16 output pixels: the 8-wave variant of the patch kernel (forward of both)
     ("enc_patch256", 0, 2, 8, 256, 256, 64, 0, 128, 0, 0),
     ("dec_patch256", 1, 2, 8, 64, 64, 128, 0, 128, 1, 0),
+    # 64 output channels on 16 x 16 pixel tiles (gg_fwd_patch_k<256, 64>): forward here, input gradient in enc_patch256
+    ("dec_patch256x64", 1, 2, 8, 64, 64, 128, 128, 64, 0, 1),
     # input gradient on the 16 x 16 patch kernel (dgrad of a stride-2 conv = 4 phases x 128 tiles)
     ("enc_dgrad256", 0, 2, 8, 128, 128, 128, 0, 128, 0, 0),
     # long reduction, few output rows: split-K slabs + finish kernel in forward and input gradient

@@ -739,6 +739,9 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
     PatchGeo pg;
     // 16 x 16 tiles when the layer still fills the chip with them (two 8-wave workgroups per CU)
     if (!no_256 && c.bn == 128 && (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= 512 && patch_geo(g, 16, &pg)) return 256;
+    // (measured and dropped: a 16 x 16 tile for the 64-wide layers -- decoders[6], input gradients of encoders[1] /
+    // D block 1, whose LDS fill rather than the matrix pipe is the bound, scripts/abl.sh -- ran 10-25 % SLOWER than
+    // the 8 x 16 tile at 4-5 workgroups per CU: 185 vs 166 us on decoders[6] forward)
     return patch_geo(g, 8, &pg) ? 128 : 0;
 }
 
