@@ -53,7 +53,8 @@ def _fp_ok(got, want_fp, rtol, what):
 
 
 # (name, N, H, W, C, K): vector-ALU kernel (K = 32), MFMA forward/dgrad + MFMA wgrad (C >= 128), split-K shape
-POINTWISE = [("c64", 2, 16, 16, 64, 32), ("c128", 3, 16, 16, 128, 64), ("c512", 4, 4, 4, 512, 256)]
+POINTWISE = [("c64", 2, 16, 16, 64, 32), ("c32", 3, 8, 24, 32, 64), ("c64_ragged", 1, 5, 7, 64, 32),
+             ("c128", 3, 16, 16, 128, 64), ("c512", 4, 4, 4, 512, 256)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -91,6 +92,35 @@ def test_pointwise_conv(pai, case, dtype):
     dx = torch.empty(N * H * W * C, dtype=dtype, device=dev())
     ops.conv_dgrad(d, DY, wd, dx, None)
     assert rel_err(from_nhwc(dx, N, H, W, C), x.grad) < tol
+    # producer backward in the input-gradient store == plain input gradient, then pai_bn_bwd_reduce (bit-equal):
+    # the gates' pointwise input gradients carry the skip sum and the decoder BatchNorm's first pass this way
+    M = N * H * W
+    Z = nhwc(q(rnd((N, C, H, W), 7), dtype), dtype)
+    ADD = nhwc(q(rnd((N, C, H, W), 8), dtype), dtype)
+    mean, rstd = rnd((C,), 9, 0.3).to(dev()), (rnd((C,), 10, 0.2).abs() + 0.5).to(dev())
+    scale = (rnd((C,), 11, 0.5) + 1.0).to(dev()) * rstd
+    shift = rnd((C,), 12, 0.3).to(dev()) - mean * scale
+    Aact = torch.empty_like(Z)
+    ops.bn_apply(dtype, Z, M, C, scale, shift, ops.ACT_RELU, Aact)
+    du2 = torch.empty_like(dx)
+    part2 = torch.zeros(ops.bn_bwd_partial_rows(M) * 2 * C, dtype=torch.float32, device=dev())
+    sums2 = torch.zeros(2 * C, dtype=torch.float32, device=dev())
+    ops.bn_bwd_reduce(dtype, dx, ops.ACT_NONE, ADD, ops.ACT_RELU, Aact, Z, M, C, mean, rstd, du2, part2, sums2,
+                      torch.zeros(C, device=dev()), torch.zeros(C, device=dev()))
+    du1 = torch.zeros_like(dx)
+    part1 = torch.zeros(ops.conv_dgrad_bn_rows_max(d) * 2 * C, dtype=torch.float32, device=dev())
+    sums1 = torch.zeros(2 * C, dtype=torch.float32, device=dev())
+    rows_f = ops.conv_dgrad_bn(d, DY, wd, du1, None, Z, ops.ACT_NONE, ADD, ops.ACT_RELU, scale, shift, mean, rstd, part1)
+    ops.bn_bwd_finalize(part1, rows_f, C, sums1, None, None)
+    plain = torch.zeros_like(dx)
+    ops.conv_dgrad_bn(d, DY, wd, plain, None, Z, ops.ACT_NONE, ADD, ops.ACT_NONE)     # dx + add, no norm
+    torch.cuda.synchronize()
+    assert 0 < rows_f <= ops.conv_dgrad_bn_rows_max(d) and torch.equal(du1, du2)
+    assert float((sums1 - sums2).abs().max()) / (float(sums2.abs().max()) + 1e-6) < 1e-4
+    want_plain = torch.empty_like(dx)
+    ops.act_bwd(dtype, dx, ops.ACT_NONE, ADD, ops.ACT_NONE, Z, dx.numel(), want_plain)
+    assert torch.equal(plain, want_plain)
+
     dw = torch.zeros(K * C, dtype=torch.float32, device=dev())
     db = torch.zeros(K, dtype=torch.float32, device=dev())
     ops.conv_wgrad(d, X, None, DY, dw, db)

@@ -254,6 +254,7 @@ extern "C" int pai_conv_fwd_stats_rows(const pai_conv_desc* d) {
     memset(&a, 0, sizeof(a));
     a.y1 = (void*)1;  // raw output present
     a.stats = (float*)1;
+    if (pw_ok(d->dtype, g, a)) return pw_rows(g);
     int mt = use_mfma(d->dtype, g, a) ? fwd_mfma_mtiles(g) : fwd_simt_mtiles(g);
     return mt * g.nphase;
 }
@@ -278,7 +279,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (wgrad_mfma_ok(d->dtype, g)) return (g.Cout % 128) == 0 ? 2 : 3;
         return 0;
     }
-    if (thin_fwd_ok(d->dtype, g, a) || thin_dgrad_ok(d->dtype, g, a)) return 4;
+    if (thin_fwd_ok(d->dtype, g, a) || thin_dgrad_ok(d->dtype, g, a) || pw_ok(d->dtype, g, a)) return 4;
     if (fwd_rowdot_ok(g, a)) return 1;
     if (fwd_mfma_ok(d->dtype, g, a))
         return ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 2 : 3;
@@ -309,6 +310,7 @@ extern "C" int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d) {
 }
 
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (pw_ok(dtype, g, a)) return launch_pw(g, a, s);
     if (thin_fwd_ok(dtype, g, a)) return launch_thin_fwd(g, a, s);
     if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);
     if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
@@ -348,6 +350,7 @@ extern "C" int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void
 }
 
 static bool dgrad_store_fusable(const pai_conv_desc* d, const GG& g, const FwdArgs& a) {
+    if (pw_ok(d->dtype, g, a)) return true;
     return !thin_fwd_ok(d->dtype, g, a) && !thin_dgrad_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) &&
            use_mfma(d->dtype, g, a);
 }
@@ -375,7 +378,8 @@ extern "C" int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const 
 extern "C" int pai_conv_dgrad_bn_rows_max(const pai_conv_desc* d) {
     GG g;
     if (gg_build_dgrad(d, &g)) return -1;
-    const int fused = cdiv(g.M, 16) * g.nphase;
+    int fused = cdiv(g.M, 16) * g.nphase;
+    if (pw_rows(g) > fused) fused = pw_rows(g);
     const int twopass = pai_bn_bwd_partial_rows((int64_t)g.N * g.OH * g.OW);
     return fused > twopass ? fused : twopass;
 }
@@ -405,7 +409,7 @@ extern "C" int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const v
         a.bscale = e->scale; a.bshift = e->shift; a.bmean = e->mean; a.brstd = e->rstd;
         a.bact1 = e->act1; a.bact2 = e->act2;
         a.bpart = e->partials;
-        if (partial_rows) *partial_rows = e->partials ? fwd_mfma_mtiles(g) * g.nphase : 0;
+        if (partial_rows) *partial_rows = !e->partials ? 0 : (pw_ok(d->dtype, g, a) ? pw_rows(g) : fwd_mfma_mtiles(g) * g.nphase);
         return run_fwd(d->dtype, g, a, s);
     }
     // other kernel families: plain input gradient, then the same arithmetic as a second pass in place

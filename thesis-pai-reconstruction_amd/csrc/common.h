@@ -170,6 +170,10 @@ extern int64_t g_workspace_bytes;
 int fwd_simt_mtiles(const GG& g);
 int fwd_mfma_mtiles(const GG& g);
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);
+// skinny pointwise convolution (64 <-> 32 channels) on the matrix cores, no LDS (gg_mfma.hip)
+bool pw_ok(int dtype, const GG& g, const FwdArgs& a);
+int pw_rows(const GG& g);
+int launch_pw(const GG& g, const FwdArgs& a, hipStream_t s);
 bool fwd_rowdot_ok(const GG& g, const FwdArgs& a);
 
 // thin layers on the matrix cores (gg_thin.hip)

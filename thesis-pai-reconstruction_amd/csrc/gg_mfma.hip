@@ -1149,14 +1149,161 @@ const char* fwd_mfma_kernel_name(const GG& g) {
 }
 
 // ------------------------------------------------------------------------------------
+// Skinny pointwise convolution (forward and input gradient of the finest attention gate)
+// ------------------------------------------------------------------------------------
+// out[M][COUT] = in[M][CIN] x W[COUT][CIN]^T with (CIN, COUT) = (64, 32) or (32, 64) over ~1 M pixels: 4 GFLOP
+// against 200 MB, i.e. HBM-bound.  No LDS: a wave keeps the whole filter in registers as the MFMA's A operand
+// (rows permuted as in gg_fwd_patch_k, so that a lane ends up with COUT/4 consecutive channels of one pixel) and
+// streams 16-pixel groups: one 16-B load per lane and 32 input channels, COUT/16 * CIN/32 MFMAs, one or two 16-B
+// stores per lane -- the 16 pixels of a group are contiguous, every load / store instruction covers whole rows.
+// Same epilogue options as the tile kernels: bias, BatchNorm partial statistics, the fused producer backward.
+bool pw_ok(int dtype, const GG& g, const FwdArgs& a) {
+    if (dtype != PAI_BF16 || g.ntaps != 1 || g.nphase != 1 || g.C2 != 0 || g.D2 != 0) return false;
+    if (!((g.C1 == 64 && g.Cout == 32) || (g.C1 == 32 && g.Cout == 64))) return false;
+    if (a.yf32 || a.skip_d1) return false;
+    if ((a.y1 != nullptr) == (a.yact != nullptr)) return false;     // exactly one storage-dtype output
+    if (a.yact && a.eact != PAI_ACT_NONE && a.eact != PAI_ACT_LRELU && a.eact != PAI_ACT_RELU) return false;
+    return true;
+}
+
+int pw_rows(const GG& g) {
+    int64_t b = ((int64_t)g.M + 63) / 64;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void pw_k(GG g, FwdArgs a, int groups_per_wave) {
+    constexpr int KB = CIN / 32, NTT = COUT / 16, CL = COUT / 4, NCH = CL / 8;
+    __shared__ float sred[4][2][COUT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* x = (const bf16_t*)a.x1;
+    const bf16_t* w = (const bf16_t*)a.w;
+    bf16_t* y = (bf16_t*)(a.yact ? a.yact : a.y1);
+    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    // filter: MFMA row (nt, i = fr) carries output channel CL (i >> 2) + 4 nt + (i & 3)
+    bf8_t wf[NTT][KB];
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            wf[nt][kb] = *(const bf8_t*)(w + (size_t)(CL * (fr >> 2) + 4 * nt + (fr & 3)) * CIN + kb * 32 + fq * 8);
+    const int c0 = CL * fq;                  // this lane's first output channel
+    float bias_v[CL], s1[CL], s2[CL];
+#pragma unroll
+    for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[c0 + c] : 0.f; s1[c] = s2[c] = 0.f; }
+    const bool bwd = a.bz != nullptr && !a.yact;
+    const bool bsum = bwd && a.bpart;
+    const bf16_t* bzp = (const bf16_t*)a.bz;
+    const bf16_t* bap = (const bf16_t*)a.badd;
+    BwdParams BP[NCH];
+    if (bwd) {
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) bwd_load_params(a, c0 + 8 * h, BP[h]);
+    }
+    const int64_t ngroups = ((int64_t)g.M + 15) / 16;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wid) * groups_per_wave;
+    for (int64_t gi = g0; gi < g0 + groups_per_wave && gi < ngroups; ++gi) {
+        const int64_t pix = gi * 16 + fr;
+        const bool valid = pix < g.M;
+        const int64_t pc = valid ? pix : 0;
+        bf8_t xb[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            xb[kb] = *(const bf8_t*)(x + pc * CIN + kb * 32 + fq * 8);
+            if (g.relu1) xb[kb] = relu_frag(xb[kb]);
+        }
+        uint4 zq[NCH], aq[NCH];
+        if (bwd) {
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) {
+                zq[h] = *(const uint4*)(bzp + pc * COUT + c0 + 8 * h);
+                aq[h] = bap ? *(const uint4*)(bap + pc * COUT + c0 + 8 * h) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        f4_t acc[NTT];
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+            acc[nt] = (f4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kb], xb[kb], acc[nt], 0, 0, 0);
+        }
+        // lane: pixel `pix`, channels c0 + 4 nt + r
+        unsigned pk[CL / 2];
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[nt][r] + bias_v[4 * nt + r];
+                if (a.stats && valid) { s1[4 * nt + r] += v[r]; s2[4 * nt + r] = fmaf(v[r], v[r], s2[4 * nt + r]); }
+                if (eact == PAI_ACT_LRELU) v[r] = fmaxf(v[r], 0.2f * v[r]);
+                else if (eact == PAI_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            pk[2 * nt] = pk2bf(v[0], v[1]);
+            pk[2 * nt + 1] = pk2bf(v[2], v[3]);
+        }
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            uint4 o = make_uint4(pk[4 * h], pk[4 * h + 1], pk[4 * h + 2], pk[4 * h + 3]);
+            if (bwd && valid)
+                o = bwd_chunk(o, zq[h], aq[h], bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP[h],
+                              s1 + 8 * h, s2 + 8 * h);
+            if (valid) *(uint4*)(y + pix * COUT + c0 + 8 * h) = o;
+        }
+    }
+    float* prow = a.stats ? a.stats : (bsum ? a.bpart : nullptr);
+    if (prow) {
+        // sum over the 16 pixels of each lane row (DPP), then over the 4 waves; one partial row per workgroup
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+            float u = s1[c], q = s2[c];
+            u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, false));
+            u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x4E, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));
+            u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x141, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x141, 0xF, 0xF, false));
+            u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x140, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x140, 0xF, 0xF, false));
+            if (fr == 0) { sred[wid][0][c0 + c] = u; sred[wid][1][c0 + c] = q; }
+        }
+        __syncthreads();
+        if (tid < COUT) {
+            float u = 0.f, q = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) { u += sred[wv][0][tid]; q += sred[wv][1][tid]; }
+            float* dst = prow + (size_t)blockIdx.x * 2 * COUT;
+            dst[tid] = u;
+            // forward statistics: sum of squares; producer backward: sum du * xhat from sum du * z
+            dst[COUT + tid] = a.stats ? q : a.brstd[tid] * (q - a.bmean[tid] * u);
+        }
+    }
+}
+
+int launch_pw(const GG& g, const FwdArgs& a, hipStream_t s) {
+    const int blocks = pw_rows(g);
+    const int64_t ngroups = ((int64_t)g.M + 15) / 16;
+    const int gpw = (int)((ngroups + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4));
+    if (g.C1 == 64) hipLaunchKernelGGL((pw_k<64, 32>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    else hipLaunchKernelGGL((pw_k<32, 64>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Weight gradient
 // ------------------------------------------------------------------------------------
 bool wgrad_mfma_ok(int dtype, const GG& g) {
     if (dtype != PAI_BF16) return false;
+    if (g.lsw < 0) return false;   // the K loop addresses pixels with shifts: power-of-two image sizes only
+    // pointwise convolutions of the finest attention gate (64 -> 32 and 32 -> 64 channels over 1 M pixels): the
+    // 64 x 128 tile is a quarter full, but the launch is bound by reading the two operands once, not by the matrix pipe
+    if (g.ntaps == 1 && g.C2 == 0 && ((g.C1 == 64 && g.Cout == 32) || (g.C1 == 32 && g.Cout == 64))) return true;
     if (g.C1 % 64 || g.C2 % 64) return false;
     if (g.Cout % 64) return false;
     if ((g.ntaps * g.Cin) % 128) return false;
-    if (g.lsw < 0) return false;   // the K loop addresses pixels with shifts: power-of-two image sizes only
     return true;
 }
 
@@ -1193,7 +1340,9 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     const int sc = lane & 15, sr = wid * 4 + (lane >> 4);
     const int gch = sc ^ tr_swz(sr);  // tr_swz(sr + 16j) == tr_swz(sr): only row bits 0..3 matter
     // gathered-column chunk -> (tap, source, channel)
-    const int jc = j0 + gch * 8;
+    const int J = g.ntaps * g.Cin;
+    const bool xvalid = j0 + gch * 8 < J;              // column tiles of a narrow problem are partly empty
+    const int jc = xvalid ? j0 + gch * 8 : 0;
     const int xt = jc / g.Cin;
     const int xci = jc - xt * g.Cin;
     const int ddy = g.dy[ph][xt], ddx = g.dx[ph][xt];
@@ -1224,7 +1373,7 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     for (int nt = 0; nt < 4; ++nt) {
         const int jcol = j0 + wn * 64 + nt * 16;
         const int ci = jcol % g.Cin;
-        nt_relu[nt] = ci < g.C1 ? g.relu1 != 0 : g.relu2 != 0;
+        nt_relu[nt] = jcol < J && (ci < g.C1 ? g.relu1 != 0 : g.relu2 != 0);
     }
 
     // bias gradient: the workgroups of the first column tile (and first tap of each phase) see every
@@ -1253,7 +1402,7 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
             const bf16_t* p = dy + ((size_t)(unsigned)opix * (unsigned)g.Cout + ycol);
             py[j] = (mv && yvalid) ? p : zero;
             const int iy = (gy << lss) + ddy, ix = (gx << lss) + ddx;
-            const bool inb = mv && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const bool inb = mv && xvalid && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             const int spix = (((n << g.lsh) + iy) << g.lsw) + ix;
             const bf16_t* q = xsrc + ((size_t)(unsigned)spix * (unsigned)xcs + xcc);
             px[j] = inb ? q : zero;
@@ -1328,6 +1477,7 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int jcol = j0 + wn * 64 + nt * 16 + fi;
+        if (jcol >= g.ntaps * g.Cin) continue;
         const int t = jcol / g.Cin;
         const int ci = jcol - t * g.Cin;
         const size_t cbase = (size_t)g.wt[ph][t] * g.Cin + ci;
@@ -1537,8 +1687,8 @@ int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hip
 
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     const bool big = (g.Cout % 128) == 0;
-    const int cotiles = big ? g.Cout / 128 : g.Cout / 64;
-    const int jtiles = g.ntaps * g.Cin / 128;
+    const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
+    const int jtiles = cdiv(g.ntaps * g.Cin, 128);
     const int tiles = cotiles * jtiles * g.nphase;
     // Split of the pixel range: enough workgroups to fill the chip (3 per CU for the 128-wide tile, 4 for the
     // lighter 64-wide one), but every split adds one fp32 atomic pass over dW -- for the small-image layers
