@@ -1505,6 +1505,9 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 // the same 5 x 17 source pixels (64 B each), so the X fill drops from 16 KB to 5.4 KB per step.
 //   X patch image: pixel p = py * 17 + px at byte 64 p; its two 32-B halves are swapped when bit 3 of p is
 //   set, which keeps the two 8-row groups of a ds_read_b64_tr_b16 on different banks for every tap shift.
+// (measured and dropped: two LDS stages with a counted vmcnt + raw barrier, 48 KB per workgroup, still three per CU:
+//  10-50 % SLOWER -- decoders[6] 194 -> 306 us, decoders[5] 145 -> 169 us; this kernel's latency is hidden across
+//  workgroups, and the second stage only adds LDS-DMA pressure)
 template <int BMC>
 __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
                                                         int splits, int blocks_per_split) {
