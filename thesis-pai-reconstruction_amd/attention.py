@@ -312,6 +312,7 @@ class AttentionUnetEngine(UnetEngine):
         ops.tanh_bwd(dtype, S["pred"], gpred, None, dh)
         d = P["dec_desc"][j]
         wgrad(d, S["r"][j - 1], S["gate"][j]["s"], dh, self.dec_conv[j], True)
+        side.mark_scratch()
         _, wd = self.dec_packs[j].get(dtype)
         ops.conv_dgrad(d, dh, wd, G["gr_raw"][j - 1], G["gs"][j])
         fused_rows = gate_backward(j, relu_out=False)
@@ -363,5 +364,8 @@ class AttentionUnetEngine(UnetEngine):
             wgrad(P["enc_desc"][i], S["a"][i - 1], None, dz, conv, False)
             _, wd = self.enc_packs[i].get(dtype)
             fused_rows = enc_dgrad(i, dz, wd)
-        wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], self.enc_conv[0], True)
+        conv0 = self.enc_conv[0]
+        with torch.cuda.stream(side.fork_tail()):
+            ops.conv_wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
         side.join()
+        done(conv0.bias)

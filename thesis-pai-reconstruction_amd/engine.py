@@ -235,6 +235,8 @@ class _SideStream:
     def __init__(self):
         import os
         self.stream = None
+        self.stream2 = None
+        self.scratch_ev = None
         self.on = _SideStream.enabled and os.environ.get("PAI_NO_OVERLAP", "0") in ("", "0")
         # optional cap (GFLOP per launch) on what goes to the side stream.  Measured at batch 64: the
         # gain comes from co-scheduling the BIG layers (11.68 -> 11.15 ms/step); small layers alone
@@ -250,9 +252,32 @@ class _SideStream:
         self.stream.wait_stream(torch.cuda.current_stream())
         return self.stream
 
+    def fork_tail(self):
+        """A second side stream for the LAST weight gradient of a backward pass (the thin first layer,
+        HBM-bound): it then runs beside the previous layer's MFMA-bound weight gradient instead of behind it,
+        which shortens the tail during which the main stream only waits for `join`."""
+        if not self.on:
+            return torch.cuda.current_stream()
+        if self.stream2 is None:
+            self.stream2 = torch.cuda.Stream()
+        self.stream2.wait_stream(torch.cuda.current_stream())
+        if self.scratch_ev is not None:
+            # the thin weight-gradient kernels share the tail of the registered scratch buffer
+            self.stream2.wait_event(self.scratch_ev)
+        return self.stream2
+
+    def mark_scratch(self):
+        """Call inside the side-stream context right after a thin-layer weight gradient has been issued."""
+        if self.on and self.stream is not None:
+            if self.scratch_ev is None:
+                self.scratch_ev = torch.cuda.Event()
+            self.scratch_ev.record(self.stream)
+
     def join(self):
         if self.on and self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        if self.on and self.stream2 is not None:
+            torch.cuda.current_stream().wait_stream(self.stream2)
 
 
 # --------------------------------------------------------------------------------------
@@ -561,6 +586,7 @@ class UnetEngine:
         x1 = S["r"][j - 1]
         x2 = S["z"][0]
         wgrad(d, x1, x2, dh, self.dec_conv[j], True)
+        side.mark_scratch()
         _, wd = self.dec_packs[j].get(dtype)
         ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
         if (j - 1) in S["drop"]:
@@ -645,9 +671,12 @@ class UnetEngine:
             wgrad(d, S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)
             fused_rows = enc_dgrad(i, dz, wd)
-        # encoder 0 (its dz came out of encoder 1's input gradient)
-        wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], self.enc_conv[0], True)
+        # encoder 0 (its dz came out of encoder 1's input gradient): on the tail stream, beside encoder 1's
+        conv0 = self.enc_conv[0]
+        with torch.cuda.stream(side.fork_tail()):
+            ops.conv_wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
         side.join()
+        done(conv0.bias)      # both side streams have been joined: the whole arena is final
 
 
 # --------------------------------------------------------------------------------------
@@ -767,18 +796,20 @@ class DiscEngine:
                 ops.conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
                 if hook is not None:
                     hook(A, A.end_of(self.convs[4].weight))
+            side.mark_scratch()
         _, wd = self.packs[4].get(dtype)
         # du[k] = LeakyReLU'(a[k]) * dgrad of block k+1: the activation backward rides on the dgrad store
         ops.conv_dgrad_act(d, dl, wd, G["du"][3], None, S["a"][3], ACT_LRELU)
         for k in range(3, -1, -1):
             conv = self.convs[k]
             d = P["desc"][k]
-            if need_params:
+            if need_params and k == 0:
+                # thin first layer: tail stream, beside block 1's weight gradient; its hook fires after the join
+                with torch.cuda.stream(side.fork_tail()):
+                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
+            elif need_params:
                 with torch.cuda.stream(side.fork(d)):
-                    if k == 0:
-                        ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
-                    else:
-                        ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
                     if hook is not None:
                         hook(A, A.end_of(conv.bias))
             if k > 0:
@@ -788,6 +819,8 @@ class DiscEngine:
                 _, wd = self.packs[0].get(dtype)
                 ops.conv_dgrad(d, G["du"][0], wd, None, G["dy"], only_c2=True)
         side.join()
+        if need_params and hook is not None:
+            hook(A, A.end_of(self.convs[0].bias))
         if not need_dy:
             return None
         gy = torch.empty(N * H * W * self.in_ch, dtype=torch.float32, device=dev)
