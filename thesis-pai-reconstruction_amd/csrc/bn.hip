@@ -60,6 +60,54 @@ __global__ void bn_finalize_k(const float* stats, const double* stage, int R, in
 
 extern "C" int pai_bn_stats_buffer_rows(int rows) { return rows + 2 * STAGE_ROWS; }
 
+// One-launch finalize for many partial rows: 8 channels x 128 row lanes per block sum the rows in fp64 (as the
+// backward finalize does), then 8 threads turn the totals into mean / rstd / scale / shift and advance the running
+// statistics.  Replaces the stage-1 + finalize pair (two dependent tiny launches per BatchNorm layer).
+__global__ __launch_bounds__(1024) void bn_finalize_wide_k(const float* stats, int R, int C, double count,
+                                                           const float* gamma, const float* beta, float eps,
+                                                           float momentum, int n_updates, float* running_mean,
+                                                           float* running_var, int64_t* nbt, float* mean_o,
+                                                           float* rstd_o, float* scale_o, float* shift_o) {
+    __shared__ double red[2][128][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += n_updates;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int r = rl; r < R; r += 128) {
+            s += (double)stats[(size_t)r * 2 * C + c];
+            q += (double)stats[(size_t)r * 2 * C + C + c];
+        }
+    }
+    red[0][rl][cl] = s;
+    red[1][rl][cl] = q;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    s = q = 0.0;
+#pragma unroll 8
+    for (int l = 0; l < 128; ++l) { s += red[0][l][cl]; q += red[1][l][cl]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    scale_o[c] = sc;
+    shift_o[c] = b - (float)mean * sc;
+    if (running_mean && running_var) {
+        const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+        float rm = running_mean[c], rv = running_var[c];
+        for (int u = 0; u < n_updates; ++u) {
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
 extern "C" int pai_bn_finalize(const float* stats, int rows, int C, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, int n_updates,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -68,6 +116,13 @@ extern "C" int pai_bn_finalize(const float* stats, int rows, int C, int64_t coun
     PAI_CHECK(rows > 0 && C > 0 && count > 0, "pai_bn_finalize: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const double* stage = nullptr;
+    if (rows > 16) {
+        hipLaunchKernelGGL(bn_finalize_wide_k, dim3(cdiv(C, 8)), dim3(1024), 0, s, stats, rows, C, (double)count, gamma,
+                           beta, eps, momentum, n_updates, running_mean, running_var, num_batches_tracked, mean, rstd,
+                           scale, shift);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     if (rows > STAGE_ROWS) {
         // scratch = the 2*STAGE_ROWS float rows that follow the partials (pai_bn_stats_buffer_rows)
         double* scratch = (double*)(stats + (size_t)rows * 2 * C);
@@ -251,15 +306,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
     }
 }
 
-// 8 channels x 32 row lanes per block: the <= 2048 partial rows are summed in fp64 by 32 lanes in parallel
-__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* partials, int rows, int C, float* sums,
-                                                         float* dgamma, float* dbeta) {
-    __shared__ double red[2][32][8];
+// 8 channels x FIN_LANES row lanes per block: the partial rows (up to 4096 from the fused input-gradient stores)
+// are summed in fp64; the launch is a chain of dependent L2 round trips, so it is as wide as a block can be
+constexpr int FIN_LANES = 128;
+__global__ __launch_bounds__(8 * FIN_LANES) void bn_bwd_finalize_k(const float* partials, int rows, int C, float* sums,
+                                                                   float* dgamma, float* dbeta) {
+    __shared__ double red[2][FIN_LANES][8];
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int r = rl; r < rows; r += 32) {
+        for (int r = rl; r < rows; r += FIN_LANES) {
             s1 += (double)partials[((size_t)r * 2 + 0) * C + c];
             s2 += (double)partials[((size_t)r * 2 + 1) * C + c];
         }
@@ -269,8 +326,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* partials, 
     __syncthreads();
     if (rl == 0 && c < C) {
         s1 = s2 = 0.0;
-#pragma unroll
-        for (int l = 0; l < 32; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
+#pragma unroll 8
+        for (int l = 0; l < FIN_LANES; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
         sums[c] = (float)s1;
         sums[C + c] = (float)s2;
         if (dbeta) dbeta[c] += (float)s1;
@@ -302,7 +359,7 @@ int bn_bwd_reduce_affine(int dtype, void* g1_du, int act1, const void* g2, int a
 extern "C" int pai_bn_bwd_finalize(const float* partials, int rows, int C, float* sums, float* dgamma,
                                    float* dbeta, void* stream) {
     PAI_CHECK(partials && sums && rows > 0 && C > 0, "pai_bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials, rows, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, (hipStream_t)stream, partials, rows, C,
                        sums, dgamma, dbeta);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -327,7 +384,7 @@ extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void
                            (const bf16_t*)g2, act2, (const bf16_t*)a, (const bf16_t*)z, M, C, rpb, mean, rstd,
                            (bf16_t*)du, partials);
     PAI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(256), 0, s, partials, rows, C, sums, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, s, partials, rows, C, sums, dgamma,
                        dbeta);
     PAI_LAUNCH_CHECK();
     return 0;
