@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, precision, q):
+def _worker(rank, world, port, precision, family, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -37,7 +37,8 @@ def _worker(rank, world, port, precision, q):
         pdist.init_from_env()
         dev = torch.device("cuda", 0)
         torch.manual_seed(100 + rank)                       # different initial weights per rank ...
-        m = pai.Pix2Pix(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
+        cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
+        m = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
         m.set_precision(precision)
         m.train()
         pdist.broadcast_parameters(m)                       # ... aligned here
@@ -71,12 +72,89 @@ def _worker(rank, world, port, precision, q):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("family", ["pix2pix", "attention_unet"])
 @pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
-def test_two_rank_step_keeps_replicas_identical(precision):
+def test_two_rank_step_keeps_replicas_identical(precision, family):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, family, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def _mean_worker(rank, world, port, family, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", PAI_DIST_BACKEND="gloo")
+    try:
+        import numpy as np
+        import torch.distributed as dist
+        import pai_bootstrap
+        pai = pai_bootstrap.load()
+        from thesis_pai_reconstruction_amd import dist as pdist
+        pdist.init_from_env()
+        dev = torch.device("cuda", 0)
+        cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
+        rng = np.random.default_rng(17 + rank)
+        x = torch.from_numpy(rng.random((4, 1, 64, 64), dtype=np.float32) * 2 - 1).to(dev)
+        t = torch.from_numpy(rng.random((4, 1, 64, 64), dtype=np.float32) * 2 - 1).to(dev)
+        captured = {}
+        for tag in ("local", "dist"):
+            torch.manual_seed(5)                           # same weights on both ranks and in both runs
+            m = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
+            m.set_precision("bf16-mixed")
+            m.train()
+            if tag == "dist":
+                red = pdist.GradReducer(bucket_bytes=256 << 10)    # many small buckets: reduced while backward runs
+                red.attach(m)
+
+                class T:
+                    reducer = red
+                    def _log(self, *a): pass
+                m.trainer = T()
+            for name, net, opt in (("g", m.unet, m.optimizers()[0]), ("d", m.discriminator, m.optimizers()[1])):
+                def grab(closure=None, name=name, net=net, tag=tag):
+                    torch.cuda.synchronize()
+                    captured[(tag, name)] = net.engine.arena().flat.detach().clone().cpu()
+                opt.step = grab                             # record the gradient arena instead of updating
+            m.training_step((x, t), 0)
+        for name in ("g", "d"):
+            local = captured[("local", name)]
+            both = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(both, local)
+            want = (both[0] + both[1]) / 2
+            got = captured[("dist", name)]
+            assert float((both[0] - both[1]).norm()) > 1e-3 * float(want.norm()), "shards gave identical gradients?"
+            # split weight gradients add their partial tiles with float atomics: the order, and so the last bits,
+            # differ between two runs of the same step
+            err = float((got - want).norm() / want.norm())
+            assert err < 1e-4, (name, err)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family", ["pix2pix", "attention_unet"])
+def test_reduced_gradients_equal_mean_of_local(family):
+    """What the optimizer sees under the reducer (buckets all-reduced on the side streams while the backward pass
+    is still running) is the mean of the ranks' local gradients -- a bucket launched before its range of the arena
+    was final would show up here as an O(1) error."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mean_worker, args=(r, 2, port, family, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
