@@ -262,7 +262,8 @@ def main():
     reuse = model._can_reuse_forward()
     gflop = step_gflop_per_image(reuse, args.model == "attention_unet")
     out = {
-        "metric": "train images/sec (256x256, bs=64) Pix2Pix step",
+        "metric": ("train images/sec (256x256, bs=64) Attention U-Net GAN step" if args.model == "attention_unet"
+                   else "train images/sec (256x256, bs=64) Pix2Pix step"),
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
