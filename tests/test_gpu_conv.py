@@ -37,6 +37,10 @@ CASES = [
     # >= 512 tiles of 16 x 16 output pixels: the 8-wave variant of the patch kernel (forward of both)
     ("enc_patch256", 0, 2, 8, 256, 256, 64, 0, 128, 0, 0),
     ("dec_patch256", 1, 2, 8, 64, 64, 128, 0, 128, 1, 0),
+    # thin layers whose wide side has 64-pixel rows: the weight gradient stages its thin patch through LDS
+    ("enc0_wide", 0, 2, 2, 128, 128, 1, 0, 64, 0, 0),
+    ("disc0_wide", 0, 2, 2, 128, 128, 1, 1, 64, 0, 0),
+    ("head_wide", 1, 2, 2, 64, 64, 64, 64, 1, 1, 1),
     # 64 output channels on 16 x 16 pixel tiles (gg_fwd_patch_k<256, 64>): forward here, input gradient in enc_patch256
     ("dec_patch256x64", 1, 2, 8, 64, 64, 128, 128, 64, 0, 1),
     # input gradient on the 16 x 16 patch kernel (dgrad of a stride-2 conv = 4 phases x 128 tiles)
