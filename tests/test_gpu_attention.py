@@ -320,3 +320,38 @@ def test_dropout2d_step_matches_reference_fixture(pai, golden_dir):
     m.train()
     with torch.no_grad():
         m.unet(batch[0])
+
+
+def test_baseline_config_properties(pai):
+    """BASELINE.json configs[2]: Attention U-Net, 256x256, batch 64, bf16 -- size-independent properties: finite
+    losses, gates in (0, 1), gated skips no larger than the skips, the reconstruction term improves over a few
+    steps, BatchNorm buffers advance twice per GAN step."""
+    m = pai.AttentionUnetGAN(1, 1, (1, 2, 4, 8, 8, 8, 8, 8), 0.0, "gan")
+    torch.manual_seed(0)
+    m.to(DEV)
+    m.set_precision("bf16-mixed")
+    m.train()
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy(rng.random((64, 1, 256, 256), dtype=np.float32) * 2 - 1).to(DEV)
+    t = torch.from_numpy(rng.random((64, 1, 256, 256), dtype=np.float32) * 2 - 1).to(DEV)
+    eng = m.unet.engine
+    pred, slot = eng.forward(x, True, 1, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert pred.shape == (64, 1, 256, 256) and bool(torch.isfinite(pred).all())
+    for j in range(1, eng.L):
+        gs = slot["gate"][j]
+        att = gs["att"]
+        assert float(att.min()) > 0.0 and float(att.max()) < 1.0, j
+        skip = eng._skip(slot, eng.L - 1 - j).float().view(gs["M"], -1)
+        gated = gs["s"].float().view(gs["M"], -1)
+        assert torch.allclose(gated, skip * att[:, None], rtol=2e-2, atol=1e-3), j
+    eng.release(slot)
+    first = None
+    for s in range(4):
+        m.logged = {}
+        m.training_step((x, t), s)
+        vals = {k: float(v) for k, v in m.logged.items()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        first = first or vals
+    assert vals["train_rmse"] < first["train_rmse"]
+    assert int(m.unet.attention_blocks[0].attention[1].num_batches_tracked) == 1 + 2 * 4

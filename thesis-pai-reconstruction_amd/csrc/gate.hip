@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256) void gate_hidden_bwd_k(const float* dl, const 
         }
         if ((tid % span) == 0) db += dlog;
     }
-    // combine the row lanes of the block: 4 quantities x 8 channels per thread, one quantity at a time
+    // combine the row lanes of the block, one quantity at a time: thread c < K sums channel c over the `lanes`
+    // row lanes (a first version let K/8 threads walk all lanes x 8 channels serially: 2048 dependent LDS reads,
+    // most of this kernel's time on the 1 M-pixel level)
 #pragma unroll
     for (int qn = 0; qn < 4; ++qn) {
         const float* src = qn == 0 ? a0 : qn == 1 ? a1 : qn == 2 ? a2 : a3;
@@ -200,24 +202,17 @@ __global__ __launch_bounds__(256) void gate_hidden_bwd_k(const float* dl, const 
         for (int k = 0; k < 8; ++k) red[tid][k] = src[k];
         red[tid][8] = db;
         __syncthreads();
-        if (tid < span) {
-            float t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = 0.f;
-            for (int l = 0; l < lanes; ++l)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] += red[tid + l * span][k];
+        for (int c = tid; c < K; c += 256) {
+            const int sp = c >> 3, k = c & 7;
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += red[sp + l * span][k];
             const size_t row = (size_t)blockIdx.x * 2;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int c = tid * 8 + k;
-                if (qn == 0) { part_i[(row + 0) * K + c] = t[k]; part_s[(row + 0) * K + c] = t[k]; }
-                else if (qn == 1) part_i[(row + 1) * K + c] = t[k];
-                else if (qn == 2) part_s[(row + 1) * K + c] = t[k];
-                else atomicAdd(dwa + c, t[k]);
-            }
+            if (qn == 0) { part_i[(row + 0) * K + c] = t; part_s[(row + 0) * K + c] = t; }
+            else if (qn == 1) part_i[(row + 1) * K + c] = t;
+            else if (qn == 2) part_s[(row + 1) * K + c] = t;
+            else atomicAdd(dwa + c, t);
         }
-        if (qn == 3 && tid == 0 && dba) {
+        if (qn == 3 && tid == 255 && dba) {
             float t = 0.f;
             for (int l = 0; l < lanes; ++l) t += red[l * span][8];
             atomicAdd(dba, t);
