@@ -62,8 +62,9 @@ typedef struct pai_conv_desc {
     int32_t N, H, W;      /* input batch / height / width */
     int32_t C1, C2;       /* input channels taken from x1 and x2 (C2 = 0: x2 unused) */
     int32_t Cout;         /* output channels */
-    int32_t kernel;       /* 4, or 1: pointwise Conv2d of the attention gates
-                             (models/attention_unet.py:72-84; stride 1, pad 0, one weight tap) */
+    int32_t kernel;       /* 4; 1: pointwise Conv2d of the attention gates (models/attention_unet.py:72-84;
+                             stride 1, pad 0, one weight tap); 3: "same" Conv2d of the residual U-Net
+                             (models/res_unet.py:59; stride 1, pad 1, 9 taps) */
     int32_t stride;       /* 2 (or 1 for Conv2d) */
     int32_t pad;          /* 1 (0 with kernel 1) */
     int32_t relu1, relu2; /* apply ReLU to x1 / x2 while loading (fused nn.ReLU of the

@@ -205,6 +205,64 @@ def test_conv_family(pai, case, dtype):
     assert rel_err(unpack_fwd(dw, Cout, Cin, bool(tr)), 2 * wr.grad) < tol_w, name
 
 
+# (name, N, H, W, Cin, Cout): vector-ALU kernel (1 -> 64), MFMA forward / input gradient with the vector-ALU weight
+# gradient (9 * 64 is not a multiple of 128), MFMA everywhere (128 -> 128), row-dot forward (64 -> 1)
+CONV3 = [("in_conv", 2, 16, 16, 1, 64), ("c64", 2, 16, 24, 64, 64), ("c128", 3, 16, 16, 128, 128),
+         ("out_conv", 2, 16, 16, 64, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV3, ids=[c[0] for c in CONV3])
+def test_conv3x3(pai, case, dtype):
+    """nn.Conv2d(kernel_size=3, padding=1) of the residual U-Net (reference models/res_unet.py:59,62,265,308)
+    through the same gather-GEMM entry points (kernel = 3: 9 taps, stride 1)."""
+    from thesis_pai_reconstruction_amd import ops
+    name, N, H, W, C, K = case
+    tol = TOL[dtype]
+    x = q(rnd((N, C, H, W), 1), dtype).requires_grad_(True)
+    w = q(rnd((K, C, 3, 3), 2, 0.05), dtype).requires_grad_(True)
+    b = rnd((K,), 3, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    dy = q(rnd(tuple(y.shape), 4), dtype)
+    y.backward(dy)
+    d = ops.make_desc(dtype, 0, N, H, W, C, 0, K, 1, 0, 0, ops.ACT_RELU, kernel=3)
+    assert ops.conv_out_hw(d) == (H, W)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())          # fwd pack [K][3][3][C]
+    wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    ops.pack_weights(dtype, wm, K, 9, C, wf, wd)
+    X, DY = nhwc(x.detach(), dtype), nhwc(dy, dtype)
+    if K > 2:
+        y_raw = torch.empty(N * H * W * K, dtype=dtype, device=dev())
+        y_act = torch.empty_like(y_raw)
+        rows = ops.conv_fwd_stats_rows(d)
+        stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * K, dtype=torch.float32,
+                            device=dev())
+        ops.conv_fwd(d, X, None, wf, b.detach().to(dev()), y_raw=y_raw, stats=stats)
+        ops.conv_fwd(d, X, None, wf, b.detach().to(dev()), y_act=y_act)
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(y_raw, N, H, W, K), y.detach()) < tol
+        assert rel_err(from_nhwc(y_act, N, H, W, K), F.relu(y.detach())) < tol
+        st = stats[:rows * 2 * K].view(rows, 2, K).double().sum(0).cpu()
+        assert rel_err(st[1], (y.detach().double() ** 2).sum((0, 2, 3))) < 1e-4
+    else:
+        y32 = torch.empty(N * H * W * K, dtype=torch.float32, device=dev())
+        d.epilogue_act = ops.ACT_TANH
+        ops.conv_fwd(d, X, None, wf, b.detach().to(dev()), y_f32=y32)
+        assert rel_err(from_nhwc(y32, N, H, W, K), torch.tanh(y.detach())) < (1e-4 if dtype == torch.float32 else 5e-3)
+    dx = torch.empty(N * H * W * C, dtype=dtype, device=dev())
+    ops.conv_dgrad(d, DY, wd, dx, None)
+    assert rel_err(from_nhwc(dx, N, H, W, C), x.grad) < tol
+    dw = torch.zeros(wm.numel(), dtype=torch.float32, device=dev())
+    db = torch.zeros(K, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(d, X, None, DY, dw, db)
+    torch.cuda.synchronize()
+    tol_w = 1e-4 if dtype == torch.float32 else 3e-3
+    assert rel_err(dw.cpu().view(K, 3, 3, C).permute(0, 3, 1, 2), w.grad) < tol_w
+    assert rel_err(db.cpu(), b.grad) < tol_w
+
+
 def test_bad_arguments_fail_loudly(pai):
     from thesis_pai_reconstruction_amd import ops
     d = ops.make_desc(torch.float32, 0, 1, 7, 8, 1, 0, 64, 2)

@@ -40,6 +40,8 @@ static int check_desc(const pai_conv_desc* d) {
     PAI_CHECK(d->dtype == PAI_F32 || d->dtype == PAI_BF16, "bad dtype %d", d->dtype);
     if (d->kernel == 1) {   // pointwise conv of the attention gates (models/attention_unet.py:72-84)
         PAI_CHECK(d->pad == 0 && d->stride == 1 && !d->transposed, "kernel=1 needs pad=0 stride=1 Conv2d");
+    } else if (d->kernel == 3) {   // 3x3 "same" conv of the residual U-Net (models/res_unet.py:59,62,90,117,265,308)
+        PAI_CHECK(d->pad == 1 && d->stride == 1 && !d->transposed, "kernel=3 needs pad=1 stride=1 Conv2d");
     } else {
         PAI_CHECK(d->kernel == 4 && d->pad == 1, "only kernel=4 pad=1 or kernel=1 pad=0 supported (got k=%d p=%d)",
                   d->kernel, d->pad);
@@ -106,6 +108,19 @@ static void fill_pointwise(GG* g) {
     g->dy[0][0] = g->dx[0][0] = g->wt[0][0] = 0;
 }
 
+// k3 s1 p1: out[i] = sum_kh in[i + kh - 1] w[kh]  (sign = +1);  its input gradient dx[i] = sum_kh dy[i + 1 - kh] w[kh]
+static void fill_3x3(GG* g, int sign) {
+    g->S = 1; g->nphase = 1; g->ntaps = 9; g->OS = 1; g->wtaps = 9;
+    g->poy[0] = g->pox[0] = 0;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            const int t = kh * 3 + kw;
+            g->dy[0][t] = (signed char)(sign * (kh - 1));
+            g->dx[0][t] = (signed char)(sign * (kw - 1));
+            g->wt[0][t] = (signed char)t;
+        }
+}
+
 static void fill_phase_taps(GG* g) {
     g->S = 1;
     g->nphase = 4;
@@ -144,6 +159,9 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
     if (d->kernel == 1) {
         g->OHg = OH; g->OWg = OW;
         fill_pointwise(g);
+    } else if (d->kernel == 3) {
+        g->OHg = OH; g->OWg = OW;
+        fill_3x3(g, +1);
     } else if (!d->transposed) {
         g->OHg = OH; g->OWg = OW;
         fill_conv_taps(g, d->stride, -d->pad);
@@ -171,6 +189,9 @@ int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
     if (d->kernel == 1) {
         g->OHg = d->H; g->OWg = d->W;
         fill_pointwise(g);    // dx = dy x W^T, pixel by pixel
+    } else if (d->kernel == 3) {
+        g->OHg = d->H; g->OWg = d->W;
+        fill_3x3(g, -1);
     } else if (!d->transposed) {
         if (d->stride == 2) {
             // dx[2a+ph] = sum_kh dy[a + off] w[kh]  -- same phase structure as ConvTranspose2d
@@ -272,7 +293,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     }
     if (op == 2) {
         if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g)) return 4;
-        if (g.Cout <= 2 && g.ntaps != 1 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+        if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
             int chunks = g.Cin / 8;
             if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
         }
@@ -437,7 +458,7 @@ extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void
     if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
     if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
     if (thin_wgrad_conv1_ok(d->dtype, g)) return launch_thin_wgrad_conv1(g, a, s);
-    if (g.Cout <= 2 && g.ntaps != 1 && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+    if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
         int chunks = g.Cin / 8;
         if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);
     }

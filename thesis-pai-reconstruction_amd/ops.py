@@ -41,7 +41,7 @@ def make_desc(dtype, transposed, N, H, W, C1, C2, Cout, stride=2, relu1=0, relu2
     d.dtype = code_of(dtype)
     d.transposed = int(transposed)
     d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
-    d.kernel, d.stride, d.pad = (4, stride, 1) if kernel == 4 else (1, 1, 0)
+    d.kernel, d.stride, d.pad = {4: (4, stride, 1), 3: (3, 1, 1), 1: (1, 1, 0)}[kernel]
     d.relu1, d.relu2, d.epilogue_act = int(relu1), int(relu2), int(act)
     return d
 
