@@ -231,6 +231,23 @@ int pai_dropout2d(int dtype, const void* x, const float* mask, int N, int64_t HW
                   void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Residual U-Net building blocks (models/res_unet.py) besides its convolutions (pai_conv_* with kernel 3 / 1)
+ * and BatchNorms: nn.MaxPool2d(2) (:199), nearest nn.Upsample(scale_factor=2) (:231), the residual sum with
+ * the optional ReLU behind it (:71-74).  NHWC tensors in the storage dtype, C a multiple of 8.
+ *   pai_maxpool2      out [N][H/2][W/2][C]; idx (one byte per output element, or NULL) keeps the arg-max
+ *                     (first maximum in row-major window order, as aten::max_pool2d_with_indices)
+ *   pai_maxpool2_bwd  dx [N][H][W][C] = dout routed to the arg-max, zeros elsewhere
+ *   pai_upsample2     out [N][2H][2W][C];  pai_upsample2_bwd  dx [N][H][W][C] = sum of the 2x2 window of dout
+ *   pai_add_act       out = act(a + b)   (backward: pai_act_bwd on the stored sum)
+ * ------------------------------------------------------------------------- */
+int pai_maxpool2(int dtype, const void* x, int N, int H, int W, int C, void* out, unsigned char* idx, void* stream);
+int pai_maxpool2_bwd(int dtype, const void* dout, const unsigned char* idx, int N, int H, int W, int C, void* dx,
+                     void* stream);
+int pai_upsample2(int dtype, const void* x, int N, int H, int W, int C, void* out, void* stream);
+int pai_upsample2_bwd(int dtype, const void* dout, int N, int H, int W, int C, void* dx, void* stream);
+int pai_add_act(int dtype, const void* a, const void* b, int64_t numel, int act, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Attention gate of the Attention U-Net skip connections.  Replaces the ATen ops behind
  * AttentionBlock.forward (models/attention_unet.py:88-96) that are not convolutions:
  *   h = ReLU(BN_s(sg) + BN_i(ig)),  logit = conv1x1(h; w_a, b_a)  (K -> 1),

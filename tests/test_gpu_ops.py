@@ -189,3 +189,51 @@ def test_cast_roundtrip(pai):
     b = torch.empty(1000, dtype=torch.bfloat16, device=dev())
     ops.cast(x, b)
     assert torch.equal(b.cpu(), x.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12), (3, 128, 4, 4), (1, 8, 2, 2)])
+def test_maxpool_upsample_add(pai, dtype, shape):
+    """nn.MaxPool2d(2), nearest nn.Upsample(scale_factor=2) and the residual sum (+ReLU) of the residual U-Net
+    (reference models/res_unet.py:199,231,74) against torch, forward and backward; exact in both dtypes (pure
+    selection / replication; the sums are compared to bf16 rounding)."""
+    from thesis_pai_reconstruction_amd import ops
+    N, C, H, W = shape
+    x = q(rnd(shape, 1), dtype).requires_grad_(True)
+    # ---- max pool ----
+    y = F.max_pool2d(x, 2)
+    gy = q(rnd(tuple(y.shape), 2), dtype)
+    y.backward(gy)
+    X = nhwc(x.detach(), dtype)
+    out = torch.empty(N * (H // 2) * (W // 2) * C, dtype=dtype, device=dev())
+    idx = torch.empty(out.numel(), dtype=torch.uint8, device=dev())
+    ops.maxpool2(dtype, X, N, H, W, C, out, idx)
+    dx = torch.empty_like(X)
+    ops.maxpool2_bwd(dtype, nhwc(gy, dtype), idx, N, H, W, C, dx)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(out, N, H // 2, W // 2, C), y.detach())
+    assert torch.equal(from_nhwc(dx, N, H, W, C), x.grad)
+    # ---- nearest upsample ----
+    x.grad = None
+    u = F.interpolate(x, scale_factor=2)              # nn.Upsample default mode='nearest'
+    gu = q(rnd(tuple(u.shape), 3), dtype)
+    u.backward(gu)
+    up = torch.empty(N * 2 * H * 2 * W * C, dtype=dtype, device=dev())
+    ops.upsample2(dtype, X, N, H, W, C, up)
+    dxu = torch.empty_like(X)
+    ops.upsample2_bwd(dtype, nhwc(gu, dtype), N, H, W, C, dxu)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(up, N, 2 * H, 2 * W, C), u.detach())
+    assert rel_err(from_nhwc(dxu, N, H, W, C), x.grad) < (1e-6 if dtype == torch.float32 else 4e-3)
+    # ---- residual sum + ReLU; backward = activation backward on the stored sum ----
+    b = q(rnd(shape, 4), dtype)
+    s = torch.empty_like(X)
+    ops.add_act(dtype, X, nhwc(b, dtype), ops.ACT_RELU, s)
+    want = F.relu(x.detach() + b)
+    assert rel_err(from_nhwc(s, N, H, W, C), want) < (1e-6 if dtype == torch.float32 else 4e-3)
+    g = nhwc(q(rnd(shape, 5), dtype), dtype)
+    ds = torch.empty_like(X)
+    ops.act_bwd(dtype, g, ops.ACT_RELU, None, ops.ACT_NONE, s, s.numel(), ds)
+    torch.cuda.synchronize()
+    mask = (from_nhwc(s, N, H, W, C) > 0).float()
+    assert torch.equal(from_nhwc(ds, N, H, W, C), from_nhwc(g, N, H, W, C) * mask)

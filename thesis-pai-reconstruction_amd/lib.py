@@ -75,6 +75,11 @@ SIGNATURES = {
     "pai_bn_bwd_reduce": (_I, [_I, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_bwd_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pai_act_bwd": (_I, [_I, _P, _I, _P, _I, _P, _L, _P, _P]),
+    "pai_maxpool2": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "pai_maxpool2_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "pai_upsample2": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "pai_upsample2_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "pai_add_act": (_I, [_I, _P, _P, _L, _I, _P, _P]),
     "pai_dropout2d": (_I, [_I, _P, _P, _I, _L, _I, _P, _P]),
     "pai_gate_partial_rows": (_I, [_L]),
     "pai_gate_hidden": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

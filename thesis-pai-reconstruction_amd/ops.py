@@ -249,6 +249,29 @@ def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
             "pai_act_bwd")
 
 
+# ---- residual U-Net building blocks (models/res_unet.py:199,231,74) -------------------------------
+def maxpool2(dtype, x, N, H, W, C_, out, idx=None):
+    L.check(L.load().pai_maxpool2(code_of(dtype), _p(x), N, H, W, C_, _p(out), _p(idx, torch.uint8), _stream()),
+            "pai_maxpool2")
+
+
+def maxpool2_bwd(dtype, dout, idx, N, H, W, C_, dx):
+    L.check(L.load().pai_maxpool2_bwd(code_of(dtype), _p(dout), _p(idx, torch.uint8), N, H, W, C_, _p(dx), _stream()),
+            "pai_maxpool2_bwd")
+
+
+def upsample2(dtype, x, N, H, W, C_, out):
+    L.check(L.load().pai_upsample2(code_of(dtype), _p(x), N, H, W, C_, _p(out), _stream()), "pai_upsample2")
+
+
+def upsample2_bwd(dtype, dout, N, H, W, C_, dx):
+    L.check(L.load().pai_upsample2_bwd(code_of(dtype), _p(dout), N, H, W, C_, _p(dx), _stream()), "pai_upsample2_bwd")
+
+
+def add_act(dtype, a, b, act, out):
+    L.check(L.load().pai_add_act(code_of(dtype), _p(a), _p(b), a.numel(), int(act), _p(out), _stream()), "pai_add_act")
+
+
 def dropout2d(dtype, x, mask, N, HW, C_, out):
     """out = x * mask[n][c] over an NHWC tensor (nn.Dropout2d forward, and its backward on gradients)."""
     L.check(L.load().pai_dropout2d(code_of(dtype), _p(x), _p(mask, torch.float32), N, HW, C_, _p(out), _stream()),
