@@ -27,8 +27,11 @@ def main(name):
     seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
     mults = tuple(int(v) for v in z["meta.mults"])
     fam = str(z["meta.family"]) if "meta.family" in z.files else "pix2pix"
-    make = oracle.make_attention_unet_state if fam == "attention" else oracle.make_unet_state
-    g = oracle.init_state_portable(make(1, 1, mults), seed, perturb_bn=True)
+    if fam.startswith("res"):
+        g0 = oracle.make_res_unet_state(1, 1, fam[3:], mults)
+    else:
+        g0 = (oracle.make_attention_unet_state if fam == "attention" else oracle.make_unet_state)(1, 1, mults)
+    g = oracle.init_state_portable(g0, seed, perturb_bn=True)
     d = oracle.init_state_portable(oracle.make_disc_state(1), seed + 1)
     g = type(g)((k, v.double() if v.is_floating_point() else v) for k, v in g.items())
     d = type(d)((k, v.double()) for k, v in d.items())

@@ -39,8 +39,9 @@ def _import_reference():
     from models.wrapper import Discriminator     # noqa
     from models.utils import init_weights        # noqa
     from models.attention_unet import AttentionUnetGAN   # noqa
-    global _ATT
-    _ATT = AttentionUnetGAN
+    from models.res_unet import ResUnetGAN                # noqa
+    global _ATT, _RES
+    _ATT, _RES = AttentionUnetGAN, ResUnetGAN
     return Pix2Pix, Discriminator, init_weights
 
 
@@ -56,10 +57,17 @@ def build_reference_model(mults, loss_type, seed, family="pix2pix", dropout=0.0)
     from oracle.pix2pix_ref import make_unet_state, make_disc_state, init_state_portable
     from oracle.attention_ref import make_attention_unet_state
     Pix2Pix, Discriminator, init_weights = _REF
-    cls = _ATT if family == "attention" else Pix2Pix
-    make = make_attention_unet_state if family == "attention" else make_unet_state
-    m = cls(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=dropout, loss_type=loss_type)
-    g_st = init_state_portable(make(1, 1, mults), seed, perturb_bn=True)
+    if family.startswith("res"):          # "res18" | "res50" | "resnext"
+        from oracle.res_unet_ref import make_res_unet_state
+        rt = family[3:]
+        m = _RES(in_channels=1, out_channels=1, res_type=rt, channel_mults=tuple(mults), dropout=dropout,
+                 loss_type=loss_type)
+        g_st = init_state_portable(make_res_unet_state(1, 1, rt, mults), seed, perturb_bn=True)
+    else:
+        cls = _ATT if family == "attention" else Pix2Pix
+        make = make_attention_unet_state if family == "attention" else make_unet_state
+        m = cls(in_channels=1, out_channels=1, channel_mults=tuple(mults), dropout=dropout, loss_type=loss_type)
+        g_st = init_state_portable(make(1, 1, mults), seed, perturb_bn=True)
     missing = m.unet.load_state_dict(g_st, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     if loss_type == "gan":
@@ -219,6 +227,15 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _REF = _import_reference()
+    if "--res" in sys.argv:           # residual U-Net family
+        for fam, seed in (("resnext", 131), ("res18", 141), ("res50", 151)):
+            run_forward_case(f"ref_{fam}_forward_tiny", (1, 2, 2), 32, 4, seed=seed, family=fam)
+            run_case(f"ref_{fam}_gan_tiny", (1, 2, 2), 32, 4, "gan", seed=seed + 5, steps=2, full_tensors=False,
+                     family=fam)
+        run_case("ref_resnext_gan_dropout_tiny", (1, 2, 2, 2), 32, 4, "gan", seed=161, steps=2, full_tensors=False,
+                 search=False, family="resnext", dropout=0.5)
+        run_forward_case("ref_resnext_forward_mid", (1, 2, 4, 8, 8), 128, 2, seed=171, family="resnext")
+        sys.exit(0)
     if "--dropout" in sys.argv:       # Dropout2d(0.5) in the widest decoders (the class default of the reference)
         run_case("ref_gan_dropout_tiny", (1, 4, 4, 4), 32, 4, "gan", seed=111, steps=2, full_tensors=False,
                  search=False, dropout=0.5)

@@ -1,0 +1,176 @@
+"""GPU parity of the residual U-Net family (reference models/res_unet.py) through the plugin
+surface (ResUnetGAN, res_type "next" / "18" / "50") against fixtures recorded from the REAL reference and the CPU
+oracle run live.  fp32 mode within 1e-4 relative; bf16 mode a looser bound."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.fingerprint import fingerprint, fingerprint_close
+from oracle.gen_golden import synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def build(pai, res_type, mults, loss_type, seed, dtype=torch.float32, dropout=0.0):
+    m = pai.ResUnetGAN(in_channels=1, out_channels=1, res_type=res_type, channel_mults=tuple(mults), dropout=dropout,
+                       loss_type=loss_type)
+    g = oracle.init_state_portable(oracle.make_res_unet_state(1, 1, res_type, tuple(mults)), seed, perturb_bn=True)
+    m.unet.load_state_dict(g, strict=True)
+    d = None
+    if loss_type == "gan":
+        d = oracle.init_state_portable(oracle.make_disc_state(1), seed + 1)
+        m.discriminator.load_state_dict(d, strict=True)
+    m.to(DEV)
+    m.set_precision("32" if dtype == torch.float32 else "bf16-mixed")
+    m.train()
+    return m, g, d
+
+
+def _fp_err(got, want_fp, rtol):
+    ok, worst = fingerprint_close(fingerprint(got), want_fp, rtol)
+    return ok, worst
+
+
+@pytest.mark.parametrize("name", ["ref_resnext_forward_tiny", "ref_res18_forward_tiny", "ref_res50_forward_tiny",
+                                  "ref_resnext_forward_mid"])
+def test_forward_matches_reference_fixture(pai, golden_dir, name):
+    z = _load(golden_dir, name)
+    seed, n, size, fam = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), str(z["meta.family"])
+    m, _, _ = build(pai, fam[3:], [int(v) for v in z["meta.mults"]], "gan", seed)
+    x, t = synth_batch(seed + 100, n, size)
+    x = x.to(DEV)
+    with torch.no_grad():
+        pred = m.unet(x)
+        lf = m.discriminator(x, pred)
+    want = torch.from_numpy(z["pred_full"])
+    # 3-level fixtures at 1e-4; the 5-level one (10 residual blocks, BatchNorm over 32 samples at the bottom) at 5e-4
+    ftol = 1e-4 if name.endswith("tiny") else 5e-4
+    assert float((pred.cpu() - want).abs().max()) < ftol * float(want.abs().max())
+    w = torch.from_numpy(z["logits_fake_full"])
+    # (the 32 x 32 fixtures give one logit of ~1e-3 per sample: bound relative to the activations that form it)
+    assert float((lf.cpu() - w).norm()) < 1e-4 * max(float(w.norm()), 1e-2)
+    m.eval()                                   # eval mode (running statistics) against the live oracle
+    g = {k: v.detach().cpu().clone() for k, v in m.unet.state_dict().items()}
+    with torch.no_grad():
+        pe = m.unet(x)
+        we = oracle.res_unet_forward(g, x.cpu(), training=False)
+    assert float((pe.cpu() - we).abs().max()) < ftol * float(we.abs().max())
+
+
+def _check_step(m, z, s, gtol, floor=None):
+    for k, v in m.logged.items():
+        want = float(z[f"step{s}.log.{k}"])
+        # after the first update the kink flips described below have moved the parameters apart by ~lr: 1e-3 from there
+        assert abs(float(v) - want) <= (1e-4 if s == 0 else 1e-3) * max(1.0, abs(want)), (s, k, float(v), want)
+    names = [k for k, _ in m.unet.named_parameters()]
+    gmax = max(float(z[f"step{s}.ggrad.{k}"][3]) for k in names)
+    bad = []
+    for k, p in m.unet.named_parameters():
+        want = z[f"step{s}.ggrad.{k}"]
+        if p.dim() == 1 and float(want[3]) < 1e-4 * gmax:
+            # analytically zero gradients (conv bias in front of a BatchNorm; per-channel shifts whose every consumer is a
+            # 1x1 conv -> BatchNorm pair): cancellation noise in the reference, see tests/test_oracle_golden.py
+            assert float(p.grad.abs().max()) < 1e-3 * gmax, (s, k)
+            continue
+        extra = 3.0 * float(floor["floor." + k]) if floor is not None and s == 0 else 0.0
+        ok, worst = _fp_err(p.grad, want, (gtol if p.numel() > 1 else 2e-2) + extra)
+        if not ok:
+            bad.append((k, worst))
+    assert not bad, (s, bad[:6])
+
+
+@pytest.mark.parametrize("name", ["ref_resnext_gan_tiny", "ref_res18_gan_tiny", "ref_res50_gan_tiny"])
+def test_gan_training_step_matches_reference_fixture(pai, golden_dir, name):
+    z = _load(golden_dir, name)
+    seed, n, size, steps = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), int(z["meta.steps"])
+    fam = str(z["meta.family"])
+    m, g, d = build(pai, fam[3:], [int(v) for v in z["meta.mults"]], "gan", seed)
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    for s in range(steps):
+        m.logged = {}
+        m.training_step(batch, s)
+        torch.cuda.synchronize()
+        # Step 0 is the parity bar (tests/test_gpu_model.py: later steps start from sign-SGD-perturbed parameters).
+        # Against the live oracle every gradient is within 1e-5 (L2) UNLESS a ReLU flips: the 32 x 32 x 64..128-channel
+        # activations of these nets have 260-520 K elements each -- beyond what the fixture's seed search keeps away from
+        # the kink -- and at our forward noise of ~1e-5 (fp32 sums of up to 1152 terms in another order) a few
+        # pre-activations per tensor change sign; one flip moves every upstream gradient by ~1/sqrt(numel) ~ 3e-3
+        # (scripts/debug_res_grad.py shows the step where it enters).  Hence 6e-3, plus the reference's own fp32
+        # distance from fp64 (oracle/gen_f64_floor.py; 2-5e-3 for res_type "50", whose 16-channel bottlenecks are tiny).
+        _check_step(m, z, s, 6e-3 if s == 0 else 0.3 * s, _load(golden_dir, name + "_f64floor"))
+    for k, v in m.unet.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 2 * steps       # two BatchNorm updates per GAN step
+    m.eval()
+    m.logged = {}
+    with torch.no_grad():
+        m.validation_step(batch, 0)
+    for k, v in m.logged.items():
+        want = float(z[f"val.log.{k}"])
+        assert abs(float(v) - want) <= 2e-3 * max(1.0, abs(want)), (k, float(v), want)
+
+
+def test_dropout2d_step_matches_reference_fixture(pai, golden_dir):
+    """Dropout2d(0.5) behind the widest decoder blocks (reference models/res_unet.py:230,286-289), masks replayed from
+    the oracle's redraw of the reference's generator state."""
+    z = _load(golden_dir, "ref_resnext_gan_dropout_tiny")
+    seed, n, size, steps = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), int(z["meta.steps"])
+    mults, p = [int(v) for v in z["meta.mults"]], float(z["meta.dropout"])
+    m, g, d = build(pai, "next", mults, "gan", seed, dropout=p)
+    assert not m.unet.supports_forward_reuse
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    og, od = oracle.AdamState(), oracle.AdamState()
+    for s in range(steps):
+        torch.manual_seed(1000 + s)
+        mask_log = []
+        oracle.gan_training_step(g, d, og, od, x, t, dropout=p, mask_log=mask_log)
+        queue = list(mask_log)
+        assert queue
+
+        def replay(j, N, C, rate, device):
+            jj, mk = queue.pop(0)
+            assert jj == j and rate == p and mk.shape[:2] == (N, C)
+            return mk.reshape(N, C).to(device)
+
+        m.unet.dropout_mask_fn = replay
+        m.logged = {}
+        m.training_step(batch, s)
+        torch.cuda.synchronize()
+        assert not queue
+        _check_step(m, z, s, 5e-3 if s == 0 else 0.3 * s)
+
+
+def test_bf16_mode_tracks_fp32(pai, golden_dir):
+    """bf16 storage: the MFMA kernels behind the 3x3 / 1x1 / block-diagonal grouped convolutions.  At random
+    initialisation in_conv's 64 channels are a bias plus a small signal of rank <= 9, and every block starts with a
+    1x1 conv -> BatchNorm that removes the constant again: the 2^-9 storage rounding of the total becomes ~1 % of the
+    signal per block (scripts/debug_res.py lists it level by level; fp32 mode stays at 7e-5 through 10 blocks).  So
+    the bound here is loose on the output and the check that matters is that training makes progress."""
+    z = _load(golden_dir, "ref_resnext_forward_tiny")
+    seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
+    mults = [int(v) for v in z["meta.mults"]]
+    m, _, _ = build(pai, "next", mults, "gan", seed, dtype=torch.bfloat16)
+    x, t = synth_batch(seed + 100, n, size)
+    batch = (x.to(DEV), t.to(DEV))
+    with torch.no_grad():
+        p16 = m.unet(batch[0])
+    want = torch.from_numpy(z["pred_full"])
+    assert float((p16.cpu() - want).norm() / want.norm()) < 0.25
+    first = None
+    for s in range(4):
+        m.logged = {}
+        m.training_step(batch, s)
+        vals = {k: float(v) for k, v in m.logged.items()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        first = first or vals
+    assert vals["loss"] < first["loss"] and vals["train_rmse"] < first["train_rmse"]
