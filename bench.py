@@ -103,8 +103,10 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the convolution launches with HIP events in the timed region (no roofline)")
     ap.add_argument("--no-reuse", action="store_true", help="literal two generator forwards per step")
-    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "attention_unet"],
-                    help="pix2pix = BASELINE configs[1] (the headline metric); attention_unet = configs[2]")
+    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "attention_unet", "resnext_unet"],
+                    help="pix2pix = BASELINE configs[1] (the headline metric); attention_unet = configs[2]; "
+                         "resnext_unet = configs[3] (use --size 512 --batch 16)")
+    ap.add_argument("--size", type=int, default=SIZE, help="image size (configs[3] is quoted at 512)")
     args = ap.parse_args()
 
     import pai_bootstrap
@@ -118,7 +120,10 @@ def main():
     dev = torch.device("cuda", local)
 
     torch.manual_seed(0)
-    model = (pai.AttentionUnetGAN if args.model == "attention_unet" else pai.Pix2Pix)(1, 1, MULTS, 0.0, "gan")
+    if args.model == "resnext_unet":
+        model = pai.ResUnetGAN(1, 1, "next", MULTS, 0.0, "gan")
+    else:
+        model = (pai.AttentionUnetGAN if args.model == "attention_unet" else pai.Pix2Pix)(1, 1, MULTS, 0.0, "gan")
     model.to(dev)
     model.set_precision(args.precision)
     model.reuse_generator_forward = not args.no_reuse
@@ -138,8 +143,8 @@ def main():
         model.trainer = tr
 
     rng = np.random.default_rng(1234 + rank)
-    x = torch.from_numpy(rng.random((args.batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1).to(dev)
-    t = torch.from_numpy(rng.random((args.batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1).to(dev)
+    x = torch.from_numpy(rng.random((args.batch, 1, args.size, args.size), dtype=np.float32) * 2 - 1).to(dev)
+    t = torch.from_numpy(rng.random((args.batch, 1, args.size, args.size), dtype=np.float32) * 2 - 1).to(dev)
     batch = (x, t)
 
     def barrier():
@@ -237,7 +242,7 @@ def main():
     # stream, which stretches every individual launch.  For the kernel's own efficiency the same
     # launches are timed once more with that overlap switched off (3 extra steps, not part of `value`).
     roofline_isolated = None
-    engines = [m.engine for m in (model.unet, model.discriminator)]
+    engines = [m.engine for m in (model.unet, model.discriminator) if hasattr(type(m), "engine")]
     if any(e._side.on for e in engines) and not args.no_kernel_events:
         saved = [e._side.on for e in engines]
         for e in engines:
@@ -261,15 +266,19 @@ def main():
     value = world * args.batch * args.steps / dt
     reuse = model._can_reuse_forward()
     gflop = step_gflop_per_image(reuse, args.model == "attention_unet")
+    if args.model == "resnext_unet":
+        gflop = float("nan")     # SURVEY 8(d) gives the MAC budget of configs[1]/[2] only
     out = {
-        "metric": ("train images/sec (256x256, bs=64) Attention U-Net GAN step" if args.model == "attention_unet"
-                   else "train images/sec (256x256, bs=64) Pix2Pix step"),
+        "metric": ("train images/sec (256x256, bs=64) Pix2Pix step" if args.model == "pix2pix" else
+                   f"train images/sec ({args.size}x{args.size}, bs={args.batch}) {args.model} GAN step"),
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
         "data": "synthetic",
         "config": {"workload": ("Attention U-Net generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
                                 "(BASELINE configs[2])" if args.model == "attention_unet" else
+                                f"Residual U-Net (ResNeXt blocks) generator+PatchGAN GAN step, {args.size}x{args.size}x1 "
+                                f"pairs, {args.batch} images/GPU (BASELINE configs[3])" if args.model == "resnext_unet" else
                                 "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
                                 "(BASELINE configs[1])"),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
@@ -277,13 +286,13 @@ def main():
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}"},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "clock_ramp_steps": prewarm_steps,
-        "step_conv_gflop_per_image": round(gflop, 2),
-        "step_mfma_frac": round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "step_conv_gflop_per_image": None if gflop != gflop else round(gflop, 2),
+        "step_mfma_frac": None if gflop != gflop else round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": roofline,
         "roofline_isolated": roofline_isolated,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(attention=args.model == "attention_unet")
+        out["cpu_baseline"] = cpu_baseline(attention=args.model == "attention_unet") if args.model != "resnext_unet" else None
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)

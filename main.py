@@ -19,7 +19,8 @@ from thesis_pai_reconstruction_amd.dataset import ImageDataModule, SyntheticData
 from thesis_pai_reconstruction_amd.callbacks import EMACallback  # noqa: E402
 from thesis_pai_reconstruction_amd.lightning import CSVLogger, ModelCheckpoint, Trainer  # noqa: E402
 
-HIP_MODELS = ("pix2pix", "attention_unet")
+RES_TYPES = {"res18_unet": "18", "res50_unet": "50", "resv2_unet": "v2", "resnext_unet": "next"}
+HIP_MODELS = ("pix2pix", "attention_unet", "res18_unet", "res50_unet", "resnext_unet")
 
 
 def main(hparams):
@@ -30,10 +31,13 @@ def main(hparams):
     elif hparams.model == "attention_unet":
         model = pai.AttentionUnetGAN(in_channels=1, out_channels=1, channel_mults=channel_mults,
                                      dropout=hparams.dropout, loss_type=hparams.loss_type)
-    elif hparams.model in ("res18_unet", "res50_unet", "resv2_unet", "resnext_unet", "trans_unet", "palette"):
+    elif hparams.model in RES_TYPES:
+        model = pai.ResUnetGAN(in_channels=1, out_channels=1, res_type=RES_TYPES[hparams.model],
+                               channel_mults=channel_mults, dropout=hparams.dropout, loss_type=hparams.loss_type)
+    elif hparams.model in ("trans_unet", "palette"):
         raise NotImplementedError(
-            f"model {hparams.model!r}: the Pix2Pix and Attention U-Net paths are built on the HIP kernels so far "
-            "(SURVEY.md section 8(f) lists the other families as next rows)")
+            f"model {hparams.model!r}: the Pix2Pix, Attention U-Net and residual U-Net paths are built on the HIP "
+            "kernels so far (SURVEY.md section 8(f) lists the other families as next rows)")
     else:
         raise ValueError(f"Incorrect model name ({hparams.model})")
 

@@ -46,6 +46,19 @@ def output_hot_image(img: torch.Tensor, filename: str):
 
 def count_macs(model) -> int:
     unet = getattr(model, "unet", None)
+    if unet is not None and hasattr(unet, "in_conv"):      # residual U-Net: every conv at the resolution it runs at
+        def conv_macs(c, sp):
+            return sp * sp * c.weight.shape[0] * c.weight.shape[1] * c.weight.shape[2] * c.weight.shape[3]
+        size, total = 256, 0
+        total += conv_macs(unet.in_conv, size)
+        sp = size
+        for enc in unet.encoders:
+            total += sum(conv_macs(m, sp) for m in enc.encode[0].modules() if isinstance(m, torch.nn.Conv2d))
+            sp //= 2
+        for dec in unet.decoders:
+            total += sum(conv_macs(m, sp) for m in dec.decode[0].modules() if isinstance(m, torch.nn.Conv2d))
+            sp *= 2
+        return total + conv_macs(unet.out[0], sp)
     if unet is None or not hasattr(unet, "engine"):
         return 0
     eng, size, total = unet.engine, 256, 0
@@ -70,6 +83,9 @@ def main(hparams):
         model.freeze()
     elif hparams.model == "attention_unet":
         model = pai.AttentionUnetGAN.load_from_checkpoint(hparams.checkpoint, map_location=dev)
+        model.freeze()
+    elif hparams.model in ("res18_unet", "res50_unet", "resv2_unet", "resnext_unet"):
+        model = pai.ResUnetGAN.load_from_checkpoint(hparams.checkpoint, map_location=dev)
         model.freeze()
     elif hparams.model == "identity":
         def model(x):

@@ -39,7 +39,7 @@ def test_train_and_report_flags_match_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["pix2pix", "attention_unet"])
+@pytest.mark.parametrize("model", ["pix2pix", "attention_unet", "resnext_unet"])
 def test_train_then_report_roundtrip(tmp_path, model):
     env = dict(os.environ, PYTHONPATH=ROOT)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "cli_run", "--synthetic", "24",
