@@ -53,7 +53,7 @@ def _fp_ok(got, want_fp, rtol, what):
 
 
 # (name, N, H, W, C, K): vector-ALU kernel (K = 32), MFMA forward/dgrad + MFMA wgrad (C >= 128), split-K shape
-POINTWISE = [("c64", 2, 16, 16, 64, 32), ("c32", 3, 8, 24, 32, 64), ("c64_ragged", 1, 5, 7, 64, 32),
+POINTWISE = [("c64", 2, 16, 16, 64, 32), ("c64_128", 2, 16, 16, 64, 128), ("c32", 3, 8, 24, 32, 64), ("c64_ragged", 1, 5, 7, 64, 32),
              ("c128", 3, 16, 16, 128, 64), ("c512", 4, 4, 4, 512, 256)]
 
 

@@ -293,7 +293,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     }
     if (op == 2) {
         if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g)) return 4;
-        if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+        if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
             int chunks = g.Cin / 8;
             if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
         }
@@ -458,7 +458,7 @@ extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void
     if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
     if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
     if (thin_wgrad_conv1_ok(d->dtype, g)) return launch_thin_wgrad_conv1(g, a, s);
-    if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
+    if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
         int chunks = g.Cin / 8;
         if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);
     }

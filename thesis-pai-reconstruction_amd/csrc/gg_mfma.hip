@@ -1301,6 +1301,8 @@ bool wgrad_mfma_ok(int dtype, const GG& g) {
     // pointwise convolutions of the finest attention gate (64 -> 32 and 32 -> 64 channels over 1 M pixels): the
     // 64 x 128 tile is a quarter full, but the launch is bound by reading the two operands once, not by the matrix pipe
     if (g.ntaps == 1 && g.C2 == 0 && ((g.C1 == 64 && g.Cout == 32) || (g.C1 == 32 && g.Cout == 64))) return true;
+    // ... and the 64-input-channel pointwise convolutions of the residual blocks (half-full column tile)
+    if (g.ntaps == 1 && g.C2 == 0 && g.C1 == 64 && (g.Cout % 64) == 0) return true;
     if (g.C1 % 64 || g.C2 % 64) return false;
     if (g.Cout % 64) return false;
     if ((g.ntaps * g.Cin) % 128) return false;

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void gg_wgrad_rowdot_k(GG g, WgradArgs a, int 
 }
 
 int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t s) {
-    PAI_CHECK(g.ntaps == 4 || g.ntaps == 16, "wgrad_rowdot: ntaps %d", g.ntaps);
+    PAI_CHECK(g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16, "wgrad_rowdot: ntaps %d", g.ntaps);
     int blocks = cdiv(g.M, 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
@@ -470,9 +470,9 @@ int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t 
     PAI_CHECK(lds <= 64 * 1024, "wgrad_rowdot: LDS %zu too large", lds);
 #define WR_LAUNCH(T, NT) hipLaunchKernelGGL((gg_wgrad_rowdot_k<T, NT>), grid, dim3(256), lds, s, g, a, rows)
     if (dtype == PAI_F32) {
-        if (g.ntaps == 4) WR_LAUNCH(float, 4); else WR_LAUNCH(float, 16);
+        if (g.ntaps == 4) WR_LAUNCH(float, 4); else if (g.ntaps == 9) WR_LAUNCH(float, 9); else WR_LAUNCH(float, 16);
     } else {
-        if (g.ntaps == 4) WR_LAUNCH(bf16_t, 4); else WR_LAUNCH(bf16_t, 16);
+        if (g.ntaps == 4) WR_LAUNCH(bf16_t, 4); else if (g.ntaps == 9) WR_LAUNCH(bf16_t, 9); else WR_LAUNCH(bf16_t, 16);
     }
 #undef WR_LAUNCH
     PAI_LAUNCH_CHECK();
