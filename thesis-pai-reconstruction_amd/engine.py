@@ -752,17 +752,32 @@ class DiscEngine:
         ops.cast(t, dst)
         return dst
 
-    def forward(self, x, y, dtype):
+    def forward(self, x, y, dtype, y2=None):
+        """y2: a second image batch evaluated against the same conditioning x in the same pass -- the rows of the
+        2N-sample batch are [x|y] then [x|y2] (what ``cat([x, x]), cat([y, y2])`` would feed), written straight into
+        the engine's input buffers without materialising the concatenations."""
         if not (x.is_cuda and y.is_cuda):
             raise ops.PaiError("Discriminator (HIP) needs HIP device tensors; there is no CPU path")
         N, C, H, W = x.shape
-        if C != self.in_ch or y.shape != x.shape:
-            raise ops.PaiError(f"Discriminator expects two [N,{self.in_ch},H,W] tensors, got {tuple(x.shape)} "
+        if C != self.in_ch or y.shape != x.shape or (y2 is not None and y2.shape != x.shape):
+            raise ops.PaiError(f"Discriminator expects [N,{self.in_ch},H,W] tensors of one shape, got {tuple(x.shape)} "
                                f"and {tuple(y.shape)}")
-        S = self.acquire(N, H, W, dtype, x.device)
+        reps = 1 if y2 is None else 2
+        S = self.acquire(N * reps, H, W, dtype, x.device)
         P = S["P"]
-        S["xin"] = self._to_nhwc(x, S["x"], dtype)
-        S["yin"] = self._to_nhwc(y, S["y"], dtype)
+        if y2 is None:
+            S["xin"] = self._to_nhwc(x, S["x"], dtype)
+            S["yin"] = self._to_nhwc(y, S["y"], dtype)
+        else:
+            half = N * H * W * C
+            for src, dst in ((x, S["x"][:half]), (x, S["x"][half:]), (y, S["y"][:half]), (y2, S["y"][half:])):
+                t = src.detach().to(torch.float32)
+                t = t.contiguous() if C == 1 else t.permute(0, 2, 3, 1).contiguous()
+                if dtype == torch.float32:
+                    dst.copy_(t.reshape(-1))
+                else:
+                    ops.cast(t, dst)
+            S["xin"], S["yin"] = S["x"], S["y"]
         wf, _ = self.packs[0].get(dtype)
         ops.conv_fwd(P["desc"][0], S["xin"], S["yin"], wf, self.convs[0].bias, y_act=S["a"][0])
         for k in range(1, 4):

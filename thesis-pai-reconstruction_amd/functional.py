@@ -70,6 +70,33 @@ class DiscFunction(torch.autograd.Function):
         return (None, gy, None, None) + (None,) * len(params)
 
 
+class DiscPairsFunction(torch.autograd.Function):
+    """D(x, y_real) and D(x, y_fake) as ONE batch of 2N (the PatchGAN has no cross-sample coupling): returns the
+    2N logits, real half first.  Only parameter gradients flow (the discriminator phase of the GAN step, reference
+    models/wrapper.py:124-138: the generator output is detached there)."""
+
+    @staticmethod
+    def forward(ctx, x, y_real, y_fake, engine, dtype, *params):
+        logits, slot = engine.forward(x, y_real, dtype, y2=y_fake)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise ops.PaiError("DiscPairsFunction carries no gradient to its image inputs; detach them")
+        if any(ctx.needs_input_grad[5:]):
+            ctx.engine, ctx.slot, ctx.params = engine, slot, params
+        else:
+            engine.release(slot)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        engine, slot, params = ctx.engine, ctx.slot, ctx.params
+        arena = engine.arena()
+        arena.begin_backward(params)
+        engine.backward(slot, glogits, True, False)
+        arena.attach(params)
+        engine.release(slot)
+        return (None,) * (5 + len(params))
+
+
 # --------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------

@@ -132,7 +132,7 @@ class UnetWrapper(LightningModule):
                 # the PatchGAN has no cross-sample coupling: D(x,target) and D(x,pred) are run as
                 # one batch of 2N (one backward pass, so gradient buckets can be reduced while it runs)
                 n = x.shape[0]
-                labels = self.discriminator(torch.cat([x, x], 0), torch.cat([target, pred], 0))
+                labels = self.discriminator.forward_pairs(x, target, pred)
                 target_label, pred_label = labels[:n], labels[n:]
             else:
                 target_label = self.discriminator(x, target)
@@ -229,3 +229,9 @@ class Discriminator(nn.Module):
         eng = self.engine
         params = [p for p, _ in eng.ordered_params()]
         return PF.DiscFunction.apply(x, y, eng, self.compute_dtype, *params)
+
+    def forward_pairs(self, x, y_real, y_fake):
+        """``forward(cat([x, x]), cat([y_real, y_fake]))`` without the concatenations; inputs carry no gradient."""
+        eng = self.engine
+        params = [p for p, _ in eng.ordered_params()]
+        return PF.DiscPairsFunction.apply(x.detach(), y_real.detach(), y_fake.detach(), eng, self.compute_dtype, *params)
