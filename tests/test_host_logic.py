@@ -28,6 +28,28 @@ def test_state_dict_keys_and_shapes_match_reference(pai):
     assert m.automatic_optimization is False
 
 
+def test_other_families_state_dicts_and_init(pai):
+    """Attention / residual U-Nets: state-dict keys, order and shapes equal the reference's (oracle.make_*_state is
+    what tests/test_oracle_golden.py loads the REAL reference's fixtures into), and init_weights leaves conv weights
+    ~N(0, 0.02), norm affines at (1, 0) (reference models/utils.py:15-28)."""
+    m = pai.AttentionUnetGAN(1, 1, (1, 2, 4, 8), 0.0, "gan")
+    want = oracle.make_attention_unet_state(1, 1, (1, 2, 4, 8))
+    got = m.unet.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in got.items()] == [(k, tuple(v.shape)) for k, v in want.items()]
+    for rt in ("18", "50", "next"):
+        r = pai.ResUnetGAN(1, 1, rt, (1, 2, 2), 0.0, "gan")
+        want = oracle.make_res_unet_state(1, 1, rt, (1, 2, 2))
+        got = r.unet.state_dict()
+        assert [(k, tuple(v.shape)) for k, v in got.items()] == [(k, tuple(v.shape)) for k, v in want.items()], rt
+    w = m.unet.attention_blocks[3].input_gate[0].weight
+    assert abs(float(w.std()) - 0.02) < 4e-3 and abs(float(w.mean())) < 4e-3
+    bn = m.unet.attention_blocks[0].input_gate[1]
+    assert torch.equal(bn.weight, torch.ones_like(bn.weight)) and torch.equal(bn.bias, torch.zeros_like(bn.bias))
+    with pytest.raises(NotImplementedError):
+        v2 = pai.ResUnetGAN(1, 1, "v2", (1, 2), 0.0, "mse")
+        v2.unet.encoders[0].encode[0].run(None, {})
+
+
 def test_fwd_pack_layout_and_arena_views(pai):
     from thesis_pai_reconstruction_amd import engine as E
     conv = nn.Conv2d(6, 64, 4, 2, 1)
