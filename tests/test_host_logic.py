@@ -41,7 +41,7 @@ def test_other_families_state_dicts_and_init(pai):
         want = oracle.make_res_unet_state(1, 1, rt, (1, 2, 2))
         got = r.unet.state_dict()
         assert [(k, tuple(v.shape)) for k, v in got.items()] == [(k, tuple(v.shape)) for k, v in want.items()], rt
-    w = m.unet.attention_blocks[3].input_gate[0].weight
+    w = m.unet.attention_blocks[0].input_gate[0].weight
     assert abs(float(w.std()) - 0.02) < 4e-3 and abs(float(w.mean())) < 4e-3
     bn = m.unet.attention_blocks[0].input_gate[1]
     assert torch.equal(bn.weight, torch.ones_like(bn.weight)) and torch.equal(bn.bias, torch.zeros_like(bn.bias))
