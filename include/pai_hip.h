@@ -248,6 +248,54 @@ int pai_upsample2_bwd(int dtype, const void* dout, int N, int H, int W, int C, v
 int pai_add_act(int dtype, const void* a, const void* b, int64_t numel, int act, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * TransUNet (models/trans_unet.py) pieces besides its convolutions / BatchNorms / Upsample (above) and its
+ * nn.Linear layers, which run as pointwise convolutions over the token rows (pai_conv_* with kernel = 1,
+ * N = 1, H = 1, W = tokens).  Token tensors are [M][D] in the storage dtype, M = tokens, D = features.
+ *
+ *   pai_layernorm_fwd   nn.LayerNorm (:142,144; norm1 / norm2 of nn.TransformerEncoderLayer :151-156) with the
+ *                       residual sum in front of it and a broadcast addend behind it fused:
+ *                         s = x + res (written to sum_out; res == NULL: s = x, sum_out unused)
+ *                         y = (s - mean) * rstd * gamma + beta + post[row % P]     (post fp32 [P][D] or NULL:
+ *                                                            the `patch_emb += pos_embedding` of :172)
+ *                       mean / rstd: fp32 [M] (biased variance, eps inside the root) for the backward pass.
+ *   pai_layernorm_bwd   dx = d/ds of the above from dy (the gradient w.r.t. y; it is also the gradient of x, res
+ *                       and, summed over the rows of equal row % P, of post); xs = the normalised tensor (sum_out
+ *                       or x).  dgamma_dbeta (fp32 [2][D]: row 0 = dbeta, row 1 = dgamma, overwritten) or NULL;
+ *                       partials: fp32 [pai_layernorm_partial_rows(M)][2][D] workspace.
+ *   pai_gelu(_bwd)      erf GELU (activation = "gelu", :155) of the stored pre-activation z.
+ *   pai_mha_fwd / _bwd  attention core of nn.MultiheadAttention on packed projections qkv [S*B][3E]
+ *                       (row = s*B + b, columns q | k | v, head h = columns h*hd..): out [S*B][E] =
+ *                       softmax(q k^T / sqrt(hd)) v per (b, h); probs fp32 [B*heads][S][S] is kept for the
+ *                       backward pass, which writes dqkv [S*B][3E]; ds_workspace fp32 like probs.
+ *                       batch_first = False in the reference: S is the IMAGE batch, B the patch count.
+ *   pai_subsample2      out[n][y][x][c] = x[n][2y][2x][c]; _bwd writes the zero-filled adjoint [N][H][W][C].
+ *                       Conv2d(k3, s2, p1) = subsample(Conv2d(k3, s1, p1)), Conv2d(k1, s2) = Conv2d(k1)(subsample)
+ *                       (EncoderBlock, :203-227).
+ *   pai_bn_stats        BatchNorm partial statistics [pai_bn_stats_rows(M)][2][C] of a stored tensor [M][C] (the
+ *                       subsampled convolution output), for pai_bn_finalize; allocate
+ *                       pai_bn_stats_buffer_rows(pai_bn_stats_rows(M)) rows.
+ * ------------------------------------------------------------------------- */
+int pai_layernorm_partial_rows(int64_t M);
+int pai_layernorm_fwd(int dtype, const void* x, const void* res, int64_t M, int D, const float* gamma,
+                      const float* beta, float eps, const float* post, int P, void* sum_out, void* y,
+                      float* mean, float* rstd, void* stream);
+int pai_layernorm_bwd(int dtype, const void* dy, const void* xs, int64_t M, int D, const float* gamma,
+                      const float* mean, const float* rstd, void* dx, float* dgamma_dbeta, float* partials,
+                      void* stream);
+int pai_gelu(int dtype, const void* z, int64_t numel, void* out, void* stream);
+int pai_gelu_bwd(int dtype, const void* dy, const void* z, int64_t numel, void* dz, void* stream);
+int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, int hd, void* out, float* probs,
+                void* stream);
+int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const float* probs, int S, int B, int heads,
+                int hd, void* dqkv, float* ds_workspace, void* stream);
+int pai_subsample2(int dtype, const void* x, int N, int H, int W, int C, void* out, void* stream);
+int pai_subsample2_bwd(int dtype, const void* dout, int N, int H, int W, int C, void* dx, void* stream);
+int pai_bn_stats_rows(int64_t M);
+int pai_bn_stats(int dtype, const void* z, int64_t M, int C, float* stats, void* stream);
+/* out[C] += column sums of x [rows][C] (storage dtype), e.g. the gradient of a broadcast addend. */
+int pai_colsum(int dtype, const void* x, int64_t rows, int C, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Attention gate of the Attention U-Net skip connections.  Replaces the ATen ops behind
  * AttentionBlock.forward (models/attention_unet.py:88-96) that are not convolutions:
  *   h = ReLU(BN_s(sg) + BN_i(ig)),  logit = conv1x1(h; w_a, b_a)  (K -> 1),

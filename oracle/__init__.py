@@ -25,6 +25,7 @@ from .pix2pix_ref import (  # noqa: F401
 )
 from .attention_ref import make_attention_unet_state, attention_unet_forward, attention_block  # noqa: F401
 from .res_unet_ref import make_res_unet_state, res_unet_forward  # noqa: F401
+from .trans_unet_ref import make_trans_unet_state, trans_unet_forward, init_trans_state_portable  # noqa: F401
 from .metrics_ref import denormalize, ssim, ssim_full, psnr, rmse, mse  # noqa: F401
 from .step_ref import (  # noqa: F401
     AdamState, adam_step, gan_training_step, plain_training_step,

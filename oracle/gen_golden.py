@@ -40,8 +40,9 @@ def _import_reference():
     from models.utils import init_weights        # noqa
     from models.attention_unet import AttentionUnetGAN   # noqa
     from models.res_unet import ResUnetGAN                # noqa
-    global _ATT, _RES
-    _ATT, _RES = AttentionUnetGAN, ResUnetGAN
+    from models.trans_unet import TransUnetGAN            # noqa
+    global _ATT, _RES, _TRANS
+    _ATT, _RES, _TRANS = AttentionUnetGAN, ResUnetGAN, TransUnetGAN
     return Pix2Pix, Discriminator, init_weights
 
 
@@ -57,7 +58,13 @@ def build_reference_model(mults, loss_type, seed, family="pix2pix", dropout=0.0)
     from oracle.pix2pix_ref import make_unet_state, make_disc_state, init_state_portable
     from oracle.attention_ref import make_attention_unet_state
     Pix2Pix, Discriminator, init_weights = _REF
-    if family.startswith("res"):          # "res18" | "res50" | "resnext"
+    if family.startswith("trans"):        # "trans2" | "trans4": TransUNet with patch_size 2 | 4
+        from oracle.trans_unet_ref import make_trans_unet_state, init_trans_state_portable
+        ps = int(family[5:])
+        m = _TRANS(in_channels=1, out_channels=1, channel_mults=tuple(mults), patch_size=ps, dropout=dropout,
+                   loss_type=loss_type)
+        g_st = init_trans_state_portable(make_trans_unet_state(1, 1, mults, ps), seed)
+    elif family.startswith("res"):        # "res18" | "res50" | "resnext"
         from oracle.res_unet_ref import make_res_unet_state
         rt = family[3:]
         m = _RES(in_channels=1, out_channels=1, res_type=rt, channel_mults=tuple(mults), dropout=dropout,
@@ -227,6 +234,14 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _REF = _import_reference()
+    if "--trans" in sys.argv:         # TransUNet; image size is fixed at 256 by TransUnetGAN
+        run_forward_case("ref_trans2_forward", (1, 1, 1, 2, 2), 256, 4, seed=211, family="trans2")
+        run_forward_case("ref_trans4_forward", (1, 1, 1, 1, 1), 256, 3, seed=221, family="trans4")
+        run_case("ref_trans2_gan", (1, 1, 1, 2, 2), 256, 4, "gan", seed=231, steps=2, full_tensors=False,
+                 family="trans2")
+        run_case("ref_trans2_ssim", (1, 1, 1, 2, 2), 256, 2, "ssim", seed=241, steps=1, full_tensors=False,
+                 family="trans2")
+        sys.exit(0)
     if "--res" in sys.argv:           # residual U-Net family
         for fam, seed in (("resnext", 131), ("res18", 141), ("res50", 151)):
             run_forward_case(f"ref_{fam}_forward_tiny", (1, 2, 2), 32, 4, seed=seed, family=fam)

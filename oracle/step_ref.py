@@ -27,6 +27,9 @@ def unet_forward(st, x, training=True, **kw):
     ``attention_blocks.*`` (models/attention_unet.py), the Pix2Pix U-Net otherwise."""
     if "attention_blocks.0.input_gate.0.weight" in st:
         return attention_unet_forward(st, x, training=training, **kw)
+    if "vit_bottleneck.pos_embedding" in st:
+        from .trans_unet_ref import trans_unet_forward
+        return trans_unet_forward(st, x, training=training, **kw)
     if "in_conv.weight" in st:
         from .res_unet_ref import res_unet_forward
         return res_unet_forward(st, x, training=training, **kw)

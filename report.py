@@ -87,6 +87,9 @@ def main(hparams):
     elif hparams.model in ("res18_unet", "res50_unet", "resv2_unet", "resnext_unet"):
         model = pai.ResUnetGAN.load_from_checkpoint(hparams.checkpoint, map_location=dev)
         model.freeze()
+    elif hparams.model == "trans_unet":
+        model = pai.TransUnetGAN.load_from_checkpoint(hparams.checkpoint, map_location=dev)
+        model.freeze()
     elif hparams.model == "identity":
         def model(x):
             return x

@@ -10,8 +10,9 @@ from .lib import PaiError  # noqa: F401
 from .models.pix2pix import Pix2Pix, Unet, EncoderBlock, DecoderBlock  # noqa: F401
 from .models.attention_unet import AttentionUnetGAN, AttentionUnet, AttentionBlock  # noqa: F401
 from .models.res_unet import ResUnetGAN, ResUnet  # noqa: F401
+from .models.trans_unet import TransUnetGAN, TransUnet  # noqa: F401
 from .models.wrapper import UnetWrapper, Discriminator, DiscriminatorBlock  # noqa: F401
 from .lightning import Trainer, CSVLogger, ModelCheckpoint, LightningModule  # noqa: F401
 
-__all__ = ["Pix2Pix", "Unet", "AttentionUnetGAN", "AttentionUnet", "ResUnetGAN", "ResUnet", "UnetWrapper", "Discriminator", "Trainer", "CSVLogger", "ModelCheckpoint",
+__all__ = ["Pix2Pix", "Unet", "AttentionUnetGAN", "AttentionUnet", "ResUnetGAN", "ResUnet", "TransUnetGAN", "TransUnet", "UnetWrapper", "Discriminator", "Trainer", "CSVLogger", "ModelCheckpoint",
            "PaiError", "lib"]

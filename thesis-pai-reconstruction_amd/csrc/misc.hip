@@ -163,6 +163,12 @@ int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hip
     return 0;
 }
 
+extern "C" int pai_colsum(int dtype, const void* x, int64_t rows, int C, float* out, void* stream) {
+    PAI_CHECK(dtype == PAI_F32 || dtype == PAI_BF16, "pai_colsum: bad dtype %d", dtype);
+    PAI_CHECK(x && out && rows > 0 && C > 0, "pai_colsum: bad arguments");
+    return launch_colsum(dtype, x, rows, C, out, (hipStream_t)stream);
+}
+
 __global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m, float* v, int64_t numel,
                                               float lr_over_bc1, float beta1, float beta2, float eps,
                                               float inv_sqrt_bc2) {

@@ -81,6 +81,18 @@ SIGNATURES = {
     "pai_upsample2_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "pai_add_act": (_I, [_I, _P, _P, _L, _I, _P, _P]),
     "pai_dropout2d": (_I, [_I, _P, _P, _I, _L, _I, _P, _P]),
+    "pai_layernorm_partial_rows": (_I, [_L]),
+    "pai_layernorm_fwd": (_I, [_I, _P, _P, _L, _I, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P]),
+    "pai_layernorm_bwd": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "pai_gelu": (_I, [_I, _P, _L, _P, _P]),
+    "pai_gelu_bwd": (_I, [_I, _P, _P, _L, _P, _P]),
+    "pai_mha_fwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "pai_mha_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "pai_subsample2": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "pai_subsample2_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "pai_bn_stats_rows": (_I, [_L]),
+    "pai_bn_stats": (_I, [_I, _P, _L, _I, _P, _P]),
+    "pai_colsum": (_I, [_I, _P, _L, _I, _P, _P]),
     "pai_gate_partial_rows": (_I, [_L]),
     "pai_gate_hidden": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_gate_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P]),

@@ -258,3 +258,215 @@ def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False):
     beta = bn.bias if bn is not None else None
     return ConvBNAct.apply(x, conv.weight, conv.bias, gamma, beta, bn, training, n_updates, act, conv.groups, dtype,
                            out_f32)
+
+
+# ---- TransUNet (reference models/trans_unet.py) ----------------------------------------------------------------
+class Subsample2(torch.autograd.Function):
+    """x[:, ::2, ::2, :] of an NHWC tensor.  Conv2d(k3, s2, p1) = Subsample2(Conv2d(k3, s1, p1)) and
+    Conv2d(k1, s2) = Conv2d(k1)(Subsample2(x)): the strided convolutions of the TransUNet EncoderBlock
+    (reference models/trans_unet.py:203-227) on the stride-1 kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check(x)
+        N, H, W, C = x.shape
+        out = torch.empty(N, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
+        ops.subsample2(x.dtype, x, N, H, W, C, out)
+        ctx.shape = (N, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, C = ctx.shape
+        dx = torch.empty(N, H, W, C, dtype=g.dtype, device=g.device)
+        ops.subsample2_bwd(g.dtype, g.contiguous(), N, H, W, C, dx)
+        return dx
+
+
+class BNAct(torch.autograd.Function):
+    """act(BatchNorm2d(z)) of a stored NHWC tensor (the BatchNorm behind a subsampled convolution, reference
+    models/trans_unet.py:213-214)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, bn, training, n_updates, act):
+        _check(z)
+        N, H, W, C = z.shape
+        M, dtype = N * H * W, z.dtype
+        f32 = dict(dtype=torch.float32, device=z.device)
+        mean, rstd = torch.empty(C, **f32), torch.empty(C, **f32)
+        scale, shift = torch.empty(C, **f32), torch.empty(C, **f32)
+        if training:
+            rows = ops.bn_stats_rows(M)
+            stats = torch.empty(ops.bn_stats_buffer_rows(rows) * 2 * C, **f32)
+            ops.bn_stats(dtype, z, M, C, stats)
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            ops.bn_finalize(stats, rows, C, M, gamma.detach(), beta.detach(), float(bn.eps), float(mom), n_updates,
+                            bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, rstd, scale, shift)
+        else:
+            ops.bn_eval_coeffs(C, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, float(bn.eps), scale, shift)
+        out = torch.empty_like(z)
+        ops.bn_apply(dtype, z, M, C, scale, shift, act, out)
+        ctx.act, ctx.training = act, training
+        ctx.save_for_backward(z, out, mean, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, out, mean, rstd, gamma = ctx.saved_tensors
+        if not ctx.training:
+            raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
+        N, H, W, C = z.shape
+        M, dtype, act = N * H * W, z.dtype, ctx.act
+        f32 = dict(dtype=torch.float32, device=z.device)
+        du = torch.empty_like(z)
+        part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * C, **f32)
+        sums = torch.empty(2 * C, **f32)
+        dgamma, dbeta = torch.zeros(C, **f32), torch.zeros(C, **f32)
+        ops.bn_bwd_reduce(dtype, g.contiguous(), act, None, ACT_NONE, out if act != ACT_NONE else None, z, M, C, mean,
+                          rstd, du, part, sums, dgamma, dbeta)
+        dz = torch.empty_like(z)
+        ops.bn_bwd_apply(dtype, du, z, M, C, mean, rstd, gamma.detach(), sums, dz)
+        return dz, dgamma, dbeta, None, None, None, None
+
+
+def _check_tokens(x):
+    if not x.is_cuda:
+        raise ops.PaiError("pai nnops need HIP device tensors (no CPU fallback exists)")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ops.PaiError("pai token ops take contiguous [tokens, features] tensors")
+
+
+class Linear(torch.autograd.Function):
+    """nn.Linear over token rows [M, K] -> [M, out] as a pointwise convolution of a 1 x M image (the gather-GEMM
+    kernels with one tap): patch embedding, attention in / out projections and the feed-forward layers of the ViT
+    bottleneck (reference models/trans_unet.py:143,151-156)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _check_tokens(x)
+        M, K = x.shape
+        out_f = weight.shape[0]
+        dtype = x.dtype
+        d = ops.make_desc(dtype, 0, 1, 1, M, K, 0, out_f, 1, 0, 0, ACT_NONE, kernel=1)
+        ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
+        wm = weight.detach()
+        if dtype == torch.float32:
+            wf = wm
+            wd = torch.empty_like(wm)
+            ops.pack_weights(dtype, wm, out_f, 1, K, None, wd)
+        else:
+            wf = torch.empty(wm.numel(), dtype=dtype, device=x.device)
+            wd = torch.empty(wm.numel(), dtype=dtype, device=x.device)
+            ops.pack_weights(dtype, wm, out_f, 1, K, wf, wd)
+        y = torch.empty(M, out_f, dtype=dtype, device=x.device)
+        ops.conv_fwd(d, x, None, wf, None if bias is None else bias.detach(), y_raw=y)
+        ctx.d = d
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wd = ctx.saved_tensors
+        d = ctx.d
+        g = g.contiguous()
+        M, K, out_f = d.W, d.C1, d.Cout
+        f32 = dict(dtype=torch.float32, device=g.device)
+        dw = torch.zeros(out_f, K, **f32)
+        db = torch.zeros(out_f, **f32) if ctx.has_bias else None
+        ops.conv_wgrad(d, x, None, g, dw, db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=g.dtype, device=g.device)
+            ops.conv_dgrad(d, g, wd, dx, None)
+        return dx, dw, db
+
+
+class LayerNorm(torch.autograd.Function):
+    """post + LayerNorm(x + res) over the last dimension of [M, D] (nn.LayerNorm, reference models/trans_unet.py:142,144
+    and norm1 / norm2 of nn.TransformerEncoderLayer; ``post`` = the pos_embedding added at :172, period P rows)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, post):
+        _check_tokens(x)
+        M, D = x.shape
+        dtype = x.dtype
+        f32 = dict(dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        s = torch.empty_like(x) if res is not None else None
+        mean, rstd = torch.empty(M, **f32), torch.empty(M, **f32)
+        P = 0
+        if post is not None:
+            P = post.numel() // D
+            if M % P:
+                raise ops.PaiError(f"LayerNorm: {M} rows are not a multiple of the addend's period {P}")
+        ops.layernorm_fwd(dtype, x, res, M, D, gamma.detach(), beta.detach(), eps, None if post is None else post.detach(),
+                          P, s, y, mean, rstd)
+        ctx.P, ctx.has_res, ctx.has_post = P, res is not None, post is not None
+        ctx.post_shape = None if post is None else post.shape
+        ctx.save_for_backward(s if res is not None else x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, gamma, mean, rstd = ctx.saved_tensors
+        M, D = xs.shape
+        g = g.contiguous()
+        f32 = dict(dtype=torch.float32, device=g.device)
+        dx = torch.empty_like(xs)
+        dgb = torch.empty(2, D, **f32)
+        part = torch.empty(ops.layernorm_partial_rows(M) * 2 * D, **f32)
+        ops.layernorm_bwd(xs.dtype, g, xs, M, D, gamma.detach(), mean, rstd, dx, dgb, part)
+        dpost = None
+        if ctx.has_post:
+            dpost = torch.zeros(ctx.P * D, **f32)
+            ops.colsum(g.dtype, g, M // ctx.P, ctx.P * D, dpost)
+            dpost = dpost.view(ctx.post_shape)
+        return dx, (dx if ctx.has_res else None), dgb[1], dgb[0], None, dpost
+
+
+class GELU(torch.autograd.Function):
+    """erf GELU (activation="gelu" of nn.TransformerEncoderLayer, reference models/trans_unet.py:155)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        _check_tokens(z)
+        out = torch.empty_like(z)
+        ops.gelu(z.dtype, z, out)
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        dz = torch.empty_like(z)
+        ops.gelu_bwd(z.dtype, g.contiguous(), z, dz)
+        return dz
+
+
+class MHACore(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v per (batch entry, head) on packed projections qkv [S * B, 3 E], row = s * B + b
+    (nn.MultiheadAttention with batch_first = False: S is the image batch)."""
+
+    @staticmethod
+    def forward(ctx, qkv, S, B, heads):
+        _check_tokens(qkv)
+        E = qkv.shape[1] // 3
+        hd = E // heads
+        if qkv.shape[0] != S * B or E * 3 != qkv.shape[1] or hd * heads != E:
+            raise ops.PaiError(f"MHACore: qkv {tuple(qkv.shape)} does not match S={S} B={B} heads={heads}")
+        out = torch.empty(S * B, E, dtype=qkv.dtype, device=qkv.device)
+        probs = torch.empty(B * heads * S * S, dtype=torch.float32, device=qkv.device)
+        ops.mha_fwd(qkv.dtype, qkv, S, B, heads, hd, out, probs)
+        ctx.dims = (S, B, heads, hd)
+        ctx.save_for_backward(qkv, probs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, probs = ctx.saved_tensors
+        S, B, heads, hd = ctx.dims
+        dqkv = torch.empty_like(qkv)
+        ds = torch.empty_like(probs)
+        ops.mha_bwd(qkv.dtype, g.contiguous(), qkv, probs, S, B, heads, hd, dqkv, ds)
+        return dqkv, None, None, None

@@ -278,6 +278,64 @@ def dropout2d(dtype, x, mask, N, HW, C_, out):
             "pai_dropout2d")
 
 
+# ---- TransUNet token ops (models/trans_unet.py:120-180) ------------------------------------------
+def layernorm_partial_rows(M) -> int:
+    return L.load().pai_layernorm_partial_rows(M)
+
+
+def layernorm_fwd(dtype, x, res, M, D, gamma, beta, eps, post, P, sum_out, y, mean, rstd):
+    L.check(L.load().pai_layernorm_fwd(code_of(dtype), _p(x), _p(res), M, D, _p(gamma, torch.float32),
+                                       _p(beta, torch.float32), float(eps), _p(post, torch.float32), int(P),
+                                       _p(sum_out), _p(y), _p(mean, torch.float32), _p(rstd, torch.float32), _stream()),
+            "pai_layernorm_fwd")
+
+
+def layernorm_bwd(dtype, dy, xs, M, D, gamma, mean, rstd, dx, dgb=None, partials=None):
+    L.check(L.load().pai_layernorm_bwd(code_of(dtype), _p(dy), _p(xs), M, D, _p(gamma, torch.float32),
+                                       _p(mean, torch.float32), _p(rstd, torch.float32), _p(dx),
+                                       _p(dgb, torch.float32), _p(partials, torch.float32), _stream()),
+            "pai_layernorm_bwd")
+
+
+def gelu(dtype, z, out):
+    L.check(L.load().pai_gelu(code_of(dtype), _p(z), z.numel(), _p(out), _stream()), "pai_gelu")
+
+
+def gelu_bwd(dtype, dy, z, dz):
+    L.check(L.load().pai_gelu_bwd(code_of(dtype), _p(dy), _p(z), z.numel(), _p(dz), _stream()), "pai_gelu_bwd")
+
+
+def mha_fwd(dtype, qkv, S, B, heads, hd, out, probs):
+    L.check(L.load().pai_mha_fwd(code_of(dtype), _p(qkv), S, B, heads, hd, _p(out), _p(probs, torch.float32), _stream()),
+            "pai_mha_fwd")
+
+
+def mha_bwd(dtype, dout, qkv, probs, S, B, heads, hd, dqkv, ds_ws):
+    L.check(L.load().pai_mha_bwd(code_of(dtype), _p(dout), _p(qkv), _p(probs, torch.float32), S, B, heads, hd,
+                                 _p(dqkv), _p(ds_ws, torch.float32), _stream()), "pai_mha_bwd")
+
+
+def subsample2(dtype, x, N, H, W, C_, out):
+    L.check(L.load().pai_subsample2(code_of(dtype), _p(x), N, H, W, C_, _p(out), _stream()), "pai_subsample2")
+
+
+def subsample2_bwd(dtype, dout, N, H, W, C_, dx):
+    L.check(L.load().pai_subsample2_bwd(code_of(dtype), _p(dout), N, H, W, C_, _p(dx), _stream()), "pai_subsample2_bwd")
+
+
+def bn_stats_rows(M) -> int:
+    return L.load().pai_bn_stats_rows(M)
+
+
+def bn_stats(dtype, z, M, C_, stats):
+    L.check(L.load().pai_bn_stats(code_of(dtype), _p(z), M, C_, _p(stats, torch.float32), _stream()), "pai_bn_stats")
+
+
+def colsum(dtype, x, rows, C_, out):
+    """out[C] += column sums of x [rows][C]."""
+    L.check(L.load().pai_colsum(code_of(dtype), _p(x), rows, C_, _p(out, torch.float32), _stream()), "pai_colsum")
+
+
 # ---- attention gate (models/attention_unet.py:88-96) -------------------------------------------
 def gate_partial_rows(M) -> int:
     return L.load().pai_gate_partial_rows(M)
