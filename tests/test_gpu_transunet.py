@@ -139,7 +139,9 @@ def test_strided_convs_through_subsample(pai, dtype):
     h = nnops.BNAct.apply(nnops.Subsample2.apply(h), bn.weight, bn.bias, bn, True, 1, ACT_RELU)
     s = nnops.conv_bn_act(nnops.Subsample2.apply(xd), conv1, None, ACT_NONE, True, 0, dtype)
     ((h.float() * gy3.permute(0, 2, 3, 1).to(DEV)).sum() + (s.float() * gy1.permute(0, 2, 3, 1).to(DEV)).sum()).backward()
-    tol = _tol(dtype, 2e-5, 2e-2)
+    # bf16: the conv output is STORED rounded, so ~0.3 % of the ReLU inputs change sign against the fp32 reference;
+    # a flipped element is wrong by its full size: L2 error ~ sqrt(0.003) = 5 % on everything upstream of the ReLU
+    tol = _tol(dtype, 2e-5, 8e-2)
     assert rel_err(h.float().cpu().permute(0, 3, 1, 2), y3.detach()) < tol
     assert rel_err(s.float().cpu().permute(0, 3, 1, 2), y1.detach()) < tol
     assert rel_err(xd.grad.float().cpu().permute(0, 3, 1, 2), xr.grad) < tol
