@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MULTS = (1, 2, 4, 8, 8, 8, 8, 8)
+TRANS_MULTS = (1, 2, 2, 4, 4)       # TransUnetGAN's class default; the CLI default of 8 levels leaves no patches
 SIZE = 256
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -103,9 +104,13 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the convolution launches with HIP events in the timed region (no roofline)")
     ap.add_argument("--no-reuse", action="store_true", help="literal two generator forwards per step")
-    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "attention_unet", "resnext_unet"],
+    ap.add_argument("--model", default="pix2pix", choices=["pix2pix", "attention_unet", "resnext_unet", "trans_unet"],
                     help="pix2pix = BASELINE configs[1] (the headline metric); attention_unet = configs[2]; "
-                         "resnext_unet = configs[3] (use --size 512 --batch 16)")
+                         "resnext_unet = configs[3] (use --size 512 --batch 16); trans_unet = configs[4] (use --batch 32; "
+                         "channel_mults pinned to 1,2,2,4,4, SURVEY Q16)")
+    ap.add_argument("--patch-size", type=int, default=4,
+                    help="trans_unet: ViT patch size (4 = what the reference's main.py passes: d_model 4096, 1.03 B "
+                         "parameters; 2 = the class default: d_model 1024, 105 M)")
     ap.add_argument("--size", type=int, default=SIZE, help="image size (configs[3] is quoted at 512)")
     args = ap.parse_args()
 
@@ -120,8 +125,11 @@ def main():
     dev = torch.device("cuda", local)
 
     torch.manual_seed(0)
+    mults = TRANS_MULTS if args.model == "trans_unet" else MULTS
     if args.model == "resnext_unet":
         model = pai.ResUnetGAN(1, 1, "next", MULTS, 0.0, "gan")
+    elif args.model == "trans_unet":
+        model = pai.TransUnetGAN(1, 1, TRANS_MULTS, args.patch_size, 0.0, "gan")
     else:
         model = (pai.AttentionUnetGAN if args.model == "attention_unet" else pai.Pix2Pix)(1, 1, MULTS, 0.0, "gan")
     model.to(dev)
@@ -266,7 +274,7 @@ def main():
     value = world * args.batch * args.steps / dt
     reuse = model._can_reuse_forward()
     gflop = step_gflop_per_image(reuse, args.model == "attention_unet")
-    if args.model == "resnext_unet":
+    if args.model in ("resnext_unet", "trans_unet"):
         gflop = float("nan")     # SURVEY 8(d) gives the MAC budget of configs[1]/[2] only
     out = {
         "metric": ("train images/sec (256x256, bs=64) Pix2Pix step" if args.model == "pix2pix" else
@@ -279,10 +287,12 @@ def main():
                                 "(BASELINE configs[2])" if args.model == "attention_unet" else
                                 f"Residual U-Net (ResNeXt blocks) generator+PatchGAN GAN step, {args.size}x{args.size}x1 "
                                 f"pairs, {args.batch} images/GPU (BASELINE configs[3])" if args.model == "resnext_unet" else
+                                f"TransUNet (ViT bottleneck, patch size {args.patch_size}) generator+PatchGAN GAN step, "
+                                f"256x256x1 pairs, {args.batch} images/GPU (BASELINE configs[4])" if args.model == "trans_unet" else
                                 "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
                                 "(BASELINE configs[1])"),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
-                   "channel_mults": list(MULTS), "loss_type": "gan",
+                   "channel_mults": list(mults), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}"},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "clock_ramp_steps": prewarm_steps,
@@ -292,7 +302,7 @@ def main():
         "roofline_isolated": roofline_isolated,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(attention=args.model == "attention_unet") if args.model != "resnext_unet" else None
+        out["cpu_baseline"] = cpu_baseline(attention=args.model == "attention_unet") if args.model not in ("resnext_unet", "trans_unet") else None
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
