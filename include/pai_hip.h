@@ -381,6 +381,12 @@ int pai_reduce_rows(const float* partial, int rows, int C, float* out, int accum
  * decay / amsgrad; models/wrapper.py:98-111).  step_count is the 1-based step. */
 int pai_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
              float lr, float beta1, float beta2, float eps, int step_count, void* stream);
+/* The same update over `count` separately allocated fp32 tensors (HOST arrays of device pointers and element
+ * counts), a few launches in all: the optimizer of the composable networks (models/res_unet.py, models/trans_unet.py),
+ * whose parameters are not one arena. */
+int pai_adam_multi(int count, void* const* params, const void* const* grads, void* const* exp_avgs,
+                   void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2, float eps,
+                   int step_count, void* stream);
 
 #ifdef __cplusplus
 }

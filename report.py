@@ -46,6 +46,24 @@ def output_hot_image(img: torch.Tensor, filename: str):
 
 def count_macs(model) -> int:
     unet = getattr(model, "unet", None)
+    if unet is not None and hasattr(unet, "vit_bottleneck"):      # TransUNet: convs at their output resolution + ViT
+        def conv_macs(c, sp_out):
+            return sp_out * sp_out * c.weight.shape[0] * c.weight.shape[1] * c.weight.shape[2] * c.weight.shape[3]
+        size = unet.image_size
+        total, sp = conv_macs(unet.in_conv, size), size
+        for enc in unet.encoders:
+            d = enc.decode
+            total += conv_macs(d[0], sp) + conv_macs(d[3], sp // 2) + conv_macs(d[6], sp // 2) + conv_macs(enc.skip[0], sp // 2)
+            sp //= 2
+        vit = unet.vit_bottleneck
+        P, D = vit.num_patches, vit.patch_dim
+        per_token = D * D + sum(l.self_attn.in_proj_weight.numel() + l.self_attn.out_proj.weight.numel() +
+                                l.linear1.weight.numel() + l.linear2.weight.numel() for l in vit.transformer.layers)
+        total += P * per_token         # (attention over the batch axis adds 2 * N * D MACs per token, batch-dependent)
+        for dec in unet.decoders:
+            total += conv_macs(dec.decode[0], sp) + conv_macs(dec.decode[3], sp)
+            sp *= 2
+        return total + conv_macs(unet.out[0], sp)
     if unet is not None and hasattr(unet, "in_conv"):      # residual U-Net: every conv at the resolution it runs at
         def conv_macs(c, sp):
             return sp * sp * c.weight.shape[0] * c.weight.shape[1] * c.weight.shape[2] * c.weight.shape[3]

@@ -39,12 +39,15 @@ def test_train_and_report_flags_match_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["pix2pix", "attention_unet", "resnext_unet"])
+@pytest.mark.parametrize("model", ["pix2pix", "attention_unet", "resnext_unet", "trans_unet"])
 def test_train_then_report_roundtrip(tmp_path, model):
     env = dict(os.environ, PYTHONPATH=ROOT)
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "cli_run", "--synthetic", "24",
-                          "--batch-size", "8", "-e", "2", "--val-epochs", "1", "--channel-mults", "1,2,2,4",
-                          "--image-size", "64", "-m", model], cwd=tmp_path, env=env, capture_output=True, text=True,
+    # TransUnetGAN fixes image_size = 256 (reference models/trans_unet.py:22) and needs a channel_mults that leaves patches
+    shape = (["--synthetic", "8", "--batch-size", "4", "--channel-mults", "1,1,1,1,1", "--image-size", "256"]
+             if model == "trans_unet" else
+             ["--synthetic", "24", "--batch-size", "8", "--channel-mults", "1,2,2,4", "--image-size", "64"])
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "cli_run", *shape, "-e", "2", "--val-epochs", "1",
+                          "-m", model], cwd=tmp_path, env=env, capture_output=True, text=True,
                          timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     vdir = tmp_path / "logs" / "cli_run" / "version_0"

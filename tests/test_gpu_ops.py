@@ -237,3 +237,26 @@ def test_maxpool_upsample_add(pai, dtype, shape):
     torch.cuda.synchronize()
     mask = (from_nhwc(s, N, H, W, C) > 0).float()
     assert torch.equal(from_nhwc(ds, N, H, W, C), from_nhwc(g, N, H, W, C) * mask)
+
+
+def test_multi_adam_equals_stock_adam(pai):
+    """MultiAdam (pai_adam_multi: separately allocated parameters, chunks of 48 tensors per launch) against
+    torch.optim.Adam over three steps, 120 tensors of mixed sizes; state_dict keeps the stock layout."""
+    from thesis_pai_reconstruction_amd.optim import MultiAdam
+    rng = np.random.default_rng(5)
+    shapes = [(int(rng.integers(1, 70)), int(rng.integers(1, 50))) for _ in range(117)] + [(1,), (300000,), (1025, 513)]
+    pa = [torch.nn.Parameter(rnd(s, 100 + i).to(dev())) for i, s in enumerate(shapes)]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = MultiAdam(pa, lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+    ob = torch.optim.Adam(pb, lr=2e-4, betas=(0.5, 0.999), eps=1e-7)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = (rnd(a.shape, 1000 * step + i) * 0.1).to(dev())
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 2e-7 + 1e-6 * float(b.abs().max())
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert len(sa) == len(sb) and float(sa[0]["step"]) == 3
+    assert rel_err(sa[5]["exp_avg_sq"].cpu(), sb[5]["exp_avg_sq"].cpu()) < 1e-6

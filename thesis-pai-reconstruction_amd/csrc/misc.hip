@@ -195,3 +195,64 @@ extern "C" int pai_adam(float* param, const float* grad, float* exp_avg, float* 
     PAI_LAUNCH_CHECK();
     return 0;
 }
+
+// Multi-tensor form for networks whose parameters are separate allocations (the composable residual / Trans U-Nets):
+// up to ADAM_CHUNK tensors per launch, their pointers travelling in the kernel-argument block (no table upload);
+// blockIdx.y selects the tensor, blockIdx.x strides over it.
+#define ADAM_CHUNK 48
+struct AdamChunk {
+    float* p[ADAM_CHUNK];
+    const float* g[ADAM_CHUNK];
+    float* m[ADAM_CHUNK];
+    float* v[ADAM_CHUNK];
+    int64_t n[ADAM_CHUNK];
+};
+
+__global__ __launch_bounds__(256) void adam_multi_k(AdamChunk c, float lr_over_bc1, float beta1, float beta2, float eps,
+                                                    float inv_sqrt_bc2) {
+    const int t = blockIdx.y;
+    const int64_t numel = c.n[t];
+    float* p = c.p[t];
+    const float* g = c.g[t];
+    float* m = c.m[t];
+    float* v = c.v[t];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+extern "C" int pai_adam_multi(int count, void* const* params, const void* const* grads, void* const* exp_avgs,
+                              void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2,
+                              float eps, int step_count, void* stream) {
+    PAI_CHECK(count >= 0 && (count == 0 || (params && grads && exp_avgs && exp_avg_sqs && numels)) && step_count >= 1,
+              "pai_adam_multi: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step_count);
+    const double bc2 = 1.0 - pow((double)beta2, step_count);
+    for (int i0 = 0; i0 < count; i0 += ADAM_CHUNK) {
+        const int nt = count - i0 < ADAM_CHUNK ? count - i0 : ADAM_CHUNK;
+        AdamChunk c;
+        memset(&c, 0, sizeof(c));
+        int64_t big = 1;
+        for (int i = 0; i < nt; ++i) {
+            PAI_CHECK(params[i0 + i] && grads[i0 + i] && exp_avgs[i0 + i] && exp_avg_sqs[i0 + i] && numels[i0 + i] >= 0,
+                      "pai_adam_multi: null tensor %d", i0 + i);
+            c.p[i] = (float*)params[i0 + i];
+            c.g[i] = (const float*)grads[i0 + i];
+            c.m[i] = (float*)exp_avgs[i0 + i];
+            c.v[i] = (float*)exp_avg_sqs[i0 + i];
+            c.n[i] = numels[i0 + i];
+            if (c.n[i] > big) big = c.n[i];
+        }
+        int64_t bx = (big + 1023) / 1024;
+        if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(adam_multi_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, c,
+                           (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}

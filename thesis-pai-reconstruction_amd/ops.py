@@ -430,3 +430,15 @@ def adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     L.check(L.load().pai_adam(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
                               _p(exp_avg_sq, torch.float32), param.numel(), lr, beta1, beta2, eps, step,
                               _stream()), "pai_adam")
+
+
+def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
+    """pai_adam over lists of separately allocated fp32 tensors (a few launches for the whole list)."""
+    n = len(params)
+    for t in (*params, *grads, *exp_avgs, *exp_avg_sqs):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise PaiError("adam_multi needs contiguous fp32 HIP tensors")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+    numels = (C.c_int64 * n)(*[p.numel() for p in params])
+    L.check(L.load().pai_adam_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numels, lr, beta1, beta2,
+                                    eps, step, _stream()), "pai_adam_multi")

@@ -77,8 +77,53 @@ class ArenaAdam(torch.optim.Adam):
         return super().state_dict()
 
 
+class MultiAdam(torch.optim.Adam):
+    """torch.optim.Adam whose step is ``pai_adam_multi``: the same fused update as ``ArenaAdam`` for networks whose
+    parameters are separate allocations (the composable residual / Trans U-Nets) -- one 28 B/parameter pass in a few
+    launches instead of the ~10 multi-tensor passes of the stock foreach implementation (17 ms -> 5 ms per step on the
+    1.03 B-parameter TransUNet).  State layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter) is the stock one;
+    anything outside the preconditions (CPU tensors, sparse / non-fp32 gradients, options other than the reference's)
+    goes to the stock implementation."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-7):
+        super().__init__(list(params), lr=lr, betas=betas, eps=eps, foreach=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None or len(self.param_groups) != 1:
+            return super().step(closure)
+        group = self.param_groups[0]
+        if group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+            return super().step()
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return None
+        if any((not p.is_cuda) or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse
+               or not p.is_contiguous() or not p.grad.is_contiguous() for p in ps):
+            return super().step()
+        steps = set()
+        for p in ps:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if st["step"].is_cuda:
+                return super().step()
+            steps.add(int(st["step"]))
+        if len(steps) != 1:          # parameters with different histories (e.g. unused in some steps): stock path
+            return super().step()
+        step = steps.pop() + 1
+        ops.adam_multi([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
+                       [self.state[p]["exp_avg_sq"] for p in ps], float(group["lr"]), float(group["betas"][0]),
+                       float(group["betas"][1]), float(group["eps"]), step)
+        for p in ps:
+            self.state[p]["step"] += 1
+        return None
+
+
 def make_adam(module: torch.nn.Module, lr, betas, eps):
     eng = getattr(module, "engine", None) if hasattr(type(module), "engine") else None
     if eng is not None:
         return ArenaAdam(module.parameters(), eng, lr=lr, betas=betas, eps=eps)
-    return torch.optim.Adam(module.parameters(), lr=lr, betas=betas, eps=eps)
+    return MultiAdam(module.parameters(), lr=lr, betas=betas, eps=eps)
