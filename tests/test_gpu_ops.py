@@ -259,4 +259,5 @@ def test_multi_adam_equals_stock_adam(pai):
         assert float((a - b).abs().max()) <= 2e-7 + 1e-6 * float(b.abs().max())
     sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
     assert len(sa) == len(sb) and float(sa[0]["step"]) == 3
-    assert rel_err(sa[5]["exp_avg_sq"].cpu(), sb[5]["exp_avg_sq"].cpu()) < 1e-6
+    # the C ABI takes beta2 as a float: 1 - 0.999f differs from torch's float(1 - 0.999) by 1.3e-5 relative
+    assert rel_err(sa[5]["exp_avg_sq"].cpu(), sb[5]["exp_avg_sq"].cpu()) < 3e-5

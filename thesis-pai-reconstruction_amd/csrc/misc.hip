@@ -170,12 +170,12 @@ extern "C" int pai_colsum(int dtype, const void* x, int64_t rows, int C, float* 
 }
 
 __global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m, float* v, int64_t numel,
-                                              float lr_over_bc1, float beta1, float beta2, float eps,
-                                              float inv_sqrt_bc2) {
+                                              float lr_over_bc1, float beta1, float beta2, float omb1, float omb2,
+                                              float eps, float inv_sqrt_bc2) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i];
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float mi = beta1 * m[i] + omb1 * gi;      // omb = 1 - beta rounded from double, as torch does
+        const float vi = beta2 * v[i] + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
@@ -191,7 +191,8 @@ extern "C" int pai_adam(float* param, const float* grad, float* exp_avg, float* 
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, numel, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+                       exp_avg_sq, numel, (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1),
+                       (float)(1.0 - (double)beta2), eps, (float)(1.0 / sqrt(bc2)));
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -208,8 +209,8 @@ struct AdamChunk {
     int64_t n[ADAM_CHUNK];
 };
 
-__global__ __launch_bounds__(256) void adam_multi_k(AdamChunk c, float lr_over_bc1, float beta1, float beta2, float eps,
-                                                    float inv_sqrt_bc2) {
+__global__ __launch_bounds__(256) void adam_multi_k(AdamChunk c, float lr_over_bc1, float beta1, float beta2, float omb1,
+                                                    float omb2, float eps, float inv_sqrt_bc2) {
     const int t = blockIdx.y;
     const int64_t numel = c.n[t];
     float* p = c.p[t];
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(256) void adam_multi_k(AdamChunk c, float lr_over_b
     float* v = c.v[t];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i];
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float mi = beta1 * m[i] + omb1 * gi;      // omb = 1 - beta rounded from double, as torch does
+        const float vi = beta2 * v[i] + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
@@ -251,7 +252,8 @@ extern "C" int pai_adam_multi(int count, void* const* params, const void* const*
         int64_t bx = (big + 1023) / 1024;
         if (bx > 2048) bx = 2048;
         hipLaunchKernelGGL(adam_multi_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, c,
-                           (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+                           (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps,
+                           (float)(1.0 / sqrt(bc2)));
         PAI_LAUNCH_CHECK();
     }
     return 0;
