@@ -267,6 +267,8 @@ int pai_add_act(int dtype, const void* a, const void* b, int64_t numel, int act,
  *                       (row = s*B + b, columns q | k | v, head h = columns h*hd..): out [S*B][E] =
  *                       softmax(q k^T / sqrt(hd)) v per (b, h); probs fp32 [B*heads][S][S] is kept for the
  *                       backward pass, which writes dqkv [S*B][3E]; ds_workspace fp32 like probs.
+ *                       mask (fp32, shaped like probs, 0 or 1 / (1 - p); NULL = none): the Dropout on the attention
+ *                       weights, out = (softmax(..) * mask) v; drawing it is the caller's RNG plumbing.
  *                       batch_first = False in the reference: S is the IMAGE batch, B the patch count.
  *   pai_subsample2      out[n][y][x][c] = x[n][2y][2x][c]; _bwd writes the zero-filled adjoint [N][H][W][C].
  *                       Conv2d(k3, s2, p1) = subsample(Conv2d(k3, s1, p1)), Conv2d(k1, s2) = Conv2d(k1)(subsample)
@@ -284,10 +286,10 @@ int pai_layernorm_bwd(int dtype, const void* dy, const void* xs, int64_t M, int 
                       void* stream);
 int pai_gelu(int dtype, const void* z, int64_t numel, void* out, void* stream);
 int pai_gelu_bwd(int dtype, const void* dy, const void* z, int64_t numel, void* dz, void* stream);
-int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, int hd, void* out, float* probs,
-                void* stream);
+int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, int hd, const float* mask, void* out,
+                float* probs, void* stream);
 int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const float* probs, int S, int B, int heads,
-                int hd, void* dqkv, float* ds_workspace, void* stream);
+                int hd, const float* mask, void* dqkv, float* ds_workspace, void* stream);
 int pai_subsample2(int dtype, const void* x, int N, int H, int W, int C, void* out, void* stream);
 int pai_subsample2_bwd(int dtype, const void* dout, int N, int H, int W, int C, void* dx, void* stream);
 int pai_bn_stats_rows(int64_t M);

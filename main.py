@@ -20,7 +20,7 @@ from thesis_pai_reconstruction_amd.callbacks import EMACallback  # noqa: E402
 from thesis_pai_reconstruction_amd.lightning import CSVLogger, ModelCheckpoint, Trainer  # noqa: E402
 
 RES_TYPES = {"res18_unet": "18", "res50_unet": "50", "resv2_unet": "v2", "resnext_unet": "next"}
-HIP_MODELS = ("pix2pix", "attention_unet", "res18_unet", "res50_unet", "resnext_unet", "trans_unet")
+HIP_MODELS = ("pix2pix", "attention_unet", "res18_unet", "res50_unet", "resv2_unet", "resnext_unet", "trans_unet")
 
 
 def main(hparams):

@@ -64,7 +64,7 @@ def build_reference_model(mults, loss_type, seed, family="pix2pix", dropout=0.0)
         m = _TRANS(in_channels=1, out_channels=1, channel_mults=tuple(mults), patch_size=ps, dropout=dropout,
                    loss_type=loss_type)
         g_st = init_trans_state_portable(make_trans_unet_state(1, 1, mults, ps), seed)
-    elif family.startswith("res"):        # "res18" | "res50" | "resnext"
+    elif family.startswith("res"):        # "res18" | "res50" | "resnext" | "resv2"
         from oracle.res_unet_ref import make_res_unet_state
         rt = family[3:]
         m = _RES(in_channels=1, out_channels=1, res_type=rt, channel_mults=tuple(mults), dropout=dropout,
@@ -241,6 +241,10 @@ if __name__ == "__main__":
                  family="trans2")
         run_case("ref_trans2_ssim", (1, 1, 1, 2, 2), 256, 2, "ssim", seed=241, steps=1, full_tensors=False,
                  family="trans2")
+        sys.exit(0)
+    if "--resv2" in sys.argv:         # pre-activation residual blocks (res_type "v2")
+        run_forward_case("ref_resv2_forward_tiny", (1, 2, 2), 32, 4, seed=181, family="resv2")
+        run_case("ref_resv2_gan_tiny", (1, 2, 2), 32, 4, "gan", seed=186, steps=2, full_tensors=False, family="resv2")
         sys.exit(0)
     if "--res" in sys.argv:           # residual U-Net family
         for fam, seed in (("resnext", 131), ("res18", 141), ("res50", 151)):

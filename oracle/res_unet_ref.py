@@ -1,7 +1,7 @@
 """Oracle: functional CPU restatement of the reference residual U-Net family.
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates ``ResUnet`` and its blocks (models/res_unet.py:52-334;
-paths relative to /root/reference) for res_type "18", "50" and "next".  State keys / shapes are those of
+paths relative to /root/reference) for res_type "18", "50", "next" and "v2".  State keys / shapes are those of
 ``ResUnet.state_dict()``.
 """
 from __future__ import annotations
@@ -19,6 +19,7 @@ BLOCKS = {
     "18": ("cbrcb", True),          # models/res_unet.py:58-64,71
     "50": ("cbrcbrcb", True),       # :86-95,102
     "next": ("cbrcbrcbr", False),   # :147-163 (last ReLU inside conv_block, no post-sum ReLU: SURVEY Q18)
+    "v2": ("brcbrc", False),        # :114-121 pre-activation; the skip is BatchNorm -> ReLU -> 1x1 conv (:123-127)
 }
 
 
@@ -31,10 +32,13 @@ def _block_state(st, p, res_type, cin, cout):
     elif res_type == "next":
         w = 4 * 32                                               # bottleneck * cardinality (:144)
         convs = [(cin, w, 1, 1), (w, w, 3, 32), (w, cout, 1, 1)]
+    elif res_type == "v2":
+        convs = [(cin, cout, 3, 1), (cout, cout, 3, 1)]
     else:
         raise ValueError(res_type)
     layout, _ = BLOCKS[res_type]
     ci = 0
+    last = cin
     for idx, kind in enumerate(layout):
         if kind == "c":
             a, b_, k, g = convs[ci]
@@ -44,7 +48,11 @@ def _block_state(st, p, res_type, cin, cout):
             ci += 1
         elif kind == "b":
             _bn_entries(f"{p}.conv_block.{idx}", last, st)
-    if cin != cout:                                              # :66-69
+    if cin != cout and res_type == "v2":                         # :123-127
+        _bn_entries(f"{p}.conv_skip.0", cin, st)
+        st[f"{p}.conv_skip.2.weight"] = torch.zeros(cout, cin, 1, 1)
+        st[f"{p}.conv_skip.2.bias"] = torch.zeros(cout)
+    elif cin != cout:                                            # :66-69
         st[f"{p}.conv_skip.0.weight"] = torch.zeros(cout, cin, 1, 1)
         st[f"{p}.conv_skip.0.bias"] = torch.zeros(cout)
         _bn_entries(f"{p}.conv_skip.1", cout, st)
@@ -74,6 +82,8 @@ def make_res_unet_state(in_channels: int = 1, out_channels: int = 1, res_type: s
 
 
 def res_type_of(st) -> str:
+    if "encoders.0.encode.0.conv_block.0.running_mean" in st:
+        return "v2"
     w3 = st.get("encoders.0.encode.0.conv_block.3.weight")
     if w3 is not None and w3.shape[2] == 3 and w3.shape[1] != w3.shape[0]:
         return "next"
@@ -97,7 +107,9 @@ def residual_block(st, p, x, res_type, training):
             h = _bn(st, q, h, training)
         else:
             h = F.relu(h)
-    if (p + ".conv_skip.0.weight") in st:
+    if (p + ".conv_skip.2.weight") in st:                       # v2: BatchNorm -> ReLU -> 1x1 conv
+        s = _conv(st, p + ".conv_skip.2", F.relu(_bn(st, p + ".conv_skip.0", x, training)))
+    elif (p + ".conv_skip.0.weight") in st:
         s = _bn(st, p + ".conv_skip.1", _conv(st, p + ".conv_skip.0", x), training)
     else:
         s = x
@@ -112,8 +124,8 @@ def res_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True, re
     first, out = Conv2d 3x3 -> Tanh."""
     rt = res_type_of(st)
     L = sum(1 for k in st if k.startswith("encoders.") and k.endswith("encode.0.conv_block.0.weight"))
-    mults = [st[f"encoders.{i}.encode.0.conv_block.{len(BLOCKS[rt][0]) - (2 if rt != 'next' else 3)}.weight"].shape[0] // 64
-             for i in range(L)]
+    last_conv = {"18": 3, "50": 6, "next": 6, "v2": 5}[rt]
+    mults = [st[f"encoders.{i}.encode.0.conv_block.{last_conv}.weight"].shape[0] // 64 for i in range(L)]
     h = x if x.dtype == torch.float64 else x.to(torch.float32)
     h = F.conv2d(h, st["in_conv.weight"], st["in_conv.bias"], padding=1)
     acts = {"in": h}

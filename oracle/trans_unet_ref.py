@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates ``TransUnet`` and i
 paths relative to /root/reference) with torch-CPU ops and an explicit multi-head attention.  State keys / shapes are
 those of ``TransUnet.state_dict()``.  The transformer layers are ``nn.TransformerEncoderLayer`` defaults of the pinned
 torch 2.0.0: post-norm, dim_feedforward 2048, LayerNorm eps 1e-5, erf GELU, ``batch_first=False`` -- the module is fed
-``[n, patches, dim]``, so the attention sequence is the image batch.  Dropout inside the transformer is
-restated for p = 0 only (the CLI default).
+``[n, patches, dim]``, so the attention sequence is the image batch.  Dropout inside the transformer
+(p > 0) is restated in distribution, with the oracle's own draws (see ``encoder_layer``).
 """
 from __future__ import annotations
 
@@ -154,8 +154,21 @@ def _ln(st, key, t):
     return F.layer_norm(t, (t.shape[-1],), st[key + ".weight"], st[key + ".bias"], 1e-5)
 
 
-def encoder_layer(st, q, t):
-    """One post-norm ``nn.TransformerEncoderLayer`` on t = [S, B, E] (sequence first), dropout = 0."""
+def _drop(x, p, site, li, mask_log):
+    """nn.Dropout in training mode: Bernoulli(1 - p) / (1 - p) drawn from the global CPU generator, logged for replay."""
+    if not p:
+        return x
+    m = torch.bernoulli(torch.full_like(x, 1.0 - p)) / (1.0 - p)
+    if mask_log is not None:
+        mask_log.append((site, li, m))
+    return x * m
+
+
+def encoder_layer(st, q, t, p=0.0, li=0, mask_log=None):
+    """One post-norm ``nn.TransformerEncoderLayer`` on t = [S, B, E] (sequence first).  ``p`` > 0 (training mode): its
+    four Dropout sites -- attention weights, dropout1 behind the attention block, dropout inside and dropout2 behind the
+    feed-forward block.  The distribution is the reference's; the draws are the oracle's own (the attention dropout of
+    the reference happens inside an ATen operator): parity with dropout > 0 is checked with replayed masks only."""
     S, B, E = t.shape
     hd = E // HEADS
     if USE_ATEN_MHA:
@@ -166,16 +179,16 @@ def encoder_layer(st, q, t):
     else:
         qkv = F.linear(t, st[q + ".self_attn.in_proj_weight"], st[q + ".self_attn.in_proj_bias"])
         qq, kk, vv = (c.reshape(S, B * HEADS, hd).transpose(0, 1) for c in qkv.chunk(3, dim=-1))   # [B*H, S, hd]
-        att = torch.softmax(qq @ kk.transpose(1, 2) / math.sqrt(hd), dim=-1)
+        att = _drop(torch.softmax(qq @ kk.transpose(1, 2) / math.sqrt(hd), dim=-1), p, "attn", li, mask_log)
         o = (att @ vv).transpose(0, 1).reshape(S, B, E)
         o = F.linear(o, st[q + ".self_attn.out_proj.weight"], st[q + ".self_attn.out_proj.bias"])
-    t = _ln(st, q + ".norm1", t + o)
-    f = F.linear(F.gelu(F.linear(t, st[q + ".linear1.weight"], st[q + ".linear1.bias"])),
-                 st[q + ".linear2.weight"], st[q + ".linear2.bias"])
+    t = _ln(st, q + ".norm1", t + _drop(o, p, "sa", li, mask_log))
+    f = _drop(F.gelu(F.linear(t, st[q + ".linear1.weight"], st[q + ".linear1.bias"])), p, "ff", li, mask_log)
+    f = _drop(F.linear(f, st[q + ".linear2.weight"], st[q + ".linear2.bias"]), p, "out", li, mask_log)
     return _ln(st, q + ".norm2", t + f)
 
 
-def vit_bottleneck(st, h, acts=None):
+def vit_bottleneck(st, h, acts=None, drop=0.0, mask_log=None):
     """``VisionTransformer.forward`` (:170-175)."""
     v = "vit_bottleneck"
     n, c, hs, ws = h.shape
@@ -189,15 +202,16 @@ def vit_bottleneck(st, h, acts=None):
     t = _ln(st, v + ".to_patch_embedding.3", t)
     t = t + st[v + ".pos_embedding"]
     for li in range(LAYERS):
-        t = encoder_layer(st, f"{v}.transformer.layers.{li}", t)  # [n, P, D] read as [S = n, B = P, E]  (Q15)
+        t = encoder_layer(st, f"{v}.transformer.layers.{li}", t, drop, li, mask_log)  # [n, P, D] read as [S = n, B = P, E]
         if acts is not None:
             acts[f"vit{li}"] = t
     # Rearrange "n (h w) (p1 p2 c) -> n c (h p1) (w p2)"
     return t.reshape(n, g, g, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(n, c, hs, ws)
 
 
-def trans_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True, return_feats: bool = False, **_):
-    """``TransUnet.forward`` (:101-117)."""
+def trans_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True, return_feats: bool = False,
+                       dropout: float = 0.0, mask_log=None, **_):
+    """``TransUnet.forward`` (:101-117).  ``dropout``: rate of the transformer layers' Dropout (training mode only)."""
     L = sum(1 for k in st if k.startswith("encoders.") and k.endswith(".decode.0.weight"))
     h = x if x.dtype == torch.float64 else x.to(torch.float32)
     h = F.conv2d(h, st["in_conv.weight"], st["in_conv.bias"], padding=1)
@@ -208,7 +222,7 @@ def trans_unet_forward(st: OrderedDict, x: torch.Tensor, training: bool = True, 
         skips.append(h)
         acts[f"enc{i}"] = h
     skips.pop()
-    h = vit_bottleneck(st, h, acts)
+    h = vit_bottleneck(st, h, acts, dropout if training else 0.0, mask_log)
     acts["vit"] = h
     for j in range(L):
         if j != 0:

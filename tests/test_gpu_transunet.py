@@ -155,9 +155,9 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
-def build(pai, mults, patch, loss_type, seed, dtype=torch.float32):
+def build(pai, mults, patch, loss_type, seed, dtype=torch.float32, dropout=0.0):
     from thesis_pai_reconstruction_amd.models.trans_unet import TransUnetGAN
-    m = TransUnetGAN(in_channels=1, out_channels=1, channel_mults=tuple(mults), patch_size=patch, dropout=0.0,
+    m = TransUnetGAN(in_channels=1, out_channels=1, channel_mults=tuple(mults), patch_size=patch, dropout=dropout,
                      loss_type=loss_type)
     g = oracle.init_trans_state_portable(oracle.make_trans_unet_state(1, 1, tuple(mults), patch), seed)
     m.unet.load_state_dict(g, strict=True)
@@ -287,3 +287,50 @@ def test_ragged_batch_and_bf16(pai, golden_dir):
         assert all(np.isfinite(v) for v in vals.values()), vals
         first = first or vals
     assert vals["loss"] < first["loss"] and vals["train_rmse"] < first["train_rmse"]
+
+
+def test_transformer_dropout_step_matches_oracle_with_replayed_masks(pai):
+    """Dropout(p) at the four sites of every encoder layer (attention weights inside pai_mha_*, behind the attention block,
+    inside and behind the feed-forward block): one GAN step (two generator forwards, 96 masks) against the live oracle
+    with the oracle's masks replayed into the HIP model, then a step on the model's own device-side draws."""
+    mults, patch, p, seed = (1, 1, 1, 1, 1), 4, 0.3, 261
+    m, g, d = build(pai, mults, patch, "gan", seed, dropout=p)
+    assert not m.unet.supports_forward_reuse
+    x, t = synth_batch(seed + 100, 3, 256)
+    torch.manual_seed(5)
+    mask_log = []
+    logs, grads = oracle.gan_training_step(g, d, oracle.AdamState(), oracle.AdamState(), x, t, dropout=p,
+                                           mask_log=mask_log, return_grads=True)
+    assert len(mask_log) == 2 * 12 * 4
+    queue = list(mask_log)
+
+    def replay(site, li, shape, rate, device):
+        s_, l_, mk = queue.pop(0)
+        assert (s_, l_) == (site, li) and rate == p and mk.numel() == int(np.prod(shape)), (s_, l_, site, li)
+        return mk.reshape(shape).to(device)
+
+    m.unet.vit_bottleneck.dropout_mask_fn = replay
+    m.logged = {}
+    batch = (x.to(DEV), t.to(DEV))
+    m.training_step(batch, 0)
+    torch.cuda.synchronize()
+    assert not queue
+    for k, v in m.logged.items():
+        assert abs(float(v) - float(logs[k])) <= 1e-4 * max(1.0, abs(float(logs[k]))), (k, float(v), float(logs[k]))
+    gmax = max(float(v.norm()) for v in grads["g"].values())
+    bad = {}
+    for k, prm in m.unet.named_parameters():
+        want = grads["g"][k]
+        if float(want.norm()) < 1e-4 * gmax:
+            continue
+        e = rel_err(prm.grad.cpu(), want)
+        if e > 1e-2:       # ReLU flips in the multi-million-element decoder tensors, as in the dropout-free step
+            bad[k] = e
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]
+    m.unet.vit_bottleneck.dropout_mask_fn = None        # device-side draws: finite, and different from step to step
+    vals = []
+    for s in range(2):
+        m.logged = {}
+        m.training_step(batch, s + 1)
+        vals.append({k: float(v) for k, v in m.logged.items()})
+        assert all(np.isfinite(v) for v in vals[-1].values()), vals[-1]

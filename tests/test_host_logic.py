@@ -36,7 +36,7 @@ def test_other_families_state_dicts_and_init(pai):
     want = oracle.make_attention_unet_state(1, 1, (1, 2, 4, 8))
     got = m.unet.state_dict()
     assert [(k, tuple(v.shape)) for k, v in got.items()] == [(k, tuple(v.shape)) for k, v in want.items()]
-    for rt in ("18", "50", "next"):
+    for rt in ("18", "50", "next", "v2"):
         r = pai.ResUnetGAN(1, 1, rt, (1, 2, 2), 0.0, "gan")
         want = oracle.make_res_unet_state(1, 1, rt, (1, 2, 2))
         got = r.unet.state_dict()
@@ -45,9 +45,6 @@ def test_other_families_state_dicts_and_init(pai):
     assert abs(float(w.std()) - 0.02) < 4e-3 and abs(float(w.mean())) < 4e-3
     bn = m.unet.attention_blocks[0].input_gate[1]
     assert torch.equal(bn.weight, torch.ones_like(bn.weight)) and torch.equal(bn.bias, torch.zeros_like(bn.bias))
-    with pytest.raises(NotImplementedError):
-        v2 = pai.ResUnetGAN(1, 1, "v2", (1, 2), 0.0, "mse")
-        v2.unet.encoders[0].encode[0].run(None, {})
 
 
 def test_fwd_pack_layout_and_arena_views(pai):

@@ -230,7 +230,7 @@ extern "C" int pai_gelu_bwd(int dtype, const void* dy, const void* z, int64_t nu
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void mha_fwd_k(const T* qkv, int S, int B, int heads, int hd, float scale,
-                                                 T* out, float* probs) {
+                                                 T* out, float* probs, const float* mask) {
     extern __shared__ float sm[];   // q[hd] | sc[S] | red[8]
     float* q = sm;
     float* sc = sm + hd;
@@ -267,10 +267,11 @@ __global__ __launch_bounds__(256) void mha_fwd_k(const T* qkv, int S, int B, int
     sum = block_sum(sum, red + 4);
     const float inv = 1.0f / sum;
     float* pr = probs + ((int64_t)bh * S + i) * S;
+    const float* mk = mask ? mask + ((int64_t)bh * S + i) * S : nullptr;   // attention dropout: 0 or 1 / (1 - p)
     for (int j = threadIdx.x; j < S; j += 256) {
         const float p = sc[j] * inv;
-        sc[j] = p;
-        pr[j] = p;
+        pr[j] = p;                      // the softmax itself is what the backward pass needs
+        sc[j] = mk ? p * mk[j] : p;
     }
     __syncthreads();
     T* o = out + ((int64_t)i * B + b) * E + h * hd;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void mha_fwd_k(const T* qkv, int S, int B, int
 // per (b, h, i): dP[j] = <dO_i, V_j>, dS[j] = P[j] (dP[j] - sum_j' P[j'] dP[j']), dQ_i = scale sum_j dS[j] K_j
 template <typename T>
 __global__ __launch_bounds__(256) void mha_bwd_q_k(const T* dout, const T* qkv, const float* probs, int S, int B,
-                                                   int heads, int hd, float scale, T* dqkv, float* ds) {
+                                                   int heads, int hd, float scale, T* dqkv, float* ds, const float* mask) {
     extern __shared__ float sm[];   // do[hd] | dp[S] | red[8]
     float* dov = sm;
     float* dp = sm + hd;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_k(const T* dout, const T* qkv, 
         float a = 0.f;
         for (int d = lane; d < hd; d += 64) a = fmaf(dov[d], Conv<T>::ld(v + d), a);
         a = wave_sum(a);
-        if (lane == 0) dp[j] = a;
+        if (lane == 0) dp[j] = mask ? a * mask[((int64_t)bh * S + i) * S + j] : a;
     }
     __syncthreads();
     const float* pr = probs + ((int64_t)bh * S + i) * S;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_k(const T* dout, const T* qkv, 
 // per (b, h, key j): dV_j = sum_i P[i][j] dO_i,  dK_j = scale sum_i dS[i][j] Q_i
 template <typename T>
 __global__ __launch_bounds__(256) void mha_bwd_kv_k(const T* dout, const T* qkv, const float* probs, const float* ds,
-                                                    int S, int B, int heads, int hd, float scale, T* dqkv) {
+                                                    int S, int B, int heads, int hd, float scale, T* dqkv, const float* mask) {
     extern __shared__ float sm[];   // p[S] | s[S]
     float* pc = sm;
     float* dc = sm + S;
@@ -339,8 +340,9 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_k(const T* dout, const T* qkv,
     const int E = heads * hd;
     const int64_t rs = (int64_t)B * 3 * E;
     for (int i = threadIdx.x; i < S; i += 256) {
-        pc[i] = probs[((int64_t)bh * S + i) * S + j];
-        dc[i] = ds[((int64_t)bh * S + i) * S + j];
+        const int64_t e = ((int64_t)bh * S + i) * S + j;
+        pc[i] = mask ? probs[e] * mask[e] : probs[e];
+        dc[i] = ds[e];
     }
     __syncthreads();
     const T* qb = qkv + (int64_t)b * 3 * E + h * hd;
@@ -366,8 +368,8 @@ static int mha_check(const char* who, int dtype, int S, int B, int heads, int hd
     return 0;
 }
 
-extern "C" int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, int hd, void* out, float* probs,
-                           void* stream) {
+extern "C" int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, int hd, const float* mask, void* out,
+                           float* probs, void* stream) {
     if (mha_check("pai_mha_fwd", dtype, S, B, heads, hd)) return 1;
     PAI_CHECK(qkv && out && probs, "pai_mha_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -376,16 +378,16 @@ extern "C" int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, 
     const dim3 grid((unsigned)(S * B * heads));
     if (dtype == PAI_F32)
         hipLaunchKernelGGL(mha_fwd_k<float>, grid, dim3(256), lds, s, (const float*)qkv, S, B, heads, hd, scale,
-                           (float*)out, probs);
+                           (float*)out, probs, mask);
     else
         hipLaunchKernelGGL(mha_fwd_k<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)qkv, S, B, heads, hd, scale,
-                           (bf16_t*)out, probs);
+                           (bf16_t*)out, probs, mask);
     PAI_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const float* probs, int S, int B, int heads,
-                           int hd, void* dqkv, float* ds_workspace, void* stream) {
+                           int hd, const float* mask, void* dqkv, float* ds_workspace, void* stream) {
     if (mha_check("pai_mha_bwd", dtype, S, B, heads, hd)) return 1;
     PAI_CHECK(dout && qkv && probs && dqkv && ds_workspace, "pai_mha_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -394,14 +396,14 @@ extern "C" int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const f
     const dim3 grid((unsigned)(S * B * heads));
     if (dtype == PAI_F32) {
         hipLaunchKernelGGL(mha_bwd_q_k<float>, grid, dim3(256), lds_q, s, (const float*)dout, (const float*)qkv, probs,
-                           S, B, heads, hd, scale, (float*)dqkv, ds_workspace);
+                           S, B, heads, hd, scale, (float*)dqkv, ds_workspace, mask);
         hipLaunchKernelGGL(mha_bwd_kv_k<float>, grid, dim3(256), lds_kv, s, (const float*)dout, (const float*)qkv,
-                           probs, ds_workspace, S, B, heads, hd, scale, (float*)dqkv);
+                           probs, ds_workspace, S, B, heads, hd, scale, (float*)dqkv, mask);
     } else {
         hipLaunchKernelGGL(mha_bwd_q_k<bf16_t>, grid, dim3(256), lds_q, s, (const bf16_t*)dout, (const bf16_t*)qkv,
-                           probs, S, B, heads, hd, scale, (bf16_t*)dqkv, ds_workspace);
+                           probs, S, B, heads, hd, scale, (bf16_t*)dqkv, ds_workspace, mask);
         hipLaunchKernelGGL(mha_bwd_kv_k<bf16_t>, grid, dim3(256), lds_kv, s, (const bf16_t*)dout, (const bf16_t*)qkv,
-                           probs, ds_workspace, S, B, heads, hd, scale, (bf16_t*)dqkv);
+                           probs, ds_workspace, S, B, heads, hd, scale, (bf16_t*)dqkv, mask);
     }
     PAI_LAUNCH_CHECK();
     return 0;

@@ -86,8 +86,8 @@ SIGNATURES = {
     "pai_layernorm_bwd": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pai_gelu": (_I, [_I, _P, _L, _P, _P]),
     "pai_gelu_bwd": (_I, [_I, _P, _P, _L, _P, _P]),
-    "pai_mha_fwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "pai_mha_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "pai_mha_fwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pai_mha_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pai_subsample2": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "pai_subsample2_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "pai_bn_stats_rows": (_I, [_L]),

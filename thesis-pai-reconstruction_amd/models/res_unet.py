@@ -4,8 +4,8 @@ Same module tree as the reference -- ``in_conv``, ``encoders`` / ``decoders`` Mo
 ``conv_block`` / ``conv_skip`` Sequentials hold stock ``nn.Conv2d`` / ``nn.BatchNorm2d`` parameter containers,
 ``out`` -- so state-dict keys and shapes are interchangeable.  The arithmetic runs through the op-level autograd
 bridges of ``nnops`` (fused conv -> BatchNorm -> activation blocks, MaxPool2d, nearest Upsample, residual sum).
-Built: ``res_type`` "18", "50" and "next"; "v2" (pre-activation blocks, BatchNorm on a tensor that no convolution
-epilogue produced) raises NotImplementedError.
+Built: ``res_type`` "18", "50", "next" and "v2" (pre-activation blocks: BatchNorm on a tensor that no convolution
+epilogue produced, ``nnops.BNAct``).
 """
 from typing import Literal
 
@@ -94,7 +94,8 @@ class ResidualBlock50(_Block):
 
 
 class ResidualBlockV2(_Block):
-    """Pre-activation block (reference models/res_unet.py:108-130): parameter container only, not executable yet."""
+    """Pre-activation block (reference models/res_unet.py:108-130): BatchNorm -> ReLU in FRONT of each convolution
+    (standalone ``nnops.BNAct``: statistics of a stored tensor), bias-only convolutions, no ReLU behind the sum."""
 
     def __init__(self, in_channels: int, out_channels: int):
         super().__init__()
@@ -106,7 +107,19 @@ class ResidualBlockV2(_Block):
         ) if in_channels != out_channels else nn.Identity()
 
     def run(self, x, ctx):
-        raise NotImplementedError("res_type 'v2' (pre-activation blocks) is not built on the HIP path yet")
+        tr, nu, dt = ctx["training"], ctx["n_updates"], ctx["dtype"]
+        cb = self.conv_block
+        h = nnops.BNAct.apply(x, cb[0].weight, cb[0].bias, cb[0], tr, nu, ACT_RELU)
+        h = nnops.conv_bn_act(h, cb[2], None, ACT_NONE, tr, 0, dt)
+        h = nnops.BNAct.apply(h, cb[3].weight, cb[3].bias, cb[3], tr, nu, ACT_RELU)
+        h = nnops.conv_bn_act(h, cb[5], None, ACT_NONE, tr, 0, dt)
+        if isinstance(self.conv_skip, nn.Identity):
+            s = x
+        else:
+            sk = self.conv_skip
+            s = nnops.BNAct.apply(x, sk[0].weight, sk[0].bias, sk[0], tr, nu, ACT_RELU)
+            s = nnops.conv_bn_act(s, sk[2], None, ACT_NONE, tr, 0, dt)
+        return nnops.AddAct.apply(h, s, ACT_NONE)
 
 
 class ResidualBlockNeXt(_Block):

@@ -12,7 +12,9 @@ Reference behaviour kept on purpose: the encoder layers are built w
 ``[n, patches, dim]``, so attention mixes the IMAGES of a batch at equal patch position (sequence = n).
 ``image_size`` is fixed at 256 by ``TransUnetGAN`` (:22): the patch grid is sized for 256 x 256 inputs.
 
-Not built: Dropout inside the transformer layers in training mode (``dropout`` > 0; the CLI default is 0) raises.
+``dropout`` > 0 (the class default is 0.5, the CLI default 0): the four Dropout sites of every encoder layer (attention
+weights, behind the attention block, inside and behind the feed-forward block) draw their masks with
+``torch.bernoulli`` on the device (or take them from ``dropout_mask_fn`` in tests); the kernels apply them.
 """
 import math
 from typing import Literal
@@ -94,6 +96,7 @@ class VisionTransformer(nn.Module):
         self.patch_size, self.patch_dim, self.num_patches, self.num_heads = patch_size, patch_dim, num_patches, num_heads
         self.grid = int(math.sqrt(num_patches))
         self.dropout = dropout
+        self.dropout_mask_fn = None      # tests: fn(site, layer, shape, p, device) -> mask of {0, 1 / (1 - p)}
         # index 0 is the reference's (parameter-free) Rearrange layer: the state-dict keys start at 1
         self.to_patch_embedding = nn.Sequential(nn.Identity(), nn.LayerNorm(patch_dim), nn.Linear(patch_dim, patch_dim),
                                                 nn.LayerNorm(patch_dim))
@@ -108,9 +111,16 @@ class VisionTransformer(nn.Module):
         if hs != g * p or ws != g * p or c * p * p != self.patch_dim:
             raise PaiError(f"ViT bottleneck built for {g * p}x{g * p}x{self.patch_dim // (p * p)} features, got "
                            f"{hs}x{ws}x{c} (TransUnetGAN fixes image_size = 256)")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("transformer Dropout in training mode is not built on the HIP path (use dropout=0)")
         P, D = self.num_patches, self.patch_dim
+        drop = self.training and self.dropout > 0
+
+        def mask(site, li, *shape):
+            """fp32 mask of {0, 1 / (1 - p)} for one Dropout site (RNG plumbing; the kernels apply it)."""
+            pr = self.dropout
+            if self.dropout_mask_fn is not None:
+                return self.dropout_mask_fn(site, li, shape, pr, h.device).to(torch.float32).reshape(shape).contiguous()
+            return torch.bernoulli(torch.full(shape, 1.0 - pr, device=h.device)) / (1.0 - pr)
+
         # "n c (h p1) (w p2) -> n (h w) (p1 p2 c)" on the NHWC tensor: data movement only
         t = h.view(n, g, p, g, p, c).permute(0, 1, 3, 2, 4, 5).reshape(n * P, D).contiguous()
         ln1, lin, ln2 = self.to_patch_embedding[1], self.to_patch_embedding[2], self.to_patch_embedding[3]
@@ -120,12 +130,19 @@ class VisionTransformer(nn.Module):
         for li, layer in enumerate(self.transformer.layers):
             sa = layer.self_attn
             qkv = nnops.Linear.apply(t, sa.in_proj_weight, sa.in_proj_bias)
-            a = nnops.MHACore.apply(qkv, n, P, self.num_heads)         # sequence axis = the image batch
+            # sequence axis = the image batch
+            a = nnops.MHACore.apply(qkv, n, P, self.num_heads, mask("attn", li, P * self.num_heads, n, n) if drop else None)
             a = nnops.Linear.apply(a, sa.out_proj.weight, sa.out_proj.bias)
+            if drop:
+                a = nnops.TokenDropout.apply(a, mask("sa", li, n * P, D))
             t = nnops.LayerNorm.apply(t, a, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, None)
             f = nnops.Linear.apply(t, layer.linear1.weight, layer.linear1.bias)
             f = nnops.GELU.apply(f)
+            if drop:
+                f = nnops.TokenDropout.apply(f, mask("ff", li, n * P, f.shape[1]))
             f = nnops.Linear.apply(f, layer.linear2.weight, layer.linear2.bias)
+            if drop:
+                f = nnops.TokenDropout.apply(f, mask("out", li, n * P, D))
             t = nnops.LayerNorm.apply(t, f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, None)
             if ctx.get("capture") is not None:
                 ctx["capture"][f"vit{li}"] = t.detach().float()

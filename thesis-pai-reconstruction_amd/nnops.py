@@ -449,7 +449,7 @@ class MHACore(torch.autograd.Function):
     (nn.MultiheadAttention with batch_first = False: S is the image batch)."""
 
     @staticmethod
-    def forward(ctx, qkv, S, B, heads):
+    def forward(ctx, qkv, S, B, heads, mask=None):
         _check_tokens(qkv)
         E = qkv.shape[1] // 3
         hd = E // heads
@@ -457,16 +457,42 @@ class MHACore(torch.autograd.Function):
             raise ops.PaiError(f"MHACore: qkv {tuple(qkv.shape)} does not match S={S} B={B} heads={heads}")
         out = torch.empty(S * B, E, dtype=qkv.dtype, device=qkv.device)
         probs = torch.empty(B * heads * S * S, dtype=torch.float32, device=qkv.device)
-        ops.mha_fwd(qkv.dtype, qkv, S, B, heads, hd, out, probs)
+        if mask is not None and (mask.numel() != probs.numel() or not mask.is_contiguous()):
+            raise ops.PaiError("MHACore: the attention-dropout mask must be a contiguous fp32 [B * heads, S, S] tensor")
+        ops.mha_fwd(qkv.dtype, qkv, S, B, heads, hd, out, probs, mask)
         ctx.dims = (S, B, heads, hd)
-        ctx.save_for_backward(qkv, probs)
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(qkv, probs, *([mask] if mask is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkv, probs = ctx.saved_tensors
+        qkv, probs = ctx.saved_tensors[:2]
+        mask = ctx.saved_tensors[2] if ctx.has_mask else None
         S, B, heads, hd = ctx.dims
         dqkv = torch.empty_like(qkv)
         ds = torch.empty_like(probs)
-        ops.mha_bwd(qkv.dtype, g.contiguous(), qkv, probs, S, B, heads, hd, dqkv, ds)
-        return dqkv, None, None, None
+        ops.mha_bwd(qkv.dtype, g.contiguous(), qkv, probs, S, B, heads, hd, dqkv, ds, mask)
+        return dqkv, None, None, None, None
+
+
+class TokenDropout(torch.autograd.Function):
+    """nn.Dropout on a token tensor [M, D] with a caller-supplied fp32 mask [M, D] of {0, 1 / (1 - p)} (dropout1 /
+    dropout / dropout2 of nn.TransformerEncoderLayer): ``pai_dropout2d`` with one pixel per sample."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        _check_tokens(x)
+        M, D = x.shape
+        out = torch.empty_like(x)
+        ops.dropout2d(x.dtype, x, mask, M, 1, D, out)
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        M, D = g.shape
+        out = torch.empty_like(g)
+        ops.dropout2d(g.dtype, g.contiguous(), mask, M, 1, D, out)
+        return out, None

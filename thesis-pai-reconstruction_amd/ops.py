@@ -305,14 +305,14 @@ def gelu_bwd(dtype, dy, z, dz):
     L.check(L.load().pai_gelu_bwd(code_of(dtype), _p(dy), _p(z), z.numel(), _p(dz), _stream()), "pai_gelu_bwd")
 
 
-def mha_fwd(dtype, qkv, S, B, heads, hd, out, probs):
-    L.check(L.load().pai_mha_fwd(code_of(dtype), _p(qkv), S, B, heads, hd, _p(out), _p(probs, torch.float32), _stream()),
-            "pai_mha_fwd")
+def mha_fwd(dtype, qkv, S, B, heads, hd, out, probs, mask=None):
+    L.check(L.load().pai_mha_fwd(code_of(dtype), _p(qkv), S, B, heads, hd, _p(mask, torch.float32), _p(out),
+                                 _p(probs, torch.float32), _stream()), "pai_mha_fwd")
 
 
-def mha_bwd(dtype, dout, qkv, probs, S, B, heads, hd, dqkv, ds_ws):
+def mha_bwd(dtype, dout, qkv, probs, S, B, heads, hd, dqkv, ds_ws, mask=None):
     L.check(L.load().pai_mha_bwd(code_of(dtype), _p(dout), _p(qkv), _p(probs, torch.float32), S, B, heads, hd,
-                                 _p(dqkv), _p(ds_ws, torch.float32), _stream()), "pai_mha_bwd")
+                                 _p(mask, torch.float32), _p(dqkv), _p(ds_ws, torch.float32), _stream()), "pai_mha_bwd")
 
 
 def subsample2(dtype, x, N, H, W, C_, out):
