@@ -95,6 +95,23 @@ def _worker(rank, world, port, q):
             both = [torch.zeros_like(g) for _ in range(world)]
             dist.all_gather(both, g)
             assert torch.allclose(p.grad, sum(both) / world, atol=1e-6)
+        # small buckets: the 144-element conv weight goes in place, the rest in coalesced buckets of >= 16 elements
+        red3 = pdist.GradReducer(bucket_bytes=64)
+        red3.attach(net)
+        net.zero_grad(set_to_none=True)
+        nn.Sequential(net, nn.Conv2d(1, 1, 1))      # (unrelated container; net's parameters are what is attached)
+        wide = nn.Conv2d(4, 4, 3, padding=1)
+        net2 = nn.Sequential(net[0], nn.ReLU(), wide, nn.ReLU(), net[2])
+        pdist.broadcast_parameters(net2, src=0)
+        red3.attach(net2)
+        net2(x).sum().backward()
+        local = [p.grad.clone() for p in net2.parameters()]
+        red3.finish()
+        assert red3.stats["buckets"] >= 3
+        for p, g in zip(net2.parameters(), local):
+            both = [torch.zeros_like(g) for _ in range(world)]
+            dist.all_gather(both, g)
+            assert torch.allclose(p.grad, sum(both) / world, atol=1e-6)
         # permuted (fwd-pack) parameters are broadcast through their storage order
         ct = nn.ConvTranspose2d(8, 4, 4, 2, 1)
         E.to_fwd_pack_(ct)

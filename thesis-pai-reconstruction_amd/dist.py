@@ -90,14 +90,46 @@ class GradReducer:
             st["sent"], st["works"], st["active"] = 0, [], False
         grads = [p.grad for p in self._foreign_params if p.requires_grad and p.grad is not None]
         if grads and self.world > 1:
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
-            flat.mul_(1.0 / self.world)
-            off = 0
-            for g in grads:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
+            self._reduce_foreign(grads)
+
+    def _reduce_foreign(self, grads):
+        """Gradients that do not live in an arena (the composable residual / Trans U-Nets, plug-in ``unet`` modules):
+        tensors of at least one bucket are all-reduced in place, the small ones coalesced into buckets of
+        ``bucket_bytes`` -- never one concatenation of everything (the TransUNet of ``patch_size = 4`` has 1.03 B
+        parameters).  All collectives are issued asynchronously, then waited for and averaged."""
+        scale = 1.0 / self.world
+        pending = []                                   # (work, flat buffer, tensors it was gathered from | None)
+        bucket, size = [], 0
+
+        def flush():
+            nonlocal bucket, size
+            if bucket:
+                flat = torch.cat([g.reshape(-1) for g in bucket])
+                pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat, bucket))
+                self.stats["buckets"] += 1
+                self.stats["bytes"] += flat.numel() * 4
+            bucket, size = [], 0
+
+        for g in grads:
+            if g.numel() >= self.bucket_elems and g.is_contiguous():
+                pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), g, None))
+                self.stats["buckets"] += 1
+                self.stats["bytes"] += g.numel() * 4
+            else:
+                bucket.append(g)
+                size += g.numel()
+                if size >= self.bucket_elems:
+                    flush()
+        flush()
+        for work, flat, members in pending:
+            work.wait()
+            flat.mul_(scale)
+            if members is not None:
+                off = 0
+                for g in members:
+                    n = g.numel()
+                    g.copy_(flat[off:off + n].view_as(g))
+                    off += n
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=None):
