@@ -37,8 +37,11 @@ def _worker(rank, world, port, precision, family, q):
         pdist.init_from_env()
         dev = torch.device("cuda", 0)
         torch.manual_seed(100 + rank)                       # different initial weights per rank ...
-        cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
-        m = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
+        if family == "resnext_unet":                        # composable path: gradients outside the arenas (MultiAdam)
+            m = pai.ResUnetGAN(1, 1, "next", (1, 2, 2), 0.0, "gan").to(dev)
+        else:
+            cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
+            m = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
         m.set_precision(precision)
         m.train()
         pdist.broadcast_parameters(m)                       # ... aligned here
@@ -72,7 +75,7 @@ def _worker(rank, world, port, precision, family, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("family", ["pix2pix", "attention_unet"])
+@pytest.mark.parametrize("family", ["pix2pix", "attention_unet", "resnext_unet"])
 @pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
 def test_two_rank_step_keeps_replicas_identical(precision, family):
     ctx = mp.get_context("spawn")
