@@ -87,7 +87,7 @@ int pai_bn_stats_buffer_rows(int rows);
 /* Kernel family a call with this descriptor runs (for profiling / roofline accounting):
  * op 0 = forward, 1 = input gradient, 2 = weight gradient.
  * returns 0 vector-ALU tile kernel, 1 row-dot kernel, 2 bf16 MFMA 128-wide tile, 3 bf16 MFMA
- * 64-wide tile, 4 thin-layer MFMA kernels, < 0 on error. */
+ * 64-wide tile, 4 thin-layer MFMA kernels, 5 small-channel (16 / 32) MFMA kernel, < 0 on error. */
 int pai_conv_kernel_id(const pai_conv_desc* d, int op);
 /* Symbol (as rocprofv3 --kernel-trace prints it, without "void " and the argument list) of the main
  * kernel such a call launches, e.g. "gg_fwd_patch_k<256, 128, true>"; bench.py keys its per-kernel

@@ -216,22 +216,47 @@ CONV3 = [("in_conv", 2, 16, 16, 1, 64), ("c64", 2, 16, 24, 64, 64), ("c128", 3, 
 def test_conv3x3(pai, case, dtype):
     """nn.Conv2d(kernel_size=3, padding=1) of the residual U-Net (reference models/res_unet.py:59,62,265,308)
     through the same gather-GEMM entry points (kernel = 3: 9 taps, stride 1)."""
-    from thesis_pai_reconstruction_amd import ops
     name, N, H, W, C, K = case
+    _same_conv_case(3, N, H, W, C, K, dtype)
+
+
+# (name, kernel, N, H, W, Cin, Cout): the 16- / 32-channel bottleneck convolutions of the TransUNet / ResNet-50 encoder
+# blocks (reference models/trans_unet.py:203-227, models/res_unet.py:86-95) -- in bf16 the no-LDS MFMA kernel of
+# gg_small.hip (forward, input gradient) and the partly filled tiles of gg_wgrad_mfma_k; ragged pixel counts and
+# non-power-of-two images included (the latter keep the vector-ALU weight gradient)
+SMALL = [("pw64_16", 1, 2, 16, 16, 64, 16), ("pw16_64", 1, 2, 16, 16, 16, 64), ("pw16_128", 1, 1, 8, 32, 16, 128),
+         ("pw128_32", 1, 2, 8, 8, 128, 32), ("pw32_256", 1, 3, 4, 4, 32, 256), ("pw256_32", 1, 2, 4, 8, 256, 32),
+         ("c16", 3, 2, 16, 16, 16, 16), ("c32", 3, 3, 8, 16, 32, 32), ("c16_ragged", 3, 1, 6, 10, 16, 16),
+         ("pw64_48", 1, 1, 5, 7, 64, 48), ("c32_16", 3, 2, 8, 8, 32, 16)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", SMALL, ids=[c[0] for c in SMALL])
+def test_small_channel_convs(pai, case, dtype):
+    from thesis_pai_reconstruction_amd import ops
+    name, k, N, H, W, C, K = case
+    d = ops.make_desc(dtype, 0, N, H, W, C, 0, K, 1, 0, 0, ops.ACT_NONE, kernel=k)
+    if dtype == torch.bfloat16:
+        assert ops.conv_kernel_id(d, 0) == 5 and ops.conv_kernel_id(d, 1) == 5, name    # small_mfma_bf16
+    _same_conv_case(k, N, H, W, C, K, dtype)
+
+
+def _same_conv_case(k, N, H, W, C, K, dtype):
+    from thesis_pai_reconstruction_amd import ops
     tol = TOL[dtype]
     x = q(rnd((N, C, H, W), 1), dtype).requires_grad_(True)
-    w = q(rnd((K, C, 3, 3), 2, 0.05), dtype).requires_grad_(True)
+    w = q(rnd((K, C, k, k), 2, 0.05), dtype).requires_grad_(True)
     b = rnd((K,), 3, 0.1).requires_grad_(True)
-    y = F.conv2d(x, w, b, padding=1)
+    y = F.conv2d(x, w, b, padding=k // 2)
     dy = q(rnd(tuple(y.shape), 4), dtype)
     y.backward(dy)
-    d = ops.make_desc(dtype, 0, N, H, W, C, 0, K, 1, 0, 0, ops.ACT_RELU, kernel=3)
+    d = ops.make_desc(dtype, 0, N, H, W, C, 0, K, 1, 0, 0, ops.ACT_RELU, kernel=k)
     assert ops.conv_out_hw(d) == (H, W)
     ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
-    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())          # fwd pack [K][3][3][C]
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())          # fwd pack [K][k][k][C]
     wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
     wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
-    ops.pack_weights(dtype, wm, K, 9, C, wf, wd)
+    ops.pack_weights(dtype, wm, K, k * k, C, wf, wd)
     X, DY = nhwc(x.detach(), dtype), nhwc(dy, dtype)
     if K > 2:
         y_raw = torch.empty(N * H * W * K, dtype=dtype, device=dev())
@@ -259,7 +284,7 @@ def test_conv3x3(pai, case, dtype):
     ops.conv_wgrad(d, X, None, DY, dw, db)
     torch.cuda.synchronize()
     tol_w = 1e-4 if dtype == torch.float32 else 3e-3
-    assert rel_err(dw.cpu().view(K, 3, 3, C).permute(0, 3, 1, 2), w.grad) < tol_w
+    assert rel_err(dw.cpu().view(K, k, k, C).permute(0, 3, 1, 2), w.grad) < tol_w
     assert rel_err(db.cpu(), b.grad) < tol_w
 
 

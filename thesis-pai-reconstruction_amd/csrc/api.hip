@@ -276,6 +276,8 @@ extern "C" int pai_conv_fwd_stats_rows(const pai_conv_desc* d) {
     a.y1 = (void*)1;  // raw output present
     a.stats = (float*)1;
     if (pw_ok(d->dtype, g, a)) return pw_rows(g);
+    if (!thin_fwd_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) && !use_mfma(d->dtype, g, a) && small_ok(d->dtype, g, a))
+        return small_rows(g);
     int mt = use_mfma(d->dtype, g, a) ? fwd_mfma_mtiles(g) : fwd_simt_mtiles(g);
     return mt * g.nphase;
 }
@@ -304,11 +306,12 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     if (fwd_rowdot_ok(g, a)) return 1;
     if (fwd_mfma_ok(d->dtype, g, a))
         return ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 2 : 3;
+    if (small_ok(d->dtype, g, a)) return 5;
     return 0;
 }
 
 extern "C" int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len) {
-    static const char* fam[5] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16"};
+    static const char* fam[6] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16", "small_mfma_bf16"};
     const int id = pai_conv_kernel_id(d, op);
     if (id < 0 || !name || name_len <= 0) return -1;
     const char* n = fam[id];
@@ -336,6 +339,7 @@ static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);
     if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
     if (use_mfma(dtype, g, a)) return launch_fwd_mfma(g, a, s);
+    if (small_ok(dtype, g, a)) return launch_small(g, a, s);
     return launch_fwd_simt(dtype, g, a, s);
 }
 

@@ -175,6 +175,10 @@ bool pw_ok(int dtype, const GG& g, const FwdArgs& a);
 int pw_rows(const GG& g);
 int launch_pw(const GG& g, const FwdArgs& a, hipStream_t s);
 bool fwd_rowdot_ok(const GG& g, const FwdArgs& a);
+// 16- / 32-channel 1x1 and 3x3 convolutions on the matrix cores, no LDS (gg_small.hip)
+bool small_ok(int dtype, const GG& g, const FwdArgs& a);
+int small_rows(const GG& g);
+int launch_small(const GG& g, const FwdArgs& a, hipStream_t s);
 
 // thin layers on the matrix cores (gg_thin.hip)
 extern float* g_scratch;

@@ -1303,6 +1303,11 @@ bool wgrad_mfma_ok(int dtype, const GG& g) {
     if (g.ntaps == 1 && g.C2 == 0 && ((g.C1 == 64 && g.Cout == 32) || (g.C1 == 32 && g.Cout == 64))) return true;
     // ... and the 64-input-channel pointwise convolutions of the residual blocks (half-full column tile)
     if (g.ntaps == 1 && g.C2 == 0 && g.C1 == 64 && (g.Cout % 64) == 0) return true;
+    // ... and the 16- / 32-channel bottleneck convolutions (1x1 and 3x3) of the TransUNet / ResNet-50 encoder blocks:
+    // both operands are staged in 8-channel chunks and every tile edge is guarded, so a partly empty tile is only
+    // idle matrix rows in a launch that is bound by streaming the two activations once
+    if (g.nphase == 1 && g.S == 1 && g.C2 == 0 && (g.C1 % 8) == 0 && (g.Cout % 8) == 0 && (g.C1 < 64 || g.Cout < 64))
+        return true;
     if (g.C1 % 64 || g.C2 % 64) return false;
     if (g.Cout % 64) return false;
     if ((g.ntaps * g.Cin) % 128) return false;
@@ -1690,6 +1695,12 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
 
 int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hipStream_t s);
 
+// shapes of the patch-resident weight gradient: full 64-channel output tiles only (the partly filled tiles of the
+// small-channel layers go to gg_wgrad_mfma_k, whose tile edges are guarded)
+static bool wgrad_patch_shape_ok(const GG& g) {
+    return g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && (g.Cout % 64) == 0 && g.Cin >= 64;
+}
+
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     const bool big = (g.Cout % 128) == 0;
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
@@ -1714,7 +1725,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     splits = cdiv(g.M, rows);
     static const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;
-    if (!no_patch && g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && patch_geo(g, 4, &pg)) {
+    if (!no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg)) {
         const int kblocks = g.M / 64;
         const int per = rows / 64;
         const int psplits = cdiv(kblocks, per);
@@ -1741,7 +1752,7 @@ const char* wgrad_mfma_kernel_name(const GG& g) {
     const bool big = (g.Cout % 128) == 0;
     const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;
-    if (!no_patch && g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && patch_geo(g, 4, &pg))
+    if (!no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg))
         return big ? "gg_wgrad_patch_k<128>" : "gg_wgrad_patch_k<64>";
     return big ? "gg_wgrad_mfma_k<128>" : "gg_wgrad_mfma_k<64>";
 }

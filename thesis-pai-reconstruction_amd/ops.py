@@ -72,7 +72,7 @@ def bn_stats_buffer_rows(rows: int) -> int:
 # the stream the kernel is launched on, and (kernel family, op, algorithmic FLOPs, events) is
 # appended.  Off (None) in normal operation.
 PROFILE = None
-KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16"}
+KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16", 5: "small_mfma_bf16"}
 
 
 def conv_kernel_id(d: ConvDesc, op: int) -> int:
