@@ -9,9 +9,11 @@ import sys
 def main(d, nsteps=5, marker="adam_k"):
     f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
+    marker_name = marker.split(":")[0]
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows)
-    adam = [i for i, e in enumerate(ev) if e[2].startswith(marker)]
-    i0, i1 = adam[-2 * nsteps - 1], adam[-1]
+    adam = [i for i, e in enumerate(ev) if marker_name in e[2]]
+    per_step = 2 if marker == "adam_k" else int(marker.split(":")[1]) if ":" in marker else 1
+    i0, i1 = adam[-per_step * nsteps - 1], adam[-1]
     seg = ev[i0 + 1:i1 + 1]
     t0, t1 = seg[0][0], seg[-1][1]
     iv = sorted((s, e) for s, e, _, _ in seg)

@@ -89,9 +89,52 @@ __global__ __launch_bounds__(256) void pack_k(const float* w, int Cout, int taps
     }
 }
 
+// bf16 fast path for Cin, Cout multiples of 64: a 64 x 64 tile per workgroup, 16-B loads of the fp32 master and
+// 16-B stores of both packs (the 32 x 32 kernel above writes 2 bytes per lane: 2.5 TB/s of the 8 -- 3.2 ms per step
+// on the 1.03 B-parameter TransUNet)
+__global__ __launch_bounds__(256) void pack64_k(const float* w, int Cout, int taps, int Cin, bf16_t* wf, bf16_t* wd) {
+    __shared__ float tile[64][65];
+    const int t = blockIdx.z;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    // load: row r = tid / 16 + 16 j, float4 column q = tid % 16
+    const int q = tid & 15, r0 = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 16 * j;
+        const float4 v = *(const float4*)(w + ((size_t)(co0 + r) * taps + t) * Cin + ci0 + 4 * q);
+        tile[r][4 * q + 0] = v.x; tile[r][4 * q + 1] = v.y; tile[r][4 * q + 2] = v.z; tile[r][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+    // store: row = tid / 8 + 32 j, 8-element chunk c = tid % 8
+    const int c = tid & 7, s0 = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = s0 + 32 * j;
+        if (wf) {
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pk2bf(tile[r][8 * c + 2 * e], tile[r][8 * c + 2 * e + 1]);
+            *(uint4*)(wf + ((size_t)(co0 + r) * taps + t) * Cin + ci0 + 8 * c) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        if (wd) {   // transposed: row r is an input channel, the chunk 8 output channels
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pk2bf(tile[8 * c + 2 * e][r], tile[8 * c + 2 * e + 1][r]);
+            *(uint4*)(wd + ((size_t)(ci0 + r) * taps + t) * Cout + co0 + 8 * c) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+    }
+}
+
 extern "C" int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,
                                 void* w_fwd, void* w_dgrad, void* stream) {
     PAI_CHECK(w_master && (w_fwd || w_dgrad), "pai_pack_weights: null pointer");
+    if (dtype == PAI_BF16 && (Cin % 64) == 0 && (Cout % 64) == 0 && Cout / 64 <= 65535 && taps <= 65535) {
+        hipLaunchKernelGGL(pack64_k, dim3(Cin / 64, Cout / 64, taps), dim3(256), 0, (hipStream_t)stream, w_master, Cout,
+                           taps, Cin, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), taps);
     if (dtype == PAI_F32)
         hipLaunchKernelGGL(pack_k<float>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
