@@ -208,7 +208,8 @@ def test_conv_family(pai, case, dtype):
 # (name, N, H, W, Cin, Cout): vector-ALU kernel (1 -> 64), MFMA forward / input gradient with the vector-ALU weight
 # gradient (9 * 64 is not a multiple of 128), MFMA everywhere (128 -> 128), row-dot forward (64 -> 1)
 CONV3 = [("in_conv", 2, 16, 16, 1, 64), ("c64", 2, 16, 24, 64, 64), ("c128", 3, 16, 16, 128, 128),
-         ("out_conv", 2, 16, 16, 64, 1)]
+         ("out_conv", 2, 16, 16, 64, 1), ("in_conv_ragged", 3, 10, 12, 1, 64), ("out_conv_ragged", 1, 6, 20, 64, 1),
+         ("in_conv_big", 2, 64, 64, 1, 64), ("out_conv_big", 2, 64, 64, 64, 1)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -253,6 +254,11 @@ def _same_conv_case(k, N, H, W, C, K, dtype):
     d = ops.make_desc(dtype, 0, N, H, W, C, 0, K, 1, 0, 0, ops.ACT_RELU, kernel=k)
     assert ops.conv_out_hw(d) == (H, W)
     ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
+    if dtype == torch.bfloat16 and k == 3 and C == 1:      # in_conv: thin -> wide kernels of gg_thin.hip (9 taps)
+        assert ops.conv_kernel_id(d, 0) == 4 and ops.conv_kernel_id(d, 2) == 4
+    if dtype == torch.bfloat16 and k == 3 and K == 1 and C % 32 == 0:     # out conv: skinny GEMM + gather, thin dgrad / wgrad
+        assert [ops.conv_kernel_id(d, op) for op in (0, 1, 2)] == [4, 4, 4]
     wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())          # fwd pack [K][k][k][C]
     wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
     wd = torch.empty(wm.numel(), dtype=dtype, device=dev())

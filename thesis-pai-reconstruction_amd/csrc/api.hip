@@ -255,8 +255,9 @@ extern "C" int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op) {
     if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
     if (op == 2) {
         if (thin_wgrad_conv_ok(d->dtype, g)) return thin_wgrad_scratch_bytes((int64_t)g.N * g.OHg * g.OWg, g.C1 + g.C2, g.Cout);
-        if (thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g))
+        if (thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g) || thin_wgrad_conv3t_ok(d->dtype, g))
             return thin_wgrad_scratch_bytes((int64_t)g.N * g.H * g.W, 1, g.Cin);
+        if (thin_wgrad_conv3_ok(d->dtype, g)) return thin_wgrad_scratch_bytes((int64_t)g.N * g.OHg * g.OWg, 1, g.Cout);
         return 0;
     }
     FwdArgs a;
@@ -294,7 +295,8 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (gg_build_fwd(d, &g)) return -1;
     }
     if (op == 2) {
-        if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g)) return 4;
+        if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g) ||
+            thin_wgrad_conv3_ok(d->dtype, g) || thin_wgrad_conv3t_ok(d->dtype, g)) return 4;
         if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
             int chunks = g.Cin / 8;
             if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return 1;
@@ -462,6 +464,8 @@ extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void
     if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
     if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
     if (thin_wgrad_conv1_ok(d->dtype, g)) return launch_thin_wgrad_conv1(g, a, s);
+    if (thin_wgrad_conv3_ok(d->dtype, g)) return launch_thin_wgrad_conv3(g, a, s);
+    if (thin_wgrad_conv3t_ok(d->dtype, g)) return launch_thin_wgrad_conv3t(g, a, s);
     if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
         int chunks = g.Cin / 8;
         if (chunks <= 256 && (chunks & (chunks - 1)) == 0) return launch_wgrad_rowdot(d->dtype, g, a, s);

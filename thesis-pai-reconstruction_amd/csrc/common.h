@@ -205,4 +205,8 @@ int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s);
 bool thin_wgrad_conv1_ok(int dtype, const GG& g);
 int launch_thin_wgrad_conv1(const GG& g, const WgradArgs& a, hipStream_t s);
+bool thin_wgrad_conv3_ok(int dtype, const GG& g);
+int launch_thin_wgrad_conv3(const GG& g, const WgradArgs& a, hipStream_t s);
+bool thin_wgrad_conv3t_ok(int dtype, const GG& g);
+int launch_thin_wgrad_conv3t(const GG& g, const WgradArgs& a, hipStream_t s);
 int64_t thin_wgrad_scratch_bytes(int64_t M, int T, int WC);

@@ -57,7 +57,10 @@ __device__ __forceinline__ void decode_row2(const GG& g, int m, int& n, int& gy,
 // registers, the patch fragment is gathered from the (L1/L2-resident) 1-channel images.
 // ------------------------------------------------------------------------------------------------
 bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a) {
-    return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 16 && g.OS == 1 && g.C1 == 1 && g.C2 <= 1 &&
+    // 16 taps: the k4 convolutions of the Pix2Pix nets; 9 taps: the 3x3 in_conv of the residual / Trans U-Nets
+    // (models/res_unet.py:265, models/trans_unet.py:66) and the input gradient of their 64 -> 1 out convolution
+    const bool taps_ok = g.ntaps == 16 || (g.ntaps == 9 && g.S == 1 && g.C2 == 0);
+    return dtype == PAI_BF16 && g.nphase == 1 && taps_ok && g.OS == 1 && g.C1 == 1 && g.C2 <= 1 &&
            (g.Cout % 64) == 0 && g.Cout <= 128 && !a.stats && !a.yf32 && !a.skip_d1 &&
            (g.D2 == 0 || (g.D1 % 16) == 0);
 }
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
     const bf16_t* x2 = (const bf16_t*)a.x2;
     const bf16_t* w = (const bf16_t*)a.w;
     const int mtiles = g.Cout / 16;
-    constexpr int KT = 16 * T;
+    const int KT = g.ntaps * T;      // 16 T, or 9 for the 3x3 layers (zero-padded to the 32 of the MFMA)
 
     // A operand: W[co][k], k = tap*T + t, zero beyond 16*T.  MFMA row i of tile mt computes output
     // channel co(mt, i) = 64*(mt>>2) + 16*(i>>2) + 4*(mt&3) + (i&3): after the four tiles of a group a
@@ -81,7 +84,15 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
     for (int mt = 0; mt < 8; ++mt) {
         us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
         const int co = 64 * (mt >> 2) + 16 * (fr >> 2) + 4 * (mt & 3) + (fr & 3);
-        if (mt < mtiles && 8 * fq < KT) z = *(const us8_t*)(w + (size_t)co * KT + 8 * fq);
+        if (mt < mtiles) {
+            if ((KT & 7) == 0) {
+                if (8 * fq < KT) z = *(const us8_t*)(w + (size_t)co * KT + 8 * fq);
+            } else {                    // 9-element filter rows: no 16-B alignment, element by element (once per wave)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (8 * fq + e < KT) z[e] = w[(size_t)co * KT + 8 * fq + e];
+            }
+        }
         af[mt] = __builtin_bit_cast(bf8_t, z);
     }
     // bias of this lane's 16 channels per group: co = 64*grp + 16*fq + e
@@ -181,8 +192,10 @@ int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a) {
 bool thin_dgrad_shape_ok(int dtype, const GG& g) {
     const bool phases = g.nphase == 4 && g.ntaps == 4 && g.OS == 2;
     const bool conv1 = g.nphase == 1 && g.ntaps == 16 && g.OS == 1;
+    // the 64 -> 1 3x3 out convolution of the residual / Trans U-Nets (models/res_unet.py:308, models/trans_unet.py:98)
+    const bool conv3 = g.nphase == 1 && g.ntaps == 9 && g.OS == 1 && g.Cout == 1;
     const int ks = g.Cin / 32;
-    return dtype == PAI_BF16 && g.S == 1 && (phases || conv1) && g.Cout <= 2 && (g.C1 % 32) == 0 &&
+    return dtype == PAI_BF16 && g.S == 1 && (phases || conv1 || conv3) && g.Cout <= 2 && (g.C1 % 32) == 0 &&
            (g.C2 % 32) == 0 && (ks == 1 || ks == 2 || ks == 4 || ks == 8 || ks == 16);
 }
 
@@ -207,7 +220,8 @@ __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float*
     for (int tt = 0; tt < T; ++tt)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            af[tt][s] = *(const bf8_t*)(w + (size_t)((t0 + tt) * 16 + fr) * g.Cin + 32 * s + 8 * fq);
+            af[tt][s] = fr < g.wtaps ? *(const bf8_t*)(w + (size_t)((t0 + tt) * g.wtaps + fr) * g.Cin + 32 * s + 8 * fq)
+                                     : __builtin_bit_cast(bf8_t, make_uint4(0, 0, 0, 0));   // 9-tap filters: rows 9..15 empty
     for (int p0 = (blockIdx.x * 4 + wid) * 16; p0 < Msrc; p0 += gridDim.x * 64) {
         const int m = min(p0 + fr, Msrc - 1);
         f4_t acc[T];
@@ -309,6 +323,7 @@ struct ThinW {
     int relu1, relu2;             // ReLU-on-load flags of the wide tensors
     int lw, lh;                   // log2 W, log2 H or -1
     int tmul, flip;               // thin pixel = tmul*wide + (flip ? 1 - k : k - 1)
+    int kw, ntaps;                // tap grid: 4 x 4 (16) or 3 x 3 (9; patch rows 9..15 stay zero)
     float* dw;
     int s_wc, s_tap, s_t;         // dw index = wc*s_wc + tap*s_tap + t*s_t
     float* dbias;                 // per wide channel, or null
@@ -349,8 +364,9 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     for (int tt = 0; tt < T; ++tt) {
         const int k = 16 * tt + fr;
         const int tap = k / T, t = k - tap * T;
-        kdy[tt] = p.flip ? 1 - (tap >> 2) : (tap >> 2) - 1;
-        kdx[tt] = p.flip ? 1 - (tap & 3) : (tap & 3) - 1;
+        const int th = tap / p.kw, tw = tap - th * p.kw;
+        kdy[tt] = p.flip ? 1 - th : th - 1;
+        kdx[tt] = tap < p.ntaps ? (p.flip ? 1 - tw : tw - 1) : -(1 << 20);   // rows beyond the tap count: never in bounds
         ksrc[tt] = t ? p.thin2 : p.thin1;
     }
 
@@ -436,7 +452,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
                     part[k * 128 + wcl] = acc[tt][nt][r];
                 } else {
                     const int tap = k / T, t = k - tap * T;
-                    atomicAdd(p.dw + (size_t)(wc0 + wcl) * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
+                    if (tap < p.ntaps)
+                        atomicAdd(p.dw + (size_t)(wc0 + wcl) * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
                 }
             }
         }
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_k(ThinW p, int T, int n
         if (wc < p.WC1 + p.WC2) {
             if (k < 16 * T) {
                 const int tap = k / T, t = k - tap * T;
-                atomicAdd(p.dw + (size_t)wc * p.s_wc + tap * p.s_tap + t * p.s_t, sum);
+                if (tap < p.ntaps) atomicAdd(p.dw + (size_t)wc * p.s_wc + tap * p.s_tap + t * p.s_t, sum);
             } else if (p.dbias) {
                 atomicAdd(p.dbias + wc, sum);
             }
@@ -564,7 +581,7 @@ int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s) {
     p.WC1 = g.Cout; p.WC2 = 0;
     p.dw = a.dw; p.s_wc = 16 * T; p.s_tap = T; p.s_t = 1;   // fwd pack [Cout][16][T]
     p.dbias = a.dbias;
-    p.tmul = 2; p.flip = 0;
+    p.tmul = 2; p.flip = 0; p.kw = 4; p.ntaps = 16;
     return launch_tw(p, T, s);
 }
 
@@ -577,7 +594,7 @@ int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s) {
     p.WC1 = g.C1; p.WC2 = g.C2; p.relu1 = g.relu1; p.relu2 = g.relu2;
     p.dw = a.dw; p.s_wc = 1; p.s_tap = g.Cin; p.s_t = 0;     // fwd pack [1][16][Cin]
     p.dbias = nullptr;
-    p.tmul = 2; p.flip = 0;
+    p.tmul = 2; p.flip = 0; p.kw = 4; p.ntaps = 16;
     if (launch_tw(p, 1, s)) return 1;
     if (a.dbias) {
         const int64_t n = (int64_t)g.N * g.OH * g.OW;
@@ -603,7 +620,52 @@ int launch_thin_wgrad_conv1(const GG& g, const WgradArgs& a, hipStream_t s) {
     p.WC1 = g.C1; p.WC2 = 0; p.relu1 = g.relu1;
     p.dw = a.dw; p.s_wc = 1; p.s_tap = g.Cin; p.s_t = 0;     // fwd pack [1][16][Cin]
     p.dbias = nullptr;
-    p.tmul = 1; p.flip = 1;
+    p.tmul = 1; p.flip = 1; p.kw = 4; p.ntaps = 16;
+    if (launch_tw(p, 1, s)) return 1;
+    if (a.dbias) {
+        const int64_t n = (int64_t)g.N * g.OH * g.OW;
+        hipLaunchKernelGGL(sum1_k, dim3(64), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// 3x3 "same" convolutions with one thin side (models/res_unet.py:265,308, models/trans_unet.py:66,98) on the same kernel:
+// in_conv (1 -> 64): thin = layer input, wide = dy, dW[co][kh][kw] = sum_pix dy[a][b][co] * x[a + kh - 1][b + kw - 1]
+bool thin_wgrad_conv3_ok(int dtype, const GG& g) {
+    return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 9 && g.S == 1 && g.OS == 1 && g.C1 == 1 && g.C2 == 0 &&
+           (g.Cout % 32) == 0 && g.Cout <= 128 && !g.relu1;
+}
+
+int launch_thin_wgrad_conv3(const GG& g, const WgradArgs& a, hipStream_t s) {
+    ThinW p;
+    memset(&p, 0, sizeof(p));
+    p.thin1 = (const bf16_t*)a.x1; p.thin2 = nullptr;
+    p.wide1 = (const bf16_t*)a.dy; p.wide2 = nullptr;
+    p.N = g.N; p.H = g.OHg; p.W = g.OWg; p.TH = g.H; p.TW = g.W;
+    p.WC1 = g.Cout; p.WC2 = 0;
+    p.dw = a.dw; p.s_wc = 9; p.s_tap = 1; p.s_t = 0;        // fwd pack [Cout][9][1]
+    p.dbias = a.dbias;
+    p.tmul = 1; p.flip = 0; p.kw = 3; p.ntaps = 9;
+    return launch_tw(p, 1, s);
+}
+
+// out convolution (64 -> 1): thin = dy, wide = layer input, dW[kh][kw][c] = sum_pix x[a][b][c] * dy[a + 1 - kh][b + 1 - kw]
+bool thin_wgrad_conv3t_ok(int dtype, const GG& g) {
+    return dtype == PAI_BF16 && g.nphase == 1 && g.ntaps == 9 && g.S == 1 && g.OS == 1 && g.Cout == 1 && g.C2 == 0 &&
+           (g.C1 % 32) == 0 && g.C1 <= 128;
+}
+
+int launch_thin_wgrad_conv3t(const GG& g, const WgradArgs& a, hipStream_t s) {
+    ThinW p;
+    memset(&p, 0, sizeof(p));
+    p.thin1 = (const bf16_t*)a.dy; p.thin2 = nullptr;
+    p.wide1 = (const bf16_t*)a.x1; p.wide2 = nullptr;
+    p.N = g.N; p.H = g.H; p.W = g.W; p.TH = g.OH; p.TW = g.OW;
+    p.WC1 = g.C1; p.WC2 = 0; p.relu1 = g.relu1;
+    p.dw = a.dw; p.s_wc = 1; p.s_tap = g.Cin; p.s_t = 0;     // fwd pack [1][9][Cin]
+    p.dbias = nullptr;
+    p.tmul = 1; p.flip = 1; p.kw = 3; p.ntaps = 9;
     if (launch_tw(p, 1, s)) return 1;
     if (a.dbias) {
         const int64_t n = (int64_t)g.N * g.OH * g.OW;

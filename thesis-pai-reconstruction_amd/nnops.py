@@ -76,6 +76,8 @@ class ConvBNAct(torch.autograd.Function):
         Cout, _, k, _ = weight.shape
         d = ops.make_desc(dtype, 0, N, H, W, Cin, 0, Cout, 1, 0, 0, act if bn is None else ACT_NONE, kernel=k)
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
+        if Cin <= 2 or Cout <= 2:            # thin layers (in_conv / out): skinny-GEMM scratch of gg_thin.hip
+            ops.ensure_scratch(ops.scratch_bytes_for([d]), x.device)
         wm = _dense_fwd_pack(weight, groups)
         if dtype == torch.float32:
             wf = wm
