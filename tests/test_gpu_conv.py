@@ -209,7 +209,9 @@ def test_conv_family(pai, case, dtype):
 # gradient (9 * 64 is not a multiple of 128), MFMA everywhere (128 -> 128), row-dot forward (64 -> 1)
 CONV3 = [("in_conv", 2, 16, 16, 1, 64), ("c64", 2, 16, 24, 64, 64), ("c128", 3, 16, 16, 128, 128),
          ("out_conv", 2, 16, 16, 64, 1), ("in_conv_ragged", 3, 10, 12, 1, 64), ("out_conv_ragged", 1, 6, 20, 64, 1),
-         ("in_conv_big", 2, 64, 64, 1, 64), ("out_conv_big", 2, 64, 64, 64, 1)]
+         ("in_conv_big", 2, 64, 64, 1, 64), ("out_conv_big", 2, 64, 64, 64, 1),
+         # 9 x Cin not a multiple of the 128-column weight-gradient tile: partly empty last column block
+         ("c64_pow2", 2, 16, 16, 64, 64), ("c192_64", 2, 8, 8, 192, 64), ("c64_128", 1, 32, 32, 64, 128)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
