@@ -16,3 +16,13 @@ cp $(ls $out/stats/*/*_kernel_stats.csv | head -1) gpurun_out/profiles_$tag/${ta
 cp $out/bench_stats.json gpurun_out/profiles_$tag/${tag}_bench.json
 python3 scripts/prof_summary.py $out/stats
 rm -rf $out/fetch $out/write   # counter CSVs are tens of MB
+# un-profiled bench lines of every model family (the default one with the CPU baseline)
+timeout -k 10 400 python3 bench.py > gpurun_out/profiles_$tag/${tag}_bench_unprofiled.json 2> $out/unprofiled.err
+timeout -k 10 300 python3 bench.py --model attention_unet --no-cpu-baseline > gpurun_out/profiles_$tag/${tag}_bench_attention_unet.json 2> $out/att.err
+timeout -k 10 300 python3 bench.py --model resnext_unet --size 512 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/profiles_$tag/${tag}_bench_resnext_unet.json 2> $out/res.err
+timeout -k 10 300 python3 bench.py --model trans_unet --batch 32 --patch-size 4 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/profiles_$tag/${tag}_bench_trans_unet_p4.json 2> $out/tr4.err
+timeout -k 10 300 python3 bench.py --model trans_unet --batch 32 --patch-size 2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/profiles_$tag/${tag}_bench_trans_unet_p2.json 2> $out/tr2.err
+# kernel statistics of the TransUNet step (BASELINE configs[4])
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_trans -- python3 bench.py --model trans_unet --batch 32 --patch-size 4 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > /dev/null 2> $out/stats_trans.err
+cp $(ls $out/stats_trans/*/*_kernel_stats.csv | head -1) gpurun_out/profiles_$tag/${tag}_bench_trans_unet_p4_kernel_stats.csv
+rm -rf $out/stats_trans

@@ -75,16 +75,6 @@ __global__ __launch_bounds__(1024) void bn_finalize_wide_k(const float* stats, i
     double s = 0.0, q = 0.0;
     if (c < C) {
         int r = rl;
-        for (; r + 7 * 128 < R; r += 8 * 128) {        // 8 rows in flight per thread (see bn_bwd_finalize_k)
-            float a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a[u] = stats[(size_t)(r + u * 128) * 2 * C + c];
-                b[u] = stats[(size_t)(r + u * 128) * 2 * C + C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s += (double)a[u]; q += (double)b[u]; }
-        }
         for (; r < R; r += 128) {
             s += (double)stats[(size_t)r * 2 * C + c];
             q += (double)stats[(size_t)r * 2 * C + C + c];
@@ -319,6 +309,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
 
 // 8 channels x FIN_LANES row lanes per block: the partial rows (up to 4096 from the fused input-gradient stores)
 // are summed in fp64; the launch is a chain of dependent L2 round trips, so it is as wide as a block can be
+// (measured and dropped: 8 rows in flight per thread -- 20.4 -> 25.5 us per launch)
 constexpr int FIN_LANES = 128;
 __global__ __launch_bounds__(8 * FIN_LANES) void bn_bwd_finalize_k(const float* partials, int rows, int C, float* sums,
                                                                    float* dgamma, float* dbeta) {
@@ -327,19 +318,7 @@ __global__ __launch_bounds__(8 * FIN_LANES) void bn_bwd_finalize_k(const float* 
     const int c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        // 8 rows (16 loads) in flight per thread: with one row per iteration the loop is a chain of L2 round trips
-        // (4096 rows / 128 lanes = 32 trips, 20 us for a 2 MB reduction)
         int r = rl;
-        for (; r + 7 * FIN_LANES < rows; r += 8 * FIN_LANES) {
-            float a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a[u] = partials[((size_t)(r + u * FIN_LANES) * 2 + 0) * C + c];
-                b[u] = partials[((size_t)(r + u * FIN_LANES) * 2 + 1) * C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
-        }
         for (; r < rows; r += FIN_LANES) {
             s1 += (double)partials[((size_t)r * 2 + 0) * C + c];
             s2 += (double)partials[((size_t)r * 2 + 1) * C + c];
