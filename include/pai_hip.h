@@ -174,6 +174,11 @@ int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const void* w_dgra
  * dbias += sum over N,OH,OW of dy              (fp32 [Cout], or NULL) */
 int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
                    float* dw, float* dbias, void* stream);
+/* dw = ..., dbias = ...  (no caller zeroing).  Launches whose every dW element has one writer (the un-split
+ * matrix-core kernel: the skinny nn.Linear layers of the TransUNet bottleneck, 1 G fp32 elements per step) store
+ * plainly -- no zero-fill pass, no read of dW; the others clear the buffers themselves and accumulate. */
+int pai_conv_wgrad_overwrite(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
+                             float* dw, float* dbias, void* stream);
 
 /* fp32 master weights (fwd pack) -> storage-dtype fwd pack and/or dgrad pack. */
 int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,

@@ -294,6 +294,12 @@ def _same_conv_case(k, N, H, W, C, K, dtype):
     tol_w = 1e-4 if dtype == torch.float32 else 3e-3
     assert rel_err(dw.cpu().view(K, k, k, C).permute(0, 3, 1, 2), w.grad) < tol_w
     assert rel_err(db.cpu(), b.grad) < tol_w
+    # overwrite form: same values into buffers that hold garbage
+    dw2 = torch.full_like(dw, float("nan"))
+    db2 = torch.full_like(db, 1e30)
+    ops.conv_wgrad_overwrite(d, X, None, DY, dw2, db2)
+    torch.cuda.synchronize()
+    assert rel_err(dw2.cpu(), dw.cpu()) < 1e-6 and rel_err(db2.cpu(), db.cpu()) < 1e-6
 
 
 def test_bad_arguments_fail_loudly(pai):

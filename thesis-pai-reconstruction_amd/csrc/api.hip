@@ -452,15 +452,44 @@ extern "C" int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const v
     return pai_act_bwd(d->dtype, dx1, e->act1, e->add, e->act2, e->z, M * g.D1, dx1, stream);
 }
 
+static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
+                           float* dbias, int overwrite, void* stream);
+
 extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2,
                               const void* dy, float* dw, float* dbias, void* stream) {
+    return conv_wgrad_impl(d, x1, x2, dy, dw, dbias, 0, stream);
+}
+
+extern "C" int pai_conv_wgrad_overwrite(const pai_conv_desc* d, const void* x1, const void* x2,
+                                        const void* dy, float* dw, float* dbias, void* stream) {
+    return conv_wgrad_impl(d, x1, x2, dy, dw, dbias, 1, stream);
+}
+
+static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
+                           float* dbias, int overwrite, void* stream) {
     GG g;
     if (gg_build_fwd(d, &g)) return 1;
     PAI_CHECK(x1 && dy && dw, "pai_conv_wgrad: null pointer");
     PAI_CHECK(d->C2 == 0 || x2, "pai_conv_wgrad: C2 > 0 but x2 is null");
     WgradArgs a;
-    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias;
+    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0;
     hipStream_t s = (hipStream_t)stream;
+    if (overwrite) {
+        const bool thin = thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) ||
+                          thin_wgrad_conv1_ok(d->dtype, g) || thin_wgrad_conv3_ok(d->dtype, g) ||
+                          thin_wgrad_conv3t_ok(d->dtype, g);
+        const bool rowdot = g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0;
+        if (!thin && !rowdot && wgrad_mfma_ok(d->dtype, g) && wgrad_mfma_can_overwrite(g)) {
+            a.overwrite = 1;       // every element has exactly one writer: plain stores, nothing to clear
+        } else {                   // the accumulating kernels: clear first
+            hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * g.wtaps * g.Cin * sizeof(float), s);
+            PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_overwrite: hipMemsetAsync: %s", hipGetErrorString(e));
+            if (dbias) {
+                e = hipMemsetAsync(dbias, 0, (size_t)g.Cout * sizeof(float), s);
+                PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_overwrite: hipMemsetAsync: %s", hipGetErrorString(e));
+            }
+        }
+    }
     if (thin_wgrad_conv_ok(d->dtype, g)) return launch_thin_wgrad_conv(g, a, s);
     if (thin_wgrad_convt_ok(d->dtype, g)) return launch_thin_wgrad_convt(g, a, s);
     if (thin_wgrad_conv1_ok(d->dtype, g)) return launch_thin_wgrad_conv1(g, a, s);

@@ -194,7 +194,10 @@ struct WgradArgs {
     const void *x1, *x2, *dy;
     float* dw;
     float* dbias;
+    int overwrite;   // dw = / dbias = instead of +=; honoured by gg_wgrad_mfma_k when wgrad_mfma_can_overwrite(g)
 };
+// un-split, single-phase launch of gg_wgrad_mfma_k: every dW element has exactly one writer
+bool wgrad_mfma_can_overwrite(const GG& g);
 int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s);

@@ -1476,8 +1476,12 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
             float t = 0.f;
 #pragma unroll
             for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
-            if (splits == 1 && g.nphase == 1) a.dbias[co0 + tid] += t;
-            else atomicAdd(a.dbias + co0 + tid, t);
+            if (splits == 1 && g.nphase == 1) {
+                if (a.overwrite) a.dbias[co0 + tid] = t;
+                else a.dbias[co0 + tid] += t;
+            } else {
+                atomicAdd(a.dbias + co0 + tid, t);
+            }
         }
     }
 
@@ -1498,8 +1502,12 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
                     float* pw = a.dw + (size_t)co * g.wtaps * g.Cin + cbase;
                     // un-split: this workgroup is the only writer of the element (taps of different phases are
                     // disjoint) -> plain read-modify-write at store bandwidth instead of the ~1.3 TB/s atomic rate
-                    if (splits == 1) *pw += acc[mt][nt][r];
-                    else atomicAdd(pw, acc[mt][nt][r]);
+                    if (splits == 1) {
+                        if (a.overwrite) *pw = acc[mt][nt][r];     // no zero-fill pass, no read of dW (skinny ViT layers)
+                        else *pw += acc[mt][nt][r];
+                    } else {
+                        atomicAdd(pw, acc[mt][nt][r]);
+                    }
                 }
             }
         }
@@ -1669,8 +1677,12 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
             float t = 0.f;
 #pragma unroll
             for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
-            if (splits == 1 && g.nphase == 1) a.dbias[co0 + tid] += t;
-            else atomicAdd(a.dbias + co0 + tid, t);
+            if (splits == 1 && g.nphase == 1) {
+                if (a.overwrite) a.dbias[co0 + tid] = t;
+                else a.dbias[co0 + tid] += t;
+            } else {
+                atomicAdd(a.dbias + co0 + tid, t);
+            }
         }
     }
 #pragma unroll
@@ -1686,8 +1698,12 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
                     float* pw = a.dw + (size_t)co * g.wtaps * g.Cin + cbase;
                     // un-split: this workgroup is the only writer of the element (taps of different phases are
                     // disjoint) -> plain read-modify-write at store bandwidth instead of the ~1.3 TB/s atomic rate
-                    if (splits == 1) *pw += acc[mt][nt][r];
-                    else atomicAdd(pw, acc[mt][nt][r]);
+                    if (splits == 1) {
+                        if (a.overwrite) *pw = acc[mt][nt][r];     // no zero-fill pass, no read of dW (skinny ViT layers)
+                        else *pw += acc[mt][nt][r];
+                    } else {
+                        atomicAdd(pw, acc[mt][nt][r]);
+                    }
                 }
             }
         }
@@ -1702,7 +1718,18 @@ static bool wgrad_patch_shape_ok(const GG& g) {
     return g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && (g.Cout % 64) == 0 && g.Cin >= 64;
 }
 
-int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
+static int wgrad_mfma_splits(const GG& g, int* rows_out);
+static bool wgrad_mfma_uses_patch(const GG& g) {
+    static const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
+    PatchGeo pg;
+    return !no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg);
+}
+bool wgrad_mfma_can_overwrite(const GG& g) {
+    int rows;
+    return g.nphase == 1 && !wgrad_mfma_uses_patch(g) && wgrad_mfma_splits(g, &rows) == 1;
+}
+
+static int wgrad_mfma_splits(const GG& g, int* rows_out) {
     const bool big = (g.Cout % 128) == 0;
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
     const int jtiles = cdiv(g.ntaps * g.Cin, 128);
@@ -1724,6 +1751,17 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     if ((tiles >= 256 && g.M <= unsplit_rows) || (tiles >= 512 && g.M <= 2 * unsplit_rows)) splits = 1;
     int rows = cdiv(cdiv(g.M, splits), 64) * 64;
     splits = cdiv(g.M, rows);
+    *rows_out = rows;
+    return splits;
+}
+
+int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
+    const bool big = (g.Cout % 128) == 0;
+    const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
+    const int jtiles = cdiv(g.ntaps * g.Cin, 128);
+    const int tiles = cotiles * jtiles * g.nphase;
+    int rows;
+    const int splits = wgrad_mfma_splits(g, &rows);
     static const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;
     if (!no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg)) {

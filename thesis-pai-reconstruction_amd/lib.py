@@ -67,6 +67,7 @@ SIGNATURES = {
     "pai_conv_dgrad_bn": (_I, [_D, _P, _P, _P, _P, C.POINTER(BwdEpilogue), C.POINTER(_I), _P]),
     "pai_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),

@@ -154,10 +154,11 @@ class ConvBNAct(torch.autograd.Function):
             dz = torch.empty_like(z)
             ops.bn_bwd_apply(dtype, du, z, M, Cout, mean, rstd, gamma.detach(), sums, dz)
         k = weight.shape[2]
-        dw = torch.zeros(Cout * k * k * Cin, **f32)
+        dw = torch.empty(Cout * k * k * Cin, **f32)
         # a conv bias in front of a BatchNorm has an identically zero gradient
-        dbias = torch.zeros(Cout, **f32) if ctx.needs_input_grad[2] else None
-        ops.conv_wgrad(d, x, None, dz, dw, dbias if (dbias is not None and not ctx.has_bn) else None)
+        with_bias = ctx.needs_input_grad[2] and not ctx.has_bn
+        dbias = (torch.empty(Cout, **f32) if with_bias else torch.zeros(Cout, **f32)) if ctx.needs_input_grad[2] else None
+        ops.conv_wgrad_overwrite(d, x, None, dz, dw, dbias if with_bias else None)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(N, H, W, Cin, dtype=dtype, device=dev)
@@ -374,9 +375,9 @@ class Linear(torch.autograd.Function):
         g = g.contiguous()
         M, K, out_f = d.W, d.C1, d.Cout
         f32 = dict(dtype=torch.float32, device=g.device)
-        dw = torch.zeros(out_f, K, **f32)
-        db = torch.zeros(out_f, **f32) if ctx.has_bias else None
-        ops.conv_wgrad(d, x, None, g, dw, db)
+        dw = torch.empty(out_f, K, **f32)
+        db = torch.empty(out_f, **f32) if ctx.has_bias else None
+        ops.conv_wgrad_overwrite(d, x, None, g, dw, db)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=g.dtype, device=g.device)
