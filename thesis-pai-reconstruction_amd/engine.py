@@ -243,6 +243,8 @@ class _SideStream:
         # gain nothing.  Each co-scheduled kernel runs longer (per-kernel TFLOP/s drop ~30 %) while
         # the step gets shorter -- the kernels are latency-bound, not throughput-bound.
         self.max_gflop = float(os.environ.get("PAI_OVERLAP_GFLOP", "1e9"))
+        # (stream priorities measured at batch 64: side stream at high priority 14.2 ms/step, at low priority
+        #  7.49, main stream at high priority 7.39 against 7.47 with both at the default -- left at the default)
 
     def fork(self, d=None):
         if not self.on or (d is not None and ops.conv_flops(d) > self.max_gflop * 1e9):
