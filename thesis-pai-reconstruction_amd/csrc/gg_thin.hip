@@ -16,6 +16,9 @@
 
 #include "common.h"
 
+#ifndef THIN_ABL
+#define THIN_ABL 0     // compile-time timing ablations of thin_fwd_k (results WRONG): 1 no gathers, 2 no stores
+#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
 typedef __attribute__((ext_vector_type(4))) float f4_t;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
             const bool inb = m < g.M && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             const size_t off = (size_t)(n * g.H + iy) * g.W + ix;
             const bf16_t* src = (T == 2 && (j & 1)) ? x2 : x1;
-            unsigned short v = inb ? src[off] : (unsigned short)0;
+            unsigned short v = (THIN_ABL & 1) ? (unsigned short)(off & 0x3fff) : (inb ? src[off] : (unsigned short)0);
             if (inb && ((T == 2 && (j & 1)) ? g.relu2 : g.relu1) && (v & 0x8000)) v = 0;
             pv[j] = v;
         }
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
                 for (int r = 0; r < 4; ++r) v[4 * q + r] = acc[r] + bias[gq][4 * q + r];
             }
             if (m >= g.M) continue;
+            if ((THIN_ABL & 2) && v[0] != 12345.f) continue;   // ablation: no stores
             const int co = 64 * gq + 16 * fq;   // first of this lane's 16 channels
             const size_t pix = (size_t)m;
             if (a.y1 || a.y2) {
