@@ -395,6 +395,20 @@ int pai_adam_multi(int count, void* const* params, const void* const* grads, voi
                    void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2, float eps,
                    int step_count, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Gradient exchange (data parallelism, one process per GPU; replaces the all-reduce Lightning's DDP wrapper issues
+ * for the reference, main.py:123-136): in-place SUM all-reduce of a device buffer over RCCL / xGMI on the caller's
+ * stream.  librccl.so is opened with dlopen on first use (PAI_RCCL_LIB overrides the name).
+ *   pai_comm_unique_id  rank 0 fills 128 bytes (host memory); the caller ships them to the other ranks
+ *   pai_comm_init       collective over all ranks of the job; the calling thread's current HIP device is the rank's GPU
+ *   pai_allreduce       dtype PAI_F32 | PAI_BF16; asynchronous, ordered on `stream`; averaging is the caller's scale
+ * ------------------------------------------------------------------------- */
+#define PAI_COMM_ID_BYTES 128
+int pai_comm_unique_id(void* id_out_host);
+int pai_comm_init(const void* id_host, int rank, int world, void** comm_out);
+int pai_allreduce(void* comm, void* ptr, int64_t count, int dtype, void* stream);
+int pai_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,3 +261,25 @@ def test_multi_adam_equals_stock_adam(pai):
     assert len(sa) == len(sb) and float(sa[0]["step"]) == 3
     # the C ABI takes beta2 as a float: 1 - 0.999f differs from torch's float(1 - 0.999) by 1.3e-5 relative
     assert rel_err(sa[5]["exp_avg_sq"].cpu(), sb[5]["exp_avg_sq"].cpu()) < 3e-5
+
+
+def test_comm_abi_single_rank(pai):
+    """pai_comm_unique_id / pai_comm_init / pai_allreduce / pai_comm_destroy on a communicator of one rank (all a 1-GPU
+    box can host): RCCL is found and loaded lazily, the in-place SUM over one rank leaves fp32 and bf16 buffers unchanged,
+    and GradReducer accepts the communicator.  The multi-rank exchange itself is the driver's 8-GPU run."""
+    from thesis_pai_reconstruction_amd import dist as pdist, ops
+    uid = ops.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = ops.Comm(uid, 0, 1)
+    for dtype in (torch.float32, torch.bfloat16):
+        t = rnd((3, 1000), 77).to(dev()).to(dtype)
+        want = t.clone()
+        comm.all_reduce(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t, want)
+    red = pdist.GradReducer(comm=comm)
+    work = red._all_reduce_async(t)
+    work.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    comm.destroy()

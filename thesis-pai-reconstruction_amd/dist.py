@@ -18,9 +18,39 @@ import torch
 import torch.distributed as dist
 
 
+class _CommWork:
+    """Completion handle of a pai_allreduce issued on the communication stream (mirrors torch's Work.wait())."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+def make_rccl_comm(process_group=None):
+    """A C-ABI RCCL communicator (ops.Comm: pai_comm_init / pai_allreduce) spanning the ranks of the initialised
+    torch.distributed job; the 128-byte id travels through torch.distributed's object broadcast."""
+    from . import ops
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    box = [ops.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=process_group)
+    return ops.Comm(box[0], rank, world)
+
+
 class GradReducer:
-    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True):
+    """``comm``: an ``ops.Comm`` (RCCL through the C ABI, ``make_rccl_comm()``; also selected by PAI_COMM=rccl) --
+    the buckets are then reduced by ``pai_allreduce`` on a communication stream of this object instead of
+    ``torch.distributed.all_reduce``; bucketing, overlap and averaging are the same."""
+
+    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, comm=None):
+        import os
         self.pg = process_group
+        self.comm = comm
+        if comm is None and os.environ.get("PAI_COMM", "") == "rccl" and dist.is_initialized() and \
+                dist.get_world_size(process_group) > 1 and torch.cuda.is_available():
+            self.comm = make_rccl_comm(process_group)
+        self._comm_stream = None
         self.bucket_elems = max(int(bucket_bytes) // 4, 1)
         self.overlap = overlap
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -58,9 +88,24 @@ class GradReducer:
             return
         buf = st["arena"].flat[lo:hi]
         if self.world > 1:
-            st["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            st["works"].append(self._all_reduce_async(buf))
         self.stats["buckets"] += 1
         self.stats["bytes"] += (hi - lo) * 4
+
+    def _all_reduce_async(self, buf):
+        """In-place SUM all-reduce of ``buf``, ordered after the work already issued on the current stream; returns a
+        handle whose wait() orders the current stream behind the collective."""
+        if self.comm is None:
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self.comm.all_reduce(buf)
+            ev = torch.cuda.Event()
+            ev.record()
+        buf.record_stream(self._comm_stream)
+        return _CommWork(ev)
 
     def _on_ready(self, arena, end: int):
         """Engine callback: gradients in arena.flat[0:end] are final for this backward pass."""
@@ -105,14 +150,14 @@ class GradReducer:
             nonlocal bucket, size
             if bucket:
                 flat = torch.cat([g.reshape(-1) for g in bucket])
-                pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat, bucket))
+                pending.append((self._all_reduce_async(flat), flat, bucket))
                 self.stats["buckets"] += 1
                 self.stats["bytes"] += flat.numel() * 4
             bucket, size = [], 0
 
         for g in grads:
             if g.numel() >= self.bucket_elems and g.is_contiguous():
-                pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), g, None))
+                pending.append((self._all_reduce_async(g), g, None))
                 self.stats["buckets"] += 1
                 self.stats["bytes"] += g.numel() * 4
             else:

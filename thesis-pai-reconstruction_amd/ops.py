@@ -449,3 +449,32 @@ def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step
     numels = (C.c_int64 * n)(*[p.numel() for p in params])
     L.check(L.load().pai_adam_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numels, lr, beta1, beta2,
                                     eps, step, _stream()), "pai_adam_multi")
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (pai_comm_* / pai_allreduce): in-place SUM all-reduce of device tensors on the
+    current stream.  ``unique_id()`` on rank 0, ship the 128 bytes to the other ranks, then ``Comm(id, rank, world)``
+    on every rank (the current device is the rank's GPU)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.load().pai_comm_unique_id(buf), "pai_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, uid: bytes, rank: int, world: int):
+        if len(uid) != 128:
+            raise PaiError("Comm: the unique id is 128 bytes")
+        self._h = C.c_void_p()
+        L.check(L.load().pai_comm_init(C.create_string_buffer(uid, 128), rank, world, C.byref(self._h)), "pai_comm_init")
+        self.rank, self.world = rank, world
+
+    def all_reduce(self, t: torch.Tensor):
+        if not t.is_cuda or not t.is_contiguous():
+            raise PaiError("Comm.all_reduce needs a contiguous HIP tensor")
+        L.check(L.load().pai_allreduce(self._h, t.data_ptr(), t.numel(), code_of(t.dtype), _stream()), "pai_allreduce")
+
+    def destroy(self):
+        if self._h:
+            L.check(L.load().pai_comm_destroy(self._h), "pai_comm_destroy")
+            self._h = C.c_void_p()
