@@ -80,13 +80,20 @@ __global__ __launch_bounds__(1024) void bn_finalize_wide_k(const float* stats, i
             q += (double)stats[(size_t)r * 2 * C + C + c];
         }
     }
-    red[0][rl][cl] = s;
-    red[1][rl][cl] = q;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {        // 8 row lanes per wave by shuffles, 16 waves through LDS
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if ((threadIdx.x & 63) < 8) {
+        red[0][threadIdx.x >> 6][cl] = s;
+        red[1][threadIdx.x >> 6][cl] = q;
+    }
     __syncthreads();
     if (rl != 0 || c >= C) return;
     s = q = 0.0;
-#pragma unroll 8
-    for (int l = 0; l < 128; ++l) { s += red[0][l][cl]; q += red[1][l][cl]; }
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { s += red[0][l][cl]; q += red[1][l][cl]; }
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -324,13 +331,23 @@ __global__ __launch_bounds__(8 * FIN_LANES) void bn_bwd_finalize_k(const float* 
             s2 += (double)partials[((size_t)r * 2 + 1) * C + c];
         }
     }
-    red[0][rl][cl] = s1;
-    red[1][rl][cl] = s2;
+    // the 8 row lanes of a wave meet by shuffles, the 16 waves through LDS (the 128-term serial sum from LDS that
+    // stood here was most of the launch)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 8) {
+        red[0][wv][cl] = s1;
+        red[1][wv][cl] = s2;
+    }
     __syncthreads();
     if (rl == 0 && c < C) {
         s1 = s2 = 0.0;
-#pragma unroll 8
-        for (int l = 0; l < FIN_LANES; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
+#pragma unroll
+        for (int l = 0; l < FIN_LANES / 8; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
         sums[c] = (float)s1;
         sums[C + c] = (float)s2;
         if (dbeta) dbeta[c] += (float)s1;
