@@ -70,7 +70,12 @@ typedef struct pai_conv_desc {
     int32_t relu1, relu2; /* apply ReLU to x1 / x2 while loading (fused nn.ReLU of the
                              decoder block, models/pix2pix.py:98) */
     int32_t epilogue_act; /* PAI_ACT_* applied to y_act / y_f32 */
-    int32_t reserved[3];
+    int32_t groups;       /* 0 or 1: dense.  > 1 (kernel = 3, Conv2d, C1 = Cout, C2 = 0): the filter packs are the
+                             BLOCK-DIAGONAL dense form of a grouped convolution (nn.Conv2d(groups=32) of
+                             ResidualBlockNeXt, models/res_unet.py:151-157) whose groups do not straddle 16-channel
+                             slices; forward / input gradient may then skip the zero blocks.  A hint: every kernel
+                             family computes the same result from the dense packs. */
+    int32_t reserved[2];
 } pai_conv_desc;
 
 /* Output spatial size of the layer. */

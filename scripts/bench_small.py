@@ -7,7 +7,8 @@ import pai_bootstrap; pai = pai_bootstrap.load()
 from thesis_pai_reconstruction_amd import ops
 dev = torch.device("cuda:0"); dt = torch.bfloat16
 # name, k, N, H, Cin, Cout, groups
-LAYERS = [("rnx 3x3 dense 512", 3, 16, 512, 128, 128, 1),
+LAYERS = [("rnx 3x3 g32 512", 3, 16, 512, 128, 128, 32), ("rnx 3x3 g32 256", 3, 16, 256, 128, 128, 32),
+          ("rnx 3x3 dense 512", 3, 16, 512, 128, 128, 1),
           ("tr 1x1 64>16 256", 1, 32, 256, 64, 16, 1),
           ("tr 3x3 16>16 256", 3, 32, 256, 16, 16, 1), ("tr 1x1 16>64 128", 1, 32, 128, 16, 64, 1),
           ("tr 3x3 32>32 64", 3, 32, 64, 32, 32, 1)]
@@ -20,7 +21,7 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 for name, k, n, H, Cin, Cout, groups in LAYERS:
-    d = ops.make_desc(dt, 0, n, H, H, Cin, 0, Cout, 1, 0, 0, kernel=k)
+    d = ops.make_desc(dt, 0, n, H, H, Cin, 0, Cout, 1, 0, 0, kernel=k, groups=groups)
     ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev)
     M = n * H * H
     x = torch.randn(M * Cin, device=dev).to(dt)

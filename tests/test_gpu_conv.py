@@ -302,6 +302,52 @@ def _same_conv_case(k, N, H, W, C, K, dtype):
     assert rel_err(dw2.cpu(), dw.cpu()) < 1e-6 and rel_err(db2.cpu(), db.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C,groups,N,H,W", [(128, 32, 2, 16, 16), (128, 32, 3, 24, 48), (32, 8, 3, 8, 16), (128, 32, 1, 6, 10)])
+def test_grouped_conv3x3(pai, dtype, C, groups, N, H, W):
+    """nn.Conv2d(C, C, 3, padding=1, groups=C/4) of ResidualBlockNeXt (reference models/res_unet.py:151-157): block-diagonal
+    dense packs + the descriptor's ``groups`` hint.  In bf16, 128 channels on 8 x 16-tileable images run forward and input
+    gradient on grouped3_k (16-channel slices, patch in LDS); every other case takes the dense kernels.  The result must
+    equal F.conv2d(groups=...) autograd either way."""
+    from thesis_pai_reconstruction_amd import nnops, ops
+    tol = TOL[dtype]
+    x = q(rnd((N, C, H, W), 1), dtype).requires_grad_(True)
+    w = q(rnd((C, C // groups, 3, 3), 2, 0.1), dtype).requires_grad_(True)
+    b = rnd((C,), 3, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1, groups=groups)
+    dy = q(rnd(tuple(y.shape), 4), dtype)
+    y.backward(dy)
+    d = ops.make_desc(dtype, 0, N, H, W, C, 0, C, 1, 0, 0, ops.ACT_RELU, kernel=3, groups=groups)
+    if dtype == torch.bfloat16 and C == 128 and H % 8 == 0 and W % 16 == 0:
+        assert ops.conv_kernel_id(d, 0) == 6 and ops.conv_kernel_id(d, 1) == 6
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    wm = nnops._dense_fwd_pack(w.detach().to(dev()), groups)                 # [C][3][3][C], block-diagonal
+    wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    ops.pack_weights(dtype, wm, C, 9, C, wf, wd)
+    X, DY = nhwc(x.detach(), dtype), nhwc(dy, dtype)
+    y_raw = torch.empty(N * H * W * C, dtype=dtype, device=dev())
+    y_act = torch.empty_like(y_raw)
+    rows = ops.conv_fwd_stats_rows(d)
+    stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * C, dtype=torch.float32, device=dev())
+    ops.conv_fwd(d, X, None, wf, b.detach().to(dev()), y_raw=y_raw, stats=stats)
+    ops.conv_fwd(d, X, None, wf, b.detach().to(dev()), y_act=y_act)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y_raw, N, H, W, C), y.detach()) < tol
+    assert rel_err(from_nhwc(y_act, N, H, W, C), F.relu(y.detach())) < tol
+    st = stats[:rows * 2 * C].view(rows, 2, C).double().sum(0).cpu()
+    assert rel_err(st[0], y.detach().double().sum((0, 2, 3))) < 1e-3
+    assert rel_err(st[1], (y.detach().double() ** 2).sum((0, 2, 3))) < 1e-4
+    dx = torch.empty(N * H * W * C, dtype=dtype, device=dev())
+    ops.conv_dgrad(d, DY, wd, dx, None)
+    assert rel_err(from_nhwc(dx, N, H, W, C), x.grad) < tol
+    dw = torch.zeros(wm.numel(), dtype=torch.float32, device=dev())
+    ops.conv_wgrad(d, X, None, DY, dw, None)
+    torch.cuda.synchronize()
+    gw = nnops._grad_from_fwd_pack(dw, w, groups)                           # block-diagonal blocks -> [C][C/g][3][3]
+    assert rel_err(gw.cpu(), w.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
+
+
 def test_bad_arguments_fail_loudly(pai):
     from thesis_pai_reconstruction_amd import ops
     d = ops.make_desc(torch.float32, 0, 1, 7, 8, 1, 0, 64, 2)

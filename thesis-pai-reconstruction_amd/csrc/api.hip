@@ -59,6 +59,11 @@ static int check_desc(const pai_conv_desc* d) {
             PAI_CHECK(d->H >= 2 && d->W >= 2, "k4 s1 p1 Conv2d needs H, W >= 2");
     }
     PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
+    if (d->groups > 1) {
+        PAI_CHECK(d->kernel == 3 && d->C2 == 0 && d->C1 == d->Cout && (d->C1 % d->groups) == 0 && (d->C1 % 16) == 0 &&
+                      (16 % (d->C1 / d->groups)) == 0,
+                  "groups=%d needs a 3x3 Conv2d with C1 = Cout = 16 k and groups that tile 16-channel slices", d->groups);
+    }
     return 0;
 }
 
@@ -152,6 +157,7 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
     g->Cout = d->Cout;
     g->D1 = d->Cout; g->D2 = 0;
     g->wtaps = 16;
+    g->gslice = d->groups > 1 ? 16 : 0;
     g->relu1 = d->relu1; g->relu2 = d->relu2;
     int OH, OW;
     pai_conv_out_hw(d, &OH, &OW);
@@ -185,6 +191,7 @@ int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
     g->Cout = d->C1 + d->C2;
     g->D1 = d->C1; g->D2 = d->C2;
     g->wtaps = 16;
+    g->gslice = d->groups > 1 ? 16 : 0;
     g->OH = d->H; g->OW = d->W;
     if (d->kernel == 1) {
         g->OHg = d->H; g->OWg = d->W;
@@ -276,6 +283,7 @@ extern "C" int pai_conv_fwd_stats_rows(const pai_conv_desc* d) {
     memset(&a, 0, sizeof(a));
     a.y1 = (void*)1;  // raw output present
     a.stats = (float*)1;
+    if (grouped3_ok(d->dtype, g, a)) return grouped3_rows(g);
     if (pw_ok(d->dtype, g, a)) return pw_rows(g);
     if (!thin_fwd_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) && !use_mfma(d->dtype, g, a) && small_ok(d->dtype, g, a))
         return small_rows(g);
@@ -304,6 +312,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (wgrad_mfma_ok(d->dtype, g)) return (g.Cout % 128) == 0 ? 2 : 3;
         return 0;
     }
+    if (op != 2 && grouped3_ok(d->dtype, g, a)) return 6;
     if (thin_fwd_ok(d->dtype, g, a) || thin_dgrad_ok(d->dtype, g, a) || pw_ok(d->dtype, g, a)) return 4;
     if (fwd_rowdot_ok(g, a)) return 1;
     if (fwd_mfma_ok(d->dtype, g, a))
@@ -313,7 +322,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
 }
 
 extern "C" int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len) {
-    static const char* fam[6] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16", "small_mfma_bf16"};
+    static const char* fam[7] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16", "small_mfma_bf16", "grouped3_k"};
     const int id = pai_conv_kernel_id(d, op);
     if (id < 0 || !name || name_len <= 0) return -1;
     const char* n = fam[id];
@@ -336,6 +345,7 @@ extern "C" int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d) {
 }
 
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (grouped3_ok(dtype, g, a)) return launch_grouped3(g, a, s);   // grouped 3x3: 16-channel slices, patch in LDS
     if (pw_ok(dtype, g, a)) return launch_pw(g, a, s);
     if (thin_fwd_ok(dtype, g, a)) return launch_thin_fwd(g, a, s);
     if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);
@@ -377,6 +387,7 @@ extern "C" int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void
 }
 
 static bool dgrad_store_fusable(const pai_conv_desc* d, const GG& g, const FwdArgs& a) {
+    if (grouped3_ok(d->dtype, g, a)) return false;
     if (pw_ok(d->dtype, g, a)) return true;
     return !thin_fwd_ok(d->dtype, g, a) && !thin_dgrad_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) &&
            use_mfma(d->dtype, g, a);

@@ -130,6 +130,7 @@ struct GG {
     int lsw, lsh, ldw, ldh;  // log2 of source W, H and destination OW, OH (all -1 unless all are powers of two)
     signed char dy[4][16], dx[4][16], wt[4][16];
     signed char poy[4], pox[4];
+    int gslice;  // > 0: block-diagonal filter (pai_conv_desc.groups): 16-channel slices are independent
 };
 
 // forward gather of a pai_conv_desc (Conv2d or ConvTranspose2d)
@@ -179,6 +180,10 @@ bool fwd_rowdot_ok(const GG& g, const FwdArgs& a);
 bool small_ok(int dtype, const GG& g, const FwdArgs& a);
 int small_rows(const GG& g);
 int launch_small(const GG& g, const FwdArgs& a, hipStream_t s);
+// grouped 3x3 convolution, patch in LDS, 16-channel slices on the matrix cores (gg_group.hip)
+bool grouped3_ok(int dtype, const GG& g, const FwdArgs& a);
+int grouped3_rows(const GG& g);
+int launch_grouped3(const GG& g, const FwdArgs& a, hipStream_t s);
 
 // thin layers on the matrix cores (gg_thin.hip)
 extern float* g_scratch;

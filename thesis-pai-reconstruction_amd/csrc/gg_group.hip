@@ -1,0 +1,213 @@
+// Grouped 3x3 "same" convolution of the ResNeXt blocks (nn.Conv2d(128, 128, 3, padding=1, groups=32), reference
+// models/res_unet.py:151-157), forward and input gradient, from the BLOCK-DIAGONAL dense filter packs
+// (pai_conv_desc.groups).  The dense tile kernels spend 32x the useful MACs on the zero blocks and run the layer
+// compute-bound (1.5 ms at 512 x 512 x 16 images); here an output tile of 16 channels only contracts with its own 16
+// input channels (K = 9 taps x 16, five MFMA K steps, 4x the useful MACs) and the layer is bound by moving the
+// activation once:
+//   * a workgroup owns an 8 x 16 block of output pixels x 64 channels (four slices; blockIdx.y picks the half) and
+//     keeps the 10 x 18 source pixels x 64 channels it touches in LDS (23 KB, one coalesced fill; 16-B chunk c of
+//     patch pixel p at slot c ^ ((p >> 1) & 7) of its 128-B row, so the 16 pixel lanes of a fragment read hit 16
+//     different bank groups for every tap shift);
+//   * its four waves take two pixel rows each and walk the four 16-channel slices: the filter slice (five 16-B
+//     fragments per lane, L1-resident) as the MFMA A operand, the shifted patch pixels as B, no operand is re-read
+//     from memory for the nine taps.  (All eight slices in one workgroup needed 336 registers: one wave per SIMD.)
+//   * bias, BatchNorm partial statistics (one row per persistent workgroup), activation in the store.
+// A first attempt without LDS (per-tap 16-B loads from L1, gg_small.hip in slice mode) ran at the speed of the dense
+// kernel: nine shifted re-reads of every pixel line through the texture path cost as much as the wasted MACs.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+
+#ifndef GROUP_ABL
+#define GROUP_ABL 0     // compile-time timing ablations (results WRONG): 1 no output stores, 2 no LDS fragment reads, 4 no patch fetch
+#endif
+namespace {
+constexpr int GC = 128;                 // channels of the tensor
+constexpr int HS = 4;                   // 16-channel slices per workgroup (64 channels = 8 chunks = a 128-B patch row)
+constexpr int TH = 8, TW = 16;          // output pixels per tile
+constexpr int PW = TW + 2, PH = TH + 2; // patch
+constexpr int PATCH_PIXELS = PW * PH;   // 180
+constexpr int MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ bf8_t relu8g(bf8_t f) {
+    s8_t x = __builtin_bit_cast(s8_t, f);
+    const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf8_t, __builtin_elementwise_max(x, z));
+}
+}  // namespace
+
+bool grouped3_ok(int dtype, const GG& g, const FwdArgs& a) {
+    if (dtype != PAI_BF16 || g.gslice != 16) return false;
+    if (g.nphase != 1 || g.S != 1 || g.OS != 1 || g.ntaps != 9 || g.wtaps != 9) return false;
+    if (g.C1 != GC || g.C2 != 0 || g.Cout != GC || g.D2 != 0) return false;
+    if ((g.OHg % TH) || (g.OWg % TW) || g.H != g.OHg || g.W != g.OWg) return false;
+    if (a.yf32 || a.skip_d1 || a.bz) return false;
+    if (a.yact && a.eact != PAI_ACT_NONE && a.eact != PAI_ACT_LRELU && a.eact != PAI_ACT_RELU) return false;
+    return true;
+}
+
+static int grouped3_tiles(const GG& g) { return g.N * (g.OHg / TH) * (g.OWg / TW); }
+
+int grouped3_rows(const GG& g) {
+    const int t = grouped3_tiles(g);
+    return t < MAX_BLOCKS ? t : MAX_BLOCKS;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[PATCH_PIXELS * 128];
+    __shared__ float sred[4][2][HS * 16];
+    const int c0 = blockIdx.y * (HS * 16);      // first channel of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* x = (const bf16_t*)a.x1;
+    const bf16_t* w = (const bf16_t*)a.w;
+    bf16_t* yraw = (bf16_t*)a.y1;
+    bf16_t* yact = (bf16_t*)a.yact;
+    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+
+    // this lane's share of a K step: tap 2 ks + (fq >> 1) (tap 9 is padding), 8 channels at (fq & 1) * 8 of the slice
+    int pofs[5];
+    bool kvalid[5];
+    int wtap[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int t = 2 * ks + (fq >> 1);
+        kvalid[ks] = t < 9;
+        const int tt = kvalid[ks] ? t : 0;
+        pofs[ks] = (1 + g.dy[0][tt]) * PW + (1 + g.dx[0][tt]);
+        wtap[ks] = g.wt[0][tt];
+    }
+    // (measured and dropped: partial sums in LDS + a rolled slice loop, 147 VGPRs / three workgroups per CU -- 1361 us
+    //  forward, 994 us input gradient at 512 x 512 x 16 against 984 / 916 us for this form at 244 VGPRs / two per CU)
+    float csum[HS][4], csq[HS][4];
+#pragma unroll
+    for (int s = 0; s < HS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[s][r] = csq[s][r] = 0.f;
+
+    const int tpi = tiles_x * tiles_y;
+    // The patch of the NEXT tile is fetched into registers while this one is multiplied (a workgroup per tile pays the
+    // HBM latency of its fill in full otherwise: 9.4 us per tile measured, two workgroups per CU do not hide it).
+    constexpr int NF = (PATCH_PIXELS * 8 + 255) / 256;      // 16-B chunks per thread
+    uint4 pre[NF];
+    auto fetch = [&](int tile) {
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i >> 3, c = i & 7;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool inb = i < PATCH_PIXELS * 8 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const size_t off = inb ? ((size_t)(n * g.H + iy) * g.W + ix) * GC + c0 + c * 8 : 0;
+            pre[j] = (GROUP_ABL & 4) ? make_uint4(i, j, 0, 0) : *(const uint4*)(x + off);
+            if (!inb) pre[j] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+        // ---- patch: registers -> LDS (180 pixels x 8 chunks, zero outside the image) ---------------
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i >> 3, c = i & 7;
+            if (i < PATCH_PIXELS * 8) *(uint4*)(patch + p * 128 + ((c ^ ((p >> 1) & 7)) << 4)) = pre[j];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        // ---- four slices x two pixel rows per wave ----------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            const int cs = c0 + 16 * s;             // first channel of the slice
+            bf8_t af[5];
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                uint4 z = make_uint4(0, 0, 0, 0);
+                if (kvalid[ks])
+                    z = *(const uint4*)(w + ((size_t)(cs + fr) * 9 + wtap[ks]) * GC + cs + (fq & 1) * 8);
+                af[ks] = __builtin_bit_cast(bf8_t, z);
+            }
+            float bias4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[cs + 4 * fq + r] : 0.f;
+            const int chunk = 2 * s + (fq & 1);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int pyo = 2 * wid + rr;
+                const int pbase = pyo * PW + fr;
+                f4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) {
+                    const int p = pbase + pofs[ks];
+                    uint4 v = (GROUP_ABL & 2) ? make_uint4(p, chunk, ks, s)
+                                              : *(const uint4*)(patch + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                    if (!kvalid[ks]) v = make_uint4(0, 0, 0, 0);
+                    bf8_t b = __builtin_bit_cast(bf8_t, v);
+                    if (g.relu1) b = relu8g(b);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b, acc, 0, 0, 0);
+                }
+                // D[i = 4 fq + r][j = fr]: channel 16 s + 4 fq + r of pixel (y0 + pyo, x0 + fr)
+                float v4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v4[r] = acc[r] + bias4[r];
+                if (STATS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        csum[s][r] += v4[r];
+                        csq[s][r] = fmaf(v4[r], v4[r], csq[s][r]);
+                    }
+                }
+                const size_t o = ((size_t)(n * g.OHg + y0 + pyo) * g.OWg + x0 + fr) * GC + cs + 4 * fq;
+                if ((GROUP_ABL & 1) && v4[0] != 12345.f) continue;
+                if (yraw) *(uint2*)(yraw + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
+                if (yact) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (eact == PAI_ACT_LRELU) v4[r] = fmaxf(v4[r], 0.2f * v4[r]);
+                        else if (eact == PAI_ACT_RELU) v4[r] = fmaxf(v4[r], 0.f);
+                    }
+                    *(uint2*)(yact + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
+                }
+            }
+        }
+        __syncthreads();   // everyone is done with the patch before the next fill
+    }
+    if (!STATS) return;
+    // ---- BatchNorm partial statistics: one row per workgroup --------------------------------------------
+#pragma unroll
+    for (int s = 0; s < HS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s1 = csum[s][r], s2 = csq[s][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            if (fr == 0) {
+                sred[wid][0][16 * s + 4 * fq + r] = s1;
+                sred[wid][1][16 * s + 4 * fq + r] = s2;
+            }
+        }
+    __syncthreads();
+    if (tid < HS * 16) {
+        float* dst = a.stats + ((size_t)blockIdx.x * 2) * GC + c0 + tid;
+        dst[0] = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
+        dst[GC] = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+    }
+}
+
+int launch_grouped3(const GG& g, const FwdArgs& a, hipStream_t s) {
+    const int tiles = grouped3_tiles(g);
+    const dim3 grid(grouped3_rows(g), GC / (HS * 16));
+    if (a.stats) hipLaunchKernelGGL(grouped3_k<true>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    else hipLaunchKernelGGL(grouped3_k<false>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ("C1", C.c_int32), ("C2", C.c_int32), ("Cout", C.c_int32),
                 ("kernel", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("relu1", C.c_int32), ("relu2", C.c_int32), ("epilogue_act", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("groups", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class BwdEpilogue(C.Structure):

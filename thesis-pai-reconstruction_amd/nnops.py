@@ -74,7 +74,10 @@ class ConvBNAct(torch.autograd.Function):
         _check(x)
         N, H, W, Cin = x.shape
         Cout, _, k, _ = weight.shape
-        d = ops.make_desc(dtype, 0, N, H, W, Cin, 0, Cout, 1, 0, 0, act if bn is None else ACT_NONE, kernel=k)
+        # grouped 3x3 (ResNeXt): block-diagonal dense packs + the groups hint (16-channel slices skip the zero blocks)
+        hint = groups if (groups > 1 and k == 3 and Cin == Cout and Cin % 16 == 0 and 16 % (Cin // groups) == 0) else 1
+        d = ops.make_desc(dtype, 0, N, H, W, Cin, 0, Cout, 1, 0, 0, act if bn is None else ACT_NONE, kernel=k,
+                          groups=hint)
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
         if Cin <= 2 or Cout <= 2:            # thin layers (in_conv / out): skinny-GEMM scratch of gg_thin.hip
             ops.ensure_scratch(ops.scratch_bytes_for([d]), x.device)

@@ -36,13 +36,14 @@ def _p(t, dtype=None):
 
 
 def make_desc(dtype, transposed, N, H, W, C1, C2, Cout, stride=2, relu1=0, relu2=0, act=ACT_NONE,
-              kernel=4) -> ConvDesc:
+              kernel=4, groups=1) -> ConvDesc:
     d = ConvDesc()
     d.dtype = code_of(dtype)
     d.transposed = int(transposed)
     d.N, d.H, d.W, d.C1, d.C2, d.Cout = N, H, W, C1, C2, Cout
     d.kernel, d.stride, d.pad = {4: (4, stride, 1), 3: (3, 1, 1), 1: (1, 1, 0)}[kernel]
     d.relu1, d.relu2, d.epilogue_act = int(relu1), int(relu2), int(act)
+    d.groups = int(groups) if groups and groups > 1 else 0
     return d
 
 
@@ -72,7 +73,7 @@ def bn_stats_buffer_rows(rows: int) -> int:
 # the stream the kernel is launched on, and (kernel family, op, algorithmic FLOPs, events) is
 # appended.  Off (None) in normal operation.
 PROFILE = None
-KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16", 5: "small_mfma_bf16"}
+KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16", 5: "small_mfma_bf16", 6: "grouped3_k"}
 
 
 def conv_kernel_id(d: ConvDesc, op: int) -> int:
