@@ -28,7 +28,7 @@ def _d(t, dtype):
 
 
 @DTYPES
-@pytest.mark.parametrize("M,D,P", [(12, 96, 4), (64, 512, 16), (7, 1000, 1), (128, 4096, 4)])
+@pytest.mark.parametrize("M,D,P", [(12, 96, 4), (64, 512, 16), (7, 1000, 1), (128, 4096, 4), (8, 8192, 4)])
 @pytest.mark.parametrize("fused", [False, True], ids=["plain", "res+post"])
 def test_layernorm(pai, dtype, M, D, P, fused):
     from thesis_pai_reconstruction_amd import nnops

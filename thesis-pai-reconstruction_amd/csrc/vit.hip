@@ -70,9 +70,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const T* x, const T* res,
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_k(const T* dy, const T* xs, int D, const float* gamma,
                                                           const float* mean, const float* rstd, T* dx) {
-    extern __shared__ float row[];   // 2 D floats + 8
-    float* gh = row + D;
-    float* red = row + 2 * D;
+    extern __shared__ float row[];   // D floats (xhat) + 8; g is recomputed in the second pass (dy, gamma are L1 / L2 hits)
+    float* red = row + D;
     const int64_t m = blockIdx.x;
     const float mu = mean[m], r = rstd[m];
     float s1 = 0.f, s2 = 0.f;
@@ -80,13 +79,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_k(const T* dy, const T* 
         const float xh = (Conv<T>::ld(xs + m * D + d) - mu) * r;
         const float g = Conv<T>::ld(dy + m * D + d) * gamma[d];
         row[d] = xh;
-        gh[d] = g;
         s1 += g;
         s2 = fmaf(g, xh, s2);
     }
     const float a = block_sum(s1, red) / (float)D;
     const float b = block_sum(s2, red) / (float)D;
-    for (int d = threadIdx.x; d < D; d += 256) Conv<T>::st(dx + m * D + d, r * (gh[d] - a - row[d] * b));
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float g = Conv<T>::ld(dy + m * D + d) * gamma[d];
+        Conv<T>::st(dx + m * D + d, r * (g - a - row[d] * b));
+    }
 }
 
 // partial[slab][0][d] = sum_rows dy, partial[slab][1][d] = sum_rows dy * xhat   (thread = column, slab = rows)
@@ -141,11 +142,11 @@ extern "C" int pai_layernorm_bwd(int dtype, const void* dy, const void* xs, int6
                                  float* partials, void* stream) {
     PAI_CHECK(dtype == PAI_F32 || dtype == PAI_BF16, "pai_layernorm_bwd: bad dtype %d", dtype);
     PAI_CHECK(dy && xs && gamma && mean && rstd && dx && M > 0 && D > 0, "pai_layernorm_bwd: bad arguments");
-    PAI_CHECK(D <= 6144, "pai_layernorm_bwd: D=%d exceeds the 6144-element row buffers", D);
+    PAI_CHECK(D <= 12288, "pai_layernorm_bwd: D=%d exceeds the 12288-element row buffer", D);
     PAI_CHECK(M < ((int64_t)1 << 31), "pai_layernorm_bwd: too many rows");
     PAI_CHECK(!dgamma_dbeta || partials, "pai_layernorm_bwd: parameter gradients need the partials workspace");
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)(2 * D + 8) * sizeof(float);
+    const size_t lds = (size_t)(D + 8) * sizeof(float);
     const int slabs = pai_layernorm_partial_rows(M);
     const int64_t rps = (M + slabs - 1) / slabs;
     if (dtype == PAI_F32) {
