@@ -6,8 +6,10 @@
 // activation once:
 //   * a workgroup owns an 8 x 16 block of output pixels x 64 channels (four slices; blockIdx.y picks the half) and
 //     keeps the 10 x 18 source pixels x 64 channels it touches in LDS (23 KB, one coalesced fill; 16-B chunk c of
-//     patch pixel p at slot c ^ ((p >> 1) & 7) of its 128-B row, so the 16 pixel lanes of a fragment read hit 16
-//     different bank groups for every tap shift);
+//     patch pixel p at slot c ^ (((p >> 1) & 3) << 1) of its 128-B row: a ds_read_b128 lane group is 8 lanes of one
+//     k-quarter (pixels 0-3, 12-15 or 4-11) plus 8 of its neighbour, so bit 0 of the slot -- the k-quarter's
+//     channel half -- is kept and the XOR spreads each set of 8 pixels over the 2 x 4 row-parity / slot-pair
+//     positions, for every tap shift);
 //   * its four waves take two pixel rows each and walk the four 16-channel slices: the filter slice (five 16-B
 //     fragments per lane, L1-resident) as the MFMA A operand, the shifted patch pixels as B, no operand is re-read
 //     from memory for the nine taps.  (All eight slices in one workgroup needed 336 registers: one wave per SIMD.)
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
         for (int j = 0; j < NF; ++j) {
             const int i = tid + 256 * j;
             const int p = i >> 3, c = i & 7;
-            if (i < PATCH_PIXELS * 8) *(uint4*)(patch + p * 128 + ((c ^ ((p >> 1) & 7)) << 4)) = pre[j];
+            if (i < PATCH_PIXELS * 8) *(uint4*)(patch + p * 128 + ((c ^ (((p >> 1) & 3) << 1)) << 4)) = pre[j];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
                 for (int ks = 0; ks < 5; ++ks) {
                     const int p = pbase + pofs[ks];
                     uint4 v = (GROUP_ABL & 2) ? make_uint4(p, chunk, ks, s)
-                                              : *(const uint4*)(patch + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                                              : *(const uint4*)(patch + p * 128 + ((chunk ^ (((p >> 1) & 3) << 1)) << 4));
                     if (!kvalid[ks]) v = make_uint4(0, 0, 0, 0);
                     bf8_t b = __builtin_bit_cast(bf8_t, v);
                     if (g.relu1) b = relu8g(b);
