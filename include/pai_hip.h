@@ -73,7 +73,9 @@ typedef struct pai_conv_desc {
     int32_t groups;       /* 0 or 1: dense.  > 1 (kernel = 3, Conv2d, C1 = Cout, C2 = 0): the filter packs are the
                              BLOCK-DIAGONAL dense form of a grouped convolution (nn.Conv2d(groups=32) of
                              ResidualBlockNeXt, models/res_unet.py:151-157) whose groups do not straddle 16-channel
-                             slices; forward / input gradient may then skip the zero blocks.  A hint: every kernel
+                             slices; forward / input gradient may then skip the zero blocks, and the weight gradient
+                             is only defined on the 64-channel diagonal blocks that contain the groups (the entries
+                             of the structurally zero blocks may be left zero).  Otherwise a hint: every kernel
                              family computes the same result from the dense packs. */
     int32_t reserved[2];
 } pai_conv_desc;

@@ -1386,6 +1386,11 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 
     // bias gradient: the workgroups of the first column tile (and first tap of each phase) see every
     // dY row of their channel tile exactly once -> column sums straight from the staged LDS tile
+    // Block-diagonal (grouped) filter with 128 channels (pai_conv_desc.groups): a column tile is one tap x 128 input
+    // channels and the wave (wm, wn) owns output channels 64 wm.. x input channels 64 wn.. -- off the diagonal the
+    // filter is structurally zero and its gradient is not used, so those waves skip the matrix work (they still take
+    // part in the fills and barriers and store zeros)
+    const bool zero_block = BMC == 128 && g.gslice != 0 && g.Cin == 128 && g.Cout == 128 && wm != wn;
     const bool do_bias = a.dbias != nullptr && jt == 0;
     const int bc = tid % BMC, bh = tid / BMC;      // channel, row group (256/BMC groups)
     constexpr int BROWS = 64 / (256 / BMC);        // rows per group
@@ -1427,6 +1432,7 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (zero_block) break;                    // grouped filter: this wave's 64 x 64 block lies off the diagonal
             bf8_t af[MT], bfr[4];
             const int row0 = kk * 32 + fg * 8 + tq;   // + 4 for the second half of the 8 k-values
 #pragma unroll
