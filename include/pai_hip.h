@@ -222,6 +222,12 @@ int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int a
                       const void* z, int64_t M, int C, const float* mean, const float* rstd,
                       void* du, float* partials, float* sums, float* dgamma, float* dbeta,
                       void* stream);
+/* pai_bn_bwd_reduce with the activation's sign taken from pre = z*scale + shift (the coefficients pai_bn_finalize
+ * produced) instead of from the stored activated output `a`: one tensor read less. */
+int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, const void* g2, int act2, const void* z,
+                             int64_t M, int C, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, void* du, float* partials, float* sums, float* dgamma,
+                             float* dbeta, void* stream);
 /* Second half of pai_bn_bwd_reduce on its own: reduces `rows` partial rows [2][C] (from
  * pai_conv_dgrad_bn) in fp64 into sums [2][C] and accumulates dbeta += sums[0], dgamma += sums[1]. */
 int pai_bn_bwd_finalize(const float* partials, int rows, int C, float* sums, float* dgamma,

@@ -410,6 +410,33 @@ extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void
     return 0;
 }
 
+// The same pass with the activation's sign rebuilt from z (pre = z * scale + shift) instead of read from the stored
+// activated output: one tensor read less (6 instead of 7 tensor passes per BatchNorm backward of the composable
+// networks, whose residual U-Net step is bound by exactly these passes).
+extern "C" int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, const void* g2, int act2,
+                                        const void* z, int64_t M, int C, const float* scale, const float* shift,
+                                        const float* mean, const float* rstd, void* du, float* partials,
+                                        float* sums, float* dgamma, float* dbeta, void* stream) {
+    PAI_CHECK(g1 && z && du && partials && sums && mean && rstd && scale && shift, "pai_bn_bwd_reduce_affine: null pointer");
+    PAI_CHECK(C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "pai_bn_bwd_reduce_affine: C=%d must be 8 * 2^k", C);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = pai_bn_bwd_partial_rows(M);
+    const int64_t rpb = (M + rows - 1) / rows;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
+                           (const float*)g2, act2, (const float*)nullptr, (const float*)z, M, C, rpb, mean, rstd,
+                           (float*)du, partials, scale, shift);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1, act1,
+                           (const bf16_t*)g2, act2, (const bf16_t*)nullptr, (const bf16_t*)z, M, C, rpb, mean, rstd,
+                           (bf16_t*)du, partials, scale, shift);
+    PAI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, s, partials, rows, C, sums, dgamma,
+                       dbeta);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* du, const T* z, int64_t nvec, int C,
                                                       float inv_m, const float* mean, const float* rstd,

@@ -123,7 +123,7 @@ class ConvBNAct(torch.autograd.Function):
         out = torch.empty_like(z)
         ops.bn_apply(dtype, z, M, Cout, scale, shift, act, out)
         ctx.training = training
-        ctx.save_for_backward(x, out, wd, weight, z, mean, rstd, gamma)
+        ctx.save_for_backward(x, out, wd, weight, z, mean, rstd, gamma, scale, shift)
         return out
 
     @staticmethod
@@ -145,15 +145,18 @@ class ConvBNAct(torch.autograd.Function):
             else:
                 ops.act_bwd(dtype, g, act, None, ACT_NONE, out, g.numel(), dz)
         else:
-            x, out, wd, weight, z, mean, rstd, gamma = ctx.saved_tensors
+            x, out, wd, weight, z, mean, rstd, gamma, scale, shift = ctx.saved_tensors
             if not ctx.training:
                 raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
             du = torch.empty_like(z)
             part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * Cout, **f32)
             sums = torch.empty(2 * Cout, **f32)
             dgamma, dbeta = torch.zeros(Cout, **f32), torch.zeros(Cout, **f32)
-            ops.bn_bwd_reduce(dtype, g, act, None, ACT_NONE, out if act != ACT_NONE else None, z, M, Cout, mean, rstd, du,
-                              part, sums, dgamma, dbeta)
+            if act != ACT_NONE:     # the activation's sign from z * scale + shift: `out` is not read again
+                ops.bn_bwd_reduce_affine(dtype, g, act, None, ACT_NONE, z, M, Cout, scale, shift, mean, rstd, du, part, sums,
+                                         dgamma, dbeta)
+            else:
+                ops.bn_bwd_reduce(dtype, g, act, None, ACT_NONE, None, z, M, Cout, mean, rstd, du, part, sums, dgamma, dbeta)
             dz = torch.empty_like(z)
             ops.bn_bwd_apply(dtype, du, z, M, Cout, mean, rstd, gamma.detach(), sums, dz)
         k = weight.shape[2]
@@ -313,12 +316,12 @@ class BNAct(torch.autograd.Function):
         out = torch.empty_like(z)
         ops.bn_apply(dtype, z, M, C, scale, shift, act, out)
         ctx.act, ctx.training = act, training
-        ctx.save_for_backward(z, out, mean, rstd, gamma)
+        ctx.save_for_backward(z, mean, rstd, gamma, scale, shift)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        z, out, mean, rstd, gamma = ctx.saved_tensors
+        z, mean, rstd, gamma, scale, shift = ctx.saved_tensors
         if not ctx.training:
             raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
         N, H, W, C = z.shape
@@ -328,8 +331,12 @@ class BNAct(torch.autograd.Function):
         part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * C, **f32)
         sums = torch.empty(2 * C, **f32)
         dgamma, dbeta = torch.zeros(C, **f32), torch.zeros(C, **f32)
-        ops.bn_bwd_reduce(dtype, g.contiguous(), act, None, ACT_NONE, out if act != ACT_NONE else None, z, M, C, mean,
-                          rstd, du, part, sums, dgamma, dbeta)
+        if act != ACT_NONE:
+            ops.bn_bwd_reduce_affine(dtype, g.contiguous(), act, None, ACT_NONE, z, M, C, scale, shift, mean, rstd, du, part,
+                                     sums, dgamma, dbeta)
+        else:
+            ops.bn_bwd_reduce(dtype, g.contiguous(), act, None, ACT_NONE, None, z, M, C, mean, rstd, du, part, sums, dgamma,
+                              dbeta)
         dz = torch.empty_like(z)
         ops.bn_bwd_apply(dtype, du, z, M, C, mean, rstd, gamma.detach(), sums, dz)
         return dz, dgamma, dbeta, None, None, None, None

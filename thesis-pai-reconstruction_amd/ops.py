@@ -247,6 +247,12 @@ def bn_bwd_reduce(dtype, g1, act1, g2, act2, a, z, M, C_, mean, rstd, du, partia
                                        _stream()), "pai_bn_bwd_reduce")
 
 
+def bn_bwd_reduce_affine(dtype, g1, act1, g2, act2, z, M, C_, scale, shift, mean, rstd, du, partials, sums, dgamma, dbeta):
+    L.check(L.load().pai_bn_bwd_reduce_affine(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(z), M, C_, _p(scale),
+                                              _p(shift), _p(mean), _p(rstd), _p(du), _p(partials), _p(sums), _p(dgamma),
+                                              _p(dbeta), _stream()), "pai_bn_bwd_reduce_affine")
+
+
 def bn_bwd_apply(dtype, du, z, M, C_, mean, rstd, gamma, sums, dz):
     L.check(L.load().pai_bn_bwd_apply(code_of(dtype), _p(du), _p(z), M, C_, _p(mean), _p(rstd), _p(gamma),
                                       _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply")
