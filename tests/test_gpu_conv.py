@@ -348,6 +348,51 @@ def test_grouped_conv3x3(pai, dtype, C, groups, N, H, W):
     assert rel_err(gw.cpu(), w.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("k,N,H,W,C1,C2,K", [(1, 2, 16, 16, 128, 128, 128), (3, 2, 16, 16, 64, 64, 64), (3, 1, 6, 10, 128, 64, 64),
+                                             (1, 3, 8, 8, 256, 256, 64), (3, 2, 8, 16, 64, 128, 128)])
+def test_same_conv_two_sources(pai, dtype, k, N, H, W, C1, C2, K):
+    """1x1 / 3x3 "same" convolutions over two tensors read as one concatenation (the torch.cat in front of the decoder
+    blocks of the residual / Trans U-Nets, reference models/res_unet.py:327, models/trans_unet.py:113): forward, both input
+    gradients and the weight gradient against F.conv2d on the concatenated tensor."""
+    from thesis_pai_reconstruction_amd import ops
+    tol = TOL[dtype]
+    x1 = q(rnd((N, C1, H, W), 1), dtype).requires_grad_(True)
+    x2 = q(rnd((N, C2, H, W), 5), dtype).requires_grad_(True)
+    w = q(rnd((K, C1 + C2, k, k), 2, 0.05), dtype).requires_grad_(True)
+    b = rnd((K,), 3, 0.1).requires_grad_(True)
+    y = F.conv2d(torch.cat([x1, x2], 1), w, b, padding=k // 2)
+    dy = q(rnd(tuple(y.shape), 4), dtype)
+    y.backward(dy)
+    d = ops.make_desc(dtype, 0, N, H, W, C1, C2, K, 1, 0, 0, ops.ACT_NONE, kernel=k)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())
+    wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    ops.pack_weights(dtype, wm, K, k * k, C1 + C2, wf, wd)
+    X1, X2, DY = nhwc(x1.detach(), dtype), nhwc(x2.detach(), dtype), nhwc(dy, dtype)
+    y_raw = torch.empty(N * H * W * K, dtype=dtype, device=dev())
+    rows = ops.conv_fwd_stats_rows(d)
+    stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * K, dtype=torch.float32, device=dev())
+    ops.conv_fwd(d, X1, X2, wf, b.detach().to(dev()), y_raw=y_raw, stats=stats)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y_raw, N, H, W, K), y.detach()) < tol
+    st = stats[:rows * 2 * K].view(rows, 2, K).double().sum(0).cpu()
+    assert rel_err(st[1], (y.detach().double() ** 2).sum((0, 2, 3))) < 1e-4
+    dx1 = torch.empty(N * H * W * C1, dtype=dtype, device=dev())
+    dx2 = torch.empty(N * H * W * C2, dtype=dtype, device=dev())
+    ops.conv_dgrad(d, DY, wd, dx1, dx2)
+    assert rel_err(from_nhwc(dx1, N, H, W, C1), x1.grad) < tol
+    assert rel_err(from_nhwc(dx2, N, H, W, C2), x2.grad) < tol
+    dw = torch.full((wm.numel(),), float("nan"), dtype=torch.float32, device=dev())
+    db = torch.zeros(K, dtype=torch.float32, device=dev())
+    ops.conv_wgrad_overwrite(d, X1, X2, DY, dw, db)
+    torch.cuda.synchronize()
+    tol_w = 1e-4 if dtype == torch.float32 else 3e-3
+    assert rel_err(dw.cpu().view(K, k, k, C1 + C2).permute(0, 3, 1, 2), w.grad) < tol_w
+    assert rel_err(db.cpu(), b.grad) < tol_w
+
+
 def test_bad_arguments_fail_loudly(pai):
     from thesis_pai_reconstruction_amd import ops
     d = ops.make_desc(torch.float32, 0, 1, 7, 8, 1, 0, 64, 2)

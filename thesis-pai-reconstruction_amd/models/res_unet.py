@@ -52,7 +52,7 @@ class _Block(nn.Module):
                 ctx["capture"][f"{ctx['name']}.conv_block.{i}"] = h.detach().float()
             i = j
         if isinstance(self.conv_skip, nn.Identity):
-            s = x
+            s = nnops.as_tensor(x)
         else:
             s = nnops.conv_bn_act(x, self.conv_skip[0], self.conv_skip[1], ACT_NONE, ctx["training"], ctx["n_updates"],
                                   ctx["dtype"])
@@ -107,6 +107,7 @@ class ResidualBlockV2(_Block):
         ) if in_channels != out_channels else nn.Identity()
 
     def run(self, x, ctx):
+        x = nnops.as_tensor(x)          # the BatchNorm in front needs the concatenation as one tensor
         tr, nu, dt = ctx["training"], ctx["n_updates"], ctx["dtype"]
         cb = self.conv_block
         h = nnops.BNAct.apply(x, cb[0].weight, cb[0].bias, cb[0], tr, nu, ACT_RELU)
@@ -219,7 +220,7 @@ class ResUnet(nn.Module):
         skips.pop()
         for j, dec in enumerate(self.decoders):
             if j != 0:
-                h = torch.cat([h, skips.pop()], dim=3)           # channel concat of NHWC tensors (data movement only)
+                h = (h, skips.pop())        # read as cat([h, skip]) by the block's convolutions (two-pointer inputs)
             ctx["name"] = f"dec{j}"
             h = dec.decode[0].run(h, ctx)
             drop = dec.decode[1]

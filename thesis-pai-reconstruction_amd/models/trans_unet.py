@@ -212,7 +212,7 @@ class TransUnet(nn.Module):
             cap["vit"] = h.detach().float()
         for j, dec in enumerate(self.decoders):
             if j != 0:
-                h = torch.cat([h, skips.pop()], dim=3)           # channel concat of NHWC tensors (data movement only)
+                h = (h, skips.pop())        # read as cat([h, skip]) by the decoder's first convolution (two-pointer input)
             h = dec.run(h, ctx)
             if cap is not None:
                 cap[f"dec{j}"] = h.detach().float()

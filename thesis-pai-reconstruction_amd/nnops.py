@@ -70,13 +70,22 @@ class ConvBNAct(torch.autograd.Function):
     blocks of reference models/res_unet.py:58-64,86-95,147-163,66-69 and the bare convolutions at :265,308."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn, training, n_updates, act, groups, dtype, out_f32):
+    def forward(ctx, x, x2, weight, bias, gamma, beta, bn, training, n_updates, act, groups, dtype, out_f32):
+        # x2 (optional): a second NHWC tensor read as if concatenated behind x along C -- the torch.cat in front of the
+        # decoder blocks (reference models/res_unet.py:327, models/trans_unet.py:113) never materialises
         _check(x)
-        N, H, W, Cin = x.shape
+        N, H, W, C1 = x.shape
+        C2 = 0
+        if x2 is not None:
+            _check(x2)
+            if x2.shape[:3] != x.shape[:3] or x2.dtype != x.dtype:
+                raise ops.PaiError("ConvBNAct: the two sources differ in shape or dtype")
+            C2 = x2.shape[3]
+        Cin = C1 + C2
         Cout, _, k, _ = weight.shape
         # grouped 3x3 (ResNeXt): block-diagonal dense packs + the groups hint (16-channel slices skip the zero blocks)
         hint = groups if (groups > 1 and k == 3 and Cin == Cout and Cin % 16 == 0 and 16 % (Cin // groups) == 0) else 1
-        d = ops.make_desc(dtype, 0, N, H, W, Cin, 0, Cout, 1, 0, 0, act if bn is None else ACT_NONE, kernel=k,
+        d = ops.make_desc(dtype, 0, N, H, W, C1, C2, Cout, 1, 0, 0, act if bn is None else ACT_NONE, kernel=k,
                           groups=hint)
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
         if Cin <= 2 or Cout <= 2:            # thin layers (in_conv / out): skinny-GEMM scratch of gg_thin.hip
@@ -93,17 +102,19 @@ class ConvBNAct(torch.autograd.Function):
         M = N * H * W
         b32 = None if bias is None else bias.detach().float()
         ctx.d, ctx.act, ctx.groups, ctx.dtype, ctx.has_bn, ctx.out_f32 = d, act, groups, dtype, bn is not None, out_f32
+        ctx.has_x2 = x2 is not None
+        extra = [x2] if x2 is not None else []
         if bn is None:
             if out_f32:                       # final conv + tanh (reference :307-315): fp32 NCHW-compatible output
                 out = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
-                ops.conv_fwd(d, x, None, wf, b32, y_f32=out)
+                ops.conv_fwd(d, x, x2, wf, b32, y_f32=out)
             elif act == ACT_NONE:
                 out = torch.empty(N, H, W, Cout, dtype=dtype, device=x.device)
-                ops.conv_fwd(d, x, None, wf, b32, y_raw=out)
+                ops.conv_fwd(d, x, x2, wf, b32, y_raw=out)
             else:
                 out = torch.empty(N, H, W, Cout, dtype=dtype, device=x.device)
-                ops.conv_fwd(d, x, None, wf, b32, y_act=out)
-            ctx.save_for_backward(x, out, wd, weight)
+                ops.conv_fwd(d, x, x2, wf, b32, y_act=out)
+            ctx.save_for_backward(x, out, wd, weight, *extra)
             return out
         z = torch.empty(N, H, W, Cout, dtype=dtype, device=x.device)
         f32 = dict(dtype=torch.float32, device=x.device)
@@ -112,31 +123,33 @@ class ConvBNAct(torch.autograd.Function):
         if training:
             rows = ops.conv_fwd_stats_rows(d)
             stats = torch.empty(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, **f32)
-            ops.conv_fwd(d, x, None, wf, b32, y_raw=z, stats=stats)
+            ops.conv_fwd(d, x, x2, wf, b32, y_raw=z, stats=stats)
             mom = bn.momentum if bn.momentum is not None else 0.1
             ops.bn_finalize(stats, rows, Cout, M, gamma.detach(), beta.detach(), float(bn.eps), float(mom), n_updates,
                             bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, rstd, scale, shift)
         else:
-            ops.conv_fwd(d, x, None, wf, b32, y_raw=z)
+            ops.conv_fwd(d, x, x2, wf, b32, y_raw=z)
             ops.bn_eval_coeffs(Cout, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, float(bn.eps),
                                scale, shift)
         out = torch.empty_like(z)
         ops.bn_apply(dtype, z, M, Cout, scale, shift, act, out)
         ctx.training = training
-        ctx.save_for_backward(x, out, wd, weight, z, mean, rstd, gamma, scale, shift)
+        ctx.save_for_backward(x, out, wd, weight, z, mean, rstd, gamma, scale, shift, *extra)
         return out
 
     @staticmethod
     def backward(ctx, g):
         d, act, dtype = ctx.d, ctx.act, ctx.dtype
-        N, H, W, Cin, Cout = d.N, d.H, d.W, d.C1, d.Cout
+        N, H, W, C1, C2, Cout = d.N, d.H, d.W, d.C1, d.C2, d.Cout
+        Cin = C1 + C2
+        x2 = ctx.saved_tensors[-1] if ctx.has_x2 else None
         M = N * H * W
         g = g.contiguous()
         dev = g.device
         f32 = dict(dtype=torch.float32, device=dev)
         dgamma = dbeta = None
         if not ctx.has_bn:
-            x, out, wd, weight = ctx.saved_tensors
+            x, out, wd, weight = ctx.saved_tensors[:4]
             dz = torch.empty(N, H, W, Cout, dtype=dtype, device=dev)
             if ctx.out_f32:
                 ops.tanh_bwd(dtype, out, g.float(), None, dz) if act == ACT_TANH else ops.cast(g.float(), dz)
@@ -145,7 +158,7 @@ class ConvBNAct(torch.autograd.Function):
             else:
                 ops.act_bwd(dtype, g, act, None, ACT_NONE, out, g.numel(), dz)
         else:
-            x, out, wd, weight, z, mean, rstd, gamma, scale, shift = ctx.saved_tensors
+            x, out, wd, weight, z, mean, rstd, gamma, scale, shift = ctx.saved_tensors[:10]
             if not ctx.training:
                 raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
             du = torch.empty_like(z)
@@ -162,15 +175,16 @@ class ConvBNAct(torch.autograd.Function):
         k = weight.shape[2]
         dw = torch.empty(Cout * k * k * Cin, **f32)
         # a conv bias in front of a BatchNorm has an identically zero gradient
-        with_bias = ctx.needs_input_grad[2] and not ctx.has_bn
-        dbias = (torch.empty(Cout, **f32) if with_bias else torch.zeros(Cout, **f32)) if ctx.needs_input_grad[2] else None
-        ops.conv_wgrad_overwrite(d, x, None, dz, dw, dbias if with_bias else None)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(N, H, W, Cin, dtype=dtype, device=dev)
-            ops.conv_dgrad(d, dz, wd, dx, None)
+        with_bias = ctx.needs_input_grad[3] and not ctx.has_bn       # inputs: x, x2, weight, bias, gamma, beta, ...
+        dbias = (torch.empty(Cout, **f32) if with_bias else torch.zeros(Cout, **f32)) if ctx.needs_input_grad[3] else None
+        ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
+        dx = dx2 = None
+        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
+            dx = torch.empty(N, H, W, C1, dtype=dtype, device=dev)
+            dx2 = torch.empty(N, H, W, C2, dtype=dtype, device=dev) if ctx.has_x2 else None
+            ops.conv_dgrad(d, dz, wd, dx, dx2)
         gw = _grad_from_fwd_pack(dw, weight, ctx.groups)
-        return dx, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class MaxPool2(torch.autograd.Function):
@@ -262,11 +276,18 @@ class Dropout2d(torch.autograd.Function):
 
 
 def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False):
-    """Run an ``nn.Conv2d`` (+ ``nn.BatchNorm2d``) parameter container through ConvBNAct."""
+    """Run an ``nn.Conv2d`` (+ ``nn.BatchNorm2d``) parameter container through ConvBNAct.  ``x``: an NHWC tensor, or a pair
+    ``(x1, x2)`` read as ``torch.cat([x1, x2], dim=3)`` without the concatenation being built."""
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
-    return ConvBNAct.apply(x, conv.weight, conv.bias, gamma, beta, bn, training, n_updates, act, conv.groups, dtype,
+    x1, x2 = x if isinstance(x, tuple) else (x, None)
+    return ConvBNAct.apply(x1, x2, conv.weight, conv.bias, gamma, beta, bn, training, n_updates, act, conv.groups, dtype,
                            out_f32)
+
+
+def as_tensor(x):
+    """The concatenation itself, for consumers that need one tensor (identity skips, standalone BatchNorm)."""
+    return torch.cat(list(x), dim=3) if isinstance(x, tuple) else x
 
 
 # ---- TransUNet (reference models/trans_unet.py) ----------------------------------------------------------------
