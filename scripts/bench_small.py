@@ -8,7 +8,9 @@ from thesis_pai_reconstruction_amd import ops
 dev = torch.device("cuda:0"); dt = torch.bfloat16
 # name, k, N, H, Cin, Cout, groups
 LAYERS = [("rnx 3x3 g32 512", 3, 16, 512, 128, 128, 32), ("rnx 3x3 g32 256", 3, 16, 256, 128, 128, 32),
-          ("rnx 3x3 dense 512", 3, 16, 512, 128, 128, 1),
+          ("rnx 3x3 dense 512", 3, 16, 512, 128, 128, 1), ("rnx 1x1 64>128 512", 1, 16, 512, 64, 128, 1),
+          ("rnx 1x1 128>64 512", 1, 16, 512, 128, 64, 1), ("rnx 1x1 128>128 512", 1, 16, 512, 128, 128, 1),
+          ("rnx 1x1 64>64 512", 1, 16, 512, 64, 64, 1),
           ("tr 1x1 64>16 256", 1, 32, 256, 64, 16, 1),
           ("tr 3x3 16>16 256", 3, 32, 256, 16, 16, 1), ("tr 1x1 16>64 128", 1, 32, 128, 16, 64, 1),
           ("tr 3x3 32>32 64", 3, 32, 64, 32, 32, 1)]
