@@ -334,6 +334,9 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // TW: thin weight gradient.  wide tile (64 pixels x <= 128 channels) staged by LDS-DMA into the
 // 256-B-row transposed-read image of the MFMA wgrad kernel; patch fragments gathered directly.
+// (measured and dropped: two LDS stages with the next chunk's tile and gathers in flight during the MFMAs, one
+//  barrier per chunk -- D block 0 at batch 128: 182 -> 216 us, at batch 64: 97 -> 113 us; like the patch-resident
+//  weight gradient, this kernel hides its latency across workgroups and loses them to the second stage)
 // ------------------------------------------------------------------------------------------------
 struct ThinW {
     const bf16_t *thin1, *thin2;  // [N][TH][TW] one channel each; thin2 may be null (T = 1)
