@@ -45,6 +45,11 @@ int pai_version(void);
 /* Device properties of the current HIP device (host out-params). */
 int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
 
+/* Kernel-selection switches (host side, process-wide), e.g. "fwd_p2" = 0 routes the layers of the pipelined
+ * one-workgroup-per-CU forward kernel back to the two-workgroup patch kernel.  For tests that pin the kernel a
+ * call runs and for A/B timing in one process; production code never needs it. */
+int pai_set_tunable(const char* name, int value);
+
 /* ---------------------------------------------------------------------------
  * Convolution family.  One descriptor serves Conv2d and ConvTranspose2d.
  * Replaces aten::convolution / aten::convolution_backward issued by

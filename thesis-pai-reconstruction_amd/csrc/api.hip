@@ -32,6 +32,29 @@ extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, i
     return 0;
 }
 
+// ---- run-time tunables ------------------------------------------------------------------------------
+// A small name -> value table (host side, process-wide): kernel-selection switches that tests use to pin the kernel
+// family a call runs and that the micro-benchmarks flip to time two kernels in one process.
+struct Tunable { char name[32]; int value; };
+static Tunable g_tunables[32];
+static int g_ntunables = 0;
+
+int pai_tunable(const char* name, int def) {
+    for (int i = 0; i < g_ntunables; ++i)
+        if (!strcmp(g_tunables[i].name, name)) return g_tunables[i].value;
+    return def;
+}
+
+extern "C" int pai_set_tunable(const char* name, int value) {
+    PAI_CHECK(name && strlen(name) < sizeof(g_tunables[0].name), "pai_set_tunable: bad name");
+    for (int i = 0; i < g_ntunables; ++i)
+        if (!strcmp(g_tunables[i].name, name)) { g_tunables[i].value = value; return 0; }
+    PAI_CHECK(g_ntunables < 32, "pai_set_tunable: table full");
+    strcpy(g_tunables[g_ntunables].name, name);
+    g_tunables[g_ntunables++].value = value;
+    return 0;
+}
+
 static void finish_gg(GG* g);
 
 // ---------------------------------------------------------------------------------

@@ -161,6 +161,12 @@ struct FwdArgs {
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s);
+// pipelined one-workgroup-per-CU forward / input-gradient kernel (gg_p2.hip); rows = 0: not eligible
+int fwd_p2_rows(const GG& g);
+int launch_fwd_p2(const GG& g, const FwdArgs& a, hipStream_t s);
+const char* fwd_p2_kernel_name(const GG& g);
+// run-time tunables (pai_set_tunable): kernel-selection switches for A/B timing and for tests that pin a kernel
+int pai_tunable(const char* name, int def);
 int fwd_mfma_ksplit(const GG& g);
 const char* fwd_mfma_kernel_name(const GG& g);
 const char* wgrad_mfma_kernel_name(const GG& g);

@@ -19,21 +19,8 @@
 // aten::convolution_backward calls.
 #include <stdlib.h>
 
-#include "common.h"
+#include "gg_tile.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
-typedef __attribute__((ext_vector_type(4))) float f4_t;
-typedef __attribute__((ext_vector_type(2))) short s2_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
-
-constexpr int MBK = 64;   // K per iteration (one tap, 64 channels)
-
-__device__ uint4 g_zero_line[16];  // 256 B of zeros: source of padding / masked rows
-
-#define GLDS16(gptr, lptr)                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),    \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (dtype != PAI_BF16) return false;
@@ -56,6 +43,10 @@ struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
     FwdCfg c;
+    if (fwd_p2_rows(g)) {   // pipelined one-workgroup-per-CU kernel (gg_p2.hip): never split
+        c.bm = 128; c.bn = 128; c.ksplit = 1;
+        return c;
+    }
     c.bn = ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 128 : 64;
     c.bm = 128;
     c.ksplit = 1;
@@ -125,114 +116,16 @@ static int fwd_effective_ksplit(const GG& g) {
 static int patch_rows(const GG& g, const FwdCfg& c);
 
 int fwd_mfma_mtiles(const GG& g) {
+    if (const int rows = fwd_p2_rows(g)) return g.M / rows;
     if (fwd_effective_ksplit(g) > 1) return cdiv(g.M, FIN_ROWS);
     const FwdCfg c = fwd_cfg(g);
     return patch_rows(g, c) == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
 }
 
-typedef __attribute__((ext_vector_type(8))) short s8_t;
-
-__device__ __forceinline__ bf8_t relu_frag(bf8_t f) {
-    // ReLU on packed bf16: as signed 16-bit integers every negative float is negative
-    // (v_pk_max_i16 x4).  Done on one 8-lane vector: element-wise writes to a 4 x u32 vector in an
-    // unrolled loop were folded to a broadcast of element 0 by hipcc 7.2.
-    s8_t x = __builtin_bit_cast(s8_t, f);
-    const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-    x = __builtin_elementwise_max(x, z);
-    return __builtin_bit_cast(bf8_t, x);
-}
-
-__device__ __forceinline__ void decode_row(const GG& g, int m, int& n, int& gy, int& gx) {
-    if (g.lw >= 0) {
-        gx = m & (g.OWg - 1);
-        gy = (m >> g.lw) & (g.OHg - 1);
-        n = m >> (g.lw + g.lh);
-    } else {
-        gx = m % g.OWg;
-        int r = m / g.OWg;
-        gy = r % g.OHg;
-        n = r / g.OHg;
-    }
-}
-
-// XCD-aware tile order: consecutive logical tiles (same A rows, neighbouring image rows) land on
-// the same XCD / L2.  Bijective for any grid size (guide T1).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
 
 // BM x BN x 64 tile, BM/64 x 2 waves of 64 x (BN/2).  DB = double-buffered LDS: the LDS-DMA of tile
 // k+1 is issued before tile k is consumed and retired with a COUNTED s_waitcnt vmcnt + raw s_barrier
 // (a __syncthreads() would drain it: guide "Pipelining across barriers").
-// Producer backward on one 16-B chunk (8 channels) of the staged bf16 gradient tile:
-//   du = act1'(pre) * g + act2'(pre) * add,  pre = z * sc + sh per channel (affine) or z itself,
-// rounded to bf16; with `sums` the BatchNorm-backward sums are accumulated from the value as stored
-// (what pai_bn_bwd_apply reads back).  Same du as bn_bwd_reduce_k / act_bwd_k on the bf16-rounded gradient.
-struct BwdParams { float sc[8], sh[8]; };
-__device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdParams& P) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        P.sc[k] = a.bscale ? a.bscale[c + k] : 1.f;
-        P.sh[k] = a.bscale ? a.bshift[c + k] : 0.f;
-    }
-}
-__device__ __forceinline__ float bwd_sel(float g, bool pos, int act) {   // act'(pre) * g
-    return act == PAI_ACT_RELU ? (pos ? g : 0.f) : (act == PAI_ACT_LRELU ? (pos ? g : 0.2f * g) : g);
-}
-// s2 accumulates du * z; the tile's sum of du * xhat is rstd * (s2 - mean * s1), formed once per channel in
-// bwd_write_partials (3 vector-ALU operations per element fewer in a store that runs behind every MFMA loop)
-__device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool has_add, bool affine, bool sums,
-                                           int act1, int act2, const BwdParams& P, float* s1, float* s2) {
-    const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w}, zw[4] = {zq.x, zq.y, zq.z, zq.w}, aw[4] = {aq.x, aq.y, aq.z, aq.w};
-    unsigned o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
-        const float z0 = __uint_as_float(zw[k] << 16), z1 = __uint_as_float(zw[k] & 0xffff0000u);
-        const bool q0 = (affine ? fmaf(z0, P.sc[2 * k], P.sh[2 * k]) : z0) > 0.f;
-        const bool q1 = (affine ? fmaf(z1, P.sc[2 * k + 1], P.sh[2 * k + 1]) : z1) > 0.f;
-        float d0 = bwd_sel(g0, q0, act1), d1 = bwd_sel(g1, q1, act1);
-        if (has_add) {
-            d0 += bwd_sel(__uint_as_float(aw[k] << 16), q0, act2);
-            d1 += bwd_sel(__uint_as_float(aw[k] & 0xffff0000u), q1, act2);
-        }
-        o[k] = pk2bf(d0, d1);
-        if (sums) {
-            const float r0 = __uint_as_float(o[k] << 16), r1 = __uint_as_float(o[k] & 0xffff0000u);
-            s1[2 * k] += r0;
-            s1[2 * k + 1] += r1;
-            s2[2 * k] = fmaf(r0, z0, s2[2 * k]);
-            s2[2 * k + 1] = fmaf(r1, z1, s2[2 * k + 1]);
-        }
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
-// Per-tile reduction of the chunk sums: lanes of a wave that own the same chunk (lane % CPR) first, then the
-// waves through `sred` [NW][2][BN]; thread c < BN writes column c of the tile's partial row.
-template <int BN, int CPR, int NW>
-__device__ __forceinline__ void bwd_write_partials(float* sred, const float* s1, const float* s2, int tid,
-                                                   float* row_dst, int D1, const float* mean, const float* rstd) {
-    const int lane = tid & 63, wid = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float a = s1[k], b = s2[k];
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if (lane < CPR) {
-            sred[(wid * 2 + 0) * BN + lane * 8 + k] = a;
-            sred[(wid * 2 + 1) * BN + lane * 8 + k] = b;
-        }
-    }
-    __syncthreads();
-    if (tid < BN) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { a += sred[(w * 2 + 0) * BN + tid]; b += sred[(w * 2 + 1) * BN + tid]; }
-        row_dst[tid] = a;
-        row_dst[D1 + tid] = rstd[tid] * (b - mean[tid] * a);   // sum du * xhat from sum du * z
-    }
-}
 
 template <int BM, int BN, bool SPLITK, bool DB, int WR = 64>   // WR: output rows per wave (64 or 32)
 __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
@@ -662,75 +555,6 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, const fl
 // slot c ^ (p & 6).  With that swizzle the 16 lanes of a ds_read_b128 group -- 16 consecutive p,
 // starting anywhere -- hit 16 different bank quads for every tap shift (the XOR only touches chunk
 // bits 1-2, the lane's own k-quarter keeps bit 0).
-struct PatchGeo {
-    int groups;                    // windows per phase: 1 or 4
-    int TY, TX;                    // 8 x 16 tiles per image
-    signed char by[4][4], bx[4][4];  // [phase][window] source offset of patch pixel (0,0) from (gy0*S, gx0*S)
-    unsigned toff4[4][4];          // 4 x 8 bit: patch offset ty*17+tx of the window's taps
-    unsigned wt4[4][4];            // 4 x 8 bit: weight tap slot of the window's taps
-};
-constexpr int PATCH_W = 17;
-// BM = 128: 8 x 16 output pixels, 4 waves;  BM = 256: 16 x 16 output pixels, 8 waves (4 x 2) -- the weight
-// tile fill is then shared by twice the rows: 25 KB of fill and 128 KB of fragment reads per 2 x 512
-// MFMA cycles, the first configuration whose LDS time (916 cycles) is below its matrix time (1024).
-template <int BM> struct PatchDims {
-    static constexpr int TH = BM / 16;
-    static constexpr int PIX = (TH + 1) * PATCH_W;
-    static constexpr int RPP = BM / 4;                       // pixels per block-wide fill instruction
-    static constexpr int PJ = (PIX + RPP - 1) / RPP;
-    static constexpr int BYTES = PJ * RPP * 128;
-};
-
-static bool patch_geo(const GG& g, int th, PatchGeo* pg) {
-    if ((g.OWg % 16) || (g.OHg % th)) return false;
-    memset(pg, 0, sizeof(*pg));
-    pg->TY = g.OHg / th;
-    pg->TX = g.OWg / 16;
-    if (g.S == 1 && g.ntaps == 4) {
-        pg->groups = 1;
-        for (int ph = 0; ph < g.nphase; ++ph) {
-            int by = 127, bx = 127;
-            for (int t = 0; t < 4; ++t) { by = g.dy[ph][t] < by ? g.dy[ph][t] : by; bx = g.dx[ph][t] < bx ? g.dx[ph][t] : bx; }
-            unsigned seen = 0;
-            for (int t = 0; t < 4; ++t) {
-                const int ty = g.dy[ph][t] - by, tx = g.dx[ph][t] - bx;
-                if (ty > 1 || tx > 1) return false;
-                seen |= 1u << (ty * 2 + tx);
-                pg->toff4[ph][0] |= (unsigned)(ty * PATCH_W + tx) << (8 * t);
-                pg->wt4[ph][0] |= (unsigned)g.wt[ph][t] << (8 * t);
-            }
-            if (seen != 15u) return false;
-            pg->by[ph][0] = (signed char)by;
-            pg->bx[ph][0] = (signed char)bx;
-        }
-        return true;
-    }
-    if (g.S == 2 && g.ntaps == 16 && g.nphase == 1) {
-        pg->groups = 4;
-        int ymin = 127, xmin = 127;
-        for (int t = 0; t < 16; ++t) { ymin = g.dy[0][t] < ymin ? g.dy[0][t] : ymin; xmin = g.dx[0][t] < xmin ? g.dx[0][t] : xmin; }
-        for (int q = 0; q < 4; ++q) {
-            const int by = ymin + (q >> 1), bx = xmin + (q & 1);
-            int k = 0;
-            unsigned seen = 0;
-            for (int t = 0; t < 16; ++t) {
-                const int ry = g.dy[0][t] - by, rx = g.dx[0][t] - bx;
-                if (ry < 0 || rx < 0 || (ry & 1) || (rx & 1)) continue;
-                const int ty = ry / 2, tx = rx / 2;
-                if (ty > 1 || tx > 1 || k == 4) return false;
-                seen |= 1u << (ty * 2 + tx);
-                pg->toff4[0][q] |= (unsigned)(ty * PATCH_W + tx) << (8 * k);
-                pg->wt4[0][q] |= (unsigned)g.wt[0][t] << (8 * k);
-                ++k;
-            }
-            if (k != 4 || seen != 15u) return false;
-            pg->by[0][q] = (signed char)by;
-            pg->bx[0][q] = (signed char)bx;
-        }
-        return true;
-    }
-    return false;
-}
 
 static int patch_rows(const GG& g, const FwdCfg& c) {
     static const bool no_patch = getenv("PAI_NO_PATCH") && atoi(getenv("PAI_NO_PATCH")) != 0;
@@ -1054,6 +878,7 @@ static size_t fwd_lds_bytes() {
 }
 
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (fwd_p2_rows(g)) return launch_fwd_p2(g, a, s);
     FwdCfg c = fwd_cfg(g);
     c.ksplit = fwd_effective_ksplit(g);
     const int mtiles = cdiv(g.M, abs(c.bm));
@@ -1131,6 +956,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
 
 // rocprofv3-visible symbol of the main kernel launch_fwd_mfma picks for this problem (same decisions, no launch)
 const char* fwd_mfma_kernel_name(const GG& g) {
+    if (fwd_p2_rows(g)) return fwd_p2_kernel_name(g);
     FwdCfg c = fwd_cfg(g);
     c.ksplit = fwd_effective_ksplit(g);
     const int mode = getenv("PAI_FWD_MODE") ? atoi(getenv("PAI_FWD_MODE")) : 0;

@@ -1,0 +1,547 @@
+// Pipelined patch-resident forward / input-gradient kernel for gfx950 ("p2"): one 512-thread workgroup per CU,
+// 256 x 256 (16 x 16 output pixels x 256 channels) or 512 x 128 (32 x 16 pixels x 128 channels) output tile, eight
+// waves of 128 pixels x 64 channels each, v_mfma_f32_16x16x32_bf16 with fp32 accumulators in VGPRs.
+//
+// Why another kernel next to gg_fwd_patch_k (gg_mfma.hip): that one hides L2 -> LDS latency by running two
+// workgroups per CU, exposes a whole patch refill every fourth K-step and, with 64 x 64 wave tiles, asks the LDS for
+// 0.9 cycles per matrix cycle (profiles/README.md).  Here
+//   * the wave tile is 128 x 64: 12 fragment reads per 32 MFMAs instead of 16 (LDS read port 37 % busy at full
+//     matrix rate instead of 50 %), and the weight tile is shared by twice the pixels (21 B of LDS-DMA fill per
+//     matrix cycle and CU instead of 25);
+//   * the source patch holds 32 channels (64 B per pixel) and is double-buffered, the weight tiles sit in a ring of
+//     three: every LDS-DMA is issued two K-steps (~2 us) before its data is needed and retired with a COUNTED
+//     s_waitcnt vmcnt + raw s_barrier (guide: "Pipelining across barriers"), one barrier per K-step of 64 MFMAs per
+//     wave;
+//   * fragment reads are software-pipelined through the barrier: the MFMAs of one tap run while the fragments of
+//     the next tap are read, so no wave waits for the LDS behind a barrier.
+// K-step = 2 taps of one 2 x 2 window x 32 channels: weight tile row = [tap a: 32 ch | tap b: 32 ch] = 128 B.
+//
+// STATUS (round 2, measured with scripts/micro/convbench on one MI355X, bit-exact against gg_fwd_patch_k on integer
+// data): NOT the default.  decoders[4] forward, 137 GFLOP: gg_fwd_patch_k 122-127 us (1.08-1.12 PFLOP/s); this kernel
+// 138 us with 8 waves / one workgroup per CU, 128 us with 4 waves / two per CU.  Compile-time ablations of the 8-wave
+// variant (P2_ABL): MFMAs alone 107 us -- of which ~15 us are prologue + epilogue that nothing overlaps when every CU
+// runs exactly one tile, i.e. the matrix pipe sustains ~1.5 PFLOP/s inside the loop (power-limited clock, not 2.5) --
+// LDS-DMA + fragment reads alone 100 us, fragment reads + MFMA 109 us, LDS-DMA + MFMA 121 us: what the deeper
+// pipeline buys is lost to (a) the exposed epilogue (33 MB of output leave the chip in one burst at the end),
+// (b) LDS-DMA instructions in the MFMA stream (spreading them one per MFMA group made it slower still: 128 -> 133 us).
+// gg_fwd_patch_k's four waves per SIMD hide both; it stays the default and this file documents the alternative.
+//
+// Serves the same reference call sites as gg_fwd_patch_k: the Conv2d k4 s2 p1 / ConvTranspose2d k4 s2 p1 layers of
+// EncoderBlock / DecoderBlock (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and
+// the input-gradient halves of their aten::convolution_backward calls.
+#include <stddef.h>
+
+#include "gg_tile.h"
+
+constexpr int P2_CK = 32;   // channels per patch chunk
+
+template <int TH, int NW> struct P2Dims {              // NW waves of 128 pixels x 64 channels
+    static constexpr int NTHR = NW * 64;
+    static constexpr int WMW = TH / 8, WNW = NW / WMW;      // waves along pixels / channels
+    static constexpr int BN = WNW * 64, BM = TH * 16;
+    static constexpr int PIX = (TH + 1) * PATCH_W;
+    static constexpr int PPI = NTHR / 4;                    // patch pixels (64 B) per block-wide fill instruction
+    static constexpr int PJ = (PIX + PPI - 1) / PPI;
+    static constexpr int PBYTES = PJ * PPI * 64;
+    static constexpr int RPI = NTHR / 8;                    // weight rows (128 B) per block-wide fill instruction
+    static constexpr int BJ = BN / RPI;
+    static constexpr int BBYTES = BN * 128;
+    static constexpr size_t lds_bytes(int nring) {
+        const size_t loop = 2 * (size_t)PBYTES + (size_t)nring * BBYTES;
+        const size_t epi = (size_t)BM * (BN * 2 + 16) + (size_t)WMW * 2 * BN * sizeof(float);
+        return loop > epi ? loop : epi;
+    }
+};
+
+// Kernel arguments: plain scalars only.  By-value structs with arrays (GG, PatchGeo) indexed by the run-time phase --
+// and even `cond ? a.x2 : a.x1` on neighbouring fields -- made hipcc 7.2 keep every argument in scratch and re-load
+// them inside the K loop (vector loads, each followed by the vmcnt(0) that drains the LDS-DMA pipeline).  The
+// per-phase tables are therefore packed into 64-bit scalars and unpacked with shifts:
+//   wby / wbx  4 bits per (phase, window): source offset of patch pixel (0,0) from (gy0*S, gx0*S), biased by 8
+//   toff       2 bits (ty, tx) per (phase, window, tap)
+//   wt[phase]  4 bits weight tap slot per (window, tap)
+//   poy / pox  1 bit per phase
+struct P2Prob {
+    int H, W, C1, C2, Cin, Cout, S, nphase, OH, OW, OS, D1, D2, wtaps, relu1, relu2;
+    int groups, TY, TX, mtiles, ntiles;
+    unsigned long long wby, wbx, toff[2], wt[4];
+    unsigned poy, pox;
+};
+
+#ifndef P2_DMA_SPREAD
+#define P2_DMA_SPREAD 1     // 1: one LDS-DMA instruction per MFMA group behind the barrier, 0: all of them at once
+#endif
+#ifndef P2_SETPRIO
+#define P2_SETPRIO 0
+#endif
+#ifndef P2_ABL
+#define P2_ABL 0            // timing ablations (results WRONG): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads
+#endif
+
+// TH: pixel rows of the tile (16 wide); NW: waves (8: one workgroup per CU, 4: two); NRING: weight tiles in the ring
+// (3: every LDS-DMA two K-steps ahead, 2: one); RELU: some input tensor is read through ReLU (decoder blocks)
+template <int TH, int NW, int NRING, bool RELU>
+__global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
+    const int mtiles = g.mtiles, ntiles = g.ntiles;
+    struct { int groups, TY, TX; } pg = {g.groups, g.TY, g.TX};
+    typedef P2Dims<TH, NW> PD;
+    constexpr int WMW = PD::WMW, WNW = PD::WNW, BN = PD::BN, BM = PD::BM, NTHR = PD::NTHR;
+    constexpr int MT = 8, NT = 4;
+    constexpr int PJ = PD::PJ, PIX = PD::PIX, PBYTES = PD::PBYTES, PPI = PD::PPI;
+    constexpr int BJ = PD::BJ, RPI = PD::RPI, BBYTES = PD::BBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [patch 0][patch 1][weights 0] .. [weights NRING-1]
+    constexpr int B_OFF = 2 * PBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WNW, wn = wid % WNW;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bn = bid % ntiles;
+    bid /= ntiles;
+    const int ph = bid % g.nphase;
+    const int bm = bid / g.nphase;
+    const int n0 = bn * BN;
+    const int tpi = pg.TY * pg.TX;
+    const int img = bm / tpi, trem = bm - img * tpi;
+    const int gy0 = (trem / pg.TX) * TH, gx0 = (trem % pg.TX) * 16;
+
+    const bf16_t* w = (const bf16_t*)a.w;
+    const bf16_t* zero = (const bf16_t*)g_zero_line;
+    const bf16_t* x1p = (const bf16_t*)a.x1;
+    const bf16_t* x2p = (const bf16_t*)a.x2;
+    const int gC1 = g.C1, gC2 = g.C2, grelu1 = g.relu1, grelu2 = g.relu2, gD1 = g.D1, gD2 = g.D2;
+    bf16_t* y1p = (bf16_t*)a.y1;
+    bf16_t* y2p = (bf16_t*)a.y2;
+    // tables of this workgroup's phase: unpacked with scalar shifts where they are used (a select chain over four
+    // precomputed values becomes a lookup table in scratch under hipcc 7.2)
+    const unsigned wby16 = (unsigned)(g.wby >> (16 * ph)) & 0xffffu, wbx16 = (unsigned)(g.wbx >> (16 * ph)) & 0xffffu;
+    const unsigned tpk32 = (unsigned)(((ph & 2) ? g.toff[1] : g.toff[0]) >> (32 * (ph & 1)));   // 8 bits per window
+    const unsigned long long wpk = ph == 0 ? g.wt[0] : (ph == 1 ? g.wt[1] : (ph == 2 ? g.wt[2] : g.wt[3]));   // 16 bits per window
+    const int poy = (int)((g.poy >> ph) & 1u), pox = (int)((g.pox >> ph) & 1u);
+    auto win_by = [&](int q) __attribute__((always_inline)) -> int { return (int)((wby16 >> (4 * q)) & 15u) - 8; };
+    auto win_bx = [&](int q) __attribute__((always_inline)) -> int { return (int)((wbx16 >> (4 * q)) & 15u) - 8; };
+    // ---- patch fill map: thread -> (pixel p = 128 j + tid / 4, 16-B slot tid % 4); the two 32-B halves of a pixel
+    // are swapped when bit 2 of its column px = p % 17 is set: every ds_read_b128 lane group (16 consecutive pixels of
+    // one patch row, at either tap shift) then covers the 16 slots of a 256-B bank row once, and -- the swizzle not
+    // depending on the row -- the eight pixel rows of a wave are one base address + immediates.
+    const int psc = tid & 3, pl = tid >> 2;
+    int pixb[PJ];      // source pixel of the patch pixel at window offset (0, 0)
+    unsigned pmeta[PJ];   // bits 0-3: inside the image for window q; bits 8-..: channel offset of this lane's 16-B chunk
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int p = j * PPI + pl;
+        const int py = p / PATCH_W, px = p - py * PATCH_W;
+        const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
+        pixb[j] = (img * g.H + y) * g.W + x;
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y + win_by(q), xx = x + win_bx(q);
+            if (q < pg.groups && p < PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
+        }
+        pmeta[j] = m | ((unsigned)((psc ^ (((px >> 2) & 1) << 1)) * 8) << 8);
+    }
+    // ---- weight fill map: thread -> (row 64 j + tid / 8, 16-B slot tid % 8), slot s of row r holds global chunk
+    // s ^ ((r >> 1) & 7); chunks 0-3 = 32 channels of the step's first tap, 4-7 = of its second tap.  LDS row
+    // rho = 16 nt + i of a wave's 64 channels holds channel 16 (i >> 2) + 4 nt + (i & 3): with the weights as the MFMA's
+    // A operand a lane ends up with 16 CONSECUTIVE channels of one pixel (16-B pieces in the epilogue).
+    const int bsr = tid >> 3;
+    const int gchB = (tid & 7) ^ ((bsr >> 1) & 7);
+    const int tapsel = gchB >> 2;
+    const bf16_t* wrow0 = w + (size_t)(n0 + 16 * ((bsr & 15) >> 2) + 4 * (bsr >> 4) + (bsr & 3)) * g.wtaps * g.Cin + (gchB & 3) * 8;
+    const int wrow_stride = g.wtaps * g.Cin;          // elements per output channel
+    // fill instruction j covers LDS rows j * RPI + bsr: channel offset of its first row from that of j = 0
+    auto wrow_ch = [](int j) __attribute__((always_inline)) -> int { return ((j * RPI) >> 6) * 64 + (((j * RPI) & 63) >> 4) * 4; };
+
+    // ---- fragment read addresses ---------------------------------------------------------------------------
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned wbase = (unsigned)(B_OFF + (wn * 64 + fr) * 128);
+    const unsigned wsw = (unsigned)(fr >> 1);
+
+    f4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int cchunks = g.Cin / P2_CK;
+    const int gsh = pg.groups == 4 ? 2 : 0;
+    const int ngroups = cchunks << gsh;
+    const int tot = 2 * ngroups;
+
+    // one LDS-DMA instruction of the patch of group gi / of the weight tile of step s
+    auto patch_piece = [&](int gi, int j) __attribute__((always_inline)) {
+        const int c0 = (gi >> gsh) * P2_CK, q = gi & (pg.groups - 1);
+        const bool second = c0 >= gC1;
+        const bf16_t* src = second ? x2p : x1p;
+        const int C = second ? gC2 : gC1;
+        const int cofs = (second ? c0 - gC1 : c0) + (int)(pmeta[j] >> 8);
+        const int dpix = win_by(q) * g.W + win_bx(q);
+        if (P2_ABL & 1) return;
+        const bf16_t* pv = src + ((size_t)(unsigned)(pixb[j] + dpix) * (unsigned)C + cofs);
+        const bf16_t* pa = ((pmeta[j] >> q) & 1u) ? pv : zero;
+        GLDS16(pa, smem + (gi & 1) * PBYTES + (j * PPI + wid * 16) * 64);
+    };
+    auto weight_piece = [&](int s, int slot, int j) __attribute__((always_inline)) {
+        const int gi = s >> 1, h = s & 1;
+        const int c0 = (gi >> gsh) * P2_CK, q = gi & (pg.groups - 1);
+        const int wt = (int)((unsigned)(wpk >> (16 * q + 8 * h + 4 * tapsel)) & 15u);   // tap 2 h + tapsel of window q
+        if (P2_ABL & 1) return;
+        GLDS16(wrow0 + ((size_t)wrow_ch(j) * wrow_stride + (wt * g.Cin + c0)), smem + B_OFF + slot * BBYTES + (j * RPI + wid * 8) * 128);
+    };
+    // fragment reads: weights of tap k (0 / 1) of the step in ring slot `slot`; pixels of patch row mt at base `pa`
+    auto read_w = [&](int slot, int k, bf8_t (&wf)[NT]) {
+        const unsigned ad = wbase + (unsigned)(slot * BBYTES) + ((((unsigned)(k * 4 + fq)) ^ wsw) << 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (P2_ABL & 4) wf[nt] = __builtin_bit_cast(bf8_t, make_uint4(ad, nt, slot, k));
+            else wf[nt] = *(const bf8_t*)(smem + ad + nt * 2048);
+        }
+    };
+    // base address (patch row wm * 8, this lane's pixel and k-quarter) for tap offset toff = ty * 17 + tx of buffer b
+    auto patch_base = [&](int b, int toff) __attribute__((always_inline)) -> unsigned {
+        const int ty = toff >= PATCH_W ? 1 : 0;
+        const unsigned px = (unsigned)(toff - ty * PATCH_W + fr);
+        return (unsigned)(b * PBYTES) + (((unsigned)((wm * 8 + ty) * PATCH_W) + px) << 6) + ((((unsigned)fq) ^ (((px >> 2) & 1u) << 1)) << 4);
+    };
+    auto read_p = [&](unsigned base, int mt) __attribute__((always_inline)) -> bf8_t {
+        if (P2_ABL & 4) return __builtin_bit_cast(bf8_t, make_uint4(base, mt, base, mt));
+        return *(const bf8_t*)(smem + base + mt * (PATCH_W * 64));
+    };
+    auto tap_off = [&](int s, int k) __attribute__((always_inline)) -> int {
+        const int gi = s >> 1;
+        const unsigned b2 = (tpk32 >> (8 * (gi & (pg.groups - 1)) + 2 * (2 * (s & 1) + k))) & 3u;   // (ty, tx) of the tap
+        return (int)((b2 >> 1) * PATCH_W + (b2 & 1u));
+    };
+    // ReLU on load as a packed signed-16-bit max against a per-step threshold: 0 (ReLU) or -32768 (identity)
+    auto relu_of = [&](int s) __attribute__((always_inline)) -> int { return (((s >> 1) >> gsh) * P2_CK >= gC1 ? grelu2 : grelu1) ? 0 : (int)0x80008000u; };
+    auto mma = [&](const bf8_t (&wf)[NT], bf8_t x, int relu, int mt) {
+        if (RELU) {
+            typedef __attribute__((ext_vector_type(4))) int i4_t;
+            i4_t xi = __builtin_bit_cast(i4_t, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int r;
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(xi[e]), "s"(relu));
+                xi[e] = r;
+            }
+            x = __builtin_bit_cast(bf8_t, xi);
+        }
+        if (P2_ABL & 2) { acc[mt][0][0] += (float)x[0] + (float)wf[0][0] + (float)wf[1][1] + (float)wf[2][2] + (float)wf[3][3]; return; }
+        if (P2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], x, acc[mt][nt], 0, 0, 0);
+        if (P2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: P[0], W[0] | W[1] .. W[NRING-1], P[1] in flight ------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) patch_piece(0, j);
+#pragma unroll
+    for (int r = 0; r < NRING; ++r) {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) weight_piece(r, r, j);
+    }
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) patch_piece(1, j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 1) * BJ + PJ) : "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // The K loop is a stream of items (step, tap, pixel row mt): 16 per step, 4 MFMAs each.  Pixel fragments live in
+    // a ring of four registers sets: the fragment of item i + 4 is read right after the MFMAs of item i.  The step's
+    // barrier sits behind item 13: by then every read of W[s] and (odd steps) P[gi] has been issued -- lgkmcnt(0)
+    // retires them -- and the data of step s + 1, issued two barriers ago, is retired by the counted vmcnt.
+    bf8_t wfA[NT], wfB[NT], pf[4];
+    read_w(0, 0, wfA);
+    unsigned pb_cur = patch_base(0, tap_off(0, 0));    // tap 0 of the current step
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = read_p(pb_cur, i);
+    int slot = 0;                                       // ring slot of W[s]
+    // P2_DMA_SPREAD == 2: the LDS-DMA batch issued behind the barrier of step s is spread over items 14, 15 of that
+    // step and items 0 .. of the next one -- (step, slot, flags) of the batch in flight are carried over
+    int b_s = 0, b_slot = 0, b_gi = 0;
+    bool b_wmore = false, b_pmore = false;
+    for (int s = 0; s < tot; ++s) {
+        const int gi = s >> 1;
+        const int relu = relu_of(s);
+        const bool more = s + 1 < tot;
+        const int gn = (s + 1) >> 1;                       // group of the next step
+        const int slot_n = slot == NRING - 1 ? 0 : slot + 1;       // W[s + 1]
+        const unsigned pb_t1 = patch_base(gi & 1, tap_off(s, 1));
+        const unsigned pb_next = more ? patch_base(gn & 1, tap_off(s + 1, 0)) : 0u;
+        const bool wmore = s + NRING < tot;               // W[s+NRING] -> the slot of W[s]
+        const bool pmore = (s & 1) && gi + 2 < ngroups;   // P[gi+2] -> the buffer of P[gi]
+        // LDS-DMA pieces of W[s+3] / P[gi+2]: piece k is issued in front of item 14 + k (wrapping into the next step's
+        // items would reorder them against that step's pieces, so at most 14 are spread; the rest go out at once)
+#define P2_DMA_PIECE(k)                                                          \
+    do {                                                                         \
+        if ((k) < BJ) { if (wmore) weight_piece(s + NRING, slot, (k)); }             \
+        else if ((k) - BJ < PJ) { if (pmore) patch_piece(gi + 2, (k) - BJ); }    \
+    } while (0)
+#define P2_DMA_PIECE_B(k)                                                        \
+    do {                                                                         \
+        if ((k) < BJ) { if (b_wmore) weight_piece(b_s + NRING, b_slot, (k)); }   \
+        else if ((k) - BJ < PJ) { if (b_pmore) patch_piece(b_gi + 2, (k) - BJ); }\
+    } while (0)
+        read_w(slot, 1, wfB);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int mt = i & 7;
+            if (P2_DMA_SPREAD == 2 && i + 2 < BJ + PJ && i < 12) P2_DMA_PIECE_B(i + 2);   // rest of the previous batch
+            if (i < 8) mma(wfA, pf[i & 3], relu, mt); else mma(wfB, pf[i & 3], relu, mt);
+            if (i == 13) {
+                if (more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // newer than what step s + 1 needs: the weight tiles W[s+2] .. W[s+NRING-1] and, behind an odd
+                    // step's barrier, a patch (each batch is issued weights first)
+                    if (s + 2 >= tot) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (s & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 2) * BJ) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 2) * BJ + PJ) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    read_w(slot_n, 0, wfA);
+                    pf[0] = read_p(pb_next, 0);
+                    pf[1] = read_p(pb_next, 1);
+                    if (P2_DMA_SPREAD == 2) {
+                        b_s = s; b_slot = slot; b_gi = gi; b_wmore = wmore; b_pmore = pmore;
+                        P2_DMA_PIECE(0);
+                    } else if (P2_DMA_SPREAD) {
+#pragma unroll
+                        for (int k = 0; k < (BJ + PJ + 1) / 2; ++k) P2_DMA_PIECE(k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < BJ + PJ; ++k) P2_DMA_PIECE(k);
+                    }
+                }
+            } else if (i == 12) {
+                // its successor (item 16) is read behind the barrier
+            } else if (i < 4) {
+                pf[i & 3] = read_p(pb_cur, i + 4);
+            } else if (i < 12) {
+                pf[i & 3] = read_p(pb_t1, i - 4);
+            } else if (more) {   // items 14, 15 -> items 2, 3 of the next step
+                pf[i & 3] = read_p(pb_next, i - 12);
+                if (P2_DMA_SPREAD == 2) {
+                    if (i == 14) P2_DMA_PIECE(1);
+                } else if (P2_DMA_SPREAD && i == 14) {
+#pragma unroll
+                    for (int k = (BJ + PJ + 1) / 2; k < BJ + PJ; ++k) P2_DMA_PIECE(k);
+                }
+            }
+        }
+        pb_cur = pb_next;
+        slot = slot_n;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the epilogue reuses the tile memory
+
+    // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores (as gg_fwd_patch_k) ----------
+    constexpr int CROW = BN * 2 + 16;
+    unsigned char* Cs = smem;
+    float* sstat = (float*)(smem + BM * CROW);  // [WMW][2][BN]
+    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    // lane (fq, fr) holds, for each of its 8 pixel rows mt (pixel fr of the row), the 16 consecutive channels
+    // wn*64 + 16 fq + (4 nt + r)
+    constexpr int CL = 4 * NT;
+    const int col0 = wn * 64 + CL * fq;
+    float csum[CL], csq[CL];
+    {
+        float bias_v[CL];
+#pragma unroll
+        for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wm * 128 + mt * 16 + fr;
+            unsigned pk[CL / 2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[mt][nt][r] + bias_v[4 * nt + r];
+                    csum[4 * nt + r] += v[r];
+                    csq[4 * nt + r] = fmaf(v[r], v[r], csq[4 * nt + r]);
+                    if (eact == PAI_ACT_LRELU) v[r] = fmaxf(v[r], 0.2f * v[r]);
+                    else if (eact == PAI_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+                }
+                pk[2 * nt] = pk2bf(v[0], v[1]);
+                pk[2 * nt + 1] = pk2bf(v[2], v[3]);
+            }
+#pragma unroll
+            for (int h = 0; h < CL / 8; ++h)
+                *(uint4*)(Cs + row * CROW + (col0 + 8 * h) * 2) = make_uint4(pk[4 * h], pk[4 * h + 1], pk[4 * h + 2], pk[4 * h + 3]);
+        }
+    }
+    if (a.stats) {
+        // sum over the 16 pixels (lanes fr) of every row of 16 lanes: quad_perm, row_half_mirror, row_mirror
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+            float s = csum[c], q = csq[c];
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, false));
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x141, 0xF, 0xF, false));
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x140, 0xF, 0xF, false));
+            if (fr == 0) {
+                sstat[(wm * 2 + 0) * BN + col0 + c] = s;
+                sstat[(wm * 2 + 1) * BN + col0 + c] = q;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.stats && tid < BN) {
+        float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + n0 + tid;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < WMW; ++i) { s += sstat[(i * 2 + 0) * BN + tid]; q += sstat[(i * 2 + 1) * BN + tid]; }
+        dst[0] = s;
+        dst[g.Cout] = q;
+    }
+    bf16_t* dst;
+    int dstride, dcol;
+    if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
+    else if (n0 < gD1) { dst = y1p; dstride = gD1; dcol = n0; }
+    else { dst = y2p; dstride = gD2; dcol = n0 - gD1; }
+    const bool bwd = a.bz && !a.yact && n0 < gD1;   // uniform per workgroup
+    const bf16_t* bzp = (const bf16_t*)a.bz;
+    const bf16_t* bap = (const bf16_t*)a.badd;
+    const bool bsum = bwd && a.bpart;
+    constexpr int CPR = BN / 8;        // 16-B chunks per row
+    constexpr int ORP = NTHR / CPR;    // rows per pass
+    const int oc = tid % CPR, orow0 = tid / CPR;
+    BwdParams BP;
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+    // producer chunks requested four passes at a time, ahead of that batch's stores (see gg_fwd_mfma_k)
+    constexpr int NP = BM / ORP, NB = 4;
+    if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
+#pragma unroll 1
+    for (int p0 = 0; p0 < NP; p0 += NB) {
+        size_t offs[NB];
+        uint4 zq[NB], aq[NB];
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int row = orow0 + (p0 + p) * ORP;
+            const int gy = gy0 + (row >> 4), gx = gx0 + (row & 15);
+            const size_t pix = (size_t)(img * g.OH + gy * g.OS + poy) * g.OW + gx * g.OS + pox;
+            offs[p] = pix * dstride + dcol + oc * 8;
+            if (bwd) {
+                zq[p] = *(const uint4*)(bzp + offs[p]);
+                aq[p] = bap ? *(const uint4*)(bap + offs[p]) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int row = orow0 + (p0 + p) * ORP;
+            uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
+            if (bwd)
+                o = bwd_chunk(o, zq[p], aq[p], bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
+            *(uint4*)(dst + offs[p]) = o;
+        }
+    }
+    if (bsum)
+        bwd_write_partials<BN, CPR, NTHR / 64>(sstat, bs1, bs2, tid,
+                                               a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1,
+                                               a.bmean + n0, a.brstd + n0);
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+// Tile choice for a problem the matrix-core path accepts (fwd_mfma_ok).  Returns 0 (not for this kernel) or the
+// variant: 1 = 16 x 16 pixels x 256 channels, 8 waves; 2 = 32 x 16 pixels x 128 channels, 8 waves (one workgroup per
+// CU each); 3 = 16 x 16 pixels x 128 channels, 4 waves, two workgroups per CU.
+// tunable "fwd_p2": 0 (default) off, 1 the 8-wave variants, 2 the 4-wave variant only, 3 the 4-wave variant where it
+// applies, else the 8-wave ones.  OFF by default: measured on MI355X (scripts/micro/convbench, round 2) every variant is
+// 3-25 % SLOWER than gg_fwd_patch_k on the layers it accepts -- see the header of this file and DESIGN.md.
+static int p2_variant(const GG& g) {
+    const int mode = pai_tunable("fwd_p2", 0);
+    if (!mode) return 0;
+    if ((g.C1 % P2_CK) || (g.C2 % P2_CK) || g.Cin < 64) return 0;
+    PatchGeo pg;
+    const bool c128 = (g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0);
+    const bool c256 = (g.Cout % 256) == 0 && (g.D2 == 0 || (g.D1 % 256) == 0);
+    if (mode >= 2 && c128 && patch_geo(g, 16, &pg) &&
+        (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= pai_tunable("fwd_p2_min_wgs4", 384))
+        return 3;
+    if (mode == 2) return 0;
+    const int min_wgs = pai_tunable("fwd_p2_min_wgs", 200);
+    if (c256 && patch_geo(g, 16, &pg) && (int64_t)(g.M / 256) * (g.Cout / 256) * g.nphase >= min_wgs) return 1;
+    if (c128 && patch_geo(g, 32, &pg) && (int64_t)(g.M / 512) * (g.Cout / 128) * g.nphase >= min_wgs) return 2;
+    return 0;
+}
+
+int fwd_p2_rows(const GG& g) {
+    const int v = p2_variant(g);
+    return v == 0 ? 0 : (v == 2 ? 512 : 256);
+}
+
+static void p2_prob(const GG& g, const PatchGeo& pg, int mtiles, int ntiles, P2Prob* o) {
+    memset(o, 0, sizeof(*o));
+    o->H = g.H; o->W = g.W; o->C1 = g.C1; o->C2 = g.C2; o->Cin = g.Cin; o->Cout = g.Cout; o->S = g.S;
+    o->nphase = g.nphase; o->OH = g.OH; o->OW = g.OW; o->OS = g.OS; o->D1 = g.D1; o->D2 = g.D2; o->wtaps = g.wtaps;
+    o->relu1 = g.relu1; o->relu2 = g.relu2;
+    o->groups = pg.groups; o->TY = pg.TY; o->TX = pg.TX; o->mtiles = mtiles; o->ntiles = ntiles;
+    for (int ph = 0; ph < 4; ++ph) {
+        for (int q = 0; q < 4; ++q) {
+            const int e = ph * 4 + q;
+            o->wby |= (unsigned long long)((pg.by[ph][q] + 8) & 15) << (4 * e);
+            o->wbx |= (unsigned long long)((pg.bx[ph][q] + 8) & 15) << (4 * e);
+            unsigned b8 = 0, b16 = 0;
+            for (int t = 0; t < 4; ++t) {
+                const unsigned toff = (pg.toff4[ph][q] >> (8 * t)) & 0xffu, wt = (pg.wt4[ph][q] >> (8 * t)) & 0xffu;
+                b8 |= ((toff / PATCH_W) * 2 + (toff % PATCH_W)) << (2 * t);
+                b16 |= (wt & 15u) << (4 * t);
+            }
+            o->toff[e >> 3] |= (unsigned long long)b8 << (8 * (e & 7));
+            o->wt[ph] |= (unsigned long long)b16 << (16 * q);
+        }
+        o->poy |= (unsigned)(g.poy[ph] & 1) << ph;
+        o->pox |= (unsigned)(g.pox[ph] & 1) << ph;
+    }
+}
+
+template <int TH, int NW, int NRING>
+static int p2_launch(const GG& g, const FwdArgs& a, const PatchGeo& pg, hipStream_t s) {
+    typedef P2Dims<TH, NW> PD;
+    const size_t lds = PD::lds_bytes(NRING);
+    static bool attr = false;
+    if (!attr) {
+        const void* fns[2] = {reinterpret_cast<const void*>(&gg_fwd_p2_k<TH, NW, NRING, false>),
+                              reinterpret_cast<const void*>(&gg_fwd_p2_k<TH, NW, NRING, true>)};
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+        }
+        attr = true;
+    }
+    const int mtiles = g.M / PD::BM, ntiles = g.Cout / PD::BN;
+    P2Prob pr;
+    p2_prob(g, pg, mtiles, ntiles, &pr);
+    const dim3 grid(mtiles * ntiles * g.nphase), block(PD::NTHR);
+    if (g.relu1 || g.relu2) hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, NRING, true>), grid, block, lds, s, pr, a);
+    else hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, NRING, false>), grid, block, lds, s, pr, a);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fwd_p2(const GG& g, const FwdArgs& a, hipStream_t s) {
+    const int v = p2_variant(g);
+    PatchGeo pg;
+    PAI_CHECK(v && patch_geo(g, v == 2 ? 32 : 16, &pg), "launch_fwd_p2: problem not eligible");
+    if (v == 1) return p2_launch<16, 8, 3>(g, a, pg, s);
+    if (v == 2) return p2_launch<32, 8, 3>(g, a, pg, s);
+    return p2_launch<16, 4, 2>(g, a, pg, s);
+}
+
+const char* fwd_p2_kernel_name(const GG& g) {
+    const bool relu = g.relu1 || g.relu2;
+    switch (p2_variant(g)) {
+        case 1: return relu ? "gg_fwd_p2_k<16, 8, 3, true>" : "gg_fwd_p2_k<16, 8, 3, false>";
+        case 2: return relu ? "gg_fwd_p2_k<32, 8, 3, true>" : "gg_fwd_p2_k<32, 8, 3, false>";
+        default: return relu ? "gg_fwd_p2_k<16, 4, 2, true>" : "gg_fwd_p2_k<16, 4, 2, false>";
+    }
+}

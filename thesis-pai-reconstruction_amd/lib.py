@@ -50,6 +50,7 @@ SIGNATURES = {
     "pai_last_error": (C.c_char_p, []),
     "pai_version": (_I, []),
     "pai_device_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
+    "pai_set_tunable": (_I, [C.c_char_p, _I]),
     "pai_conv_out_hw": (_I, [_D, C.POINTER(_I), C.POINTER(_I)]),
     "pai_conv_fwd_stats_rows": (_I, [_D]),
     "pai_conv_fwd_stats_rows_max": (_I, [_D]),
