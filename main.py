@@ -51,12 +51,15 @@ def main(hparams):
     torch.cuda.set_device(device)
 
     if hparams.synthetic:
+        # one data set (one seed) for the whole job; the module shards it across the ranks
         data_module = SyntheticDataModule(n_train=hparams.synthetic, n_val=max(hparams.batch_size, 8),
                                           batch_size=hparams.batch_size, size=hparams.image_size,
-                                          seed=1234 + rank)
+                                          seed=1234, world=world, rank=rank)
     else:
+        # every rank reads its own shard of the lists (DistributedSampler semantics, as Lightning-DDP gives the
+        # reference): an epoch is one pass over the data, not `world` passes
         data_module = ImageDataModule(hparams.data, hparams.val_data, batch_size=hparams.batch_size,
-                                      normalize=True, num_workers=hparams.num_workers)
+                                      normalize=True, num_workers=hparams.num_workers, world=world, rank=rank)
 
     checkpoint_callback = ModelCheckpoint(save_top_k=1, monitor="val_ssim", mode="max", filename="best",
                                           save_last=False)

@@ -173,7 +173,9 @@ def test_trainer_fit_logs_and_keeps_best_checkpoint(pai, tmp_path):
     tr = Trainer(max_epochs=4, max_steps=-1, log_every_n_steps=2, check_val_every_n_epoch=2, logger=[logger],
                  callbacks=[ckpt], enable_progress_bar=False)
     tr.fit(m, train_dataloaders=data, val_dataloaders=data[:2])
-    assert tr.global_step == 20
+    # Lightning 2.0, manual optimisation: global_step counts optimizer.step() calls -- two per batch for the GAN loss
+    # (reference models/wrapper.py:136,160); the CSV "step" column and the logging cadence count batches
+    assert tr.batches_seen == 20 and tr.global_step == 40
     csv_path = tmp_path / "logs" / "run" / "version_0" / "metrics.csv"
     rows = open(csv_path).read().strip().splitlines()
     assert rows[0].split(",")[:1] == ["loss"] and "val_ssim" in rows[0] and "step" in rows[0]
@@ -181,7 +183,8 @@ def test_trainer_fit_logs_and_keeps_best_checkpoint(pai, tmp_path):
     best = tmp_path / "logs" / "run" / "version_0" / "checkpoints" / "best.ckpt"
     assert os.path.exists(best) and ckpt.best_model_path == str(best)
     ck = torch.load(best, weights_only=False)
-    assert set(ck) >= {"state_dict", "hyper_parameters", "epoch", "global_step"}
+    assert set(ck) >= {"state_dict", "hyper_parameters", "epoch", "global_step", "optimizer_states", "callbacks"}
+    assert len(ck["optimizer_states"]) == 2 and all("state" in o and "param_groups" in o for o in ck["optimizer_states"])
     m2 = ToyGAN.load_from_checkpoint(best)
     m2.freeze()
     assert not any(p.requires_grad for p in m2.parameters()) and not m2.training
@@ -190,7 +193,14 @@ def test_trainer_fit_logs_and_keeps_best_checkpoint(pai, tmp_path):
     # max_steps stops mid-epoch
     tr2 = Trainer(max_epochs=100, max_steps=7, logger=None, enable_progress_bar=False)
     tr2.fit(ToyGAN(), train_dataloaders=data)
-    assert tr2.global_step == 7
+    assert tr2.global_step == 8 and tr2.batches_seen == 4      # --steps counts optimizer steps: 7 is reached inside batch 4
+    # resume: weights, Adam moments / step counts and the counters continue from the checkpoint
+    torch.manual_seed(1)
+    m3 = ToyGAN()
+    tr3 = Trainer(max_epochs=6, enable_progress_bar=False, logger=None)
+    tr3.fit(m3, train_dataloaders=data, ckpt_path=best)
+    # the best checkpoint was written after epoch index 1 or 3; training continues with the NEXT epoch up to max_epochs = 6
+    assert tr3.batches_seen == ck["batches_seen"] + 5 * (6 - ck["epoch"] - 1) and tr3.global_step == 2 * tr3.batches_seen
 
 
 def test_precision_strings(pai):
@@ -199,6 +209,8 @@ def test_precision_strings(pai):
     assert precision_to_dtype("bf16-mixed") == torch.bfloat16
     with pytest.raises(ValueError):
         precision_to_dtype("8")
+    with pytest.raises(ValueError, match="fp16"):
+        precision_to_dtype("16-mixed")        # no silent remapping to bf16
     m = pai.Pix2Pix(1, 1, (1, 2), 0.0, "gan")
     m.set_precision("bf16-mixed")
     assert m.unet.compute_dtype == torch.bfloat16 and m.discriminator.compute_dtype == torch.bfloat16

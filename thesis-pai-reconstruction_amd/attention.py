@@ -234,6 +234,9 @@ class AttentionUnetEngine(UnetEngine):
                 if training and self.dec_drop[j] > 0:
                     self._dropout(S, j, M, self.dec_c[j], dtype)
             else:
+                # the prediction is handed to the caller: a fresh tensor per call (the caching allocator makes this a
+                # pointer bump), so that a later forward through the same slot cannot overwrite what the caller holds
+                S["pred"] = torch.empty_like(S["pred"])
                 ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_f32=S["pred"])
         pred = S["pred"]
         if self.out_ch != 1:

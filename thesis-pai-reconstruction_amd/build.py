@@ -13,6 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpai_hip.so")
+STAMPS = os.path.join(CSRC, ".build_stamps.json")     # object / library -> content hash of what it was built from
 SOURCES = ["api.hip", "gg_simt.hip", "gg_mfma.hip", "gg_p2.hip", "gg_thin.hip", "gg_small.hip", "gg_group.hip", "bn.hip", "gate.hip", "resnet.hip", "vit.hip", "loss.hip", "ssim.hip", "misc.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gg_tile.h"), os.path.join(HERE, "..", "include", "pai_hip.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in the (unified) VGPR file.  Without it hipcc 7.2
@@ -29,21 +30,44 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=""):
+    """Content hash of the inputs of one build step (sources, headers, flags): a fresh checkout with shipped
+    objects, or a touched-but-unchanged file, must not decide what gets rebuilt -- file times do not travel."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
+def _load_stamps():
+    import json
+    try:
+        with open(STAMPS) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _save_stamps(stamps):
+    import json
+    tmp = STAMPS + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(stamps, f, indent=0, sort_keys=True)
+    os.replace(tmp, STAMPS)
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
-    objs, jobs = [], []
+    stamps = _load_stamps()
+    objs, jobs, new = [], [], {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + HEADERS):
+        new[os.path.basename(o)] = _digest([s] + HEADERS, " ".join(FLAGS))
+        if force or not os.path.exists(o) or stamps.get(os.path.basename(o)) != new[os.path.basename(o)]:
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
 
     def run(cmd):
@@ -57,8 +81,10 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+    new["libpai_hip.so"] = _digest([], " ".join(new[os.path.basename(o)] for o in objs))
+    if force or jobs or not os.path.exists(LIB) or stamps.get("libpai_hip.so") != new["libpai_hip.so"]:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
+    _save_stamps(new)
     return LIB
 
 

@@ -60,6 +60,18 @@ class EMACallback(Callback):
         return {"decay": self.decay, "num_updates": self.num_updates,
                 "shadow_params": [s.detach().cpu().contiguous() for s in self.shadow]}
 
+    def load_state_dict(self, state):
+        """Counterpart of ``state_dict`` (torch_ema's load_state_dict, reference callbacks/ema.py:64-72): call after
+        ``on_fit_start`` has sized the shadow list."""
+        self.decay = state["decay"]
+        self.num_updates = int(state["num_updates"])
+        shadow = state["shadow_params"]
+        if len(shadow) != len(self.shadow):
+            raise ValueError(f"EMA state holds {len(shadow)} tensors, the module has {len(self.shadow)} parameters")
+        with torch.no_grad():
+            for dst, src in zip(self.shadow, shadow):
+                dst.copy_(src.to(dst.device).reshape(dst.shape))
+
 
 def _bump_weight_generation(module: torch.nn.Module):
     """copy_() bumps torch's version counters, which the engines watch; nothing else to do -- kept as

@@ -12,6 +12,7 @@ from typing import Optional
 import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
 
 from .lightning import LightningDataModule
 
@@ -51,18 +52,54 @@ def _read_list(list_file):
     return [(os.path.join(base, it["input"]), os.path.join(base, it["ground_truth"])) for it in items]
 
 
+class ShardedLoader:
+    """A DataLoader over this rank's shard of a dataset.  With ``world > 1`` the indices come from a
+    ``DistributedSampler`` (what Lightning's DDP strategy wraps around the reference's loaders, reference
+    main.py:123-136 + dataset.py:77-83): every epoch is ONE pass over the data split across the ranks, shuffled with
+    a seed all ranks share and the epoch number (``set_epoch``), padded by wrap-around so that every rank draws the
+    same number of batches (the collective gradient exchange needs that)."""
+
+    def __init__(self, dataset, batch_size, shuffle, world=1, rank=0, seed=0, **loader_kw):
+        self.sampler = (DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed,
+                                           drop_last=False) if world > 1 else None)
+        self.loader = DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and self.sampler is None,
+                                 sampler=self.sampler, drop_last=False, **loader_kw)
+        self.dataset, self.batch_size = dataset, batch_size
+
+    def set_epoch(self, epoch: int):
+        if self.sampler is not None:
+            self.sampler.set_epoch(epoch)
+
+    def __iter__(self):
+        return iter(self.loader)
+
+    def __len__(self):
+        return len(self.loader)
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
 class ImageDataModule(LightningDataModule):
     """``ImageDataModule(data_list_file, val_list_file, batch_size, normalize)`` (reference
     dataset.py:11-107).  ``num_workers`` / ``pin_memory`` are additions: the reference decodes on
-    the main process, which cannot feed a GPU at >2k images/s."""
+    the main process, which cannot feed a GPU at >2k images/s.  ``world`` / ``rank`` (default: taken from
+    torch.distributed when it is initialised) shard every split across the data-parallel ranks."""
 
     def __init__(self, data_list_file: str, val_list_file: Optional[str] = None, batch_size: int = 1,
-                 normalize: bool = True, num_workers: int = 0, pin_memory: bool = True):
+                 normalize: bool = True, num_workers: int = 0, pin_memory: bool = True,
+                 world: Optional[int] = None, rank: Optional[int] = None, seed: int = 0):
         super().__init__()
         self.data_tuples = _read_list(data_list_file)
         self.val_tuples = _read_list(val_list_file) if val_list_file is not None else None
         self.batch_size, self.normalize = batch_size, normalize
         self.num_workers, self.pin_memory = num_workers, pin_memory
+        dw, dr = _dist_info()
+        self.world, self.rank, self.seed = (dw if world is None else world), (dr if rank is None else rank), seed
 
     def setup(self, stage: str):
         if stage == "fit":
@@ -75,9 +112,9 @@ class ImageDataModule(LightningDataModule):
             self.pred_split = self.data_tuples
 
     def _loader(self, split, shuffle):
-        return DataLoader(ImageDataset(split, self.normalize), batch_size=self.batch_size, shuffle=shuffle,
-                          drop_last=False, num_workers=self.num_workers,
-                          pin_memory=self.pin_memory and torch.cuda.is_available())
+        return ShardedLoader(ImageDataset(split, self.normalize), self.batch_size, shuffle, self.world, self.rank,
+                             self.seed, num_workers=self.num_workers,
+                             pin_memory=self.pin_memory and torch.cuda.is_available())
 
     def train_dataloader(self):
         return self._loader(self.train_split, True)
@@ -124,20 +161,25 @@ class _TensorPairs(Dataset):
 
 
 class SyntheticDataModule(LightningDataModule):
-    def __init__(self, n_train=256, n_val=32, batch_size=8, size=256, seed=1234, kind="blobs"):
+    """Synthetic pairs, the same data set on every rank (one seed), sharded across the ranks like ImageDataModule."""
+
+    def __init__(self, n_train=256, n_val=32, batch_size=8, size=256, seed=1234, kind="blobs",
+                 world: Optional[int] = None, rank: Optional[int] = None):
         super().__init__()
         self.n_train, self.n_val, self.batch_size, self.size, self.seed, self.kind = \
             n_train, n_val, batch_size, size, seed, kind
+        dw, dr = _dist_info()
+        self.world, self.rank = (dw if world is None else world), (dr if rank is None else rank)
 
     def setup(self, stage: str):
         self.train = _TensorPairs(*synthetic_pairs(self.n_train, self.size, self.seed, self.kind))
         self.val = _TensorPairs(*synthetic_pairs(self.n_val, self.size, self.seed + 1, self.kind))
 
     def train_dataloader(self):
-        return DataLoader(self.train, batch_size=self.batch_size, shuffle=True, drop_last=False)
+        return ShardedLoader(self.train, self.batch_size, True, self.world, self.rank, self.seed)
 
     def val_dataloader(self):
-        return DataLoader(self.val, batch_size=self.batch_size, shuffle=False)
+        return ShardedLoader(self.val, self.batch_size, False, self.world, self.rank, self.seed)
 
     def predict_dataloader(self):
         return DataLoader(self.val, batch_size=self.batch_size, shuffle=False)

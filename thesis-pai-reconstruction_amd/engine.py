@@ -545,6 +545,9 @@ class UnetEngine:
                     # ReLU(Dropout2d(y)) == Dropout2d(ReLU(y)) (mask >= 0): applied to the stored activation
                     self._dropout(S, j, M, self.dec_c[j], dtype)
             else:
+                # the prediction is handed to the caller: a fresh tensor per call (the caching allocator makes this a
+                # pointer bump), so that a later forward through the same slot cannot overwrite what the caller holds
+                S["pred"] = torch.empty_like(S["pred"])
                 ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_f32=S["pred"])
         if L == 1:
             raise ops.PaiError("Unet needs at least two levels")
@@ -786,6 +789,7 @@ class DiscEngine:
             wf, _ = self.packs[k].get(dtype)
             ops.conv_fwd(P["desc"][k], S["a"][k - 1], None, wf, self.convs[k].bias, y_act=S["a"][k])
         wf, _ = self.packs[4].get(dtype)
+        S["logits"] = torch.empty_like(S["logits"])    # owned by the caller, see UnetEngine.forward
         ops.conv_fwd(P["desc"][4], S["a"][3], None, wf, None, y_f32=S["logits"])
         return S["logits"], S
 

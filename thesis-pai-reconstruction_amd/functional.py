@@ -15,6 +15,32 @@ from . import ops
 # --------------------------------------------------------------------------------------
 # networks
 # --------------------------------------------------------------------------------------
+class _SlotRef:
+    """Ownership of one activation slot of an engine between a forward and its backward.  The slot goes back to the
+    engine's pool exactly once: after the (single) backward pass, or when the autograd context is dropped without
+    one (a grad-enabled forward that is never backpropagated must not leak a full set of activations)."""
+
+    def __init__(self, engine, slot):
+        self.engine, self.slot = engine, slot
+
+    def take(self):
+        """The slot for the backward pass; a second backward through the same graph (retain_graph) is refused --
+        the activations of the slot are overwritten in place by the first one."""
+        if self.slot is None:
+            raise ops.PaiError("second backward through the same forward: the engine's activation slot has already "
+                               "been consumed (retain_graph is not supported)")
+        slot, self.slot = self.slot, None
+        return slot
+
+    def __del__(self):
+        if self.slot is not None:
+            try:
+                self.engine.release(self.slot)
+            except Exception:      # interpreter shutdown
+                pass
+            self.slot = None
+
+
 class UnetFunction(torch.autograd.Function):
     """Generator forward/backward through UnetEngine.  Parameter gradients are written into
     the engine's gradient arena and attached as ``p.grad`` directly (autograd receives None
@@ -27,14 +53,14 @@ class UnetFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise ops.PaiError("gradient w.r.t. the generator input is not supported")
         if keep:
-            ctx.engine, ctx.slot, ctx.params = engine, slot, params
+            ctx.engine, ctx.ref, ctx.params = engine, _SlotRef(engine, slot), params
         else:
             engine.release(slot)
         return pred
 
     @staticmethod
     def backward(ctx, gpred):
-        engine, slot, params = ctx.engine, ctx.slot, ctx.params
+        engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
         arena = engine.arena()
         arena.begin_backward(params)
         engine.backward(slot, gpred)
@@ -50,7 +76,7 @@ class DiscFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise ops.PaiError("gradient w.r.t. the conditioning image is not supported")
         if any(ctx.needs_input_grad):
-            ctx.engine, ctx.slot, ctx.params = engine, slot, params
+            ctx.engine, ctx.ref, ctx.params = engine, _SlotRef(engine, slot), params
             ctx.need_dy = ctx.needs_input_grad[1]
             ctx.need_params = any(ctx.needs_input_grad[4:])
         else:
@@ -59,7 +85,7 @@ class DiscFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, glogits):
-        engine, slot, params = ctx.engine, ctx.slot, ctx.params
+        engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
         if ctx.need_params:
             arena = engine.arena()
             arena.begin_backward(params)
@@ -81,14 +107,14 @@ class DiscPairsFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise ops.PaiError("DiscPairsFunction carries no gradient to its image inputs; detach them")
         if any(ctx.needs_input_grad[5:]):
-            ctx.engine, ctx.slot, ctx.params = engine, slot, params
+            ctx.engine, ctx.ref, ctx.params = engine, _SlotRef(engine, slot), params
         else:
             engine.release(slot)
         return logits
 
     @staticmethod
     def backward(ctx, glogits):
-        engine, slot, params = ctx.engine, ctx.slot, ctx.params
+        engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
         arena = engine.arena()
         arena.begin_backward(params)
         engine.backward(slot, glogits, True, False)

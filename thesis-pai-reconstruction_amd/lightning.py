@@ -30,7 +30,8 @@ class LightningModule(nn.Module):
         self._pai_optimizers = None
         self._pai_toggle_state: Dict[Any, bool] = {}
         self._pai_hparams: Dict[str, Any] = {}
-        self.logged: Dict[str, Any] = {}
+        self._pai_opt_steps = 0          # optimizer.step() calls: what Lightning 2.0 calls global_step under
+        self.logged: Dict[str, Any] = {}  # manual optimisation (two per batch for loss_type="gan")
 
     # ---- hyper-parameters / checkpoints ------------------------------------------------
     def save_hyperparameters(self, *args, **kwargs):
@@ -96,7 +97,24 @@ class LightningModule(nn.Module):
         if self._pai_optimizers is None:
             o = self.configure_optimizers()
             self._pai_optimizers = list(o) if isinstance(o, (tuple, list)) else o
+            for opt in (self._pai_optimizers if isinstance(self._pai_optimizers, list) else [self._pai_optimizers]):
+                self._count_steps(opt)
         return self._pai_optimizers
+
+    def _count_steps(self, opt):
+        """Lightning wraps every optimizer so that each ``step()`` advances ``trainer.global_step``; with manual
+        optimisation and two optimizers (reference models/wrapper.py:136,160) that is two per batch, which is what
+        ``--steps`` (max_steps, reference main.py:125) and the checkpoint's ``global_step`` count."""
+        if getattr(opt, "_pai_counted", False):
+            return
+        orig = opt.step
+
+        def step(*args, **kwargs):
+            out = orig(*args, **kwargs)
+            self._pai_opt_steps += 1
+            return out
+        opt.step = step
+        opt._pai_counted = True
 
     def _all_optimizers(self) -> List[torch.optim.Optimizer]:
         o = self.optimizers()
@@ -146,9 +164,13 @@ def precision_to_dtype(precision) -> torch.dtype:
     p = str(precision)
     if p in ("32", "32-true", "64", "64-true"):
         return torch.float32
-    if p in ("bf16", "bf16-mixed", "bf16-true", "16", "16-mixed", "16-true"):
-        # fp16 autocast has no counterpart on the HIP path; bf16 storage + fp32 accumulate is used
+    if p in ("bf16", "bf16-mixed", "bf16-true"):
         return torch.bfloat16
+    if p in ("16", "16-mixed", "16-true"):
+        # fp16 autocast (loss scaling, 5 exponent bits) has no counterpart on the HIP path: refuse rather than
+        # silently train in another format
+        raise ValueError(f"precision {precision!r} (fp16) is not built; use 'bf16-mixed' (bf16 storage, fp32 "
+                         f"accumulate) or '32'")
     raise ValueError(f"unknown precision {precision!r}")
 
 
@@ -239,6 +261,60 @@ class ModelCheckpoint(Callback):
             trainer.save_checkpoint(os.path.join(d, "last.ckpt"))
 
 
+class DevicePrefetcher:
+    """Iterates a loader one batch AHEAD of the consumer: while step i runs, batch i + 1 is already being copied host ->
+    device on a copy stream of its own (pinned staging, non_blocking), so the H2D transfer of 2 x N x 256 x 256 fp32
+    never sits on the step's critical path (reference: Lightning moves each batch synchronously, main.py:136).
+    On a CPU "device" (tests) it is a plain pass-through."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        dev = self.device
+        if dev is None or torch.device(dev).type != "cuda":
+            for batch in self.loader:
+                yield batch if dev is None else tuple(b.to(dev) if torch.is_tensor(b) else b for b in batch)
+            return
+        copy_stream = torch.cuda.Stream(dev)
+        it = iter(self.loader)
+
+        def stage():
+            batch = next(it, None)
+            if batch is None:
+                return None
+            with torch.cuda.stream(copy_stream):
+                out = tuple((b if b.is_pinned() else b.pin_memory()).to(dev, non_blocking=True)
+                            if torch.is_tensor(b) else b for b in batch)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+            return out, done
+
+        nxt = stage()
+        while nxt is not None:
+            cur, done = nxt
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(done)
+            for b in cur:
+                if torch.is_tensor(b):
+                    b.record_stream(main)        # allocated on the copy stream, consumed on the main one
+            nxt = stage()                        # the next copy is in flight while the caller trains on `cur`
+            yield cur
+
+
+def _to_cpu(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().cpu().contiguous()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
+
+
 # --------------------------------------------------------------------------------------
 class Trainer:
     def __init__(self, max_epochs=None, max_steps=-1, log_every_n_steps=50, check_val_every_n_epoch=1,
@@ -256,7 +332,8 @@ class Trainer:
         self.enable_progress_bar = enable_progress_bar
         self.device = device
         self.reducer = reducer
-        self.global_step = 0
+        self.global_step = 0        # optimizer steps (Lightning 2.0 semantics): max_steps, checkpoint field
+        self.batches_seen = 0       # training batches: logging cadence and the CSV "step" column
         self.current_epoch = 0
         self.callback_metrics: Dict[str, float] = {}
         self._step_logs: Dict[str, Any] = {}
@@ -282,20 +359,48 @@ class Trainer:
         self.callback_metrics.update(vals)
         if self.logger is not None and self.global_rank == 0:
             vals["epoch"] = self.current_epoch
-            self.logger.log_metrics(vals, self.global_step)
+            self.logger.log_metrics(vals, self.batches_seen)
 
     def save_checkpoint(self, path):
+        """Lightning-2.0-shaped checkpoint: weights, hyper-parameters, optimizer states (one per configured optimizer,
+        in ``configure_optimizers`` order) and the state of every callback that has one (the EMA shadow weights:
+        the reference returns them from ``on_save_checkpoint``, callbacks/ema.py:54-62) -- enough to resume."""
         m = self.model
+        opts = m._all_optimizers() if m._pai_optimizers is not None else []
         ckpt = {
             "epoch": self.current_epoch,
             "global_step": self.global_step,
+            "batches_seen": self.batches_seen,
             "pytorch-lightning_version": "2.0.2",
             "state_dict": {k: v.detach().cpu().contiguous() for k, v in m.state_dict().items()},
             "hyper_parameters": m.hparams,
+            "optimizer_states": [_to_cpu(o.state_dict()) for o in opts],
+            "callbacks": {type(cb).__name__: cb.state_dict() for cb in self.callbacks if hasattr(cb, "state_dict")},
         }
         tmp = str(path) + ".tmp"
         torch.save(ckpt, tmp)
         os.replace(tmp, str(path))
+
+    def restore(self, model: "LightningModule", checkpoint_path):
+        """Load weights, optimizer states, callback states and the step counters saved by ``save_checkpoint``;
+        call before ``fit`` (``fit(..., ckpt_path=...)`` does)."""
+        ckpt = torch.load(str(checkpoint_path), map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["state_dict"])
+        if self.device is not None:
+            model.to(self.device)
+        opts = model._all_optimizers()
+        for o, st in zip(opts, ckpt.get("optimizer_states", [])):
+            o.load_state_dict(st)
+        for cb in self.callbacks:
+            st = ckpt.get("callbacks", {}).get(type(cb).__name__)
+            if st is not None and hasattr(cb, "load_state_dict"):
+                cb.load_state_dict(st)
+        self.global_step = int(ckpt.get("global_step", 0))
+        model._pai_opt_steps = self.global_step
+        self.batches_seen = int(ckpt.get("batches_seen", 0))
+        # checkpoints are written by ModelCheckpoint after the validation that closes an epoch: continue with the next
+        self.current_epoch = int(ckpt.get("epoch", -1)) + 1
+        return ckpt
 
     # ---- loops -------------------------------------------------------------------------------------
     def _to_device(self, batch):
@@ -310,27 +415,36 @@ class Trainer:
             cb.on_validation_start(self, model)
         self._val_acc = {}
         with torch.no_grad():
-            for bi, batch in enumerate(loader):
-                batch = self._to_device(batch)
+            for bi, batch in enumerate(DevicePrefetcher(loader, self.device)):
                 self._val_bs = int(batch[0].shape[0])
                 model.validation_step(batch, bi)
         acc, self._val_acc = self._val_acc, None
         out = {}
-        for k, items in acc.items():
-            tot = sum(bs for _, bs in items)
-            out[k] = sum(float(v) * bs for v, bs in items) / max(tot, 1)
+        keys = sorted(acc)
+        sums = torch.tensor([[sum(float(v) * bs for v, bs in acc[k]), float(sum(bs for _, bs in acc[k]))] for k in keys],
+                            dtype=torch.float64).reshape(len(keys), 2)
+        if self.world_size > 1 and keys:
+            # the validation split is sharded across the ranks: batch-size-weighted mean over ALL ranks, so that
+            # every rank (and the ModelCheckpoint on rank 0) sees the same epoch value
+            import torch.distributed as dist
+            buf = sums.to(self.device) if (self.device is not None and dist.get_backend() == "nccl") else sums
+            dist.all_reduce(buf)
+            sums = buf.cpu()
+        for i, k in enumerate(keys):
+            out[k] = float(sums[i, 0]) / max(float(sums[i, 1]), 1.0)
         self.callback_metrics.update(out)
         if self.logger is not None and self.global_rank == 0 and out:
             row = dict(out)
             row["epoch"] = self.current_epoch
-            self.logger.log_metrics(row, self.global_step)
+            self.logger.log_metrics(row, self.batches_seen)
             self.logger.save()
         for cb in self.callbacks:
             cb.on_validation_end(self, model)
         model.train()
         return out
 
-    def fit(self, model: LightningModule, datamodule=None, train_dataloaders=None, val_dataloaders=None):
+    def fit(self, model: LightningModule, datamodule=None, train_dataloaders=None, val_dataloaders=None,
+            ckpt_path=None):
         self.model = model
         model.trainer = self
         if self.device is not None:
@@ -348,26 +462,29 @@ class Trainer:
             self.reducer.attach(model)
         for cb in self.callbacks:
             cb.on_fit_start(self, model)
+        if ckpt_path is not None:
+            self.restore(model, ckpt_path)
         t0 = time.time()
         done = False
-        epoch = 0
+        epoch = self.current_epoch
         while not done and (self.max_epochs is None or epoch < self.max_epochs):
             self.current_epoch = epoch
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
-            for bi, batch in enumerate(train_loader):
-                batch = self._to_device(batch)
+            for bi, batch in enumerate(DevicePrefetcher(train_loader, self.device)):
                 self._step_logs = {}
                 model.training_step(batch, bi)
-                self.global_step += 1
+                self.batches_seen += 1
+                self.global_step = model._pai_opt_steps
                 for cb in self.callbacks:
                     cb.on_train_batch_end(self, model, None, batch, bi)
-                if self.global_step % self.log_every_n_steps == 0:
+                if self.batches_seen % self.log_every_n_steps == 0:
                     self._flush_step_logs()
                     if self.enable_progress_bar and self.global_rank == 0:
                         msg = " ".join(f"{k}={v:.4g}" for k, v in self.callback_metrics.items()
                                        if not k.startswith("val_"))
-                        print(f"[epoch {epoch} step {self.global_step} {time.time() - t0:.1f}s] {msg}", flush=True)
+                        print(f"[epoch {epoch} batch {self.batches_seen} step {self.global_step} "
+                              f"{time.time() - t0:.1f}s] {msg}", flush=True)
                 if self.max_steps != -1 and self.global_step >= self.max_steps:
                     done = True
                     break

@@ -76,6 +76,31 @@ class ArenaAdam(torch.optim.Adam):
             self._mirror_state(self._engine.arena())
         return super().state_dict()
 
+    def load_state_dict(self, state_dict):
+        """Restore moments and step count.  On the fused path the moments LIVE in the arena (``mflat`` / ``vflat``):
+        the loaded tensors are copied into the arena views and the per-parameter state is re-pointed at those views, so
+        that the next fused step continues from the loaded moments and bias correction instead of from zero."""
+        if self._arena_steps:
+            self._mirror_state(self._engine.arena())
+        super().load_state_dict(state_dict)
+        params = self.param_groups[0]["params"]
+        if not params or not params[0].is_cuda:
+            return
+        arena = self._engine.arena()
+        if len(params) != len(arena.params) or not arena.adopt_parameters():
+            return
+        with torch.no_grad():
+            for p in params:
+                st = self.state.get(p)
+                if not st or "exp_avg" not in st:
+                    continue
+                m, v = arena.moment_views(p)
+                m.copy_(st["exp_avg"].to(m.device).reshape(m.shape))
+                v.copy_(st["exp_avg_sq"].to(v.device).reshape(v.shape))
+                st["exp_avg"], st["exp_avg_sq"] = m, v
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32)   # host scalar, as _mirror_state keeps it
+        self._arena_steps = 0
+
 
 class MultiAdam(torch.optim.Adam):
     """torch.optim.Adam whose step is ``pai_adam_multi``: the same fused update as ``ArenaAdam`` for networks whose
