@@ -71,26 +71,34 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(batch=4, warmup=1, steps=36, attention=False):
+def cpu_baseline(attention=False, b4_steps=20, b64_steps=1):
+    """The oracle's CPU restatement of the same GAN step (fp32, the ATen kernels the reference dispatches to) on this
+    box's host cores, at BOTH batch sizes BASELINE.md section 4 asks for: batch 4 (BASELINE configs[0], the headline
+    `value`) and batch 64 (the GPU workload's batch; one step, no warm-up -- it takes ~15 s)."""
     import oracle
     torch.set_num_threads(host_cores())
     make = oracle.make_attention_unet_state if attention else oracle.make_unet_state
-    g = oracle.init_state_portable(make(1, 1, MULTS), 1)
-    d = oracle.init_state_portable(oracle.make_disc_state(1), 2)
-    rng = np.random.default_rng(1234)
-    x = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
-    t = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
-    og, od = oracle.AdamState(), oracle.AdamState()
-    for _ in range(warmup):
-        oracle.gan_training_step(g, d, og, od, x, t)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        oracle.gan_training_step(g, d, og, od, x, t)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{steps} fp32 GAN steps at batch {batch} (BASELINE configs[0]), {warmup} warm-up, "
-                      f"oracle/step_ref.py on torch-CPU"}
+
+    def run(batch, warmup, steps):
+        g = oracle.init_state_portable(make(1, 1, MULTS), 1)
+        d = oracle.init_state_portable(oracle.make_disc_state(1), 2)
+        rng = np.random.default_rng(1234)
+        x = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
+        t = torch.from_numpy(rng.random((batch, 1, SIZE, SIZE), dtype=np.float32) * 2 - 1)
+        og, od = oracle.AdamState(), oracle.AdamState()
+        for _ in range(warmup):
+            oracle.gan_training_step(g, d, og, od, x, t)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            oracle.gan_training_step(g, d, og, od, x, t)
+        return batch * steps / (time.perf_counter() - t0)
+
+    v4 = run(4, 1, b4_steps)
+    v64 = run(64, 0, b64_steps) if b64_steps > 0 else None
+    return {"value": round(v4, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{b4_steps} fp32 GAN steps at batch 4 (BASELINE configs[0]), 1 warm-up, oracle/step_ref.py on "
+                      f"torch-CPU; value_b64: {b64_steps} step at batch 64, no warm-up",
+            "value_b64": None if v64 is None else round(v64, 3)}
 
 
 def main():
@@ -98,7 +106,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling: fixed as N grows)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: total images per step, split evenly over the ranks (overrides --batch; the "
+                         "JSON line then says scaling = strong)")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="wire format of the gradient buckets (dist.GradReducer)")
     ap.add_argument("--precision", default="bf16-mixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -123,6 +136,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {world} ranks")
+        args.batch, scaling = args.global_batch // world, "strong"
 
     torch.manual_seed(0)
     mults = TRANS_MULTS if args.model == "trans_unet" else MULTS
@@ -140,7 +158,7 @@ def main():
     reducer = None
     if world > 1:
         pdist.broadcast_parameters(model)
-        reducer = pdist.GradReducer()
+        reducer = pdist.GradReducer(grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
         reducer.attach(model)
 
         class _T:  # the hooks UnetWrapper needs from a trainer
@@ -281,7 +299,7 @@ def main():
                    f"train images/sec ({args.size}x{args.size}, bs={args.batch}) {args.model} GAN step"),
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
+        "scaling": scaling, "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
         "data": "synthetic",
         "config": {"workload": ("Attention U-Net generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
                                 "(BASELINE configs[2])" if args.model == "attention_unet" else
@@ -293,7 +311,8 @@ def main():
                                 "(BASELINE configs[1])"),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "channel_mults": list(mults), "loss_type": "gan",
-                   "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}"},
+                   "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}",
+                   "grad_bucket_dtype": args.grad_dtype},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "clock_ramp_steps": prewarm_steps,
         "step_conv_gflop_per_image": None if gflop != gflop else round(gflop, 2),

@@ -12,6 +12,9 @@
  *   - all pointers are DEVICE pointers unless a parameter says "host".
  *   - nothing is allocated or freed on behalf of the caller: outputs and
  *     workspaces are caller-provided (sizes from the *_rows / *_bytes queries).
+ *   - no process-wide mutable state except the per-device HANDLE (pai_create): it owns the
+ *     caller-provided split-K workspace and scratch; launches use the active handle of the
+ *     calling thread's current HIP device.  One host thread drives a device at a time.
  *   - every launch goes on the caller's hipStream_t (passed as void*), is
  *     asynchronous and never synchronises: all entry points are hipGraph-capturable.
  *   - activations are NHWC ("channels last"): [N][H][W][C], C contiguous.
@@ -107,17 +110,37 @@ int pai_conv_kernel_id(const pai_conv_desc* d, int op);
  * Families without a single dominant kernel report their family name.  Returns 0, < 0 on error. */
 int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len);
 
-/* Split-K scratch.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
+/* ---------------------------------------------------------------------------
+ * Per-device handle.  Owns the two caller-provided work buffers below; nothing else in the library is
+ * stateful.  pai_create(device_id) returns a handle for that HIP device (the first one created for a
+ * device becomes its ACTIVE handle); pai_bind(handle) makes a handle the active one of its device;
+ * every launch uses the active handle of the calling thread's current device; pai_destroy releases the
+ * handle (never the buffers).  A device without a handle runs every layer un-split / on the fallback
+ * kernels.
+ * STREAM CONTRACT of the two buffers (per handle):
+ *   workspace  used by forward / input-gradient calls whose GEMM is split over K: those calls must be
+ *              ordered with respect to each other (one stream, or events).
+ *   scratch    forward / input-gradient calls of the thin layers use its HEAD, weight-gradient calls its
+ *              TAIL: calls within each class must be ordered, the two classes may run concurrently
+ *              (the engine runs weight gradients on a second stream).
+ * ------------------------------------------------------------------------- */
+int pai_create(int device_id, void** handle_out);
+int pai_bind(void* handle);
+int pai_destroy(void* handle);
+int pai_handle_set_workspace(void* handle, void* zeroed_device_memory, int64_t bytes);
+int pai_handle_set_scratch(void* handle, void* device_memory, int64_t bytes);
+
+/* Split-K workspace.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
  * bottleneck: M <= 1024 rows, K up to 8192) are split over K; every split writes its fp32 partial
- * tile into its own slab of a caller-provided scratch buffer (plain stores, no atomics) and a
- * finish kernel sums the slabs in a fixed order.  Register ONE buffer per process with
- * pai_set_workspace, at least max(pai_conv_workspace_bytes(desc, op)) over the forward (op 0) and
- * input-gradient (op 1) calls that will be made; its contents need not be preserved between
- * calls, but calls that use it must be issued on one stream.  Calls that would need more scratch
- * than is registered run un-split. */
+ * tile into its own slab of the handle's workspace (plain stores, no atomics) and a finish kernel sums
+ * the slabs in a fixed order.  Size: at least max(pai_conv_workspace_bytes(desc, op)) over the forward
+ * (op 0) and input-gradient (op 1) calls that will be made; contents need not be preserved between
+ * calls.  Calls that would need more than is registered run un-split.
+ * pai_set_workspace / pai_set_scratch: the same on the active handle of the current device, which is
+ * created on first use (convenience for callers with one model per device). */
 int pai_set_workspace(void* zeroed_device_memory, int64_t bytes);
 int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op);
-/* General (dirty) scratch: the wide->thin layers (ConvTranspose2d(128,1) head, input gradient of
+/* General (dirty) scratch of the handle: the wide->thin layers (ConvTranspose2d(128,1) head, input gradient of
  * the first discriminator conv) run as a skinny GEMM into fp32 scratch followed by a col2im pass.
  * Their weight gradients (op 2) collect one partial tile per workgroup there and add them in a second
  * pass.  Forward / input-gradient calls use the HEAD of the buffer, weight-gradient calls its TAIL, so

@@ -74,3 +74,21 @@ def test_product_path_refuses_cpu_tensors(pai):
         PF.ssim(x, x)
     with pytest.raises(pai.PaiError):
         PF.l1_loss(x.requires_grad_(True), x)
+
+
+def test_handle_api_host_side(pai):
+    """pai_create / pai_bind / pai_destroy and the per-handle buffer registration are pure host bookkeeping: two handles
+    of one device keep their own workspace / scratch, the first one created is active, destroying the active one
+    leaves the device without buffers (split-K queries then answer "un-split")."""
+    lib = pai.lib.load()
+    h1, h2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.pai_create(0, ctypes.byref(h1)) == 0 and lib.pai_create(0, ctypes.byref(h2)) == 0
+    assert h1.value and h2.value and h1.value != h2.value
+    assert lib.pai_create(-1, ctypes.byref(h1)) != 0 and b"out of range" in lib.pai_last_error()
+    fake = ctypes.c_void_p(0x10000)       # never dereferenced on the host
+    assert lib.pai_handle_set_workspace(h1, fake, 1 << 20) == 0
+    assert lib.pai_handle_set_scratch(h2, fake, 1 << 10) == 0
+    assert lib.pai_bind(h2) == 0 and lib.pai_bind(h1) == 0
+    assert lib.pai_bind(None) != 0
+    assert lib.pai_destroy(h2) == 0 and lib.pai_destroy(h1) == 0
+    assert lib.pai_destroy(None) != 0

@@ -76,6 +76,33 @@ def _worker(rank, world, port, q):
             eng.grad_ready_hook(A, A.end_of(params[0]))
         red.finish()
 
+        # ---- bf16 wire format: same buckets, half the bytes, bf16 rounding of the summands; fp32 master gradients ----
+        eng16 = FakeEngine()
+        red16 = pdist.GradReducer(bucket_bytes=4096, overlap=True, grad_dtype=torch.bfloat16)
+        red16.attach_engine(eng16)
+        A = eng16.arena()
+        for p in params:
+            p.grad = None                           # the views of the first engine's arena
+        A.begin_backward(params)
+        gen = torch.Generator().manual_seed(1234 + rank)
+        local = {}
+        for p in params:
+            g = torch.randn(p.numel(), generator=gen)
+            local[id(p)] = g
+            A.seg(p).copy_(g)
+            eng16.grad_ready_hook(A, A.end_of(p))
+        A.attach(params)
+        red16.finish()
+        assert red16.stats["bytes"] * 2 == A.flat.numel() * 4 and A.flat.dtype == torch.float32
+        for p in params:
+            both = [torch.zeros_like(local[id(p)]) for _ in range(world)]
+            dist.all_gather(both, local[id(p)])
+            want32 = sum(both) / world                                     # what the fp32 buckets give
+            want16 = sum(b.bfloat16() for b in both).float() / world       # summands and sum rounded to bf16
+            got = A.seg(p)
+            assert torch.allclose(got, want16, atol=1e-6), (rank, float((got - want16).abs().max()))
+            assert float((got - want32).abs().max()) <= 2 ** -7 * float(sum(b.abs() for b in both).max()) + 1e-6
+
         # ---- plug-in module path + parameter broadcast ---------------------------------------------
         torch.manual_seed(100 + rank)              # ranks start from DIFFERENT weights
         net = nn.Sequential(nn.Conv2d(1, 4, 3, padding=1), nn.ReLU(), nn.Conv2d(4, 1, 3, padding=1))

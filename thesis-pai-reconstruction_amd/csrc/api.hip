@@ -259,13 +259,84 @@ static void finish_gg(GG* g) {
         g->lsw = g->lsh = g->ldw = g->ldh = -1;
 }
 
-float* g_workspace = nullptr;
-int64_t g_workspace_bytes = 0;
+// ---- per-device handles ---------------------------------------------------------------------------------
+// "no hidden global state except a per-device handle".  A handle owns the caller-provided split-K
+// workspace and scratch of ONE device; several handles may exist per device (e.g. one per model replica), one of them
+// is ACTIVE per device at a time (pai_bind) and serves the launches issued while that device is current.  The table
+// below only maps device -> active handle.  Threading contract: one host thread drives a device at a time.
+constexpr int PAI_MAX_DEVICES = 64;
+static pai_handle_s* g_active[PAI_MAX_DEVICES];
+static const pai_handle_s g_empty_handle = {-1, nullptr, 0, nullptr, 0};
+
+static int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < PAI_MAX_DEVICES ? dev : -1;
+}
+
+const pai_handle_s* pai_ctx() {
+    const int dev = current_device();
+    return dev >= 0 && g_active[dev] ? g_active[dev] : &g_empty_handle;
+}
+
+extern "C" int pai_create(int device_id, void** handle_out) {
+    PAI_CHECK(handle_out != nullptr, "pai_create: null handle_out");
+    PAI_CHECK(device_id >= 0 && device_id < PAI_MAX_DEVICES, "pai_create: device id %d out of range", device_id);
+    pai_handle_s* h = new pai_handle_s{device_id, nullptr, 0, nullptr, 0};
+    if (!g_active[device_id]) g_active[device_id] = h;      // the first handle of a device is active at once
+    *handle_out = h;
+    return 0;
+}
+
+extern "C" int pai_bind(void* handle) {
+    PAI_CHECK(handle != nullptr, "pai_bind: null handle");
+    pai_handle_s* h = (pai_handle_s*)handle;
+    g_active[h->device] = h;
+    return 0;
+}
+
+extern "C" int pai_destroy(void* handle) {
+    PAI_CHECK(handle != nullptr, "pai_destroy: null handle");
+    pai_handle_s* h = (pai_handle_s*)handle;
+    if (g_active[h->device] == h) g_active[h->device] = nullptr;
+    delete h;          // the buffers are the caller's
+    return 0;
+}
+
+extern "C" int pai_handle_set_workspace(void* handle, void* zeroed_device_memory, int64_t bytes) {
+    PAI_CHECK(handle != nullptr, "pai_handle_set_workspace: null handle");
+    pai_handle_s* h = (pai_handle_s*)handle;
+    h->workspace = (float*)zeroed_device_memory;
+    h->workspace_bytes = zeroed_device_memory ? bytes : 0;
+    return 0;
+}
+
+extern "C" int pai_handle_set_scratch(void* handle, void* device_memory, int64_t bytes) {
+    PAI_CHECK(handle != nullptr, "pai_handle_set_scratch: null handle");
+    pai_handle_s* h = (pai_handle_s*)handle;
+    h->scratch = (float*)device_memory;
+    h->scratch_bytes = device_memory ? bytes : 0;
+    return 0;
+}
+
+// The active handle of the current device, created on first use: convenience for single-model callers
+// (pai_set_workspace / pai_set_scratch without an explicit pai_create).
+static pai_handle_s* active_or_new() {
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    if (!g_active[dev]) g_active[dev] = new pai_handle_s{dev, nullptr, 0, nullptr, 0};
+    return g_active[dev];
+}
 
 extern "C" int pai_set_workspace(void* zeroed_device_memory, int64_t bytes) {
-    g_workspace = (float*)zeroed_device_memory;
-    g_workspace_bytes = zeroed_device_memory ? bytes : 0;
-    return 0;
+    pai_handle_s* h = active_or_new();
+    PAI_CHECK(h != nullptr, "pai_set_workspace: no current HIP device");
+    return pai_handle_set_workspace(h, zeroed_device_memory, bytes);
+}
+
+extern "C" int pai_set_scratch(void* device_memory, int64_t bytes) {
+    pai_handle_s* h = active_or_new();
+    PAI_CHECK(h != nullptr, "pai_set_scratch: no current HIP device");
+    return pai_handle_set_scratch(h, device_memory, bytes);
 }
 
 extern "C" int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op) {

@@ -171,9 +171,18 @@ int fwd_mfma_ksplit(const GG& g);
 const char* fwd_mfma_kernel_name(const GG& g);
 const char* wgrad_mfma_kernel_name(const GG& g);
 int64_t fwd_mfma_workspace_bytes(const GG& g);
-// registered scratch for split-K partial sums (fp32, kept all-zero between calls)
-extern float* g_workspace;
-extern int64_t g_workspace_bytes;
+// Per-device handle (pai_create / pai_bind): owner of the caller-provided split-K workspace and general scratch.
+// Entry points use the ACTIVE handle of the current HIP device (pai_ctx()); there is no process-wide buffer.
+struct pai_handle_s {
+    int device;
+    float* workspace;          // split-K partial sums (fp32 slabs)
+    int64_t workspace_bytes;
+    float* scratch;            // thin layers: skinny-GEMM output (head of the buffer), weight-gradient partial tiles (tail)
+    int64_t scratch_bytes;
+};
+// active handle of the calling thread's current HIP device; never null (a device without a handle has an empty one:
+// no workspace, no scratch -> un-split / fallback kernels)
+const pai_handle_s* pai_ctx();
 int fwd_simt_mtiles(const GG& g);
 int fwd_mfma_mtiles(const GG& g);
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);
@@ -192,8 +201,6 @@ int grouped3_rows(const GG& g);
 int launch_grouped3(const GG& g, const FwdArgs& a, hipStream_t s);
 
 // thin layers on the matrix cores (gg_thin.hip)
-extern float* g_scratch;
-extern int64_t g_scratch_bytes;
 bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a);
 bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a);
 bool thin_dgrad_shape_ok(int dtype, const GG& g);

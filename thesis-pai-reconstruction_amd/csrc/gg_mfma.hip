@@ -107,7 +107,7 @@ int64_t fwd_mfma_workspace_bytes(const GG& g) {
 // the split actually used: only when the registered scratch is large enough
 static int fwd_effective_ksplit(const GG& g) {
     const int ks = fwd_cfg(g).ksplit;
-    if (ks > 1 && (g_workspace == nullptr || g_workspace_bytes < fwd_mfma_workspace_bytes(g))) return 1;
+    if (ks > 1 && (pai_ctx()->workspace == nullptr || pai_ctx()->workspace_bytes < fwd_mfma_workspace_bytes(g))) return 1;
     return ks;
 }
 
@@ -886,7 +886,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     const dim3 grid(mtiles * ntiles * g.nphase * c.ksplit);
 #define FWD_LAUNCH(BM, BN, SK, DB)                                                                  \
     hipLaunchKernelGGL((gg_fwd_mfma_k<BM, BN, SK, DB>), grid, dim3(BM * 2), (fwd_lds_bytes<BM, BN, DB>()), s, g, \
-                       a, mtiles, ntiles, c.ksplit, g_workspace)
+                       a, mtiles, ntiles, c.ksplit, pai_ctx()->workspace)
     if (c.bm == 256) {
         static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
         if (!attr_set) {
@@ -901,13 +901,13 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         FWD_LAUNCH(128, 128, false, true);
     } else if (c.bm == 128 && c.bn == 128 && c.ksplit == 1 && getenv("PAI_FWD_MODE") && atoi(getenv("PAI_FWD_MODE")) == 3) {
         hipLaunchKernelGGL((gg_fwd_mfma_k<128, 128, false, false, 32>), grid, dim3(512),
-                           (fwd_lds_bytes<128, 128, false, 32>()), s, g, a, mtiles, ntiles, c.ksplit, g_workspace);
+                           (fwd_lds_bytes<128, 128, false, 32>()), s, g, a, mtiles, ntiles, c.ksplit, pai_ctx()->workspace);
     } else if (c.ksplit > 1) {
         if (c.bn == 128) FWD_LAUNCH(128, 128, true, false); else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
         const int ftiles = cdiv(g.M, FIN_ROWS);
         hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
-                           g_workspace, ftiles, c.ksplit);
+                           pai_ctx()->workspace, ftiles, c.ksplit);
     } else {
         PatchGeo pg;
         const int prow = patch_rows(g, c);

@@ -27,14 +27,6 @@ typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
 
 __device__ uint4 g_zero_line_thin[16];  // 256 B of zeros (device symbols are per translation unit)
 
-float* g_scratch = nullptr;
-int64_t g_scratch_bytes = 0;
-
-extern "C" int pai_set_scratch(void* device_memory, int64_t bytes) {
-    g_scratch = (float*)device_memory;
-    g_scratch_bytes = device_memory ? bytes : 0;
-    return 0;
-}
 
 __device__ __forceinline__ bf8_t relu8(bf8_t f) {
     s8_t x = __builtin_bit_cast(s8_t, f);
@@ -220,7 +212,7 @@ bool thin_dgrad_shape_ok(int dtype, const GG& g) {
 
 bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (!thin_dgrad_shape_ok(dtype, g) || a.stats) return false;
-    return g_scratch != nullptr && g_scratch_bytes >= thin_dgrad_scratch_bytes(g, a);
+    return pai_ctx()->scratch != nullptr && pai_ctx()->scratch_bytes >= thin_dgrad_scratch_bytes(g, a);
 }
 
 // KS = Cin / 32 is a template parameter: with a run-time trip count the fragment arrays are indexed
@@ -310,7 +302,7 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     // every wave keeps the whole filter in registers: give it >= 4 pixel groups to amortise that
     int blocks = cdiv((int64_t)g.N * g.H * g.W, 256);
     if (blocks > 4096) blocks = 4096;
-#define TDG(TT, KK) hipLaunchKernelGGL((thin_dgrad_gemm_k<TT, KK>), dim3(blocks), dim3(256), 0, s, g, a, g_scratch, t0)
+#define TDG(TT, KK) hipLaunchKernelGGL((thin_dgrad_gemm_k<TT, KK>), dim3(blocks), dim3(256), 0, s, g, a, pai_ctx()->scratch, t0)
 #define TDG_K(TT)                                     \
     switch (g.Cin / 32) {                             \
         case 1: TDG(TT, 1); break;                    \
@@ -326,7 +318,7 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     PAI_LAUNCH_CHECK();
     int64_t b2 = ((int64_t)g.N * g.OH * g.OW + 255) / 256;
     if (b2 > 8192) b2 = 8192;
-    hipLaunchKernelGGL(thin_col2im_k, dim3((int)b2), dim3(256), 0, s, g, a, (const float*)g_scratch, T, t0);
+    hipLaunchKernelGGL(thin_col2im_k, dim3((int)b2), dim3(256), 0, s, g, a, (const float*)pai_ctx()->scratch, T, t0);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -578,10 +570,11 @@ static int launch_tw(ThinW& p, int T, hipStream_t s) {
     const int groups = cdiv(p.WC1 + p.WC2, 128);
     const int64_t need = thin_wgrad_scratch_bytes(p.M, T, p.WC1 + p.WC2);
     static const bool no_two = getenv("PAI_TW_ATOMIC") && atoi(getenv("PAI_TW_ATOMIC")) != 0;
-    const bool two_stage = !no_two && g_scratch != nullptr && g_scratch_bytes >= need;
+    const pai_handle_s* ctx = pai_ctx();
+    const bool two_stage = !no_two && ctx->scratch != nullptr && ctx->scratch_bytes >= need;
     int blocks = tw_blocks(p.M, groups, two_stage);
     const int cpb = cdiv(chunks, blocks);
-    p.partial = two_stage ? (float*)((char*)g_scratch + (g_scratch_bytes - need)) : nullptr;
+    p.partial = two_stage ? (float*)((char*)ctx->scratch + (ctx->scratch_bytes - need)) : nullptr;
     if (T == 1) hipLaunchKernelGGL(thin_wgrad_k<1>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
     else hipLaunchKernelGGL(thin_wgrad_k<2>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
     PAI_LAUNCH_CHECK();

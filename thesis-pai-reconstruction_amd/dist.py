@@ -43,9 +43,19 @@ class GradReducer:
     the buckets are then reduced by ``pai_allreduce`` on a communication stream of this object instead of
     ``torch.distributed.all_reduce``; bucketing, overlap and averaging are the same."""
 
-    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, comm=None):
+    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, comm=None,
+                 grad_dtype: Optional[torch.dtype] = None):
+        """``grad_dtype``: wire format of the arena buckets, torch.float32 (default) or torch.bfloat16 (also
+        PAI_GRAD_DTYPE=bf16).  With bf16 every bucket is cast into a persistent bf16 staging arena, reduced there and
+        cast back when it is waited for: half the bytes per xGMI link (109 MB instead of 218 MB for the Pix2Pix
+        generator) at bf16 rounding of the summands; the master gradients stay fp32."""
         import os
         self.pg = process_group
+        if grad_dtype is None:
+            grad_dtype = torch.bfloat16 if os.environ.get("PAI_GRAD_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"GradReducer: grad_dtype must be float32 or bfloat16, not {grad_dtype}")
+        self.grad_dtype = grad_dtype
         self.comm = comm
         if comm is None and os.environ.get("PAI_COMM", "") == "rccl" and dist.is_initialized() and \
                 dist.get_world_size(process_group) > 1 and torch.cuda.is_available():
@@ -79,7 +89,7 @@ class GradReducer:
     def _state(self, arena):
         st = self._arenas.get(id(arena))
         if st is None:
-            st = {"arena": arena, "sent": 0, "works": [], "active": False}
+            st = {"arena": arena, "sent": 0, "works": [], "active": False, "stage": None}
             self._arenas[id(arena)] = st
         return st
 
@@ -88,9 +98,16 @@ class GradReducer:
             return
         buf = st["arena"].flat[lo:hi]
         if self.world > 1:
-            st["works"].append(self._all_reduce_async(buf))
+            if self.grad_dtype == torch.float32:
+                st["works"].append((self._all_reduce_async(buf), None, lo, hi))
+            else:
+                if st["stage"] is None:
+                    st["stage"] = torch.empty(st["arena"].flat.numel(), dtype=self.grad_dtype, device=buf.device)
+                stage = st["stage"][lo:hi]
+                stage.copy_(buf)                                   # fp32 -> bf16, ordered before the collective
+                st["works"].append((self._all_reduce_async(stage), stage, lo, hi))
         self.stats["buckets"] += 1
-        self.stats["bytes"] += (hi - lo) * 4
+        self.stats["bytes"] += (hi - lo) * (4 if self.grad_dtype == torch.float32 else 2)
 
     def _all_reduce_async(self, buf):
         """In-place SUM all-reduce of ``buf``, ordered after the work already issued on the current stream; returns a
@@ -128,8 +145,10 @@ class GradReducer:
                 continue
             total = st["arena"].flat.numel()
             self._launch(st, st["sent"], total)
-            for w in st["works"]:
+            for w, stage, lo, hi in st["works"]:
                 w.wait()
+                if stage is not None:
+                    st["arena"].flat[lo:hi].copy_(stage)           # reduced bf16 sum back into the fp32 master gradient
             if self.world > 1:
                 st["arena"].flat.mul_(1.0 / self.world)
             st["sent"], st["works"], st["active"] = 0, [], False

@@ -51,6 +51,11 @@ SIGNATURES = {
     "pai_version": (_I, []),
     "pai_device_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     "pai_set_tunable": (_I, [C.c_char_p, _I]),
+    "pai_create": (_I, [_I, C.POINTER(C.c_void_p)]),
+    "pai_bind": (_I, [C.c_void_p]),
+    "pai_destroy": (_I, [C.c_void_p]),
+    "pai_handle_set_workspace": (_I, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pai_handle_set_scratch": (_I, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pai_conv_out_hw": (_I, [_D, C.POINTER(_I), C.POINTER(_I)]),
     "pai_conv_fwd_stats_rows": (_I, [_D]),
     "pai_conv_fwd_stats_rows_max": (_I, [_D]),

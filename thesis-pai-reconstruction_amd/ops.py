@@ -117,7 +117,60 @@ class _Timed:
         return False
 
 
-_WORKSPACE = None
+class Handle:
+    """A per-device handle of libpai_hip.so (pai_create / pai_bind / pai_destroy, include/pai_hip.h) together with the
+    torch tensors registered as its split-K workspace and scratch (the library never allocates).  One per device is
+    created on first use (``handle_for``); more can be made for independent model replicas and switched with
+    ``bind()``."""
+
+    def __init__(self, device):
+        dev = torch.device(device)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self._h = C.c_void_p()
+        L.check(L.load().pai_create(self.device.index, C.byref(self._h)), "pai_create")
+        self.workspace = None
+        self.scratch = None
+
+    def bind(self):
+        L.check(L.load().pai_bind(self._h), "pai_bind")
+        return self
+
+    def ensure_workspace(self, nbytes: int) -> None:
+        """Register (grow) the zero-filled split-K workspace (pai_handle_set_workspace)."""
+        if nbytes <= 0:
+            return
+        if self.workspace is None or self.workspace.numel() * 4 < nbytes:
+            self.workspace = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            L.check(L.load().pai_handle_set_workspace(self._h, self.workspace.data_ptr(), self.workspace.numel() * 4),
+                    "pai_handle_set_workspace")
+
+    def ensure_scratch(self, nbytes: int) -> None:
+        """Register (grow) the general scratch buffer (pai_handle_set_scratch)."""
+        if nbytes <= 0:
+            return
+        if self.scratch is None or self.scratch.numel() * 4 < nbytes:
+            self.scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            L.check(L.load().pai_handle_set_scratch(self._h, self.scratch.data_ptr(), self.scratch.numel() * 4),
+                    "pai_handle_set_scratch")
+
+    def close(self):
+        if self._h:
+            L.check(L.load().pai_destroy(self._h), "pai_destroy")
+            self._h = C.c_void_p()
+            _HANDLES.pop(self.device.index, None) if _HANDLES.get(self.device.index) is self else None
+
+
+_HANDLES = {}
+
+
+def handle_for(device) -> Handle:
+    """The default handle of ``device`` (created, and therefore active, on first use)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    h = _HANDLES.get(idx)
+    if h is None:
+        h = _HANDLES[idx] = Handle(torch.device("cuda", idx))
+    return h
 
 
 def conv_workspace_bytes(d: ConvDesc, op: int) -> int:
@@ -125,16 +178,8 @@ def conv_workspace_bytes(d: ConvDesc, op: int) -> int:
 
 
 def ensure_workspace(nbytes: int, device) -> None:
-    """Register (grow) the zero-filled split-K scratch buffer of libpai_hip.so (pai_set_workspace)."""
-    global _WORKSPACE
-    if nbytes <= 0:
-        return
-    if _WORKSPACE is None or _WORKSPACE.numel() * 4 < nbytes or _WORKSPACE.device != torch.device(device):
-        _WORKSPACE = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        L.check(L.load().pai_set_workspace(_WORKSPACE.data_ptr(), _WORKSPACE.numel() * 4), "pai_set_workspace")
-
-
-_SCRATCH = None
+    """Grow the split-K workspace of the device's default handle."""
+    handle_for(device).ensure_workspace(nbytes)
 
 
 def conv_scratch_bytes(d: ConvDesc, op: int) -> int:
@@ -143,20 +188,15 @@ def conv_scratch_bytes(d: ConvDesc, op: int) -> int:
 
 def scratch_bytes_for(descs) -> int:
     """Scratch to register for a set of layers: forward / input-gradient calls use the head of the buffer, the
-    weight-gradient calls (which run on a second stream) its tail -- see pai_set_scratch in include/pai_hip.h."""
+    weight-gradient calls (which run on a second stream) its tail -- see the stream contract in include/pai_hip.h."""
     head = max((conv_scratch_bytes(d, op) for d in descs for op in (0, 1)), default=0)
     tail = max((conv_scratch_bytes(d, 2) for d in descs), default=0)
     return head + tail
 
 
 def ensure_scratch(nbytes: int, device) -> None:
-    """Register (grow) the general scratch buffer of libpai_hip.so (pai_set_scratch)."""
-    global _SCRATCH
-    if nbytes <= 0:
-        return
-    if _SCRATCH is None or _SCRATCH.numel() * 4 < nbytes or _SCRATCH.device != torch.device(device):
-        _SCRATCH = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        L.check(L.load().pai_set_scratch(_SCRATCH.data_ptr(), _SCRATCH.numel() * 4), "pai_set_scratch")
+    """Grow the general scratch buffer of the device's default handle."""
+    handle_for(device).ensure_scratch(nbytes)
 
 
 def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None):
