@@ -221,6 +221,23 @@ def test_bf16_mode_tracks_fp32_oracle(pai, golden_dir):
     s16 = PF.ssim_per_image(PF.denormalize(p16), PF.denormalize(batch[1]))
     s32 = PF.ssim_per_image(PF.denormalize(p32), PF.denormalize(batch[1]))
     assert float((s16 - s32).abs().max()) < 5e-3
+    # north_star: "SSIM/PSNR bit-identical ordering".  Rank the images by quality against targets of graded
+    # difficulty (the fp32 prediction plus noise of increasing strength, so that neighbouring scores are several
+    # times further apart than the bf16 deviation bounded above): both metrics must order the batch identically
+    # whether the prediction came from the bf16 matrix-core path or the fp32 parity path.
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    order = torch.randperm(n, generator=gen)
+    tgt = torch.empty_like(p32)
+    for rank_, i in enumerate(order.tolist()):
+        noise = torch.randn(p32[i].shape, generator=gen).to(DEV)
+        tgt[i] = (p32[i] + (0.05 + 0.15 * rank_) * noise).clamp(-1, 1)
+    q16 = PF.ssim_per_image(PF.denormalize(p16), PF.denormalize(tgt))
+    q32 = PF.ssim_per_image(PF.denormalize(p32), PF.denormalize(tgt))
+    assert float(q32.sort().values.diff().min()) > 4 * 5e-3           # the ranking is not decided by bf16 noise
+    assert torch.equal(q16.argsort(), q32.argsort()) and q32.argsort(descending=True).tolist() == order.tolist()
+    mse16 = ((PF.denormalize(p16) - PF.denormalize(tgt)) ** 2).flatten(1).mean(1)
+    mse32 = ((PF.denormalize(p32) - PF.denormalize(tgt)) ** 2).flatten(1).mean(1)
+    assert torch.equal((-mse16.log()).argsort(), (-mse32.log()).argsort())       # per-image PSNR ordering
     for s in range(2):
         m.logged = {}
         m.training_step(batch, s)

@@ -166,12 +166,21 @@ def test_bf16_mode_tracks_fp32(pai, golden_dir):
     with torch.no_grad():
         p16 = m.unet(batch[0])
     want = torch.from_numpy(z["pred_full"])
+    # noise-dominated at random initialisation (docstring): a sanity bound only; the bounds that mean something are
+    # the trajectory ones below (and tests/test_gpu_configs.py at the full configs[3] size)
     assert float((p16.cpu() - want).norm() / want.norm()) < 0.25
+    m32, _, _ = build(pai, "next", mults, "gan", seed)
     first = None
     for s in range(4):
-        m.logged = {}
-        m.training_step(batch, s)
-        vals = {k: float(v) for k, v in m.logged.items()}
+        logs = []
+        for mm in (m, m32):
+            mm.logged = {}
+            mm.training_step(batch, s)
+            logs.append({k: float(v) for k, v in mm.logged.items()})
+        vals, vals32 = logs
         assert all(np.isfinite(v) for v in vals.values()), vals
+        for k in ("loss", "d_loss", "train_rmse", "train_psnr"):
+            # bf16 storage follows the fp32 parity path step by step (measured <= 0.4 % at the configs[3] size)
+            assert abs(vals[k] - vals32[k]) <= 0.02 * max(abs(vals32[k]), 1.0), (s, k, vals[k], vals32[k])
         first = first or vals
     assert vals["loss"] < first["loss"] and vals["train_rmse"] < first["train_rmse"]

@@ -278,13 +278,21 @@ def test_ragged_batch_and_bf16(pai, golden_dir):
     with torch.no_grad():
         p16 = m16.unet(batch[0])
     w4 = torch.from_numpy(z["pred_full"])
+    # rounding-noise dominated at random initialisation (0.54 at the configs[4] size): sanity bound only; what is held
+    # tightly is the training trajectory against the fp32 parity path (tests/test_gpu_configs.py: <= 0.05 % at full size)
     assert float((p16.cpu() - w4).norm() / w4.norm()) < 0.25
+    m32, _, _ = build(pai, mults, 2, "gan", seed)
     first = None
     for s in range(4):
-        m16.logged = {}
-        m16.training_step(batch, s)
-        vals = {k: float(v) for k, v in m16.logged.items()}
+        logs = []
+        for mm in (m16, m32):
+            mm.logged = {}
+            mm.training_step(batch, s)
+            logs.append({k: float(v) for k, v in mm.logged.items()})
+        vals, vals32 = logs
         assert all(np.isfinite(v) for v in vals.values()), vals
+        for k in ("loss", "d_loss", "train_rmse", "train_psnr"):
+            assert abs(vals[k] - vals32[k]) <= 0.02 * max(abs(vals32[k]), 1.0), (s, k, vals[k], vals32[k])
         first = first or vals
     assert vals["loss"] < first["loss"] and vals["train_rmse"] < first["train_rmse"]
 
