@@ -110,6 +110,11 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling: total images per step, split evenly over the ranks (overrides --batch; the "
                          "JSON line then says scaling = strong)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as ONE hipGraph launch (graph.GraphedStep; single process only) instead of issuing "
+                         "every launch from Python.  Measured on MI355X (round 2): host time per step 3.96 -> 0.73 ms, but the "
+                         "step itself 7.42 -> 7.72 ms -- the replay overlaps the three streams of the step less well than "
+                         "eager submission does, and the run is GPU-bound -- so eager stays the default")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="wire format of the gradient buckets (dist.GradReducer)")
     ap.add_argument("--precision", default="bf16-mixed")
@@ -177,6 +182,17 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # --graph: one hipGraph launch per step (the same kernels on the same three streams, captured after three eager
+    # steps); with more than one rank the bucketed RCCL exchange is not captured and the step is issued from Python.
+    from thesis_pai_reconstruction_amd.graph import GraphedStep
+    graphed = GraphedStep(model, warmup=3) if (world == 1 and args.graph) else None
+
+    def run_step(b, i):
+        if graphed is not None:
+            graphed(b, i)
+        else:
+            model.training_step(b, i)
+
     # Clock ramp: a box that has been idle starts in a low-power state and takes a few seconds of load
     # to reach its sustained clocks (first 25 steps measured 20-25 % slower than the next 25).  Untimed
     # groups of 10 steps run until two consecutive groups agree within 2 % (at least 2 s, at most 20 s);
@@ -186,7 +202,7 @@ def main():
         torch.cuda.synchronize()
         tg = time.perf_counter()
         for i in range(10):
-            model.training_step(batch, i)
+            run_step(batch, i)
         torch.cuda.synchronize()
         cur = time.perf_counter() - tg
         prewarm_steps += 10
@@ -201,20 +217,20 @@ def main():
         if float(flag) == 0.0:
             break
     for i in range(args.warmup):
-        model.training_step(batch, i)
+        run_step(batch, i)
     torch.cuda.synchronize()
-    # host-side cost of issuing one step (launches + autograd plumbing), measured without waiting
-    # for the GPU: if this approaches ms_per_step the run is launch-bound, not kernel-bound
+    # host-side cost of issuing one step (launches + autograd plumbing, or one graph launch), measured without
+    # waiting for the GPU: if this approaches ms_per_step the run is launch-bound, not kernel-bound
     tq = time.perf_counter()
     for i in range(3):
-        model.training_step(batch, i)
+        run_step(batch, i)
     host_issue_ms = (time.perf_counter() - tq) / 3 * 1e3
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        model.training_step(batch, i)
+        run_step(batch, i)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -314,6 +330,8 @@ def main():
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}",
                    "grad_bucket_dtype": args.grad_dtype},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
+        "launch_mode": ("hipGraph replay (one launch per step)" if graphed is not None and graphed.graph is not None else
+                        "eager" + (f" ({graphed.disabled})" if graphed is not None and graphed.disabled else "")),
         "clock_ramp_steps": prewarm_steps,
         "step_conv_gflop_per_image": None if gflop != gflop else round(gflop, 2),
         "step_mfma_frac": None if gflop != gflop else round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),

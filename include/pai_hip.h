@@ -429,6 +429,11 @@ int pai_reduce_rows(const float* partial, int rows, int C, float* out, int accum
  * decay / amsgrad; models/wrapper.py:98-111).  step_count is the 1-based step. */
 int pai_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
              float lr, float beta1, float beta2, float eps, int step_count, void* stream);
+/* pai_adam with the step count in device memory (*step_dev is advanced by the call; coeff2_dev: two floats of device
+ * scratch): what a training step captured into a hipGraph needs -- a host-side step count would be frozen into the
+ * graph and every replay would reuse the captured step's bias correction. */
+int pai_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                 float lr, float beta1, float beta2, float eps, int64_t* step_dev, float* coeff2_dev, void* stream);
 /* The same update over `count` separately allocated fp32 tensors (HOST arrays of device pointers and element
  * counts), a few launches in all: the optimizer of the composable networks (models/res_unet.py, models/trans_unet.py),
  * whose parameters are not one arena. */

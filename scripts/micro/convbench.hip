@@ -74,7 +74,9 @@ static const Layer LAYERS[] = {
     {"enc7", 0, 2, 512, 0, 512, 1}, {"dec0", 1, 1, 512, 0, 512, 1}, {"dec1", 1, 2, 512, 512, 512, 1},
     {"dec2", 1, 4, 512, 512, 512, 1}, {"dec3", 1, 8, 512, 512, 512, 1}, {"dec4", 1, 16, 512, 512, 256, 1},
     {"dec5", 1, 32, 256, 256, 128, 1}, {"dec6", 1, 64, 128, 128, 64, 1},
-    {"D1x2", 0, 128, 64, 0, 128, 2}, {"D2x2", 0, 64, 128, 0, 256, 2}, {"D3x2", 0, 32, 256, 0, 512, 2}};
+    {"D1x2", 0, 128, 64, 0, 128, 2}, {"D2x2", 0, 64, 128, 0, 256, 2}, {"D3x2", 0, 32, 256, 0, 512, 2},
+    // thin (HBM-bound) layers: encoders[0], discriminator block 0 (two 1-channel sources), decoders[7] (head)
+    {"thin_enc0", 0, 256, 1, 0, 64, 1}, {"thin_D0x2", 0, 256, 1, 1, 64, 2}, {"thin_dec7", 1, 128, 64, 64, 1, 1}};
 
 struct Setting { std::string label; std::vector<std::pair<std::string, int>> kv; };
 
@@ -144,7 +146,7 @@ int main(int argc, char** argv) {
         pai_conv_desc d;
         memset(&d, 0, sizeof(d));
         d.dtype = PAI_BF16; d.transposed = L.tr; d.N = n; d.H = L.H; d.W = L.H; d.C1 = L.C1; d.C2 = L.C2; d.Cout = L.Cout;
-        d.kernel = 4; d.stride = 2; d.pad = 1; d.relu1 = L.tr; d.relu2 = L.C2 ? L.tr : 0; d.epilogue_act = PAI_ACT_NONE;
+        d.kernel = 4; d.stride = 2; d.pad = 1; d.relu1 = L.tr && L.Cout > 2; d.relu2 = (L.C2 && L.Cout > 2) ? L.tr : 0; d.epilogue_act = PAI_ACT_NONE;
         int OH, OW;
         PCHECK(pai_conv_out_hw(&d, &OH, &OW));
         const int Cin = L.C1 + L.C2;
@@ -174,7 +176,7 @@ int main(int argc, char** argv) {
             HCHECK(hipStreamSynchronize(st));
         };
         auto run = [&](char op, int k) {
-            if (op == 'f') PCHECK(pai_conv_fwd(&d, x1, x2, wf, nullptr, y[k], nullptr, nullptr, stats, st));
+            if (op == 'f') PCHECK(pai_conv_fwd(&d, x1, x2, wf, nullptr, y[k], nullptr, nullptr, (L.C1 > 2 && L.Cout > 2) ? stats : nullptr, st));
             else if (op == 'd') PCHECK(pai_conv_dgrad(&d, dy, wd, dx1[k], dx2[k], 0, st));
             else {
                 HCHECK(hipMemsetAsync(dw[k], 0, nw * 4, st));

@@ -19,7 +19,7 @@ from _gpu_util import dev, fwd_pack, from_nhwc, nhwc, unpack_fwd
 
 pytestmark = pytest.mark.gpu
 
-SPLIT = ("gg_fwd_mfma_k<128, 128, true, false, 64>", "gg_fwd_mfma_k<128, 128, false, false, 64>")
+SPLIT = ("gg_fwd_mfma_k<128, 128, true, true, 64>", "gg_fwd_mfma_k<128, 128, false, false, 64>")
 # (name, transposed, N, H, C1, C2, Cout, relu, (forward, input-gradient, weight-gradient kernel))
 CASES = [
     ("enc_patch", 0, 4, 128, 64, 0, 256, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch_k<128>")),

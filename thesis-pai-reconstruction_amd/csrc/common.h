@@ -220,6 +220,9 @@ int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s)
 int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s);
 bool wgrad_mfma_ok(int dtype, const GG& g);
+// 128 x 256-tile patch-resident weight gradient (gg_wg2.hip)
+bool wgrad2_ok(const GG& g);
+int launch_wgrad2(const GG& g, const WgradArgs& a, hipStream_t s);
 bool thin_wgrad_conv_ok(int dtype, const GG& g);
 bool thin_wgrad_convt_ok(int dtype, const GG& g);
 int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s);

@@ -63,7 +63,8 @@ static FwdCfg fwd_cfg(const GG& g) {
     }
     const int tiles = cdiv(g.M, 128) * ntiles * g.nphase;
     if (tiles >= 768 || niter < 8) return c;
-    static const int fixed = getenv("PAI_FWD_KSPLIT") ? atoi(getenv("PAI_FWD_KSPLIT")) : 0;
+    static const int fixed_env = getenv("PAI_FWD_KSPLIT") ? atoi(getenv("PAI_FWD_KSPLIT")) : 0;
+    const int fixed = pai_tunable("fwd_ksplit", fixed_env);
     if (fixed > 0) {
         int ks = fixed > niter / 2 ? niter / 2 : fixed;
         while (ks > 1 && (niter % ks)) --ks;
@@ -903,7 +904,12 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gg_fwd_mfma_k<128, 128, false, false, 32>), grid, dim3(512),
                            (fwd_lds_bytes<128, 128, false, 32>()), s, g, a, mtiles, ntiles, c.ksplit, pai_ctx()->workspace);
     } else if (c.ksplit > 1) {
-        if (c.bn == 128) FWD_LAUNCH(128, 128, true, false); else FWD_LAUNCH(128, 64, true, false);
+        if (c.bn == 128) {
+            // two LDS stages (counted vmcnt + raw barrier): these launches have few workgroups and a long K loop per
+            // workgroup, i.e. nobody else hides their L2 -> LDS latency (encoders[4] forward 50 -> 45 us, decoders[3]
+            // input gradient 83 -> 76 us, scripts/micro/convbench)
+            if (pai_tunable("fwd_splitk_db", 1)) FWD_LAUNCH(128, 128, true, true); else FWD_LAUNCH(128, 128, true, false);
+        } else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
         const int ftiles = cdiv(g.M, FIN_ROWS);
         hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
@@ -963,7 +969,9 @@ const char* fwd_mfma_kernel_name(const GG& g) {
     if (c.bm == 256) return "gg_fwd_mfma_k<256, 128, false, true, 64>";
     if (c.bm == -128) return "gg_fwd_mfma_k<128, 128, false, true, 64>";
     if (c.bm == 128 && c.bn == 128 && c.ksplit == 1 && mode == 3) return "gg_fwd_mfma_k<128, 128, false, false, 32>";
-    if (c.ksplit > 1) return c.bn == 128 ? "gg_fwd_mfma_k<128, 128, true, false, 64>" : "gg_fwd_mfma_k<128, 64, true, false, 64>";
+    if (c.ksplit > 1)
+        return c.bn == 128 ? (pai_tunable("fwd_splitk_db", 1) ? "gg_fwd_mfma_k<128, 128, true, true, 64>" : "gg_fwd_mfma_k<128, 128, true, false, 64>")
+                           : "gg_fwd_mfma_k<128, 64, true, false, 64>";
     const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
     const int prow = patch_rows(g, c);
     if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";
@@ -1356,8 +1364,13 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 // (measured and dropped: two LDS stages with a counted vmcnt + raw barrier, 48 KB per workgroup, still three per CU:
 //  10-50 % SLOWER -- decoders[6] 194 -> 306 us, decoders[5] 145 -> 169 us; this kernel's latency is hidden across
 //  workgroups, and the second stage only adds LDS-DMA pressure)
+// Compile-time timing ablations of gg_wgrad_patch_k (results WRONG; scripts/micro/variants.sh):
+// 1 no dW accumulation (atomics / stores), 2 no MFMA, 4 no LDS-DMA fills, 8 no fragment reads
+#ifndef WGRAD_ABL
+#define WGRAD_ABL 0
+#endif
 template <int BMC>
-__global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
+__global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
                                                         int splits, int blocks_per_split) {
     constexpr int MT = BMC / 32;
     constexpr int YBUF = 64 * 256;
@@ -1393,13 +1406,12 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
     const int poy = g.poy[ph], pox = g.pox[ph];
     // X patch fill map: thread -> (pixel 64 jj + tid / 4, 16-B slot tid % 4)
     const int xs = tid & 3;
-    int xpy[2], xpx[2], xch[2];
+    int xpp[2], xch[2];      // patch pixel (py << 8 | px; -1: beyond the patch), channel offset of this lane's chunk
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int p = jj * 64 + (tid >> 2);
-        xpy[jj] = p / PATCH_W;
-        xpx[jj] = p - xpy[jj] * PATCH_W;
-        if (p >= 5 * PATCH_W) xpy[jj] = -1000;   // beyond the patch: never inside the image
+        const int py_ = p / PATCH_W, px_ = p - py_ * PATCH_W;
+        xpp[jj] = p >= 5 * PATCH_W ? -1 : ((py_ << 8) | px_);
         xch[jj] = (second ? ci0 - g.C1 : ci0) + ((xs ^ (((p >> 3) & 1) << 1)) * 8);
     }
     const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
@@ -1420,6 +1432,25 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
             xrow[kk][h] = (unsigned)((r >> 4) * PATCH_W + (r & 15));
         }
     const unsigned toff4 = pg.toff4[ph][q];
+    // Fragment addresses: one base per k-half for dY, one per (kk, tap, k-half) for X, plus an XOR constant per 16-column
+    // tile (the swizzles only touch address bits the tile index owns alone).  hipcc otherwise keeps all 32 addresses in
+    // registers across the K loop: 162 VGPRs = three workgroups per CU; with 128 a fourth one fits, and this kernel
+    // hides its LDS-DMA latency across workgroups (scripts/micro/convbench: fills alone and MFMAs alone take ~110 us each
+    // on decoders[4], together 150-160).
+    unsigned ybase[2], xbase[2][2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rowl = fg * 8 + tq + 4 * h;
+        ybase[h] = (unsigned)(256 * rowl + 16 * ((wm * (BMC / 16) + (tp >> 1)) ^ tr_swz(rowl)) + 8 * (tp & 1));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const unsigned p = xrow[kk][h] + ((toff4 >> (8 * (wn * 2 + t2))) & 0xffu);
+                xbase[kk][t2][h] = (unsigned)YBUF + p * 64 + (((p >> 3) & 1u) << 5) + tp * 8;
+            }
+    }
+#define WGP_XOR(dst, src, imm) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(dst) : "v"(src), "s"(imm))
 
     f4_t acc[MT][4];
 #pragma unroll
@@ -1432,65 +1463,71 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
     constexpr int BROWS = 64 / (256 / BMC);
     float bsum = 0.f;
 
-    const bf16_t* py[4];
-    const bf16_t* px[2];
+    // next step's sources as 32-bit element offsets (pointers would cost twice the registers): the four dY rows of a
+    // thread are consecutive pixel rows, the X offsets carry an "inside the image" flag in bit 31
+    unsigned yofs = 0, xofs[2] = {0u, 0u};
+    const unsigned yrow1 = (unsigned)(((1 << los) << g.ldw) * g.Cout);
     auto prepare = [&](int kb) {
         const int gx0 = (kb & ((1 << lbx) - 1)) << 4;
         const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << 2;
         const int n = kb >> (lbx + lby);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int opix = ((((n << g.ldh) + ((gy0 + j) << los) + poy) << g.ldw) + ((gx0 + sr) << los) + pox);
-            py[j] = yvalid ? dy + ((size_t)(unsigned)opix * (unsigned)g.Cout + ycol) : zero;
-        }
+        const int opix = ((((n << g.ldh) + (gy0 << los) + poy) << g.ldw) + ((gx0 + sr) << los) + pox);
+        yofs = (unsigned)opix * (unsigned)g.Cout + ycol;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int iy = (gy0 + xpy[jj]) * g.S + wby, ix = (gx0 + xpx[jj]) * g.S + wbx;
-            const bool inb = xpy[jj] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const int iy = (gy0 + (xpp[jj] >> 8)) * g.S + wby, ix = (gx0 + (xpp[jj] & 0xff)) * g.S + wbx;
+            const bool inb = xpp[jj] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             const int spix = (((n << g.lsh) + iy) << g.lsw) + ix;
-            px[jj] = inb ? xsrc + ((size_t)(unsigned)spix * (unsigned)xcs + xch[jj]) : zero;
+            xofs[jj] = inb ? ((unsigned)spix * (unsigned)xcs + xch[jj]) | 0x80000000u : 0u;
         }
     };
     if (kb0 < kb1) prepare(kb0);
     for (int kb = kb0; kb < kb1; ++kb) {
+        if (!(WGRAD_ABL & 4)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) GLDS16(py[j], Ys + (16 * j + wid * 4) * 256);
+            for (int j = 0; j < 4; ++j) GLDS16(yvalid ? dy + ((size_t)yofs + (unsigned)j * yrow1) : zero, Ys + (16 * j + wid * 4) * 256);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) GLDS16(px[jj], Xs + (jj * 64 + wid * 16) * 64);
+            for (int jj = 0; jj < 2; ++jj)
+                GLDS16((xofs[jj] >> 31) ? xsrc + (size_t)(xofs[jj] & 0x7fffffffu) : zero, Xs + (jj * 64 + wid * 16) * 64);
+        }
         if (kb + 1 < kb1) prepare(kb + 1);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf8_t af[MT], bfr[4];
-            const int row0 = kk * 32 + fg * 8 + tq;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int ch = (wm * (BMC / 2) + mt * 16) / 8 + (tp >> 1);
+                // channel chunk (wm * BMC/16 + 2 mt + (tp >> 1)) ^ swz(row): the tile index is an XOR of address bits 5-6
+                unsigned a0 = ybase[0], a1 = ybase[1];
+                if (mt) { WGP_XOR(a0, ybase[0], mt << 5); WGP_XOR(a1, ybase[1], mt << 5); }
                 const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row0, ch) + 8 * (tp & 1)));
+                    (bf4_t __attribute__((address_space(3)))*)(smem + a0 + kk * 8192));
                 const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf4_t __attribute__((address_space(3)))*)(Ys + tr_off(row0 + 4, ch) + 8 * (tp & 1)));
+                    (bf4_t __attribute__((address_space(3)))*)(smem + a1 + kk * 8192));
                 af[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const unsigned toff = (toff4 >> (8 * (wn * 2 + (nt >> 1)))) & 0xffu;
-                const unsigned p0 = xrow[kk][0] + toff, p1 = xrow[kk][1] + toff;
-                const unsigned o0 = p0 * 64 + ((((unsigned)(nt & 1)) ^ ((p0 >> 3) & 1u)) << 5) + tp * 8;
-                const unsigned o1 = p1 * 64 + ((((unsigned)(nt & 1)) ^ ((p1 >> 3) & 1u)) << 5) + tp * 8;
-                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(Xs + o0));
-                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(Xs + o1));
+                unsigned o0 = xbase[kk][nt >> 1][0], o1 = xbase[kk][nt >> 1][1];
+                if (nt & 1) { WGP_XOR(o0, xbase[kk][nt >> 1][0], 32); WGP_XOR(o1, xbase[kk][nt >> 1][1], 32); }
+                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(smem + o0));
+                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(smem + o1));
                 bfr[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             if (xrelu) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) bfr[nt] = relu_frag(bfr[nt]);
             }
+            if (WGRAD_ABL & 2) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) acc[mt][0][0] += (float)af[mt][0] + (float)bfr[mt & 3][0];
+            } else {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
         if (do_bias) {
 #pragma unroll 8
@@ -1530,7 +1567,8 @@ __global__ __launch_bounds__(256) void gg_wgrad_patch_k(GG g, WgradArgs a, Patch
                     float* pw = a.dw + (size_t)co * g.wtaps * g.Cin + cbase;
                     // un-split: this workgroup is the only writer of the element (taps of different phases are
                     // disjoint) -> plain read-modify-write at store bandwidth instead of the ~1.3 TB/s atomic rate
-                    if (splits == 1) {
+                    if (WGRAD_ABL & 1) { if (acc[mt][nt][r] == 123.456f) *pw = 0.f; }
+                    else if (splits == 1) {
                         if (a.overwrite) *pw = acc[mt][nt][r];     // no zero-fill pass, no read of dW (skinny ViT layers)
                         else *pw += acc[mt][nt][r];
                     } else {
@@ -1558,6 +1596,7 @@ static bool wgrad_mfma_uses_patch(const GG& g) {
 }
 bool wgrad_mfma_can_overwrite(const GG& g) {
     int rows;
+    if (wgrad2_ok(g)) return false;
     return g.nphase == 1 && !wgrad_mfma_uses_patch(g) && wgrad_mfma_splits(g, &rows) == 1;
 }
 
@@ -1570,7 +1609,9 @@ static int wgrad_mfma_splits(const GG& g, int* rows_out) {
     // lighter 64-wide one), but every split adds one fp32 atomic pass over dW -- for the small-image layers
     // that pass, not the MFMA loop, is the cost, so a split never gets fewer than 512 pixels.
     static const int target_env = getenv("PAI_WGRAD_TARGET") ? atoi(getenv("PAI_WGRAD_TARGET")) : 0;
-    const int target = target_env ? target_env : (big ? 768 : 1024);
+    const int target_tun = pai_tunable("wgrad_target", 0);
+    // gg_wgrad_patch_k fits four workgroups per CU (128 VGPRs), gg_wgrad_mfma_k<128> three
+    const int target = target_tun ? target_tun : (target_env ? target_env : ((big && !wgrad_mfma_uses_patch(g)) ? 768 : 1024));
     int splits = cdiv(target, tiles);
     static const int min_rows = getenv("PAI_WGRAD_MINROWS") ? atoi(getenv("PAI_WGRAD_MINROWS")) : 512;
     const int max_splits = cdiv(g.M, min_rows);
@@ -1588,6 +1629,7 @@ static int wgrad_mfma_splits(const GG& g, int* rows_out) {
 }
 
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
+    if (wgrad2_ok(g)) return launch_wgrad2(g, a, s);
     const bool big = (g.Cout % 128) == 0;
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
     const int jtiles = cdiv(g.ntaps * g.Cin, 128);
@@ -1620,6 +1662,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
 }
 
 const char* wgrad_mfma_kernel_name(const GG& g) {
+    if (wgrad2_ok(g)) return "gg_wgrad_patch2_k<128>";
     const bool big = (g.Cout % 128) == 0;
     const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;

@@ -240,6 +240,49 @@ extern "C" int pai_adam(float* param, const float* grad, float* exp_avg, float* 
     return 0;
 }
 
+// The same update with the step count in DEVICE memory, for a step captured into a hipGraph: a host-side count would be
+// frozen into the graph's kernel arguments and every replay would apply the bias correction of the captured step.
+// adam_coeff_k advances *step and derives the two step-dependent coefficients (in double, like the host path);
+// adam_dev_k is adam_k reading them.
+__global__ void adam_coeff_k(long long* step, float* coeff, float lr, float beta1, float beta2) {
+    const long long t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    coeff[0] = (float)((double)lr / bc1);
+    coeff[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_k(float* p, const float* g, float* m, float* v, int64_t numel,
+                                                  const float* coeff, float beta1, float beta2, float omb1, float omb2,
+                                                  float eps) {
+    const float lr_over_bc1 = coeff[0], inv_sqrt_bc2 = coeff[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + omb1 * gi;
+        const float vi = beta2 * v[i] + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+extern "C" int pai_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                            float lr, float beta1, float beta2, float eps, int64_t* step_dev, float* coeff2_dev,
+                            void* stream) {
+    PAI_CHECK(param && grad && exp_avg && exp_avg_sq && step_dev && coeff2_dev, "pai_adam_dev: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_coeff_k, dim3(1), dim3(1), 0, s, (long long*)step_dev, coeff2_dev, lr, beta1, beta2);
+    PAI_LAUNCH_CHECK();
+    int64_t blocks = (numel + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_dev_k, dim3((int)blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, numel,
+                       (const float*)coeff2_dev, beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
 // Multi-tensor form for networks whose parameters are separate allocations (the composable residual / Trans U-Nets):
 // up to ADAM_CHUNK tensors per launch, their pointers travelling in the kernel-argument block (no table upload);
 // blockIdx.y selects the tensor, blockIdx.x strides over it.

@@ -64,52 +64,100 @@ __device__ __forceinline__ void block_add2(double a, double b, double* da, doubl
 template <int MODE>
 __global__ __launch_bounds__(256) void ssim_k(const float* pred, const float* target, int H, int W, int denorm,
                                               Gauss gk, double inv_crop, double* out2, double* per_image,
-                                              float* full_map, float* dmaps, int NC, float wscale) {
+                                              float* full_map, float* dmaps, int NC, float wscale, int xtiles) {
     __shared__ float P[TI][TI + 1], T[TI][TI + 1];
     __shared__ float Hb[5][TI][TS];
     const int tid = threadIdx.x;
     const int nc = blockIdx.z;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int y0 = blockIdx.y * TS;
     const float* p = pred + (size_t)nc * H * W;
     const float* t = target + (size_t)nc * H * W;
-    for (int idx = tid; idx < TI * TI; idx += 256) {
-        const int r = idx / TI, c = idx - r * TI;
-        const int gy = reflect_idx(y0 - PADW + r, H), gx = reflect_idx(x0 - PADW + c, W);
-        P[r][c] = denorm_val(p[(size_t)gy * W + gx], denorm);
-        T[r][c] = denorm_val(t[(size_t)gy * W + gx], denorm);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < TI * TS; idx += 256) {
-        const int r = idx / TS, c = idx - r * TS;
-        float sp = 0.f, st = 0.f, spp = 0.f, stt = 0.f, spt = 0.f;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const float a = P[r][c + k], b = T[r][c + k], g = gk.g[k];
-            sp = fmaf(g, a, sp);
-            st = fmaf(g, b, st);
-            spp = fmaf(g, a * a, spp);
-            stt = fmaf(g, b * b, stt);
-            spt = fmaf(g, a * b, spt);
-        }
-        Hb[0][r][c] = sp; Hb[1][r][c] = st; Hb[2][r][c] = spp; Hb[3][r][c] = stt; Hb[4][r][c] = spt;
-    }
-    __syncthreads();
+    // One workgroup walks `xtiles` 32-pixel tiles of its tile row (MODE 0: the whole row, so that the three fp64
+    // atomics per workgroup -- all workgroups add to the same two or three words -- happen 512 instead of 4096
+    // times per 64-image batch: same-address atomics serialise at the memory side and were most of the 154 us)
     double acc = 0.0, sse = 0.0;
+    for (int xt = blockIdx.x * xtiles; xt < (blockIdx.x + 1) * xtiles && xt * TS < W; ++xt) {
+    const int x0 = xt * TS;
+    if (xt != blockIdx.x * xtiles) __syncthreads();      // the previous tile's readers are done with P, T, Hb
+    {
+        // all 2 x 7 loads of a thread are issued before the first one is consumed: written as "load, store to LDS,
+        // next" the loop was seven dependent HBM round trips per tile
+        constexpr int NL = (TI * TI + 255) / 256;
+        float pv[NL], tv[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / TI, c = idx - r * TI;
+            const int gy = reflect_idx(y0 - PADW + (idx < TI * TI ? r : 0), H), gx = reflect_idx(x0 - PADW + c, W);
+            pv[i] = p[(size_t)gy * W + gx];
+            tv[i] = t[(size_t)gy * W + gx];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / TI, c = idx - r * TI;
+            if (idx < TI * TI) {
+                P[r][c] = denorm_val(pv[i], denorm);
+                T[r][c] = denorm_val(tv[i], denorm);
+            }
+        }
+    }
+    __syncthreads();
+    // horizontal pass, four neighbouring outputs per thread from one 14-value window: a third of the LDS reads and
+    // of the products a*a, b*b, a*b of the one-output-per-thread form (the kernel is instruction-bound, not HBM-bound)
+    for (int idx = tid; idx < TI * (TS / 4); idx += 256) {
+        const int r = idx / (TS / 4), c = (idx - r * (TS / 4)) * 4;
+        float wa[KS + 3], wb[KS + 3];
+#pragma unroll
+        for (int k = 0; k < KS + 3; ++k) { wa[k] = P[r][c + k]; wb[k] = T[r][c + k]; }
+        float sp[4] = {0.f, 0.f, 0.f, 0.f}, st[4] = {0.f, 0.f, 0.f, 0.f}, spp[4] = {0.f, 0.f, 0.f, 0.f},
+              stt[4] = {0.f, 0.f, 0.f, 0.f}, spt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS + 3; ++k) {
+            const float a = wa[k], b = wb[k], aa = a * a, bb = b * b, ab = a * b;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (k - o >= 0 && k - o < KS) {          // same tap order per output as the scalar form: bit-identical sums
+                    const float g = gk.g[k - o];
+                    sp[o] = fmaf(g, a, sp[o]);
+                    st[o] = fmaf(g, b, st[o]);
+                    spp[o] = fmaf(g, aa, spp[o]);
+                    stt[o] = fmaf(g, bb, stt[o]);
+                    spt[o] = fmaf(g, ab, spt[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            Hb[0][r][c + o] = sp[o]; Hb[1][r][c + o] = st[o]; Hb[2][r][c + o] = spp[o]; Hb[3][r][c + o] = stt[o];
+            Hb[4][r][c + o] = spt[o];
+        }
+    }
+    __syncthreads();
+    // vertical pass: a thread owns column ox and the four rows 4 (tid >> 5) .. +3, one 14-row window per map
+    float vm[5][4];
+    {
+        const int oyb = (tid >> 5) * 4, ox = tid & 31;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            float w[KS + 3];
+#pragma unroll
+            for (int k = 0; k < KS + 3; ++k) w[k] = Hb[m][oyb + k][ox];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float acc_ = 0.f;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) acc_ = fmaf(gk.g[k], w[o + k], acc_);
+                vm[m][o] = acc_;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int oy = (tid >> 5) + 8 * j, ox = tid & 31;
+        const int oy = (tid >> 5) * 4 + j, ox = tid & 31;
         const int y = y0 + oy, x = x0 + ox;
         if (y >= H || x >= W) continue;
-        float mp = 0.f, mt = 0.f, epp = 0.f, ett = 0.f, ept = 0.f;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const float g = gk.g[k];
-            mp = fmaf(g, Hb[0][oy + k][ox], mp);
-            mt = fmaf(g, Hb[1][oy + k][ox], mt);
-            epp = fmaf(g, Hb[2][oy + k][ox], epp);
-            ett = fmaf(g, Hb[3][oy + k][ox], ett);
-            ept = fmaf(g, Hb[4][oy + k][ox], ept);
-        }
+        const float mp = vm[0][j], mt = vm[1][j], epp = vm[2][j], ett = vm[3][j], ept = vm[4][j];
         const float spp = epp - mp * mp, stt = ett - mt * mt, spt = ept - mp * mt;
         const float A1 = 2.f * mp * mt + SSIM_C1, A2 = 2.f * spt + SSIM_C2;
         const float B1 = mp * mp + mt * mt + SSIM_C1, B2 = spp + stt + SSIM_C2;
@@ -136,6 +184,7 @@ __global__ __launch_bounds__(256) void ssim_k(const float* pred, const float* ta
             dmaps[2 * (size_t)NC * plane + o] = dpt;
         }
     }
+    }   // x tiles
     if (MODE == 0)
         block_add2(acc * inv_crop, sse, out2, out2 ? out2 + 1 : nullptr, per_image ? per_image + nc : nullptr);
 }
@@ -146,9 +195,14 @@ extern "C" int pai_ssim_sse(const float* pred, const float* target, int NC, int 
     PAI_CHECK(H > 2 * PADW && W > 2 * PADW, "pai_ssim_sse: image %dx%d smaller than the 11x11 window", H, W);
     static const Gauss gk = make_gauss();
     const double inv_crop = 1.0 / ((double)(H - 2 * PADW) * (double)(W - 2 * PADW));
-    dim3 grid(cdiv(W, TS), cdiv(H, TS), NC);
+    // whole tile rows per workgroup once there are enough of them to fill the chip
+    const int xt_all = cdiv(W, TS);
+    int xtiles = pai_tunable("ssim_rowtiles", 8);
+    if (xtiles < 1 || (int64_t)cdiv(H, TS) * NC < 512) xtiles = 1;
+    if (xtiles > xt_all) xtiles = xt_all;
+    dim3 grid(cdiv(xt_all, xtiles), cdiv(H, TS), NC);
     hipLaunchKernelGGL(ssim_k<0>, grid, dim3(256), 0, (hipStream_t)stream, pred, target, H, W, denorm, gk,
-                       inv_crop, out2, per_image, full_map, (float*)nullptr, NC, 0.f);
+                       inv_crop, out2, per_image, full_map, (float*)nullptr, NC, 0.f, xtiles);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -229,7 +283,7 @@ extern "C" int pai_ssim_psnr_bwd(const float* pred, const float* target, int NC,
     dim3 grid(cdiv(W, TS), cdiv(H, TS), NC);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ssim_k<1>, grid, dim3(256), 0, s, pred, target, H, W, denorm, gk, 0.0,
-                       (double*)nullptr, (double*)nullptr, (float*)nullptr, workspace, NC, wscale);
+                       (double*)nullptr, (double*)nullptr, (float*)nullptr, workspace, NC, wscale, 1);
     PAI_LAUNCH_CHECK();
     hipLaunchKernelGGL(ssim_bwd2_k, grid, dim3(256), 0, s, pred, target, H, W, denorm, gk, workspace, NC,
                        w_psnr, sse, grad);

@@ -486,6 +486,13 @@ def adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
                               _stream()), "pai_adam")
 
 
+def adam_dev(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_dev, coeff_dev):
+    """pai_adam_dev: the step count lives in ``step_dev`` (int64 device scalar, advanced by the call)."""
+    L.check(L.load().pai_adam_dev(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
+                                  _p(exp_avg_sq, torch.float32), param.numel(), lr, beta1, beta2, eps,
+                                  _p(step_dev, torch.int64), _p(coeff_dev, torch.float32), _stream()), "pai_adam_dev")
+
+
 def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
     """pai_adam over lists of separately allocated fp32 tensors (a few launches for the whole list)."""
     n = len(params)

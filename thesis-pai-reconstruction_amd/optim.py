@@ -21,6 +21,21 @@ class ArenaAdam(torch.optim.Adam):
         super().__init__(list(params), lr=lr, betas=betas, eps=eps, foreach=True)
         self._engine = engine
         self._arena_steps = 0          # steps taken on the fused path and not yet mirrored into `state`
+        self._dev_step = None          # graph mode: int64 device scalar holding the step count (see graph.py)
+        self._dev_coeff = None
+
+    # ---- hipGraph support -----------------------------------------------------------------------------
+    def enable_device_step(self):
+        """Keep the step count on the device from now on (pai_adam_dev): needed when ``step()`` is captured into a
+        hipGraph, where a host-side count would be frozen into the captured kernel arguments.  ``note_replays(n)``
+        tells the host-side bookkeeping (state_dict, total_steps) about n replays of a graph containing one step."""
+        if self._dev_step is None:
+            dev = self.param_groups[0]["params"][0].device
+            self._dev_step = torch.tensor(self.total_steps, dtype=torch.int64, device=dev)
+            self._dev_coeff = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def note_replays(self, n: int = 1):
+        self._arena_steps += n
 
     # ---- helpers --------------------------------------------------------------------------------
     def _arena_ready(self):
@@ -64,9 +79,13 @@ class ArenaAdam(torch.optim.Adam):
                 self._mirror_state(self._engine.arena())
             return super().step(closure)
         group = self.param_groups[0]
-        step = self.total_steps + 1
-        ops.adam(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
-                 float(group["betas"][1]), float(group["eps"]), step)
+        if self._dev_step is not None:
+            ops.adam_dev(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
+                         float(group["betas"][1]), float(group["eps"]), self._dev_step, self._dev_coeff)
+        else:
+            step = self.total_steps + 1
+            ops.adam(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
+                     float(group["betas"][1]), float(group["eps"]), step)
         self._arena_steps += 1
         self._engine.weights_generation[0] += 1   # master weights changed behind torch's version counters
         return None
