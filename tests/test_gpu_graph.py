@@ -29,18 +29,22 @@ def test_graphed_step_matches_eager(pai, dtype):
     from thesis_pai_reconstruction_amd.graph import GraphedStep
     mults, n, size, steps = (1, 2, 4, 8), 4, 64, 7
     batches = [tuple(t.to(DEV) for t in synth_batch(100 + s, n, size)) for s in range(steps)]
-    eager, graphed = _build(pai, mults, 3, dtype), _build(pai, mults, 3, dtype)
+    eager, eager2, graphed = (_build(pai, mults, 3, dtype) for _ in range(3))
     gs = GraphedStep(graphed, warmup=2)
     for s, b in enumerate(batches):
-        eager.logged, graphed.logged = {}, {}
+        eager.logged, eager2.logged, graphed.logged = {}, {}, {}
         eager.training_step(b, s)
+        eager2.training_step(b, s)
         gs(b, s)
         torch.cuda.synchronize()
         assert gs.disabled is None, gs.disabled
         for k, v in eager.logged.items():
-            a, g = float(v), float(graphed.logged[k])
-            # fp32 atomics of the weight gradients make two runs differ in the last bits; Adam amplifies that slowly
-            assert abs(a - g) <= 2e-3 * max(1.0, abs(a)), (s, k, a, g)
+            a, a2, g = float(v), float(eager2.logged[k]), float(graphed.logged[k])
+            # fp32 atomics of the weight gradients make two runs differ in the last bits and Adam (and bf16 storage)
+            # amplifies that step by step: two EAGER runs of the same step are held to the same bound as graph vs eager
+            # (measured at step 6, d_loss: eager vs eager 2.6e-3 in fp32, graph vs eager 3.7e-3 in bf16)
+            tol = 1.5e-2 * max(1.0, abs(a))
+            assert abs(a - a2) <= tol and abs(a - g) <= tol, (s, k, a, a2, g)
     assert gs.graph is not None and gs.opt_steps_per_replay == 2
     assert graphed._pai_opt_steps == eager._pai_opt_steps == 2 * steps
     for (k, p), (_, q) in zip(eager.state_dict().items(), graphed.state_dict().items()):

@@ -25,6 +25,13 @@
 // pipeline buys is lost to (a) the exposed epilogue (33 MB of output leave the chip in one burst at the end),
 // (b) LDS-DMA instructions in the MFMA stream (spreading them one per MFMA group made it slower still: 128 -> 133 us).
 // gg_fwd_patch_k's four waves per SIMD hide both; it stays the default and this file documents the alternative.
+// A fourth variant (MT = 4: 8 waves of 64 x 64, 128 VGPRs, two workgroups per CU = gg_fwd_patch_k's occupancy, but
+// with this file's prefetched 32-channel patches) is 5-7 % slower than gg_fwd_patch_k too (decoders[4] forward 126 vs
+// 119 us, input gradient 118 vs 110): the exposed patch refill of gg_fwd_patch_k is NOT what holds it at half the
+// matrix peak.  Counters (scripts/micro/pmc_variant.sh): with LDS-DMA and fragment reads compiled out the loop still
+// keeps the matrix pipe only 52-55 % busy at 2.35-2.39 GHz -- the SIMD's vector issue is the shared resource: an
+// MFMA 16x16x32 holds it for 8 of its 16 cycles and every other vector instruction for 4 (guide, cycle constants),
+// so more than two vector instructions per MFMA (ReLU-on-load alone is one) cap the pipe below its peak.
 //
 // Serves the same reference call sites as gg_fwd_patch_k: the Conv2d k4 s2 p1 / ConvTranspose2d k4 s2 p1 layers of
 // EncoderBlock / DecoderBlock (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and
@@ -35,19 +42,22 @@
 
 constexpr int P2_CK = 32;   // channels per patch chunk
 
-template <int TH, int NW> struct P2Dims {              // NW waves of 128 pixels x 64 channels
+template <int TH, int NW, int MT> struct P2Dims {      // NW waves of MT pixel rows (16 pixels each) x 64 channels
     static constexpr int NTHR = NW * 64;
-    static constexpr int WMW = TH / 8, WNW = NW / WMW;      // waves along pixels / channels
+    static constexpr int WMW = TH / MT, WNW = NW / WMW;     // waves along pixels / channels
     static constexpr int BN = WNW * 64, BM = TH * 16;
     static constexpr int PIX = (TH + 1) * PATCH_W;
     static constexpr int PPI = NTHR / 4;                    // patch pixels (64 B) per block-wide fill instruction
     static constexpr int PJ = (PIX + PPI - 1) / PPI;
-    static constexpr int PBYTES = PJ * PPI * 64;
+    // a wave's piece of a fill instruction is 16 pixels: pieces wholly behind the last patch pixel land in one shared
+    // 1-KB dump area instead of padding both patch buffers to PJ * PPI pixels
+    static constexpr int PIXR = (PIX + 15) / 16 * 16;
+    static constexpr int PBYTES = PIXR * 64;
     static constexpr int RPI = NTHR / 8;                    // weight rows (128 B) per block-wide fill instruction
     static constexpr int BJ = BN / RPI;
     static constexpr int BBYTES = BN * 128;
     static constexpr size_t lds_bytes(int nring) {
-        const size_t loop = 2 * (size_t)PBYTES + (size_t)nring * BBYTES;
+        const size_t loop = 2 * (size_t)PBYTES + (size_t)nring * BBYTES + 1024;
         const size_t epi = (size_t)BM * (BN * 2 + 16) + (size_t)WMW * 2 * BN * sizeof(float);
         return loop > epi ? loop : epi;
     }
@@ -69,7 +79,7 @@ struct P2Prob {
 };
 
 #ifndef P2_DMA_SPREAD
-#define P2_DMA_SPREAD 1     // 1: one LDS-DMA instruction per MFMA group behind the barrier, 0: all of them at once
+#define P2_DMA_SPREAD 1     // 1: the step's LDS-DMA instructions in two batches (behind the barrier, two items later), 0: one
 #endif
 #ifndef P2_SETPRIO
 #define P2_SETPRIO 0
@@ -78,20 +88,23 @@ struct P2Prob {
 #define P2_ABL 0            // timing ablations (results WRONG): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads
 #endif
 
-// TH: pixel rows of the tile (16 wide); NW: waves (8: one workgroup per CU, 4: two); NRING: weight tiles in the ring
-// (3: every LDS-DMA two K-steps ahead, 2: one); RELU: some input tensor is read through ReLU (decoder blocks)
-template <int TH, int NW, int NRING, bool RELU>
-__global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
+// TH: pixel rows of the tile (16 wide); NW: waves; MT: pixel rows per wave (8: 128 x 64 wave tiles in 256 VGPRs, two
+// waves per SIMD; 4: 64 x 64 wave tiles in 128 VGPRs, four); NRING: weight tiles in the ring (3: every LDS-DMA two
+// K-steps ahead, 2: one); RELU: some input tensor is read through ReLU (decoder blocks)
+template <int TH, int NW, int MT, int NRING, bool RELU>
+__global__ __launch_bounds__(NW * 64, MT == 4 ? 4 : 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
     const int mtiles = g.mtiles, ntiles = g.ntiles;
     struct { int groups, TY, TX; } pg = {g.groups, g.TY, g.TX};
-    typedef P2Dims<TH, NW> PD;
+    typedef P2Dims<TH, NW, MT> PD;
     constexpr int WMW = PD::WMW, WNW = PD::WNW, BN = PD::BN, BM = PD::BM, NTHR = PD::NTHR;
-    constexpr int MT = 8, NT = 4;
-    constexpr int PJ = PD::PJ, PIX = PD::PIX, PBYTES = PD::PBYTES, PPI = PD::PPI;
+    constexpr int NT = 4, NI = 2 * MT;
+    constexpr int PFD = MT == 4 ? 2 : 4;                  // pixel fragments in flight (register sets)
+    constexpr int BAR = PFD == 4 ? NI - 3 : NI - 2;       // the step's barrier sits behind this item
+    constexpr int PJ = PD::PJ, PIX = PD::PIX, PBYTES = PD::PBYTES, PPI = PD::PPI, PIXR = PD::PIXR;
     constexpr int BJ = PD::BJ, RPI = PD::RPI, BBYTES = PD::BBYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [patch 0][patch 1][weights 0] .. [weights NRING-1]
-    constexpr int B_OFF = 2 * PBYTES;
+    // [patch 0][patch 1][weights 0] .. [weights NRING-1][dump]
+    constexpr int B_OFF = 2 * PBYTES, DUMP_OFF = B_OFF + NRING * BBYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,21 +139,21 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
     // one patch row, at either tap shift) then covers the 16 slots of a 256-B bank row once, and -- the swizzle not
     // depending on the row -- the eight pixel rows of a wave are one base address + immediates.
     const int psc = tid & 3, pl = tid >> 2;
-    int pixb[PJ];      // source pixel of the patch pixel at window offset (0, 0)
-    unsigned pmeta[PJ];   // bits 0-3: inside the image for window q; bits 8-..: channel offset of this lane's 16-B chunk
+    // per fill instruction, one register: bits 0-25 source pixel of the patch pixel at window offset (0, 0) (host:
+    // N * H * W < 2^26), bits 26-27 this lane's 16-B chunk of the 32 channels, bits 28-31 inside the image for window q
+    unsigned pixb[PJ];
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int p = j * PPI + pl;
         const int py = p / PATCH_W, px = p - py * PATCH_W;
         const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
-        pixb[j] = (img * g.H + y) * g.W + x;
         unsigned m = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int yy = y + win_by(q), xx = x + win_bx(q);
             if (q < pg.groups && p < PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
         }
-        pmeta[j] = m | ((unsigned)((psc ^ (((px >> 2) & 1) << 1)) * 8) << 8);
+        pixb[j] = ((unsigned)((img * g.H + y) * g.W + x) & 0x3ffffffu) | ((unsigned)(psc ^ (((px >> 2) & 1) << 1)) << 26) | (m << 28);
     }
     // ---- weight fill map: thread -> (row 64 j + tid / 8, 16-B slot tid % 8), slot s of row r holds global chunk
     // s ^ ((r >> 1) & 7); chunks 0-3 = 32 channels of the step's first tap, 4-7 = of its second tap.  LDS row
@@ -149,7 +162,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
     const int bsr = tid >> 3;
     const int gchB = (tid & 7) ^ ((bsr >> 1) & 7);
     const int tapsel = gchB >> 2;
-    const bf16_t* wrow0 = w + (size_t)(n0 + 16 * ((bsr & 15) >> 2) + 4 * (bsr >> 4) + (bsr & 3)) * g.wtaps * g.Cin + (gchB & 3) * 8;
+    // element offset of this lane's chunk from w (host: Cout * wtaps * Cin < 2^31)
+    const unsigned wrow0 = (unsigned)(n0 + 16 * ((bsr & 15) >> 2) + 4 * (bsr >> 4) + (bsr & 3)) * (unsigned)(g.wtaps * g.Cin) + (unsigned)(gchB & 3) * 8u;
     const int wrow_stride = g.wtaps * g.Cin;          // elements per output channel
     // fill instruction j covers LDS rows j * RPI + bsr: channel offset of its first row from that of j = 0
     auto wrow_ch = [](int j) __attribute__((always_inline)) -> int { return ((j * RPI) >> 6) * 64 + (((j * RPI) & 63) >> 4) * 4; };
@@ -176,19 +190,20 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
         const bool second = c0 >= gC1;
         const bf16_t* src = second ? x2p : x1p;
         const int C = second ? gC2 : gC1;
-        const int cofs = (second ? c0 - gC1 : c0) + (int)(pmeta[j] >> 8);
+        const int cofs = (second ? c0 - gC1 : c0) + (int)((pixb[j] >> 26) & 3u) * 8;
         const int dpix = win_by(q) * g.W + win_bx(q);
         if (P2_ABL & 1) return;
-        const bf16_t* pv = src + ((size_t)(unsigned)(pixb[j] + dpix) * (unsigned)C + cofs);
-        const bf16_t* pa = ((pmeta[j] >> q) & 1u) ? pv : zero;
-        GLDS16(pa, smem + (gi & 1) * PBYTES + (j * PPI + wid * 16) * 64);
+        const bf16_t* pv = src + ((size_t)(unsigned)((int)(pixb[j] & 0x3ffffffu) + dpix) * (unsigned)C + cofs);
+        const bf16_t* pa = ((pixb[j] >> (28 + q)) & 1u) ? pv : zero;
+        const int p0 = j * PPI + wid * 16;       // first pixel of this wave's piece (wave-uniform)
+        GLDS16(pa, smem + (p0 < PIXR ? (gi & 1) * PBYTES + p0 * 64 : DUMP_OFF));
     };
     auto weight_piece = [&](int s, int slot, int j) __attribute__((always_inline)) {
         const int gi = s >> 1, h = s & 1;
         const int c0 = (gi >> gsh) * P2_CK, q = gi & (pg.groups - 1);
         const int wt = (int)((unsigned)(wpk >> (16 * q + 8 * h + 4 * tapsel)) & 15u);   // tap 2 h + tapsel of window q
         if (P2_ABL & 1) return;
-        GLDS16(wrow0 + ((size_t)wrow_ch(j) * wrow_stride + (wt * g.Cin + c0)), smem + B_OFF + slot * BBYTES + (j * RPI + wid * 8) * 128);
+        GLDS16(w + (size_t)(wrow0 + (unsigned)(wrow_ch(j) * wrow_stride + (wt * g.Cin + c0))), smem + B_OFF + slot * BBYTES + (j * RPI + wid * 8) * 128);
     };
     // fragment reads: weights of tap k (0 / 1) of the step in ring slot `slot`; pixels of patch row mt at base `pa`
     auto read_w = [&](int slot, int k, bf8_t (&wf)[NT]) {
@@ -199,11 +214,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
             else wf[nt] = *(const bf8_t*)(smem + ad + nt * 2048);
         }
     };
-    // base address (patch row wm * 8, this lane's pixel and k-quarter) for tap offset toff = ty * 17 + tx of buffer b
+    // base address (patch row wm * MT, this lane's pixel and k-quarter) for tap offset toff = ty * 17 + tx of buffer b
     auto patch_base = [&](int b, int toff) __attribute__((always_inline)) -> unsigned {
         const int ty = toff >= PATCH_W ? 1 : 0;
         const unsigned px = (unsigned)(toff - ty * PATCH_W + fr);
-        return (unsigned)(b * PBYTES) + (((unsigned)((wm * 8 + ty) * PATCH_W) + px) << 6) + ((((unsigned)fq) ^ (((px >> 2) & 1u) << 1)) << 4);
+        return (unsigned)(b * PBYTES) + (((unsigned)((wm * MT + ty) * PATCH_W) + px) << 6) + ((((unsigned)fq) ^ (((px >> 2) & 1u) << 1)) << 4);
     };
     auto read_p = [&](unsigned base, int mt) __attribute__((always_inline)) -> bf8_t {
         if (P2_ABL & 4) return __builtin_bit_cast(bf8_t, make_uint4(base, mt, base, mt));
@@ -249,20 +264,18 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 1) * BJ + PJ) : "memory");
     __builtin_amdgcn_s_barrier();
 
-    // The K loop is a stream of items (step, tap, pixel row mt): 16 per step, 4 MFMAs each.  Pixel fragments live in
-    // a ring of four registers sets: the fragment of item i + 4 is read right after the MFMAs of item i.  The step's
-    // barrier sits behind item 13: by then every read of W[s] and (odd steps) P[gi] has been issued -- lgkmcnt(0)
-    // retires them -- and the data of step s + 1, issued two barriers ago, is retired by the counted vmcnt.
-    bf8_t wfA[NT], wfB[NT], pf[4];
+    // The K loop is a stream of items (step, tap, pixel row mt): NI = 2 MT per step, 4 MFMAs each.  Pixel fragments
+    // live in a ring of four register sets: the fragment of item i + 4 is read right after the MFMAs of item i.  The
+    // step's barrier sits behind item BAR = NI - 3: by then every read of W[s] and (odd steps) P[gi] has been issued
+    // (the last one behind item NI - 5) -- lgkmcnt(0) retires them -- and the data of step s + 1 is retired by the
+    // counted vmcnt.  Fragments of the next step that items NI - 4 .. BAR would have fetched are read right behind the
+    // barrier instead.
+    bf8_t wfA[NT], wfB[NT], pf[PFD];
     read_w(0, 0, wfA);
     unsigned pb_cur = patch_base(0, tap_off(0, 0));    // tap 0 of the current step
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pf[i] = read_p(pb_cur, i);
+    for (int i = 0; i < PFD; ++i) pf[i] = read_p(pb_cur, i);
     int slot = 0;                                       // ring slot of W[s]
-    // P2_DMA_SPREAD == 2: the LDS-DMA batch issued behind the barrier of step s is spread over items 14, 15 of that
-    // step and items 0 .. of the next one -- (step, slot, flags) of the batch in flight are carried over
-    int b_s = 0, b_slot = 0, b_gi = 0;
-    bool b_wmore = false, b_pmore = false;
     for (int s = 0; s < tot; ++s) {
         const int gi = s >> 1;
         const int relu = relu_of(s);
@@ -273,25 +286,21 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
         const unsigned pb_next = more ? patch_base(gn & 1, tap_off(s + 1, 0)) : 0u;
         const bool wmore = s + NRING < tot;               // W[s+NRING] -> the slot of W[s]
         const bool pmore = (s & 1) && gi + 2 < ngroups;   // P[gi+2] -> the buffer of P[gi]
-        // LDS-DMA pieces of W[s+3] / P[gi+2]: piece k is issued in front of item 14 + k (wrapping into the next step's
-        // items would reorder them against that step's pieces, so at most 14 are spread; the rest go out at once)
+        // LDS-DMA pieces of W[s+NRING] / P[gi+2]
 #define P2_DMA_PIECE(k)                                                          \
     do {                                                                         \
-        if ((k) < BJ) { if (wmore) weight_piece(s + NRING, slot, (k)); }             \
+        if ((k) < BJ) { if (wmore) weight_piece(s + NRING, slot, (k)); }         \
         else if ((k) - BJ < PJ) { if (pmore) patch_piece(gi + 2, (k) - BJ); }    \
-    } while (0)
-#define P2_DMA_PIECE_B(k)                                                        \
-    do {                                                                         \
-        if ((k) < BJ) { if (b_wmore) weight_piece(b_s + NRING, b_slot, (k)); }   \
-        else if ((k) - BJ < PJ) { if (b_pmore) patch_piece(b_gi + 2, (k) - BJ); }\
     } while (0)
         read_w(slot, 1, wfB);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int mt = i & 7;
-            if (P2_DMA_SPREAD == 2 && i + 2 < BJ + PJ && i < 12) P2_DMA_PIECE_B(i + 2);   // rest of the previous batch
-            if (i < 8) mma(wfA, pf[i & 3], relu, mt); else mma(wfB, pf[i & 3], relu, mt);
-            if (i == 13) {
+        for (int i = 0; i < NI; ++i) {
+            const int mt = i % MT;
+            if (i < MT) mma(wfA, pf[i % PFD], relu, mt); else mma(wfB, pf[i % PFD], relu, mt);
+            const int nx = i + PFD;                     // the item whose fragment goes into the register set just freed
+            if (nx < NI) {
+                pf[i % PFD] = read_p(nx < MT ? pb_cur : pb_t1, nx % MT);
+            } else if (i == BAR) {
                 if (more) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     // newer than what step s + 1 needs: the weight tiles W[s+2] .. W[s+NRING-1] and, behind an odd
@@ -301,12 +310,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 2) * BJ + PJ) : "memory");
                     __builtin_amdgcn_s_barrier();
                     read_w(slot_n, 0, wfA);
-                    pf[0] = read_p(pb_next, 0);
-                    pf[1] = read_p(pb_next, 1);
-                    if (P2_DMA_SPREAD == 2) {
-                        b_s = s; b_slot = slot; b_gi = gi; b_wmore = wmore; b_pmore = pmore;
-                        P2_DMA_PIECE(0);
-                    } else if (P2_DMA_SPREAD) {
+#pragma unroll
+                    for (int d = NI - PFD; d <= BAR; ++d) pf[d % PFD] = read_p(pb_next, d + PFD - NI);
+                    if (P2_DMA_SPREAD) {
 #pragma unroll
                         for (int k = 0; k < (BJ + PJ + 1) / 2; ++k) P2_DMA_PIECE(k);
                     } else {
@@ -314,17 +320,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
                         for (int k = 0; k < BJ + PJ; ++k) P2_DMA_PIECE(k);
                     }
                 }
-            } else if (i == 12) {
-                // its successor (item 16) is read behind the barrier
-            } else if (i < 4) {
-                pf[i & 3] = read_p(pb_cur, i + 4);
-            } else if (i < 12) {
-                pf[i & 3] = read_p(pb_t1, i - 4);
-            } else if (more) {   // items 14, 15 -> items 2, 3 of the next step
-                pf[i & 3] = read_p(pb_next, i - 12);
-                if (P2_DMA_SPREAD == 2) {
-                    if (i == 14) P2_DMA_PIECE(1);
-                } else if (P2_DMA_SPREAD && i == 14) {
+            } else if (i > BAR && more) {   // the last items of the step fetch for the next one
+                pf[i % PFD] = read_p(pb_next, nx - NI);
+                if (P2_DMA_SPREAD && i == BAR + 1) {
 #pragma unroll
                     for (int k = (BJ + PJ + 1) / 2; k < BJ + PJ; ++k) P2_DMA_PIECE(k);
                 }
@@ -341,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WMW][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
-    // lane (fq, fr) holds, for each of its 8 pixel rows mt (pixel fr of the row), the 16 consecutive channels
+    // lane (fq, fr) holds, for each of its MT pixel rows mt (pixel fr of the row), the 16 consecutive channels
     // wn*64 + 16 fq + (4 nt + r)
     constexpr int CL = 4 * NT;
     const int col0 = wn * 64 + CL * fq;
@@ -352,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
         for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int row = wm * 128 + mt * 16 + fr;
+            const int row = wm * (MT * 16) + mt * 16 + fr;
             unsigned pk[CL / 2];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -453,21 +451,23 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_fwd_p2_k(P2Prob g, FwdArgs a) {
 // ---- host side --------------------------------------------------------------------------------------------
 // Tile choice for a problem the matrix-core path accepts (fwd_mfma_ok).  Returns 0 (not for this kernel) or the
 // variant: 1 = 16 x 16 pixels x 256 channels, 8 waves; 2 = 32 x 16 pixels x 128 channels, 8 waves (one workgroup per
-// CU each); 3 = 16 x 16 pixels x 128 channels, 4 waves, two workgroups per CU.
+// CU each); 3 = 16 x 16 pixels x 128 channels, 4 waves, two workgroups per CU; 4 = the same tile with 8 waves of
+// 64 x 64 (128 VGPRs), two workgroups per CU = four waves per SIMD like gg_fwd_patch_k.
 // tunable "fwd_p2": 0 (default) off, 1 the 8-wave variants, 2 the 4-wave variant only, 3 the 4-wave variant where it
-// applies, else the 8-wave ones.  OFF by default: measured on MI355X (scripts/micro/convbench, round 2) every variant is
+// applies, else the 8-wave ones, 4 the 64 x 64-wave variant only.  OFF by default: measured on MI355X (scripts/micro/convbench, round 2) every variant is
 // 3-25 % SLOWER than gg_fwd_patch_k on the layers it accepts -- see the header of this file and DESIGN.md.
 static int p2_variant(const GG& g) {
     const int mode = pai_tunable("fwd_p2", 0);
     if (!mode) return 0;
     if ((g.C1 % P2_CK) || (g.C2 % P2_CK) || g.Cin < 64) return 0;
+    if (((int64_t)g.N * g.H + 4) * (g.W + 4) >= (1 << 26) || (int64_t)g.Cout * g.wtaps * g.Cin >= (1ll << 31)) return 0;   // packed offsets
     PatchGeo pg;
     const bool c128 = (g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0);
     const bool c256 = (g.Cout % 256) == 0 && (g.D2 == 0 || (g.D1 % 256) == 0);
     if (mode >= 2 && c128 && patch_geo(g, 16, &pg) &&
         (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= pai_tunable("fwd_p2_min_wgs4", 384))
-        return 3;
-    if (mode == 2) return 0;
+        return mode == 4 ? 4 : 3;
+    if (mode == 2 || mode == 4) return 0;
     const int min_wgs = pai_tunable("fwd_p2_min_wgs", 200);
     if (c256 && patch_geo(g, 16, &pg) && (int64_t)(g.M / 256) * (g.Cout / 256) * g.nphase >= min_wgs) return 1;
     if (c128 && patch_geo(g, 32, &pg) && (int64_t)(g.M / 512) * (g.Cout / 128) * g.nphase >= min_wgs) return 2;
@@ -504,14 +504,14 @@ static void p2_prob(const GG& g, const PatchGeo& pg, int mtiles, int ntiles, P2P
     }
 }
 
-template <int TH, int NW, int NRING>
+template <int TH, int NW, int MT, int NRING>
 static int p2_launch(const GG& g, const FwdArgs& a, const PatchGeo& pg, hipStream_t s) {
-    typedef P2Dims<TH, NW> PD;
+    typedef P2Dims<TH, NW, MT> PD;
     const size_t lds = PD::lds_bytes(NRING);
     static bool attr = false;
     if (!attr) {
-        const void* fns[2] = {reinterpret_cast<const void*>(&gg_fwd_p2_k<TH, NW, NRING, false>),
-                              reinterpret_cast<const void*>(&gg_fwd_p2_k<TH, NW, NRING, true>)};
+        const void* fns[2] = {reinterpret_cast<const void*>(&gg_fwd_p2_k<TH, NW, MT, NRING, false>),
+                              reinterpret_cast<const void*>(&gg_fwd_p2_k<TH, NW, MT, NRING, true>)};
         for (int i = 0; i < 2; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
@@ -522,8 +522,8 @@ static int p2_launch(const GG& g, const FwdArgs& a, const PatchGeo& pg, hipStrea
     P2Prob pr;
     p2_prob(g, pg, mtiles, ntiles, &pr);
     const dim3 grid(mtiles * ntiles * g.nphase), block(PD::NTHR);
-    if (g.relu1 || g.relu2) hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, NRING, true>), grid, block, lds, s, pr, a);
-    else hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, NRING, false>), grid, block, lds, s, pr, a);
+    if (g.relu1 || g.relu2) hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, MT, NRING, true>), grid, block, lds, s, pr, a);
+    else hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, MT, NRING, false>), grid, block, lds, s, pr, a);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -532,16 +532,18 @@ int launch_fwd_p2(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int v = p2_variant(g);
     PatchGeo pg;
     PAI_CHECK(v && patch_geo(g, v == 2 ? 32 : 16, &pg), "launch_fwd_p2: problem not eligible");
-    if (v == 1) return p2_launch<16, 8, 3>(g, a, pg, s);
-    if (v == 2) return p2_launch<32, 8, 3>(g, a, pg, s);
-    return p2_launch<16, 4, 2>(g, a, pg, s);
+    if (v == 1) return p2_launch<16, 8, 8, 3>(g, a, pg, s);
+    if (v == 2) return p2_launch<32, 8, 8, 3>(g, a, pg, s);
+    if (v == 4) return p2_launch<16, 8, 4, 2>(g, a, pg, s);
+    return p2_launch<16, 4, 8, 2>(g, a, pg, s);
 }
 
 const char* fwd_p2_kernel_name(const GG& g) {
     const bool relu = g.relu1 || g.relu2;
     switch (p2_variant(g)) {
-        case 1: return relu ? "gg_fwd_p2_k<16, 8, 3, true>" : "gg_fwd_p2_k<16, 8, 3, false>";
-        case 2: return relu ? "gg_fwd_p2_k<32, 8, 3, true>" : "gg_fwd_p2_k<32, 8, 3, false>";
-        default: return relu ? "gg_fwd_p2_k<16, 4, 2, true>" : "gg_fwd_p2_k<16, 4, 2, false>";
+        case 1: return relu ? "gg_fwd_p2_k<16, 8, 8, 3, true>" : "gg_fwd_p2_k<16, 8, 8, 3, false>";
+        case 2: return relu ? "gg_fwd_p2_k<32, 8, 8, 3, true>" : "gg_fwd_p2_k<32, 8, 8, 3, false>";
+        case 4: return relu ? "gg_fwd_p2_k<16, 8, 4, 2, true>" : "gg_fwd_p2_k<16, 8, 4, 2, false>";
+        default: return relu ? "gg_fwd_p2_k<16, 4, 8, 2, true>" : "gg_fwd_p2_k<16, 4, 8, 2, false>";
     }
 }
