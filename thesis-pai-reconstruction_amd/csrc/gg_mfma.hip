@@ -1397,24 +1397,44 @@ __global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, Pa
     const int xcs = second ? g.C2 : g.C1;
     const int xrelu = second ? g.relu2 : g.relu1;
 
+    // Both tiles are filled by LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): the per-lane part of
+    // an address is a 32-bit byte offset, the per-step part rides in the instruction's scalar offset, and a lane whose
+    // offset lies beyond the buffer writes ZEROS to LDS (scripts/micro/oob_probe.hip) -- padding pixels, pixels beyond
+    // the patch and absent channels need no zero line and no select.  What is left per step and thread: one compare
+    // pair + select per X piece.  (The pointer form cost ~70 vector instructions per 32 MFMAs; the SIMD issues two
+    // per MFMA at most before the matrix pipe starves.)
+    // host: every tensor of the layer is smaller than 2 GB, so vector + scalar offset of an absent lane cannot wrap
+    // back into the buffer whether or not the range check counts the scalar part
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.dy), 0, (unsigned)((g.N << (g.ldh + g.ldw)) * g.Cout) * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>((const void*)xsrc), 0, (unsigned)(g.N * g.H * g.W * xcs) * 2u, 0x00020000);
     // dY tile fill map (as gg_wgrad_mfma_k): row sr + 16 j = pixel (gy0 + j, gx0 + sr) of the step's block
     const int sc = lane & 15, sr = wid * 4 + (lane >> 4);
     const int gch = sc ^ tr_swz(sr);
     const bool yvalid = gch < BMC / 8 && (co0 + gch * 8) < g.Cout;
-    const int ycol = co0 + gch * 8;
     const int los = g.OS == 2 ? 1 : 0;
     const int poy = g.poy[ph], pox = g.pox[ph];
-    // X patch fill map: thread -> (pixel 64 jj + tid / 4, 16-B slot tid % 4)
+    // byte offset of this thread's chunk from the step's first output pixel; beyond the buffer for absent channels
+    const unsigned ythr = yvalid ? (unsigned)((sr << los) * g.Cout + co0 + gch * 8) * 2u : OOB;
+    const unsigned yrow1 = (unsigned)(((1 << los) << g.ldw) * g.Cout) * 2u;    // bytes between the thread's four rows
+    // X patch fill map: thread -> (pixel 64 jj + tid / 4, 16-B slot tid % 4).  Invariant per thread: the pixel's
+    // source coordinates relative to the step's origin (beyond-the-patch pixels get a row no image has) and the
+    // byte offset of its chunk from the origin pixel.
     const int xs = tid & 3;
-    int xpp[2], xch[2];      // patch pixel (py << 8 | px; -1: beyond the patch), channel offset of this lane's chunk
+    const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
+    int xty[2], xtx[2];
+    unsigned xthr[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int p = jj * 64 + (tid >> 2);
         const int py_ = p / PATCH_W, px_ = p - py_ * PATCH_W;
-        xpp[jj] = p >= 5 * PATCH_W ? -1 : ((py_ << 8) | px_);
-        xch[jj] = (second ? ci0 - g.C1 : ci0) + ((xs ^ (((p >> 3) & 1) << 1)) * 8);
+        xty[jj] = p >= 5 * PATCH_W ? 0x40000000 : py_ * g.S + wby;
+        xtx[jj] = px_ * g.S + wbx;
+        const int xch = (second ? ci0 - g.C1 : ci0) + ((xs ^ (((p >> 3) & 1) << 1)) * 8);
+        xthr[jj] = (unsigned)(((py_ * g.S + wby) * g.W + px_ * g.S + wbx) * xcs + xch) * 2u;
     }
-    const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
 
     const int lbx = g.lw - 4, lby = g.lh - 2;
     const int kb0 = split * blocks_per_split;
@@ -1451,6 +1471,11 @@ __global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, Pa
             }
     }
 #define WGP_XOR(dst, src, imm) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(dst) : "v"(src), "s"(imm))
+    // Fragment reads take the LDS byte address as an integer: the dynamic LDS block of this kernel (it has no static
+    // one) starts at LDS address 0, checked here.  `smem + offset` costs a v_add_u32 with the link-time constant 0 per
+    // read, 44 per K-step.
+#define WGP_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(unsigned)(addr))
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
 
     f4_t acc[MT][4];
 #pragma unroll
@@ -1463,32 +1488,30 @@ __global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, Pa
     constexpr int BROWS = 64 / (256 / BMC);
     float bsum = 0.f;
 
-    // next step's sources as 32-bit element offsets (pointers would cost twice the registers): the four dY rows of a
-    // thread are consecutive pixel rows, the X offsets carry an "inside the image" flag in bit 31
-    unsigned yofs = 0, xofs[2] = {0u, 0u};
-    const unsigned yrow1 = (unsigned)(((1 << los) << g.ldw) * g.Cout);
+    // step kb: scalar origin of its output block / source patch (byte offsets), then the per-thread X offsets
+    unsigned ysof = 0, xofs[2] = {0u, 0u};
     auto prepare = [&](int kb) {
         const int gx0 = (kb & ((1 << lbx) - 1)) << 4;
         const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << 2;
         const int n = kb >> (lbx + lby);
-        const int opix = ((((n << g.ldh) + (gy0 << los) + poy) << g.ldw) + ((gx0 + sr) << los) + pox);
-        yofs = (unsigned)opix * (unsigned)g.Cout + ycol;
+        ysof = (unsigned)(((((n << g.ldh) + (gy0 << los) + poy) << g.ldw) + (gx0 << los) + pox) * g.Cout) * 2u;
+        const int oy = gy0 * g.S, ox = gx0 * g.S;
+        const unsigned xsof = (unsigned)(((((n << g.lsh) + oy) << g.lsw) + ox) * xcs) * 2u;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const int iy = (gy0 + (xpp[jj] >> 8)) * g.S + wby, ix = (gx0 + (xpp[jj] & 0xff)) * g.S + wbx;
-            const bool inb = xpp[jj] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            const int spix = (((n << g.lsh) + iy) << g.lsw) + ix;
-            xofs[jj] = inb ? ((unsigned)spix * (unsigned)xcs + xch[jj]) | 0x80000000u : 0u;
+            const bool inb = (unsigned)(xty[jj] + oy) < (unsigned)g.H && (unsigned)(xtx[jj] + ox) < (unsigned)g.W;
+            xofs[jj] = inb ? xthr[jj] + xsof : OOB;
         }
     };
+#define WGP_BLDS16(rs, voff, soff, lptr) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
     if (kb0 < kb1) prepare(kb0);
     for (int kb = kb0; kb < kb1; ++kb) {
         if (!(WGRAD_ABL & 4)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) GLDS16(yvalid ? dy + ((size_t)yofs + (unsigned)j * yrow1) : zero, Ys + (16 * j + wid * 4) * 256);
+            for (int j = 0; j < 4; ++j) WGP_BLDS16(yrs, ythr, ysof + (unsigned)j * yrow1, Ys + (16 * j + wid * 4) * 256);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                GLDS16((xofs[jj] >> 31) ? xsrc + (size_t)(xofs[jj] & 0x7fffffffu) : zero, Xs + (jj * 64 + wid * 16) * 64);
+            for (int jj = 0; jj < 2; ++jj) WGP_BLDS16(xrs, xofs[jj], 0, Xs + (jj * 64 + wid * 16) * 64);
         }
         if (kb + 1 < kb1) prepare(kb + 1);
         __syncthreads();
@@ -1500,18 +1523,16 @@ __global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, Pa
                 // channel chunk (wm * BMC/16 + 2 mt + (tp >> 1)) ^ swz(row): the tile index is an XOR of address bits 5-6
                 unsigned a0 = ybase[0], a1 = ybase[1];
                 if (mt) { WGP_XOR(a0, ybase[0], mt << 5); WGP_XOR(a1, ybase[1], mt << 5); }
-                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf4_t __attribute__((address_space(3)))*)(smem + a0 + kk * 8192));
-                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (bf4_t __attribute__((address_space(3)))*)(smem + a1 + kk * 8192));
+                const bf4_t lo = WGP_TR(a0 + kk * 8192);
+                const bf4_t hi = WGP_TR(a1 + kk * 8192);
                 af[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 unsigned o0 = xbase[kk][nt >> 1][0], o1 = xbase[kk][nt >> 1][1];
                 if (nt & 1) { WGP_XOR(o0, xbase[kk][nt >> 1][0], 32); WGP_XOR(o1, xbase[kk][nt >> 1][1], 32); }
-                const bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(smem + o0));
-                const bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(smem + o1));
+                const bf4_t lo = WGP_TR(o0);
+                const bf4_t hi = WGP_TR(o1);
                 bfr[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             if (xrelu) {
@@ -1585,6 +1606,9 @@ int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hip
 // shapes of the patch-resident weight gradient: full 64-channel output tiles only (the partly filled tiles of the
 // small-channel layers go to gg_wgrad_mfma_k, whose tile edges are guarded)
 static bool wgrad_patch_shape_ok(const GG& g) {
+    // 32-bit byte offsets into buffer descriptors: every tensor below 2 GB
+    const int64_t xb = (int64_t)g.N * g.H * g.W * (g.C1 > g.C2 ? g.C1 : g.C2) * 2, yb = (int64_t)g.N * g.OH * g.OW * g.Cout * 2;
+    if (xb >= (1ll << 31) || yb >= (1ll << 31)) return false;
     return g.lw >= 4 && g.lh >= 2 && (g.C1 % 32) == 0 && (g.C2 % 32) == 0 && (g.Cout % 64) == 0 && g.Cin >= 64;
 }
 
