@@ -561,6 +561,9 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
     static const bool no_patch = getenv("PAI_NO_PATCH") && atoi(getenv("PAI_NO_PATCH")) != 0;
     static const bool no_256 = getenv("PAI_NO_PATCH256") && atoi(getenv("PAI_NO_PATCH256")) != 0;
     if (no_patch || c.ksplit > 1 || c.bm != 128) return 0;
+    // the kernel addresses its sources with 32-bit byte offsets into buffer descriptors
+    if ((int64_t)g.N * g.H * g.W * (g.C1 > g.C2 ? g.C1 : g.C2) * 2 >= (1ll << 31) || (int64_t)g.Cout * g.wtaps * g.Cin * 2 >= (1ll << 31))
+        return 0;
     PatchGeo pg;
     // 16 x 16 tiles when the layer still fills the chip with them (two 8-wave workgroups per CU)
     if (!no_256 && c.bn == 128 && (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= 512 && patch_geo(g, 16, &pg)) return 256;
@@ -601,8 +604,28 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     const int img = bm / tpi, trem = bm - img * tpi;
     const int gy0 = (trem / pg.TX) * PD::TH, gx0 = (trem % pg.TX) * 16;
 
-    const bf16_t* w = (const bf16_t*)a.w;
-    const bf16_t* zero = (const bf16_t*)g_zero_line;
+    // Both tiles are filled by LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): the per-lane part of
+    // an address is a 32-bit byte offset, the per-step part (tap and channel chunk of the weight tile) rides in the
+    // scalar offset, and a lane whose offset lies beyond the buffer writes ZEROS to LDS (scripts/micro/oob_probe.hip):
+    // padding pixels need no zero line and no 64-bit select.  host (patch_rows): every tensor is smaller than 2 GB.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.w), 0, (unsigned)(g.Cout * g.wtaps * g.Cin) * 2u, 0x00020000);
+    const unsigned xpix = (unsigned)(g.N * g.H * g.W);
+    const __amdgpu_buffer_rsrc_t x1rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x1), 0, xpix * (unsigned)g.C1 * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x2 ? a.x2 : a.x1), 0, a.x2 ? xpix * (unsigned)g.C2 * 2u : 0u, 0x00020000);
+    // window offsets of this phase, 4 bits each (biased by 8): indexing the by-value PatchGeo byte arrays with the
+    // run-time window made hipcc read them with vector loads -- and wait for vmcnt(0) -- in front of every patch fill
+    unsigned wby16 = 0, wbx16 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wby16 |= (unsigned)((pg.by[ph][q] + 8) & 15) << (4 * q);
+        wbx16 |= (unsigned)((pg.bx[ph][q] + 8) & 15) << (4 * q);
+    }
+    wby16 = __builtin_amdgcn_readfirstlane(wby16);
+    wbx16 = __builtin_amdgcn_readfirstlane(wbx16);
 
     // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
     const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
@@ -616,9 +639,10 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
         const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
         pixb[j] = (img * g.H + y) * g.W + x;
         unsigned m = 0;
-        for (int q = 0; q < pg.groups; ++q) {
-            const int yy = y + pg.by[ph][q], xx = x + pg.bx[ph][q];
-            if (p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y + (int)((wby16 >> (4 * q)) & 15u) - 8, xx = x + (int)((wbx16 >> (4 * q)) & 15u) - 8;
+            if (q < pg.groups && p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
         }
         vmask[j] = m;
     }
@@ -626,12 +650,12 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     // LDS row rho = 16 nt + i of a wave's half of the weight tile holds output channel
     // (4 NT) (i >> 2) + 4 nt + (i & 3) of that half: with the weights as the MFMA's A operand a lane then ends
     // up with 4 NT CONSECUTIVE channels of one pixel, and the epilogue stages 16-B pieces instead of 2-B ones
-    const bf16_t* wrow[BJ];
+    unsigned wrow[BJ];                       // byte offset of this lane's chunk of weight row j (tap 0, channel 0)
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int lr = sr + RPP * j, half = lr / (BN / 2), rho = lr % (BN / 2);
         const int ch = half * (BN / 2) + (4 * NT) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
-        wrow[j] = w + (size_t)(n0 + ch) * g.wtaps * g.Cin + gchB;
+        wrow[j] = (unsigned)((n0 + ch) * g.wtaps * g.Cin + gchB) * 2u;
     }
 
     // ---- fragment read addresses -----------------------------------------------------------------
@@ -654,26 +678,28 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     const int cchunks = g.Cin / MBK;
     const int ngroups = cchunks * pg.groups;
     const int gsh = pg.groups == 4 ? 2 : 0;
+#define FP_BLDS16(rs, voff, soff, lptr) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
     auto fire_patch = [&](int gi) {
         const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
         const bool second = c0 >= g.C1;
-        const bf16_t* src = second ? (const bf16_t*)a.x2 : (const bf16_t*)a.x1;
         const int C = second ? g.C2 : g.C1;
         const int cofs = (second ? c0 - g.C1 : c0) + gchA;
-        const int dpix = pg.by[ph][q] * g.W + pg.bx[ph][q];
+        const int dpix = ((int)((wby16 >> (4 * q)) & 15u) - 8) * g.W + (int)((wbx16 >> (4 * q)) & 15u) - 8;
         if (abl & 2) return;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const bf16_t* pa = ((vmask[j] >> q) & 1u) ? src + ((pixb[j] + dpix) * C + cofs) : zero;
-            GLDS16(pa, smem + (j * RPP + wid * 8) * 128);
+            const unsigned vo = ((vmask[j] >> q) & 1u) ? (unsigned)((pixb[j] + dpix) * C + cofs) * 2u : OOB;
+            if (second) FP_BLDS16(x2rs, vo, 0, smem + (j * RPP + wid * 8) * 128);
+            else FP_BLDS16(x1rs, vo, 0, smem + (j * RPP + wid * 8) * 128);
         }
     };
     auto fire_b = [&](int gi, int k, int buf) {
         const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
-        const int woff = (int)((pg.wt4[ph][q] >> (8 * k)) & 0xffu) * g.Cin + c0;
+        const unsigned woff = (unsigned)((int)((pg.wt4[ph][q] >> (8 * k)) & 0xffu) * g.Cin + c0) * 2u;
         if (abl & 1) return;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) GLDS16(wrow[j] + woff, Bs + buf * (BN * 128) + (j * RPP + wid * 8) * 128);
+        for (int j = 0; j < BJ; ++j) FP_BLDS16(wrs, wrow[j], woff, Bs + buf * (BN * 128) + (j * RPP + wid * 8) * 128);
     };
     fire_patch(0);
     fire_b(0, 0, 0);
@@ -1474,7 +1500,7 @@ __global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, Pa
     // Fragment reads take the LDS byte address as an integer: the dynamic LDS block of this kernel (it has no static
     // one) starts at LDS address 0, checked here.  `smem + offset` costs a v_add_u32 with the link-time constant 0 per
     // read, 44 per K-step.
-#define WGP_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(unsigned)(addr))
+#define WGP_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(size_t)(unsigned)(addr))
     if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
 
     f4_t acc[MT][4];
