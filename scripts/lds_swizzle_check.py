@@ -13,6 +13,8 @@ group).  1 everywhere = conflict-free.  Run: python scripts/lds_swizzle_check.py
 Layouts covered (file: the function the formula is taken from):
   fwd_patch   gg_mfma.hip gg_fwd_patch_k     64-channel patch pixels, 128 B each, 16-B chunk c at slot c ^ (p & 6)
   fwd_weight  gg_mfma.hip gg_fwd_patch_k     weight tile rows of 128 B, chunk c at slot c ^ (row >> 1)
+  fwd_patch32 gg_mfma.hip gg_fwd_patch32_k   the 32x32x16 form: a lane group spans two patch rows; chunk c at slot c ^ (px & 7)
+  fwd_weight32                               its weight rows: 32 consecutive rows per read, chunk c at slot c ^ (row >> 1)
   p2_patch    gg_p2.hip   gg_fwd_p2_k        32-channel patch pixels, 64 B each, halves swapped when bit 2 of px is set
   wg_dy       gg_mfma.hip gg_wgrad_patch_k   dY rows of 256 B read transposed, chunk ch at slot ch ^ tr_swz(row)
   wg_x        gg_mfma.hip gg_wgrad_patch_k   X patch pixels of 64 B read transposed, halves swapped on bit 3 of p
@@ -62,6 +64,28 @@ def fwd_weight():
         def addr(lane):
             fr, fq = lane & 15, lane >> 4
             return fr * 128 + (((kk * 4 + fq) ^ (fr >> 1)) << 4)
+        worst = max(worst, ways(addr, B128_GROUPS, 16))
+    return worst
+
+
+def fwd_patch32():
+    worst = 1
+    for row0, ty, tx, ks, gq in itertools.product(range(0, 16, 4), range(2), range(2), range(4), range(2)):
+        def addr(lane):
+            n, h = lane & 31, lane >> 5
+            px = (n & 15) + tx
+            base = ((row0 + (n >> 4)) * PATCH_W + px) * 128 + ((h ^ (px & 7)) << 4)
+            return ((base + ty * PATCH_W * 128) ^ (ks << 5)) + gq * 2 * PATCH_W * 128
+        worst = max(worst, ways(addr, B128_GROUPS, 16))
+    return worst
+
+
+def fwd_weight32():
+    worst = 1
+    for ks, j in itertools.product(range(4), range(2)):
+        def addr(lane):
+            n, h = lane & 31, lane >> 5
+            return ((n * 128 + ((h ^ ((n >> 1) & 7)) << 4)) ^ (ks << 5)) + j * 32 * 128
         worst = max(worst, ways(addr, B128_GROUPS, 16))
     return worst
 
@@ -124,7 +148,8 @@ def wg2_x():
 
 def main():
     bad = 0
-    for name, fn in (("fwd_patch", fwd_patch), ("fwd_weight", fwd_weight), ("p2_patch", p2_patch), ("wg_dy", wg_dy),
+    for name, fn in (("fwd_patch", fwd_patch), ("fwd_weight", fwd_weight), ("fwd_patch32", fwd_patch32),
+                     ("fwd_weight32", fwd_weight32), ("p2_patch", p2_patch), ("wg_dy", wg_dy),
                      ("wg_x", wg_x), ("wg2_x", wg2_x)):
         w = fn()
         print(f"{name:11s} worst {w}-way" + ("" if w == 1 else "   <-- conflicts"))

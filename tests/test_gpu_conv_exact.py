@@ -159,6 +159,14 @@ def test_pipelined_p2_kernels_bit_exact(pai, case, mode):
     assert any(u.startswith("gg_fwd_p2_k<") for u in used[:2]), used
 
 
+@pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
+def test_mfma_32x32x16_form_bit_exact(pai, case):
+    """gg_fwd_patch32_k (off by default, tunable fwd_m32): the v_mfma_f32_32x32x16_bf16 form of the patch-resident
+    kernel -- other LDS image, other accumulator layout, other epilogue mapping -- gives the same bits."""
+    used = _run_case(pai, case, tunables=(("fwd_m32", 1),))
+    assert any(u.startswith("gg_fwd_patch32_k<") for u in used[:2]), used
+
+
 def test_two_handles_keep_their_own_buffers(pai):
     """workspace and scratch belong to a per-device handle.  Two handles of one device, bound in turn,
     run the same split-K layer into their OWN workspaces with identical results; a handle without a workspace runs the

@@ -58,7 +58,8 @@ template <int TH, int NW, int MT> struct P2Dims {      // NW waves of MT pixel r
     static constexpr int BBYTES = BN * 128;
     static constexpr size_t lds_bytes(int nring) {
         const size_t loop = 2 * (size_t)PBYTES + (size_t)nring * BBYTES + 1024;
-        const size_t epi = (size_t)BM * (BN * 2 + 16) + (size_t)WMW * 2 * BN * sizeof(float);
+        // staged tile + statistics rows: [WMW][2][BN] (forward) or [NW][2][BN] (bwd_write_partials)
+        const size_t epi = (size_t)BM * (BN * 2 + 16) + (size_t)(WMW > NW ? WMW : NW) * 2 * BN * sizeof(float);
         return loop > epi ? loop : epi;
     }
 };
@@ -464,6 +465,12 @@ static int p2_variant(const GG& g) {
     PatchGeo pg;
     const bool c128 = (g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0);
     const bool c256 = (g.Cout % 256) == 0 && (g.D2 == 0 || (g.D1 % 256) == 0);
+    // 5: 32 x 16 pixels x 128 channels, 16 waves of 64 x 64 (128 VGPRs), ONE workgroup per CU: the weight tile and the
+    // patch halo are shared by twice the pixels -- 4.1 B of LDS-DMA fill per kFLOP instead of gg_fwd_patch_k's 6.2
+    if (mode == 5) {
+        if (c128 && patch_geo(g, 32, &pg) && (int64_t)(g.M / 512) * (g.Cout / 128) * g.nphase >= pai_tunable("fwd_p2_min_wgs5", 200)) return 5;
+        return 0;
+    }
     if (mode >= 2 && c128 && patch_geo(g, 16, &pg) &&
         (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= pai_tunable("fwd_p2_min_wgs4", 384))
         return mode == 4 ? 4 : 3;
@@ -476,7 +483,7 @@ static int p2_variant(const GG& g) {
 
 int fwd_p2_rows(const GG& g) {
     const int v = p2_variant(g);
-    return v == 0 ? 0 : (v == 2 ? 512 : 256);
+    return v == 0 ? 0 : ((v == 2 || v == 5) ? 512 : 256);
 }
 
 static void p2_prob(const GG& g, const PatchGeo& pg, int mtiles, int ntiles, P2Prob* o) {
@@ -531,7 +538,8 @@ static int p2_launch(const GG& g, const FwdArgs& a, const PatchGeo& pg, hipStrea
 int launch_fwd_p2(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int v = p2_variant(g);
     PatchGeo pg;
-    PAI_CHECK(v && patch_geo(g, v == 2 ? 32 : 16, &pg), "launch_fwd_p2: problem not eligible");
+    PAI_CHECK(v && patch_geo(g, (v == 2 || v == 5) ? 32 : 16, &pg), "launch_fwd_p2: problem not eligible");
+    if (v == 5) return pai_tunable("fwd_p2_ring5", 3) == 3 ? p2_launch<32, 16, 4, 3>(g, a, pg, s) : p2_launch<32, 16, 4, 2>(g, a, pg, s);
     if (v == 1) return p2_launch<16, 8, 8, 3>(g, a, pg, s);
     if (v == 2) return p2_launch<32, 8, 8, 3>(g, a, pg, s);
     if (v == 4) return p2_launch<16, 8, 4, 2>(g, a, pg, s);
@@ -543,6 +551,8 @@ const char* fwd_p2_kernel_name(const GG& g) {
     switch (p2_variant(g)) {
         case 1: return relu ? "gg_fwd_p2_k<16, 8, 8, 3, true>" : "gg_fwd_p2_k<16, 8, 8, 3, false>";
         case 2: return relu ? "gg_fwd_p2_k<32, 8, 8, 3, true>" : "gg_fwd_p2_k<32, 8, 8, 3, false>";
+        case 5: return pai_tunable("fwd_p2_ring5", 3) == 3 ? (relu ? "gg_fwd_p2_k<32, 16, 4, 3, true>" : "gg_fwd_p2_k<32, 16, 4, 3, false>")
+                                                           : (relu ? "gg_fwd_p2_k<32, 16, 4, 2, true>" : "gg_fwd_p2_k<32, 16, 4, 2, false>");
         case 4: return relu ? "gg_fwd_p2_k<16, 8, 4, 2, true>" : "gg_fwd_p2_k<16, 8, 4, 2, false>";
         default: return relu ? "gg_fwd_p2_k<16, 4, 8, 2, true>" : "gg_fwd_p2_k<16, 4, 8, 2, false>";
     }
