@@ -32,6 +32,11 @@
 // keeps the matrix pipe only 52-55 % busy at 2.35-2.39 GHz -- the SIMD's vector issue is the shared resource: an
 // MFMA 16x16x32 holds it for 8 of its 16 cycles and every other vector instruction for 4 (guide, cycle constants),
 // so more than two vector instructions per MFMA (ReLU-on-load alone is one) cap the pipe below its peak.
+// Two more forms were measured and dropped: variant 5 (32 x 16 pixels x 128 channels, sixteen 64 x 64 waves, ONE
+// 1024-thread workgroup per CU: 34 % fewer LDS-DMA bytes per FLOP) runs 10-15 % slower than gg_fwd_patch_k on
+// decoders[5], D block 2 and encoders[2]; and the v_mfma_f32_32x32x16_bf16 form of variants 1, 2 and 4 (which a bare
+// MFMA loop favours by 40 % once other instructions sit between the MFMAs, scripts/micro/mfma_issue.hip) ran 3-8 %
+// slower than their 16x16x32 form -- that code was not kept.
 //
 // Serves the same reference call sites as gg_fwd_patch_k: the Conv2d k4 s2 p1 / ConvTranspose2d k4 s2 p1 layers of
 // EncoderBlock / DecoderBlock (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and
