@@ -390,6 +390,13 @@ int pai_l1(const float* pred, const float* target, int64_t numel, float loss_sca
            float grad_scale, float* grad, void* stream);
 int pai_mse(const float* pred, const float* target, int64_t numel, float loss_scale, double* loss,
             float grad_scale, float* grad, void* stream);
+/* *out = (float)*acc; *acc = 0.  The fp64 accumulator a group of loss launches added into becomes the fp32 loss value
+ * and is re-armed for the next step in one single-thread launch (the reference sums fp32 scalars with tensor ops,
+ * models/wrapper.py:50,94). */
+int pai_scalar_take(double* acc, float* out, void* stream);
+/* sums = {sum of per-image SSIM, sum of squared errors} as pai_ssim_sse accumulates them ->
+ * out3 = {mean SSIM, PSNR = -10 log10(mse), RMSE = sqrt(mse)} (models/utils.py:38-47), sums re-armed to 0. */
+int pai_metrics_take(double* sums, int64_t n_images, int64_t numel, float* out3, void* stream);
 /* Generator head backward: dh = (g_disc + g_rec) * (1 - pred^2)  (tanh', models/pix2pix.py:216);
  * g_disc / g_rec fp32 or NULL; dh in storage dtype. */
 int pai_tanh_bwd(int dtype, const float* pred, const float* g_a, const float* g_b, int64_t numel,

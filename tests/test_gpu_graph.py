@@ -40,10 +40,11 @@ def test_graphed_step_matches_eager(pai, dtype):
         assert gs.disabled is None, gs.disabled
         for k, v in eager.logged.items():
             a, a2, g = float(v), float(eager2.logged[k]), float(graphed.logged[k])
-            # fp32 atomics of the weight gradients make two runs differ in the last bits and Adam (and bf16 storage)
-            # amplifies that step by step: two EAGER runs of the same step are held to the same bound as graph vs eager
-            # (measured at step 6, d_loss: eager vs eager 2.6e-3 in fp32, graph vs eager 3.7e-3 in bf16)
-            tol = 1.5e-2 * max(1.0, abs(a))
+            # fp32 atomics of the weight gradients make two runs differ in the last bits and Adam (lr 2e-4 against
+            # weights of std 0.02) amplifies that step by step: two EAGER runs of the same step are held to the same
+            # bound as graph vs eager.  Measured: differences roughly double per step; at step 6 (d_loss) eager vs
+            # eager reaches 2.6e-3 in fp32 and graph vs eager 1.6e-2 in bf16 on some boxes.
+            tol = min(5e-2, 1e-3 * 2 ** s) * max(1.0, abs(a))
             assert abs(a - a2) <= tol and abs(a - g) <= tol, (s, k, a, a2, g)
     assert gs.graph is not None and gs.opt_steps_per_replay == 2
     assert graphed._pai_opt_steps == eager._pai_opt_steps == 2 * steps

@@ -265,32 +265,53 @@ __global__ __launch_bounds__(256) void thin_dgrad_gemm_k(GG g, FwdArgs a, float*
     }
 }
 
+// One thread per output pixel.  32-bit index arithmetic (host: N * OH * OW < 2^31) with shifts where the extents are
+// powers of two: the 64-bit divisions that stood here were most of the launch (decoders[7]: 36 -> see DESIGN.md).
+// Lanes walk along ox, so the <= 4 source rows of 64 B a pixel reads are shared by its neighbours through L1.
 __global__ __launch_bounds__(256) void thin_col2im_k(GG g, FwdArgs a, const float* Y, int T, int t0) {
-    const int64_t total = (int64_t)g.N * g.OH * g.OW;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ox = (int)(i % g.OW);
-        const int64_t r = i / g.OW;
-        const int oy = (int)(r % g.OH), n = (int)(r / g.OH);
-        const bool phases = g.nphase == 4;
-        const int ph = phases ? (oy & 1) * 2 + (ox & 1) : 0;
-        const int ay = phases ? oy >> 1 : oy, bx = phases ? ox >> 1 : ox;
+    const unsigned total = (unsigned)(g.N * g.OH * g.OW);
+    const bool phases = g.nphase == 4;
+    // the phase differs from lane to lane: indexing the by-value tables with it means per-lane loads from the kernel
+    // argument segment; a copy in LDS serves them in one cycle
+    __shared__ int tab[4][16];     // dy | dx << 8 | wt << 16 per (phase, tap)
+    if (threadIdx.x < 64) {
+        const int p = threadIdx.x >> 4, k = threadIdx.x & 15;
+        tab[p][k] = (g.dy[p][k] & 0xff) | ((g.dx[p][k] & 0xff) << 8) | ((g.wt[p][k] & 0xff) << 16);
+    }
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        unsigned ox, oy, n;
+        if (g.ldw >= 0) {
+            ox = i & ((unsigned)g.OW - 1u);
+            oy = (i >> g.ldw) & ((unsigned)g.OH - 1u);
+            n = i >> (g.ldw + g.ldh);
+        } else {
+            ox = i % (unsigned)g.OW;
+            const unsigned r = i / (unsigned)g.OW;
+            oy = r % (unsigned)g.OH;
+            n = r / (unsigned)g.OH;
+        }
+        const int ph = phases ? (int)((oy & 1u) * 2u + (ox & 1u)) : 0;
+        const int ay = (int)(phases ? oy >> 1 : oy), bx = (int)(phases ? ox >> 1 : ox);
+        const unsigned rowbase = n * (unsigned)g.H;
         for (int tt = 0; tt < T; ++tt) {
             const int t = t0 + tt;
             float v = a.bias ? a.bias[t] : 0.f;
             for (int k = 0; k < g.ntaps; ++k) {
-                const int iy = ay + g.dy[ph][k], ix = bx + g.dx[ph][k];
+                const int e = tab[ph][k];
+                const int iy = ay + (int)(signed char)(e & 0xff), ix = bx + (int)(signed char)((e >> 8) & 0xff);
                 if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                    v += Y[(((size_t)(n * g.H + iy) * g.W + ix) * T + tt) * 16 + g.wt[ph][k]];
+                    v += Y[(((size_t)((rowbase + (unsigned)iy) * (unsigned)g.W + (unsigned)ix)) * T + tt) * 16 + ((e >> 16) & 0xff)];
             }
             if (t < g.D1) {
-                if (a.y1 && !a.skip_d1) ((bf16_t*)a.y1)[i * g.D1 + t] = f2bf(v);
+                if (a.y1 && !a.skip_d1) ((bf16_t*)a.y1)[(size_t)i * g.D1 + t] = f2bf(v);
             } else if (a.y2) {
-                ((bf16_t*)a.y2)[i * g.D2 + (t - g.D1)] = f2bf(v);
+                ((bf16_t*)a.y2)[(size_t)i * g.D2 + (t - g.D1)] = f2bf(v);
             }
             if (a.yact || a.yf32) {
                 const float av = act_apply(v, a.eact);
-                if (a.yact) ((bf16_t*)a.yact)[i * g.Cout + t] = f2bf(av);
-                if (a.yf32) a.yf32[i * g.Cout + t] = av;
+                if (a.yact) ((bf16_t*)a.yact)[(size_t)i * g.Cout + t] = f2bf(av);
+                if (a.yf32) a.yf32[(size_t)i * g.Cout + t] = av;
             }
         }
     }
@@ -316,6 +337,7 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
 #undef TDG_K
 #undef TDG
     PAI_LAUNCH_CHECK();
+    PAI_CHECK((int64_t)g.N * g.OH * g.OW < (1ll << 31), "thin dgrad: more than 2^31 output pixels");
     int64_t b2 = ((int64_t)g.N * g.OH * g.OW + 255) / 256;
     if (b2 > 8192) b2 = 8192;
     hipLaunchKernelGGL(thin_col2im_k, dim3((int)b2), dim3(256), 0, s, g, a, (const float*)pai_ctx()->scratch, T, t0);

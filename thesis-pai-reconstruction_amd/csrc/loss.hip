@@ -72,6 +72,34 @@ extern "C" int pai_mse(const float* pred, const float* target, int64_t numel, fl
     return launch_loss<L_MSE>(pred, target, 0.f, numel, loss_scale, loss, grad_scale, grad, stream);
 }
 
+// The scalar glue of a loss / metric (fp64 accumulator -> fp32 value, log / sqrt of the logged metrics, re-arming the
+// accumulator) in ONE single-thread launch instead of the fill / divide / log / sqrt / neg / cast chain of tensor ops
+// (5-9 us of launch latency each, ~25 of them per GAN step).
+__global__ void scalar_take_k(double* acc, float* out) {
+    out[0] = (float)acc[0];
+    acc[0] = 0.0;
+}
+extern "C" int pai_scalar_take(double* acc, float* out, void* stream) {
+    PAI_CHECK(acc && out, "pai_scalar_take: null pointer");
+    hipLaunchKernelGGL(scalar_take_k, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void metrics_take_k(double* sums, double inv_images, double inv_numel, float* out3) {
+    const double mse = sums[1] * inv_numel;
+    out3[0] = (float)(sums[0] * inv_images);
+    out3[1] = (float)(-log(mse) * (10.0 / 2.302585092994045684));      // PSNR, data range 1
+    out3[2] = (float)sqrt(mse);                                        // RMSE
+    sums[0] = sums[1] = 0.0;
+}
+extern "C" int pai_metrics_take(double* sums, int64_t n_images, int64_t numel, float* out3, void* stream) {
+    PAI_CHECK(sums && out3 && n_images > 0 && numel > 0, "pai_metrics_take: bad arguments");
+    hipLaunchKernelGGL(metrics_take_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, 1.0 / (double)n_images,
+                       1.0 / (double)numel, out3);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void tanh_bwd_k(const float* pred, const float* ga, const float* gb,
                                                   int64_t numel, T* dh) {

@@ -158,6 +158,102 @@ class _MeanLoss(torch.autograd.Function):
         return None, grad * gout, None
 
 
+class _Accumulators:
+    """Persistent fp64 device accumulators, zero between uses: the ``*_take`` launch that reads one also re-arms it,
+    so a step spends no fill launch on it.  One per (device, stream, purpose); a use that did not reach its take
+    (an exception in between) leaves the buffer dirty -- it is then replaced, not trusted."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, device, purpose, n=1):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream, purpose)
+        ent = self.bufs.get(key)
+        if ent is None or ent[1] or ent[0].numel() != n:
+            ent = [torch.zeros(n, dtype=torch.float64, device=device), False]
+            self.bufs[key] = ent
+        ent[1] = True          # armed: being accumulated into
+        return ent
+
+    @staticmethod
+    def taken(ent):
+        ent[1] = False
+
+
+_ACC = _Accumulators()
+
+
+class _GanDiscLoss(torch.autograd.Function):
+    """BCE(real logits, 1) + BCE(fake logits, 0), each mean-reduced (reference models/wrapper.py:68-95), over ONE
+    tensor of 2N logits with the real half first: two loss launches accumulate into one fp64 scalar, a third turns it
+    into the fp32 loss.  The gradient w.r.t. all 2N logits comes out of the same two passes."""
+
+    @staticmethod
+    def forward(ctx, labels, n_real):
+        _check_f32_cuda(labels)
+        x = labels.contiguous().float()
+        flat = x.view(-1)
+        k = (flat.numel() // x.shape[0]) * int(n_real)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(flat) if need else None
+        ent = _ACC.get(x.device, "gan_d")
+        ops.bce_logits(flat[:k], 1.0, 1.0, ent[0], 1.0, grad[:k] if need else None)
+        ops.bce_logits(flat[k:], 0.0, 1.0, ent[0], 1.0, grad[k:] if need else None)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ops.scalar_take(ent[0], out)
+        _ACC.taken(ent)
+        if need:
+            ctx.save_for_backward(grad)
+            ctx.shape = labels.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).view(ctx.shape), None
+
+
+def gan_discriminator_loss_pairs(labels: torch.Tensor, n_real: int) -> torch.Tensor:
+    """discriminator_loss(labels[n_real:], labels[:n_real]) of reference models/wrapper.py:68-95 for the logits of a
+    batched (real | fake) discriminator pass."""
+    return _GanDiscLoss.apply(labels, n_real)
+
+
+class _GanGenLoss(torch.autograd.Function):
+    """BCE(D(x, pred), 1) + l1_weight * L1(pred, target) (reference models/wrapper.py:44-50): both mean losses
+    accumulate into one fp64 scalar (the L1 launch scaled by l1_weight), a third launch makes the fp32 value."""
+
+    @staticmethod
+    def forward(ctx, pred_label, pred, target, l1_weight):
+        _check_f32_cuda(pred_label, pred, target)
+        lc, pc, tc = pred_label.contiguous().float(), pred.contiguous().float(), target.contiguous().float()
+        need_l, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gl = torch.empty_like(lc) if need_l else None
+        gp = torch.empty_like(pc) if need_p else None
+        ent = _ACC.get(pc.device, "gan_g")
+        ops.bce_logits(lc, 1.0, 1.0, ent[0], 1.0, gl)
+        ops.l1(pc, tc, float(l1_weight), ent[0], float(l1_weight), gp)
+        out = torch.empty((), dtype=torch.float32, device=pc.device)
+        ops.scalar_take(ent[0], out)
+        _ACC.taken(ent)
+        ctx.save_for_backward(*[g for g in (gl, gp) if g is not None])
+        ctx.which = (need_l, need_p)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        saved = list(ctx.saved_tensors)
+        gl = saved.pop(0) * gout if ctx.which[0] else None
+        gp = saved.pop(0) * gout if ctx.which[1] else None
+        return gl, gp, None, None
+
+
+def gan_generator_loss(pred_label, pred, target, l1_weight: float) -> torch.Tensor:
+    """bce(D(x, pred), ones) + l1_weight * l1(pred, target): the ``loss_type == "gan"`` branch of reference
+    models/wrapper.py:44-50."""
+    return _GanGenLoss.apply(pred_label, pred, target, float(l1_weight))
+
+
 def bce_with_logits_const(logits: torch.Tensor, target: float) -> torch.Tensor:
     """F.binary_cross_entropy_with_logits(logits, full_like(logits, target)) (reference
     models/wrapper.py:45-48,84-93)."""
@@ -263,11 +359,15 @@ def ssim_psnr_of_normalized(pred, target, w_ssim, w_psnr):
 def metrics_of_normalized(pred, target):
     """(ssim, psnr, rmse) of the denormalised pair in ONE pass over the images, no graph
     (the per-step logging of reference models/wrapper.py:150-156,168-173)."""
-    p, t, out2, _, _ = _ssim_sse(pred.detach(), target.detach(), 1)
-    n, c = p.shape[:2]
-    mse_v = out2[1] / p.numel()
-    return ((out2[0] / (n * c)).float(), (-torch.log(mse_v) * (10.0 / math.log(10.0))).float(),
-            torch.sqrt(mse_v).float())
+    _check_f32_cuda(pred, target)
+    p, t = pred.detach().contiguous().float(), target.detach().contiguous().float()
+    n, c, h, w = p.shape
+    ent = _ACC.get(p.device, "metrics", 2)
+    ops.ssim_sse(p, t, n * c, h, w, 1, ent[0], None, None)
+    out3 = torch.empty(3, dtype=torch.float32, device=p.device)
+    ops.metrics_take(ent[0], n * c, p.numel(), out3)
+    _ACC.taken(ent)
+    return out3[0], out3[1], out3[2]
 
 
 def ssim_per_image(pred, target, return_full_image=False):

@@ -109,6 +109,8 @@ SIGNATURES = {
     "pai_bce_logits": (_I, [_P, _L, _F, _F, _P, _F, _P, _P]),
     "pai_l1": (_I, [_P, _P, _L, _F, _P, _F, _P, _P]),
     "pai_mse": (_I, [_P, _P, _L, _F, _P, _F, _P, _P]),
+    "pai_scalar_take": (_I, [_P, _P, _P]),
+    "pai_metrics_take": (_I, [_P, _L, _L, _P, _P]),
     "pai_tanh_bwd": (_I, [_I, _P, _P, _P, _L, _P, _P]),
     "pai_denormalize": (_I, [_P, _P, _L, _P, _P]),
     "pai_ssim_sse": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),

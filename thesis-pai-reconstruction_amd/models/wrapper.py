@@ -50,6 +50,9 @@ class UnetWrapper(LightningModule):
         """Reference models/wrapper.py:42-66."""
         if self.loss_type == "gan":
             pred_label = self.discriminator(x, pred)
+            if pred.is_cuda:
+                # bce(pred_label, ones) + L1_WEIGHT * l1(pred, target) in three launches, no tensor-op glue
+                return PF.gan_generator_loss(pred_label, pred, target, L1_WEIGHT)
             bce_loss = PF.bce_with_logits_const(pred_label, 1.0)
             l1_loss = PF.l1_loss(pred, target)
             return bce_loss + L1_WEIGHT * l1_loss
@@ -133,11 +136,12 @@ class UnetWrapper(LightningModule):
                 # one batch of 2N (one backward pass, so gradient buckets can be reduced while it runs)
                 n = x.shape[0]
                 labels = self.discriminator.forward_pairs(x, target, pred)
-                target_label, pred_label = labels[:n], labels[n:]
+                # discriminator_loss(labels[n:], labels[:n]) without slicing the logits inside the autograd graph
+                d_loss = PF.gan_discriminator_loss_pairs(labels, n)
             else:
                 target_label = self.discriminator(x, target)
                 pred_label = self.discriminator(x, pred)
-            d_loss = self.discriminator_loss(pred_label, target_label)
+                d_loss = self.discriminator_loss(pred_label, target_label)
             self.log("d_loss", d_loss, prog_bar=True)
             self.discriminator.zero_grad(set_to_none=True)
             self.manual_backward(d_loss)

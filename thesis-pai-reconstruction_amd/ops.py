@@ -442,6 +442,17 @@ def mse(pred, target, loss_scale, loss, grad_scale=0.0, grad=None):
             "pai_mse")
 
 
+def scalar_take(acc, out):
+    """out = float(acc); acc = 0 (one single-thread launch)."""
+    L.check(L.load().pai_scalar_take(_p(acc, torch.float64), _p(out, torch.float32), _stream()), "pai_scalar_take")
+
+
+def metrics_take(sums, n_images, numel, out3):
+    """{sum SSIM, SSE} -> out3 = {mean SSIM, PSNR, RMSE}; sums = 0."""
+    L.check(L.load().pai_metrics_take(_p(sums, torch.float64), int(n_images), int(numel), _p(out3, torch.float32),
+                                      _stream()), "pai_metrics_take")
+
+
 def tanh_bwd(dtype, pred, g_a, g_b, dh):
     L.check(L.load().pai_tanh_bwd(code_of(dtype), _p(pred, torch.float32), _p(g_a, torch.float32),
                                   _p(g_b, torch.float32), pred.numel(), _p(dh), _stream()), "pai_tanh_bwd")
