@@ -218,6 +218,10 @@ int pai_conv_wgrad_overwrite(const pai_conv_desc* d, const void* x1, const void*
 /* fp32 master weights (fwd pack) -> storage-dtype fwd pack and/or dgrad pack. */
 int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,
                      void* w_fwd_or_null, void* w_dgrad_or_null, void* stream);
+/* The same for n layers in one launch (bf16 packs, Cin and Cout multiples of 64): after an optimizer step every pack of
+ * a network is stale at once.  All arrays are HOST arrays of n entries; w_fwd[i] or w_dgrad[i] may be NULL. */
+int pai_pack_weights_multi(int n, const float* const* w_master, const int32_t* cout, const int32_t* taps,
+                           const int32_t* cin, void* const* w_fwd, void* const* w_dgrad, void* stream);
 
 /* ---------------------------------------------------------------------------
  * BatchNorm2d (training and eval).  Replaces aten::native_batch_norm(_backward)

@@ -283,3 +283,58 @@ def test_comm_abi_single_rank(pai):
     torch.cuda.synchronize()
     assert torch.equal(t, want)
     comm.destroy()
+
+
+def test_pack_weights_multi_equals_per_layer_packs(pai):
+    """pai_pack_weights_multi (every 64-multiple layer of a network in one launch) writes the same bf16 forward and
+    input-gradient packs as one pai_pack_weights launch per layer; NULL outputs are skipped."""
+    from thesis_pai_reconstruction_amd import ops
+    torch.manual_seed(5)
+    shapes = [(128, 16, 64), (64, 16, 256), (512, 16, 512), (64, 9, 64)]        # (Cout, taps, Cin)
+    items, want = [], []
+    for i, (co, taps, ci) in enumerate(shapes):
+        w = torch.randn(co * taps * ci, device=dev())
+        wf, wd = (torch.empty(w.numel(), dtype=torch.bfloat16, device=dev()) for _ in range(2))
+        ops.pack_weights(torch.bfloat16, w, co, taps, ci, wf, wd)
+        mf = torch.full_like(wf, -7.0)
+        md = None if i == 1 else torch.full_like(wd, -7.0)       # one layer without an input-gradient pack
+        items.append((w, co, taps, ci, mf, md))
+        want.append((wf, wd))
+    ops.pack_weights_multi(items)
+    for (w, co, taps, ci, mf, md), (wf, wd) in zip(items, want):
+        assert torch.equal(mf, wf)
+        if md is not None:
+            assert torch.equal(md, wd)
+    with pytest.raises(ops.PaiError, match="multiples of 64"):
+        ops.pack_weights_multi([(torch.zeros(32 * 16 * 64, device=dev()), 32, 16, 64,
+                                 torch.empty(32 * 16 * 64, dtype=torch.bfloat16, device=dev()), None)])
+
+
+def test_fused_gan_losses_equal_the_composed_ones(pai):
+    """gan_discriminator_loss_pairs / gan_generator_loss (two loss launches into one fp64 scalar + pai_scalar_take)
+    against the composed bce / l1 functions the reference spells out (models/wrapper.py:44-50,68-95): values and
+    gradients; metrics_of_normalized (pai_metrics_take) against ssim / psnr / rmse of the denormalised pair."""
+    from thesis_pai_reconstruction_amd import functional as PF
+    torch.manual_seed(2)
+    n = 3
+    labels = torch.randn(2 * n, 1, 6, 6, device=dev(), requires_grad=True)
+    d1 = PF.gan_discriminator_loss_pairs(labels, n)
+    (g1,) = torch.autograd.grad(d1 * 1.5, labels)
+    l2 = labels.detach().clone().requires_grad_(True)
+    d2 = PF.bce_with_logits_const(l2[n:], 0.0) + PF.bce_with_logits_const(l2[:n], 1.0)
+    (g2,) = torch.autograd.grad(d2 * 1.5, l2)
+    assert abs(float(d1) - float(d2)) <= 1e-6 * max(1.0, abs(float(d2))) and torch.allclose(g1, g2, rtol=1e-6, atol=1e-9)
+    for _ in range(2):          # twice: the accumulator is re-armed by the take
+        pl = torch.randn(n, 1, 6, 6, device=dev(), requires_grad=True)
+        pred = torch.tanh(torch.randn(n, 1, 32, 32, device=dev())).requires_grad_(True)
+        tgt = torch.tanh(torch.randn(n, 1, 32, 32, device=dev()))
+        a = PF.gan_generator_loss(pl, pred, tgt, 100.0)
+        ga = torch.autograd.grad(a, (pl, pred))
+        b = PF.bce_with_logits_const(pl, 1.0) + 100.0 * PF.l1_loss(pred, tgt)
+        gb = torch.autograd.grad(b, (pl, pred))
+        assert abs(float(a) - float(b)) <= 1e-6 * max(1.0, abs(float(b)))
+        assert torch.allclose(ga[0], gb[0], rtol=1e-6, atol=1e-9) and torch.allclose(ga[1], gb[1], rtol=1e-6, atol=1e-9)
+        s, p, r = PF.metrics_of_normalized(pred.detach(), tgt)
+        dp, dt = PF.denormalize(pred.detach()), PF.denormalize(tgt)
+        assert abs(float(s) - float(PF.ssim(dp, dt))) <= 1e-6
+        assert abs(float(p) - float(PF.psnr(dp, dt))) <= 1e-5 and abs(float(r) - float(PF.rmse(dp, dt))) <= 1e-7

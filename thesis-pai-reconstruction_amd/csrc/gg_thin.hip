@@ -542,7 +542,15 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_k(ThinW p, int T, int n
 __global__ __launch_bounds__(256) void sum1_k(const bf16_t* x, int64_t n, float* out) {
     __shared__ float ws[4];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += bf2f(x[i]);
+    // 16-B loads (x is a device allocation: 16-B aligned), the tail element by element
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = ((const uint4*)x)[i];
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
+    }
+    for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += bf2f(x[i]);
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();

@@ -126,6 +126,83 @@ __global__ __launch_bounds__(256) void pack64_k(const float* w, int Cout, int ta
     }
 }
 
+// Every 64-multiple layer of a network in ONE launch: after an optimizer step all filter packs are stale at once, and
+// 17 launches of 8 us each is launch latency, not work.  Block b belongs to the item whose [blk0, blk0 + blocks) range
+// holds it; inside an item the blocks are (input-channel tile, output-channel tile, tap) as in pack64_k.
+struct PackItem {
+    const float* w;
+    bf16_t *wf, *wd;
+    int Cout, taps, Cin, blk0;
+};
+constexpr int PACK_MULTI_MAX = 32;
+struct PackMulti {
+    PackItem it[PACK_MULTI_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack64_multi_k(PackMulti pm) {
+    __shared__ float tile[64][65];
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < pm.n; ++i)
+        if ((int)blockIdx.x >= pm.it[i].blk0) k = i;
+    // one item's fields as scalars (the table is indexed by a run-time value)
+    const float* w = pm.it[k].w;
+    bf16_t *wf = pm.it[k].wf, *wd = pm.it[k].wd;
+    const int Cout = pm.it[k].Cout, taps = pm.it[k].taps, Cin = pm.it[k].Cin;
+    const int lb = blockIdx.x - pm.it[k].blk0;
+    const int nci = Cin / 64, nco = Cout / 64;
+    const int ci0 = (lb % nci) * 64, co0 = ((lb / nci) % nco) * 64, t = lb / (nci * nco);
+    const int tid = threadIdx.x;
+    const int q = tid & 15, r0 = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 16 * j;
+        const float4 v = *(const float4*)(w + ((size_t)(co0 + r) * taps + t) * Cin + ci0 + 4 * q);
+        tile[r][4 * q + 0] = v.x; tile[r][4 * q + 1] = v.y; tile[r][4 * q + 2] = v.z; tile[r][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+    const int c = tid & 7, s0 = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = s0 + 32 * j;
+        if (wf) {
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pk2bf(tile[r][8 * c + 2 * e], tile[r][8 * c + 2 * e + 1]);
+            *(uint4*)(wf + ((size_t)(co0 + r) * taps + t) * Cin + ci0 + 8 * c) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        if (wd) {
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pk2bf(tile[8 * c + 2 * e][r], tile[8 * c + 2 * e + 1][r]);
+            *(uint4*)(wd + ((size_t)(ci0 + r) * taps + t) * Cout + co0 + 8 * c) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+    }
+}
+
+extern "C" int pai_pack_weights_multi(int n, const float* const* w_master, const int32_t* cout, const int32_t* taps,
+                                      const int32_t* cin, void* const* w_fwd, void* const* w_dgrad, void* stream) {
+    PAI_CHECK(n > 0 && w_master && cout && taps && cin && w_fwd && w_dgrad, "pai_pack_weights_multi: null pointer");
+    for (int i0 = 0; i0 < n; i0 += PACK_MULTI_MAX) {
+        PackMulti pm;
+        memset(&pm, 0, sizeof(pm));
+        pm.n = n - i0 < PACK_MULTI_MAX ? n - i0 : PACK_MULTI_MAX;
+        int64_t blocks = 0;
+        for (int i = 0; i < pm.n; ++i) {
+            const int k = i0 + i;
+            PAI_CHECK(w_master[k] && (w_fwd[k] || w_dgrad[k]), "pai_pack_weights_multi: item %d: null pointer", k);
+            PAI_CHECK(cin[k] > 0 && cout[k] > 0 && taps[k] > 0 && (cin[k] % 64) == 0 && (cout[k] % 64) == 0,
+                      "pai_pack_weights_multi: item %d: Cin=%d, Cout=%d must be multiples of 64 (bf16 packs)", k, cin[k], cout[k]);
+            pm.it[i] = PackItem{w_master[k], (bf16_t*)w_fwd[k], (bf16_t*)w_dgrad[k], cout[k], taps[k], cin[k], (int)blocks};
+            blocks += (int64_t)(cin[k] / 64) * (cout[k] / 64) * taps[k];
+            PAI_CHECK(blocks < (1ll << 31), "pai_pack_weights_multi: too many tiles");
+        }
+        hipLaunchKernelGGL(pack64_multi_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pm);
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,
                                 void* w_fwd, void* w_dgrad, void* stream) {
     PAI_CHECK(w_master && (w_fwd || w_dgrad), "pai_pack_weights: null pointer");

@@ -260,6 +260,22 @@ def pack_weights(dtype, w_master, Cout, taps, Cin, w_fwd=None, w_dgrad=None):
                                       _p(w_dgrad), _stream()), "pai_pack_weights")
 
 
+def pack_weights_multi(items):
+    """items: [(w_master fp32, Cout, taps, Cin, w_fwd | None, w_dgrad | None)], bf16 packs, Cin and Cout multiples of
+    64: every layer in one launch."""
+    import ctypes as C
+    n = len(items)
+    if n == 0:
+        return
+    ptrs = lambda k: (C.c_void_p * n)(*[_p(it[k]) if k == 0 else (_p(it[k]) if it[k] is not None else None) for it in items])
+    ints = lambda k: (C.c_int32 * n)(*[int(it[k]) for it in items])
+    for it in items:
+        if it[0].dtype != torch.float32:
+            raise PaiError("pack_weights_multi: fp32 master weights expected")
+    L.check(L.load().pai_pack_weights_multi(n, ptrs(0), ints(1), ints(2), ints(3), ptrs(4), ptrs(5), _stream()),
+            "pai_pack_weights_multi")
+
+
 def bn_finalize(stats, rows, C_, count, gamma, beta, eps, momentum, n_updates, running_mean, running_var,
                 nbt, mean, rstd, scale, shift):
     L.check(L.load().pai_bn_finalize(_p(stats), rows, C_, count, _p(gamma), _p(beta), eps, momentum, n_updates,
