@@ -34,6 +34,57 @@ __device__ __forceinline__ bf8_t relu8(bf8_t f) {
     return __builtin_bit_cast(bf8_t, __builtin_elementwise_max(x, z));
 }
 
+// Eight elements thin[e0 + ix0 + S * j], j = 0..7 (S = 1 or 2) of one row of a 1-channel bf16 image, as two / one
+// 16-B buffer loads + byte permutes instead of eight 2-byte gathers with their own index arithmetic (the gathers were
+// 60 % of D block 0's weight gradient).  e0 = element index of the row start; the row is `valid` or reads as zero;
+// elements left of 0 or right of TW - 1 read as zero.  The wide loads start at the even element below ix0.
+template <int S>
+__device__ __forceinline__ us8_t thin_gather8(__amdgpu_buffer_rsrc_t rs, int e0, int ix0, int TW, bool valid) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    const int base = ix0 & ~1, o = ix0 & 1;
+    // the very first row of the tensor, left edge: the wide load would start one dword BEFORE the tensor and come back
+    // all zero (the range check is per instruction, not per dword) -- start at 0 and shift by a dword instead
+    const bool neg = valid && e0 + base < 0;
+    const unsigned vo = valid ? (neg ? 0u : (unsigned)(e0 + base) * 2u) : 0x80000000u;
+    unsigned out[4];
+    if (S == 2) {
+        u4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0);
+        u4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo + 16, 0, 0);
+        if (__builtin_amdgcn_ballot_w64(neg) != 0) {
+            if (neg) { b = (u4_t){a[3], b[0], b[1], b[2]}; a = (u4_t){0u, a[0], a[1], a[2]}; }
+        }
+        const unsigned sel = o ? 0x07060302u : 0x05040100u;      // half o of the low dword | half o of the high dword
+        out[0] = __builtin_amdgcn_perm(a[1], a[0], sel);
+        out[1] = __builtin_amdgcn_perm(a[3], a[2], sel);
+        out[2] = __builtin_amdgcn_perm(b[1], b[0], sel);
+        out[3] = __builtin_amdgcn_perm(b[3], b[2], sel);
+    } else {
+        u4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0);
+        unsigned a4 = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo + 16, 0, 0);
+        if (__builtin_amdgcn_ballot_w64(neg) != 0) {
+            if (neg) { a4 = a[3]; a = (u4_t){0u, a[0], a[1], a[2]}; }
+        }
+        const unsigned sh = (unsigned)o * 16u;
+        out[0] = __builtin_amdgcn_alignbit(a[1], a[0], sh);
+        out[1] = __builtin_amdgcn_alignbit(a[2], a[1], sh);
+        out[2] = __builtin_amdgcn_alignbit(a[3], a[2], sh);
+        out[3] = __builtin_amdgcn_alignbit(a4, a[3], sh);
+    }
+    // edges (the first / last pixels of an image row): elements outside [0, TW) read as zero; wave-uniform branch
+    const bool edge = valid && (ix0 < 0 || ix0 + S * 7 >= TW);
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool lo = (unsigned)(ix0 + S * (2 * i)) < (unsigned)TW, hi = (unsigned)(ix0 + S * (2 * i + 1)) < (unsigned)TW;
+            out[i] &= (lo ? 0xffffu : 0u) | (hi ? 0xffff0000u : 0u);
+        }
+    }
+    us8_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[2 * i] = (unsigned short)(out[i] & 0xffffu); r[2 * i + 1] = (unsigned short)(out[i] >> 16); }
+    return r;
+}
+
 __device__ __forceinline__ void decode_row2(const GG& g, int m, int& n, int& gy, int& gx) {
     if (g.lw >= 0) {
         gx = m & (g.OWg - 1);
@@ -364,6 +415,7 @@ struct ThinW {
     int s_wc, s_tap, s_t;         // dw index = wc*s_wc + tap*s_tap + t*s_t
     float* dbias;                 // per wide channel, or null
     int M;                        // N*H*W
+    int fast;                     // patch rows by thin_gather8 (set by launch_tw)
     float* partial;               // per-workgroup partial sums [grid.x][grid.y][16 T + 1][128] or null (atomics)
 };
 
@@ -396,6 +448,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     // patch row k = 16*tt + fr -> (tap, t)
     int kdy[T], kdx[T];
     const bf16_t* ksrc[T];
+    int kt[T];
 #pragma unroll
     for (int tt = 0; tt < T; ++tt) {
         const int k = 16 * tt + fr;
@@ -404,7 +457,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
         kdy[tt] = p.flip ? 1 - th : th - 1;
         kdx[tt] = tap < p.ntaps ? (p.flip ? 1 - tw : tw - 1) : -(1 << 20);   // rows beyond the tap count: never in bounds
         ksrc[tt] = t ? p.thin2 : p.thin1;
+        kt[tt] = t;
     }
+    // fast patch rows: the 8 pixels of a lane lie in one image row (W % 8 == 0) and the thin tensors fit 32-bit byte
+    // offsets -> thin_gather8; host sets p.fast
+    const unsigned thin_bytes = (unsigned)(p.N * p.TH * p.TW) * 2u;
+    const __amdgpu_buffer_rsrc_t trs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.thin1), 0, thin_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.thin2 ? p.thin2 : p.thin1), 0, p.thin2 ? thin_bytes : 0u, 0x00020000);
 
     f4_t acc[T][4];
 #pragma unroll
@@ -430,6 +490,17 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
             us8_t pv;
+            if (p.fast) {
+                const int m = p0 + 32 * ks + 8 * fq;        // first of the lane's 8 pixels, all in one image row
+                int n, ay, bx;
+                if (p.lw >= 0) { bx = m & (p.W - 1); ay = (m >> p.lw) & (p.H - 1); n = m >> (p.lw + p.lh); }
+                else { bx = m % p.W; const int r = m / p.W; ay = r % p.H; n = r / p.H; }
+                const int iy = p.tmul * ay + kdy[tt], ix0 = p.tmul * bx + kdx[tt];
+                const bool rowok = m < p.M && (unsigned)iy < (unsigned)p.TH && kdx[tt] > -(1 << 19);
+                const int e0 = (n * p.TH + iy) * p.TW;
+                if (p.tmul == 2) pv = kt[tt] ? thin_gather8<2>(trs2, e0, ix0, p.TW, rowok) : thin_gather8<2>(trs1, e0, ix0, p.TW, rowok);
+                else pv = kt[tt] ? thin_gather8<1>(trs2, e0, ix0, p.TW, rowok) : thin_gather8<1>(trs1, e0, ix0, p.TW, rowok);
+            } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int m = p0 + 32 * ks + 8 * fq + j;
@@ -439,6 +510,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
                 const int iy = p.tmul * ay + kdy[tt], ix = p.tmul * bx + kdx[tt];
                 const bool inb = m < p.M && (unsigned)iy < (unsigned)p.TH && (unsigned)ix < (unsigned)p.TW;
                 pv[j] = inb ? ksrc[tt][(size_t)(n * p.TH + iy) * p.TW + ix] : (unsigned short)0;
+            }
             }
             af[tt] = __builtin_bit_cast(bf8_t, pv);
         }
@@ -593,6 +665,8 @@ int64_t thin_wgrad_scratch_bytes(int64_t M, int T, int WC) {
 
 static int launch_tw(ThinW& p, int T, hipStream_t s) {
     p.M = p.N * p.H * p.W;
+    p.fast = pai_tunable("thin_fast", 1) && (p.W % 8) == 0 && (p.TW % 2) == 0 && (p.tmul == 1 || p.tmul == 2) &&
+             (int64_t)p.N * p.TH * p.TW * 2 < (1ll << 31);
     p.lw = ilog2_exact(p.W);
     p.lh = ilog2_exact(p.H);
     if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
