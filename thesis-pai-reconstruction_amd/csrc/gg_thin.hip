@@ -85,6 +85,34 @@ __device__ __forceinline__ us8_t thin_gather8(__amdgpu_buffer_rsrc_t rs, int e0,
     return r;
 }
 
+// ReLU on two packed bf16: as signed 16-bit integers every negative float is negative
+__device__ __forceinline__ unsigned relu2u(unsigned v) {
+    typedef __attribute__((ext_vector_type(2))) short s2_t;
+    const s2_t z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2_t, v), z));
+}
+
+// Four CONTIGUOUS elements thin[e0 + ix0 .. + 3] of one row (the four kx taps of one kernel row at one pixel) as one
+// 12-B buffer load + two funnel shifts; same conventions as thin_gather8.  Returns two packed pairs.
+__device__ __forceinline__ uint2 thin_gather4(__amdgpu_buffer_rsrc_t rs, int e0, int ix0, int TW, bool valid) {
+    typedef __attribute__((ext_vector_type(3))) unsigned u3_t;
+    const int base = ix0 & ~1, o = ix0 & 1;
+    const bool neg = valid && e0 + base < 0;
+    const unsigned vo = valid ? (neg ? 0u : (unsigned)(e0 + base) * 2u) : 0x80000000u;
+    u3_t a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)vo, 0, 0);
+    if (__builtin_amdgcn_ballot_w64(neg) != 0) {
+        if (neg) a = (u3_t){0u, a[0], a[1]};
+    }
+    const unsigned sh = (unsigned)o * 16u;
+    uint2 out = make_uint2(__builtin_amdgcn_alignbit(a[1], a[0], sh), __builtin_amdgcn_alignbit(a[2], a[1], sh));
+    const bool edge = valid && (ix0 < 0 || ix0 + 3 >= TW);
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) {
+        out.x &= ((unsigned)ix0 < (unsigned)TW ? 0xffffu : 0u) | ((unsigned)(ix0 + 1) < (unsigned)TW ? 0xffff0000u : 0u);
+        out.y &= ((unsigned)(ix0 + 2) < (unsigned)TW ? 0xffffu : 0u) | ((unsigned)(ix0 + 3) < (unsigned)TW ? 0xffff0000u : 0u);
+    }
+    return out;
+}
+
 __device__ __forceinline__ void decode_row2(const GG& g, int m, int& n, int& gy, int& gx) {
     if (g.lw >= 0) {
         gx = m & (g.OWg - 1);
@@ -112,7 +140,7 @@ bool thin_fwd_ok(int dtype, const GG& g, const FwdArgs& a) {
 }
 
 template <int T>  // thin channels (1 or 2, one per source tensor)
-__global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
+__global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16_t* x1 = (const bf16_t*)a.x1;
@@ -178,14 +206,57 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a) {
         }
         return pv;
     };
+    // 4 x 4 kernels (tap = 4 ky + kx): a lane's eight patch elements are the four kx taps of two kernel rows (T = 1) or
+    // of one kernel row in both source tensors (T = 2) -- contiguous in the source row: two 12-B loads (thin_gather4)
+    // instead of eight 2-byte gathers.  The 3 x 3 layers keep the element-wise path.
+    const bool fast = fast_ok && g.ntaps == 16;
+    const unsigned thin_bytes = (unsigned)(g.N * g.H * g.W) * 2u;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x1), 0, thin_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(T == 2 ? x2 : x1), 0, thin_bytes, 0x00020000);
+    const bool lane_k = 8 * fq < KT;             // this lane's k range holds taps at all (T = 1: fq < 2)
+    auto gather_fast = [&](int p0) {
+        const int m = p0 + fr;
+        int n, gy, gx;
+        decode_row2(g, m < g.M ? m : 0, n, gy, gx);
+        const int ix0 = gx * g.S + pdx[0];
+        const int iyA = gy * g.S + pdy[0], iyB = gy * g.S + pdy[4];
+        const bool okA = lane_k && m < g.M && (unsigned)iyA < (unsigned)g.H;
+        uint2 pa, pb;
+        if (T == 1) {
+            const bool okB = lane_k && m < g.M && (unsigned)iyB < (unsigned)g.H;
+            pa = thin_gather4(rs1, (n * g.H + iyA) * g.W, ix0, g.W, okA);
+            pb = thin_gather4(rs1, (n * g.H + iyB) * g.W, ix0, g.W, okB);
+            if (g.relu1) {
+                pa.x = relu2u(pa.x);
+                pa.y = relu2u(pa.y);
+                pb.x = relu2u(pb.x);
+                pb.y = relu2u(pb.y);
+            }
+        } else {
+            uint2 qa = thin_gather4(rs1, (n * g.H + iyA) * g.W, ix0, g.W, okA);
+            uint2 qb = thin_gather4(rs2, (n * g.H + iyA) * g.W, ix0, g.W, okA);
+            if (g.relu1) {
+                qa.x = relu2u(qa.x);
+                qa.y = relu2u(qa.y);
+            }
+            if (g.relu2) {
+                qb.x = relu2u(qb.x);
+                qb.y = relu2u(qb.y);
+            }
+            // k = 2 tap + t: (x1 kx0, x2 kx0, x1 kx1, x2 kx1 | x1 kx2, ...)
+            pa = make_uint2(__builtin_amdgcn_perm(qb.x, qa.x, 0x05040100u), __builtin_amdgcn_perm(qb.x, qa.x, 0x07060302u));
+            pb = make_uint2(__builtin_amdgcn_perm(qb.y, qa.y, 0x05040100u), __builtin_amdgcn_perm(qb.y, qa.y, 0x07060302u));
+        }
+        return __builtin_bit_cast(us8_t, make_uint4(pa.x, pa.y, pb.x, pb.y));
+    };
     const int pstep = gridDim.x * 64;
     int p0 = (blockIdx.x * 4 + wid) * 16;
     us8_t pv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p0 < g.M) pv = gather(p0);
+    if (p0 < g.M) pv = fast ? gather_fast(p0) : gather(p0);
     for (; p0 < g.M; p0 += pstep) {
         const int m = p0 + fr;
         us8_t pnext = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p0 + pstep < g.M) pnext = gather(p0 + pstep);
+        if (p0 + pstep < g.M) pnext = fast ? gather_fast(p0 + pstep) : gather(p0 + pstep);
         const bf8_t bfrag = __builtin_bit_cast(bf8_t, pv);
         // rows beyond M carry an all-zero patch; the MFMAs run unconditionally (full wave), only the
         // stores are predicated
@@ -234,8 +305,10 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
     int blocks = cdiv(g.M, 64);
     static const int cap = getenv("PAI_TF_BLOCKS") ? atoi(getenv("PAI_TF_BLOCKS")) : 4096;
     if (blocks > cap) blocks = cap;
-    if (g.C2 == 0) hipLaunchKernelGGL(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a);
-    else hipLaunchKernelGGL(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a);
+    // thin_gather4: even row length, 32-bit byte offsets
+    const int fast_ok = pai_tunable("thin_fast", 1) && (g.W % 2) == 0 && (int64_t)g.N * g.H * g.W * 2 < (1ll << 31);
+    if (g.C2 == 0) hipLaunchKernelGGL(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
+    else hipLaunchKernelGGL(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
     PAI_LAUNCH_CHECK();
     return 0;
 }
