@@ -130,6 +130,9 @@ def main():
                     help="trans_unet: ViT patch size (4 = what the reference's main.py passes: d_model 4096, 1.03 B "
                          "parameters; 2 = the class default: d_model 1024, 105 M)")
     ap.add_argument("--size", type=int, default=SIZE, help="image size (configs[3] is quoted at 512)")
+    ap.add_argument("--set", dest="tunables", default="",
+                    help="name=value,... launch-configuration switches (pai_set_tunable) for A/B runs on one box; the "
+                         "line then carries them under config.tunables")
     args = ap.parse_args()
 
     import pai_bootstrap
@@ -141,6 +144,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    tunables = {}
+    for kv in filter(None, args.tunables.split(",")):
+        k, v = kv.split("=")
+        tunables[k] = int(v)
+        pai.lib.check(pai.lib.load().pai_set_tunable(k.encode(), int(v)), "pai_set_tunable")
     scaling = "weak"
     if args.global_batch:
         if args.global_batch % world:
@@ -325,6 +333,7 @@ def main():
                                 f"256x256x1 pairs, {args.batch} images/GPU (BASELINE configs[4])" if args.model == "trans_unet" else
                                 "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
                                 "(BASELINE configs[1])"),
+                   **({"tunables": tunables} if tunables else {}),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "channel_mults": list(mults), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}",
