@@ -155,7 +155,7 @@ class _MeanLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
-        return None, grad * gout, None
+        return None, _scaled(grad, gout), None
 
 
 class _Accumulators:
@@ -181,6 +181,26 @@ class _Accumulators:
 
 
 _ACC = _Accumulators()
+
+
+_UNIT = {}
+
+
+def unit_seed(device) -> torch.Tensor:
+    """The cached fp32 scalar 1.0 of a device: ``LightningModule.manual_backward`` seeds scalar losses with it."""
+    t = _UNIT.get(device.index)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _UNIT[device.index] = t
+    return t
+
+
+def _scaled(grad, gout):
+    """grad * gout -- without the launch when gout IS the cached unit seed (a loss backpropagated directly)."""
+    u = _UNIT.get(gout.device.index) if gout.is_cuda else None
+    if u is not None and gout.data_ptr() == u.data_ptr():
+        return grad
+    return grad * gout
 
 
 class _GanDiscLoss(torch.autograd.Function):
@@ -210,7 +230,7 @@ class _GanDiscLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
-        return (grad * gout).view(ctx.shape), None
+        return _scaled(grad, gout).view(ctx.shape), None
 
 
 def gan_discriminator_loss_pairs(labels: torch.Tensor, n_real: int) -> torch.Tensor:
@@ -243,8 +263,8 @@ class _GanGenLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         saved = list(ctx.saved_tensors)
-        gl = saved.pop(0) * gout if ctx.which[0] else None
-        gp = saved.pop(0) * gout if ctx.which[1] else None
+        gl = _scaled(saved.pop(0), gout) if ctx.which[0] else None
+        gp = _scaled(saved.pop(0), gout) if ctx.which[1] else None
         return gl, gp, None, None
 
 

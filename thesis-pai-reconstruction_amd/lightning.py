@@ -147,7 +147,13 @@ class LightningModule(nn.Module):
         self._pai_toggle_state = {}
 
     def manual_backward(self, loss, *args, **kwargs):
-        loss.backward(*args, **kwargs)
+        if not args and not kwargs and loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+            # the implicit seed of a scalar backward is a fresh ones_like (a fill launch per call); a cached one is
+            # recognised by the fused loss functions, which then skip their `grad * seed` launches as well
+            from . import functional as PF
+            loss.backward(gradient=PF.unit_seed(loss.device))
+        else:
+            loss.backward(*args, **kwargs)
         if self.trainer is not None and self.trainer.reducer is not None:
             self.trainer.reducer.finish()
 
