@@ -247,8 +247,8 @@ int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const float* scale,
  *   a   : the stored activated output (its sign gives act'), or NULL when act1 = act2 = none
  *   sums[0][C] = sum(du), sums[1][C] = sum(du * xhat)   with xhat = (z-mean)*rstd
  *   dbeta += sums[0], dgamma += sums[1]   (fp32 [C], either may be NULL)
- * du (storage dtype) is written for pass 2.  `partials` is fp32 workspace of
- * pai_bn_bwd_partial_rows(M) * 2 * C floats. */
+ * du (storage dtype) is written for pass 2; du may be NULL when g2 = a = NULL and act1 = none (du IS g1 then: hand
+ * g1 to pass 2).  `partials` is fp32 workspace of pai_bn_bwd_partial_rows(M) * 2 * C floats. */
 int pai_bn_bwd_partial_rows(int64_t M);
 int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,
                       const void* z, int64_t M, int C, const float* mean, const float* rstd,

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const T* g1, int act1, co
                         for (int k = 0; k < 8; ++k) d[k] += q.g2v[k];
                     }
                 }
-                V8<T>::st(du + r * C + cg * 8, d);
+                if (du) V8<T>::st(du + r * C + cg * 8, d);     // du == null: du IS g1 (no activation, no second gradient)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // statistics from the value as stored (what pass 2 will read back)
@@ -389,7 +389,8 @@ extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void
                                  const void* a, const void* z, int64_t M, int C, const float* mean,
                                  const float* rstd, void* du, float* partials, float* sums,
                                  float* dgamma, float* dbeta, void* stream) {
-    PAI_CHECK(g1 && z && du && partials && sums && mean && rstd, "pai_bn_bwd_reduce: null pointer");
+    PAI_CHECK(g1 && z && partials && sums && mean && rstd, "pai_bn_bwd_reduce: null pointer");
+    PAI_CHECK(du || (!g2 && !a && act1 == PAI_ACT_NONE), "pai_bn_bwd_reduce: du may be null only when du == g1");
     PAI_CHECK(C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "pai_bn_bwd_reduce: C=%d must be 8 * 2^k", C);
     PAI_CHECK(a || (act1 == PAI_ACT_NONE && act2 == PAI_ACT_NONE), "pai_bn_bwd_reduce: act without a");
     hipStream_t s = (hipStream_t)stream;

@@ -646,9 +646,10 @@ class UnetEngine:
             act = ACT_RELU if j < L - 2 else ACT_NONE
             dz = G["dz_dec"][j]
             if fused_rows is None:
-                du = G["du"][:n]
+                # no activation between this BatchNorm and its consumer: du IS the incoming gradient, not a copy of it
+                du = G["du"][:n] if act != ACT_NONE else G["gr"][j]
                 ops.bn_bwd_reduce(dtype, G["gr"][j], act, None, ACT_NONE, S["r"][j] if act != ACT_NONE else None,
-                                  S["w"][j], M, C, st.mean, st.rstd, du, part, st.sums,
+                                  S["w"][j], M, C, st.mean, st.rstd, du if act != ACT_NONE else None, part, st.sums,
                                   A.seg(bn.weight), A.seg(bn.bias))
             else:
                 du = G["gr"][j]
