@@ -241,6 +241,9 @@ if __name__ == "__main__":
                  family="trans2")
         run_case("ref_trans2_ssim", (1, 1, 1, 2, 2), 256, 2, "ssim", seed=241, steps=1, full_tensors=False,
                  family="trans2")
+    if "--trans-dropout" in sys.argv:     # Dropout(0.3) at the four sites of every transformer layer (class default 0.5)
+        run_case("ref_trans4_gan_dropout", (1, 1, 1, 1, 1), 256, 3, "gan", seed=261, steps=1, full_tensors=False,
+                 search=False, family="trans4", dropout=0.3)
         sys.exit(0)
     if "--resv2" in sys.argv:         # pre-activation residual blocks (res_type "v2")
         run_forward_case("ref_resv2_forward_tiny", (1, 2, 2), 32, 4, seed=181, family="resv2")

@@ -155,10 +155,14 @@ def _ln(st, key, t):
 
 
 def _drop(x, p, site, li, mask_log):
-    """nn.Dropout in training mode: Bernoulli(1 - p) / (1 - p) drawn from the global CPU generator, logged for replay."""
+    """nn.Dropout in training mode, logged for replay.  The mask is what ``F.dropout`` draws for a tensor of this size
+    from the global CPU generator (ATen: ``empty_like(x).bernoulli_(1 - p).div_(1 - p)``), obtained by dropping out a
+    tensor of ones -- so that, from the same generator state, the oracle consumes the generator exactly as the
+    reference's ``nn.Dropout`` modules and the attention operator's internal ``at::dropout`` do (pinned by the
+    ``ref_trans4_gan_dropout`` fixture, tests/test_oracle_golden.py)."""
     if not p:
         return x
-    m = torch.bernoulli(torch.full_like(x, 1.0 - p)) / (1.0 - p)
+    m = F.dropout(torch.ones(x.shape, dtype=x.dtype), p, True)
     if mask_log is not None:
         mask_log.append((site, li, m))
     return x * m
@@ -167,14 +171,15 @@ def _drop(x, p, site, li, mask_log):
 def encoder_layer(st, q, t, p=0.0, li=0, mask_log=None):
     """One post-norm ``nn.TransformerEncoderLayer`` on t = [S, B, E] (sequence first).  ``p`` > 0 (training mode): its
     four Dropout sites -- attention weights, dropout1 behind the attention block, dropout inside and dropout2 behind the
-    feed-forward block.  The distribution is the reference's; the draws are the oracle's own (the attention dropout of
-    the reference happens inside an ATen operator): parity with dropout > 0 is checked with replayed masks only."""
+    feed-forward block, drawn in that order.  The attention dropout of the reference happens inside the ATen attention
+    operator (``at::dropout`` on the [B, H, S, S] weights of the math path); the written-out branch draws a mask of the
+    same size at the same point of the generator stream."""
     S, B, E = t.shape
     hd = E // HEADS
     if USE_ATEN_MHA:
         o, _ = F.multi_head_attention_forward(
             t, t, t, E, HEADS, st[q + ".self_attn.in_proj_weight"], st[q + ".self_attn.in_proj_bias"], None, None, False,
-            0.0, st[q + ".self_attn.out_proj.weight"], st[q + ".self_attn.out_proj.bias"], training=True,
+            float(p), st[q + ".self_attn.out_proj.weight"], st[q + ".self_attn.out_proj.bias"], training=True,
             need_weights=False)
     else:
         qkv = F.linear(t, st[q + ".self_attn.in_proj_weight"], st[q + ".self_attn.in_proj_bias"])

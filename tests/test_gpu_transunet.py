@@ -297,6 +297,38 @@ def test_ragged_batch_and_bf16(pai, golden_dir):
     assert vals["loss"] < first["loss"] and vals["train_rmse"] < first["train_rmse"]
 
 
+def test_transformer_dropout_step_matches_reference_fixture(pai, golden_dir):
+    """``dropout = 0.3`` against the REAL reference (tests/golden/ref_trans4_gan_dropout.npz, recorded with the global
+    CPU generator seeded per step): the 96 masks of the step are re-drawn on the CPU from the same generator state by the
+    oracle -- whose draws are pinned to the reference's by that same fixture, the attention operator's internal dropout
+    included (tests/test_oracle_golden.py) -- and replayed into the HIP model's four Dropout sites per layer."""
+    z = _load(golden_dir, "ref_trans4_gan_dropout")
+    seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
+    p = float(z["meta.dropout"])
+    mults = [int(v) for v in z["meta.mults"]]
+    m, g, d = build(pai, mults, 4, "gan", seed, dropout=p)
+    x, t = synth_batch(seed + 100, n, size)
+    torch.manual_seed(1000)               # step 0 of the recording run
+    mask_log = []
+    g0 = {k: v.clone() for k, v in g.items()}
+    d0 = {k: v.clone() for k, v in d.items()}
+    oracle.gan_training_step(g0, d0, oracle.AdamState(), oracle.AdamState(), x, t, dropout=p, mask_log=mask_log)
+    assert len(mask_log) == 2 * 12 * 4
+    queue = list(mask_log)
+
+    def replay(site, li, shape, rate, device):
+        s_, l_, mk = queue.pop(0)
+        assert (s_, l_) == (site, li) and rate == p and mk.numel() == int(np.prod(shape)), (s_, l_, site, li)
+        return mk.reshape(shape).to(device)
+
+    m.unet.vit_bottleneck.dropout_mask_fn = replay
+    m.logged = {}
+    m.training_step((x.to(DEV), t.to(DEV)), 0)
+    torch.cuda.synchronize()
+    assert not queue
+    _check_step(m, z, 0, 1e-2)
+
+
 def test_transformer_dropout_step_matches_oracle_with_replayed_masks(pai):
     """Dropout(p) at the four sites of every encoder layer (attention weights inside pai_mha_*, behind the attention block,
     inside and behind the feed-forward block): one GAN step (two generator forwards, 96 masks) against the live oracle

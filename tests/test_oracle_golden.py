@@ -78,7 +78,7 @@ def test_forward_matches_reference(golden_dir, name):
                                   "ref_att_gan_tiny", "ref_att_ssim_tiny", "ref_att_gan_full",
                                   "ref_gan_dropout_tiny", "ref_att_gan_dropout_tiny", "ref_resnext_gan_tiny",
                                   "ref_res18_gan_tiny", "ref_res50_gan_tiny", "ref_resnext_gan_dropout_tiny",
-                                  "ref_resv2_gan_tiny", "ref_trans2_gan", "ref_trans2_ssim"])
+                                  "ref_resv2_gan_tiny", "ref_trans2_gan", "ref_trans2_ssim", "ref_trans4_gan_dropout"])
 def test_training_step_matches_reference(golden_dir, name, monkeypatch):
     z = _load(golden_dir, name)
     if name.startswith("ref_trans"):
@@ -145,14 +145,23 @@ def test_training_step_matches_reference(golden_dir, name, monkeypatch):
         assert abs(float(v) - want) <= 5e-5 * max(1.0, abs(want)), (k, float(v), want)
 
 
-def test_trans_written_out_attention(golden_dir):
+@pytest.mark.parametrize("name", ["ref_trans2_gan", "ref_trans4_gan_dropout"])
+def test_trans_written_out_attention(golden_dir, name):
     """The restated (written-out) attention of oracle/trans_unet_ref.py against the reference's fixture: logged scalars
-    at 1e-5, every generator gradient within 1e-2 (L2-type fingerprint; see the comment above for why not tighter)."""
-    z = _load(golden_dir, "ref_trans2_gan")
+    at 1e-5, every generator gradient within 1e-2 (L2-type fingerprint; see the comment above for why not tighter).
+    With dropout > 0 this also pins the ATTENTION dropout mask the written-out branch draws (same size, same point of
+    the generator stream as the ``at::dropout`` inside the reference's attention operator) -- the masks the GPU test
+    replays into the HIP model."""
+    z = _load(golden_dir, name)
     seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
     g, d = _states(z["meta.mults"], seed, family=_family(z))
     x, t = synth_batch(seed + 100, n, size)
-    logs, grads = oracle.gan_training_step(g, d, oracle.AdamState(), oracle.AdamState(), x, t, return_grads=True)
+    dropout = float(z["meta.dropout"]) if "meta.dropout" in z.files else 0.0
+    torch.manual_seed(1000)          # step 0 of the recording run
+    mask_log = []
+    logs, grads = oracle.gan_training_step(g, d, oracle.AdamState(), oracle.AdamState(), x, t, return_grads=True,
+                                           dropout=dropout, mask_log=mask_log)
+    assert len(mask_log) == (2 * 12 * 4 if dropout > 0 else 0)
     for k, v in logs.items():
         want = float(z[f"step0.log.{k}"])
         assert abs(float(v) - want) <= 1e-5 * max(1.0, abs(want)), (k, float(v), want)
