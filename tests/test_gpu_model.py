@@ -337,6 +337,46 @@ def test_arena_adam_equals_stock_adam(pai):
     assert arena.params_adopted()
 
 
+def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch):
+    """ArenaAdam.arm_streaming: ranges of the arena are updated from the engine's gradient-ready hook while the backward
+    pass is still running (from the second step on: the first fused step moves the parameters into the arena).  Same
+    arithmetic as one step() at the end: parameters, moments and step counts agree; the hook is released after every
+    step; an optimizer whose hook belongs to someone else (a gradient reducer) is left alone."""
+    mults, seed = (1, 2, 2, 4), 35
+    x, t = synth_batch(seed + 100, 4, 32)
+    batch = (x.to(DEV), t.to(DEV))
+    ma, _, _ = build(pai, mults, "gan", seed)
+    mb, _, _ = build(pai, mults, "gan", seed)
+    armed = []
+    for o in ma.optimizers():
+        orig = o.arm_streaming
+        o.arm_streaming = (lambda orig=orig: armed.append(orig()) or armed[-1])
+    monkeypatch.setenv("PAI_NO_STREAM_ADAM", "1")
+    for s in range(3):
+        mb.training_step(batch, s)
+    monkeypatch.setenv("PAI_NO_STREAM_ADAM", "0")
+    for s in range(3):
+        ma.training_step(batch, s)
+        assert ma.unet.engine.grad_ready_hook is None and ma.discriminator.engine.grad_ready_hook is None
+    assert armed == [False, False, True, True, True, True]        # (D, G) per step; step 0 adopts the parameters
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        if sa[k].is_floating_point():
+            err = float((sa[k].double() - sb[k].double()).norm())
+            assert err <= 1e-4 * max(float(sb[k].double().norm()), 1e-3), (k, err)
+    for oa, ob in zip(ma.optimizers(), mb.optimizers()):
+        assert oa.total_steps == ob.total_steps == 3
+        for (ka, va), (kb, vb) in zip(oa.state_dict()["state"].items(), ob.state_dict()["state"].items()):
+            assert float(va["step"]) == float(vb["step"]) == 3
+            err = float((va["exp_avg"].double() - vb["exp_avg"].double()).norm())
+            assert err <= 1e-4 * max(float(vb["exp_avg"].double().norm()), 1e-6), ka
+    # a foreign hook owner: arming refuses and step() takes the ordinary path
+    og = ma.optimizers()[0]
+    ma.unet.engine.grad_ready_hook = lambda arena, end: None
+    assert og.arm_streaming() is False
+    ma.unet.engine.grad_ready_hook = None
+
+
 def test_dropout2d_step_matches_reference_fixture(pai, golden_dir):
     """Dropout2d(0.5) in the widest decoder blocks (the reference's class default, models/pix2pix.py:108,
     176-179): two generator forwards per GAN step, each with its own masks.  The masks the reference drew are

@@ -106,6 +106,14 @@ class UnetWrapper(LightningModule):
             v.record_stream(cur)   # allocated on the side stream's pool, consumed on this one
         return vals
 
+    @staticmethod
+    def _arm(opt):
+        """The optimizer whose ``step()`` follows the coming backward pass may start updating while the pass is still
+        running (``ArenaAdam.arm_streaming``); a no-op for every other optimizer."""
+        arm = getattr(opt, "arm_streaming", None)
+        if arm is not None:
+            arm()
+
     def training_step(self, batch, batch_idx):
         """Reference models/wrapper.py:117-162 (manual optimisation, D step then G step)."""
         x, target = batch
@@ -144,6 +152,7 @@ class UnetWrapper(LightningModule):
                 d_loss = self.discriminator_loss(pred_label, target_label)
             self.log("d_loss", d_loss, prog_bar=True)
             self.discriminator.zero_grad(set_to_none=True)
+            self._arm(opt_d)
             self.manual_backward(d_loss)
             opt_d.step()
             self.untoggle_optimizer(opt_d)
@@ -170,6 +179,7 @@ class UnetWrapper(LightningModule):
         self.log("train_rmse", r, prog_bar=True)
 
         self.unet.zero_grad(set_to_none=True)
+        self._arm(opt_g)
         self.manual_backward(loss)
         opt_g.step()
         self.untoggle_optimizer(opt_g)

@@ -11,6 +11,8 @@ same moment tensors.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -23,6 +25,8 @@ class ArenaAdam(torch.optim.Adam):
         self._arena_steps = 0          # steps taken on the fused path and not yet mirrored into `state`
         self._dev_step = None          # graph mode: int64 device scalar holding the step count (see graph.py)
         self._dev_coeff = None
+        self._streamed = None          # streaming step armed: elements of the arena already updated by the hook
+        self._stream_step = 0
 
     # ---- hipGraph support -----------------------------------------------------------------------------
     def enable_device_step(self):
@@ -36,6 +40,53 @@ class ArenaAdam(torch.optim.Adam):
 
     def note_replays(self, n: int = 1):
         self._arena_steps += n
+
+    # ---- streaming step -------------------------------------------------------------------------------
+    def arm_streaming(self) -> bool:
+        """Let the NEXT backward pass of this optimizer's network start the update while it is still running: the
+        engine reports every range of the gradient arena the moment it is final (the hook data-parallel buckets hang
+        on), and that range's Adam launch goes out right there, on the stream that produced the last gradient of the
+        range.  Adam is a 28 B/parameter HBM stream and the backward pass is matrix-bound, so the two overlap well
+        (the 54 M-parameter generator: 250 us of a 7 ms step).  Same arithmetic, same step count: the result is the
+        one ``step()`` alone would give; ``step()`` then only updates what the hook has not reached, bumps the
+        bookkeeping and disarms.  Returns False (and changes nothing) when something else owns the hook (a gradient
+        reducer: the all-reduce has to come first), when the step count lives on the device (graph capture) or the
+        arena preconditions do not hold."""
+        if self._dev_step is not None or getattr(self._engine, "grad_ready_hook", None) is not None:
+            return False
+        if os.environ.get("PAI_NO_STREAM_ADAM", "0") not in ("", "0"):      # A/B switch
+            return False
+        group = self.param_groups[0]
+        if len(self.param_groups) != 1 or group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+            return False
+        params = group["params"]
+        if not params or not params[0].is_cuda:
+            return False
+        arena = self._engine.arena()
+        # only once the parameters already LIVE in the arena (the first fused step() moves them there): moving them
+        # between a forward pass and its backward pass would invalidate the filter packs that forward made
+        if len(params) != len(arena.params) or not arena.params_adopted():
+            return False
+        self._streamed = 0
+        self._stream_step = self.total_steps + 1
+        self._engine.grad_ready_hook = self._on_ready
+        return True
+
+    def _adam_range(self, arena, a, b, step):
+        group = self.param_groups[0]
+        if b > a:
+            ops.adam(arena.pflat[a:b], arena.flat[a:b], arena.mflat[a:b], arena.vflat[a:b], float(group["lr"]),
+                     float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), step)
+
+    def _on_ready(self, arena, end_offset):
+        with torch.no_grad():
+            self._adam_range(arena, self._streamed, int(end_offset), self._stream_step)
+        self._streamed = max(self._streamed, int(end_offset))
+
+    def _disarm(self):
+        if getattr(self._engine, "grad_ready_hook", None) == self._on_ready:
+            self._engine.grad_ready_hook = None
+        self._streamed = None
 
     # ---- helpers --------------------------------------------------------------------------------
     def _arena_ready(self):
@@ -73,12 +124,23 @@ class ArenaAdam(torch.optim.Adam):
     # ---- optimizer API ------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):
+        streamed = self._streamed
+        if streamed is not None:
+            self._disarm()
         arena = self._arena_ready()
         if arena is None:
+            if streamed:
+                raise ops.PaiError("ArenaAdam: a streaming step was armed and partly applied, but the gradients are "
+                                   "not the arena's any more")
             if self._arena_steps:
                 self._mirror_state(self._engine.arena())
             return super().step(closure)
         group = self.param_groups[0]
+        if streamed is not None:
+            self._adam_range(arena, streamed, arena.flat.numel(), self._stream_step)     # what the hook did not reach
+            self._arena_steps += 1
+            self._engine.weights_generation[0] += 1
+            return None
         if self._dev_step is not None:
             ops.adam_dev(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
                          float(group["betas"][1]), float(group["eps"]), self._dev_step, self._dev_coeff)
