@@ -56,9 +56,48 @@ def _worker(rank, world, port, precision, family, q):
         x = torch.from_numpy(rng.random((4, 1, 64, 64), dtype=np.float32) * 2 - 1).to(dev)
         t = torch.from_numpy(rng.random((4, 1, 64, 64), dtype=np.float32) * 2 - 1).to(dev)
         before = torch.cat([p.detach().reshape(-1).clone() for p in m.parameters()])
-        for s in range(2):
-            m.training_step((x, t), s)
+        # a twin that takes the ordinary path (x 1/R pass and Adam behind the last bucket) on the same shards
+        twin = None
+        if family != "resnext_unet":
+            import copy
+            twin = copy.deepcopy(m)
+            red2 = pdist.GradReducer(bucket_bytes=1 << 20)
+            red2.attach(twin)
+
+            class T2:
+                reducer = red2
+                def _log(self, *a): pass
+            twin.trainer = T2()
+        os.environ["PAI_NO_STREAM_ADAM"] = "1"
+        m.training_step((x, t), 0)             # the first fused step moves the parameters into the arena
+        os.environ["PAI_NO_STREAM_ADAM"] = "0"
+        if twin is not None:
+            twin.training_step((x, t), 0)
+            twin.load_state_dict(m.state_dict())
+            for oa, ob in zip(m.optimizers(), twin.optimizers()):
+                ob.load_state_dict(oa.state_dict())
+        m.training_step((x, t), 1)             # streamed: every reduced bucket is averaged + updated on the post stream
+        if twin is not None:
+            os.environ["PAI_NO_STREAM_ADAM"] = "1"
+            twin.training_step((x, t), 1)      # ordinary: x 1/R pass and one Adam pass behind the last bucket
+            os.environ["PAI_NO_STREAM_ADAM"] = "0"
         torch.cuda.synchronize()
+        if twin is not None:
+            assert red.stats.get("post_buckets", 0) >= 2 and red2.stats.get("post_buckets", 0) == 0, red.stats
+            # same state before the step, same shards: the averaged gradients and the moments (linear / quadratic in
+            # them -- a missed or doubled x 1/R would show) agree up to the fp32-atomics noise of two runs
+            gmax = max(float(q2.grad.double().norm()) for q2 in twin.parameters())
+            for (k, p), (_, q2) in zip(m.named_parameters(), twin.named_parameters()):
+                assert float((p.grad.double() - q2.grad.double()).norm()) <= 1e-3 * float(q2.grad.double().norm()) + 1e-5 * gmax, k
+            for oa, ob in zip(m.optimizers(), twin.optimizers()):
+                sa_, sb_ = oa.state_dict()["state"], ob.state_dict()["state"]
+                assert len(sa_) == len(sb_) > 0
+                emax = max(float(sb_[i]["exp_avg"].double().norm()) for i in sb_)
+                for i in sa_:
+                    assert float(sa_[i]["step"]) == float(sb_[i]["step"]) == 2
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        ea, eb = sa_[i][key].double(), sb_[i][key].double()
+                        assert float((ea - eb).norm()) <= 2e-3 * float(eb.norm()) + 1e-5 * emax, (i, key)
         after = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
         both = [torch.zeros_like(after) for _ in range(world)]
         dist.all_gather(both, after)

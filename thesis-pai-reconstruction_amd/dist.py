@@ -65,6 +65,8 @@ class GradReducer:
         self.overlap = overlap
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._arenas = {}       # id(arena) -> state
+        self._subs = {}         # id(arena) -> callback(arena, lo, hi): run on every bucket once it is reduced + averaged
+        self._post_stream = None
         self._engines = []
         self._foreign_params: List[torch.nn.Parameter] = []
         self.stats = {"buckets": 0, "bytes": 0}
@@ -89,23 +91,50 @@ class GradReducer:
     def _state(self, arena):
         st = self._arenas.get(id(arena))
         if st is None:
-            st = {"arena": arena, "sent": 0, "works": [], "active": False, "stage": None}
+            st = {"arena": arena, "sent": 0, "works": [], "active": False, "stage": None, "post": False}
             self._arenas[id(arena)] = st
         return st
+
+    def subscribe(self, arena, fn) -> bool:
+        """``fn(arena, lo, hi)`` is called for every bucket of the COMING backward pass of ``arena`` as soon as it is
+        reduced and averaged -- on a stream of this object that waits for the collective, i.e. beside the rest of the
+        backward pass (``optim.ArenaAdam.arm_streaming`` hangs the optimizer update on it: neither the x 1/R pass nor
+        the 28 B/parameter Adam pass is left for the end of the step).  One-shot: ``finish()`` drops it.  HIP arenas
+        only."""
+        if not arena.flat.is_cuda or self.world < 2:
+            return False
+        self._subs[id(arena)] = fn
+        return True
 
     def _launch(self, st, lo, hi):
         if hi <= lo:
             return
-        buf = st["arena"].flat[lo:hi]
+        arena = st["arena"]
+        buf = arena.flat[lo:hi]
         if self.world > 1:
+            stage = None
             if self.grad_dtype == torch.float32:
-                st["works"].append((self._all_reduce_async(buf), None, lo, hi))
+                work = self._all_reduce_async(buf)
             else:
                 if st["stage"] is None:
-                    st["stage"] = torch.empty(st["arena"].flat.numel(), dtype=self.grad_dtype, device=buf.device)
+                    st["stage"] = torch.empty(arena.flat.numel(), dtype=self.grad_dtype, device=buf.device)
                 stage = st["stage"][lo:hi]
                 stage.copy_(buf)                                   # fp32 -> bf16, ordered before the collective
-                st["works"].append((self._all_reduce_async(stage), stage, lo, hi))
+                work = self._all_reduce_async(stage)
+            fn = self._subs.get(id(arena))
+            if fn is None:
+                st["works"].append((work, stage, lo, hi))
+            else:
+                if self._post_stream is None:
+                    self._post_stream = torch.cuda.Stream(device=buf.device)
+                with torch.cuda.stream(self._post_stream):
+                    work.wait()                                    # this stream (only) runs behind the collective
+                    if stage is not None:
+                        buf.copy_(stage)
+                    buf.mul_(1.0 / self.world)
+                    fn(arena, lo, hi)
+                st["post"] = True
+                self.stats["post_buckets"] = self.stats.get("post_buckets", 0) + 1
         self.stats["buckets"] += 1
         self.stats["bytes"] += (hi - lo) * (4 if self.grad_dtype == torch.float32 else 2)
 
@@ -149,9 +178,13 @@ class GradReducer:
                 w.wait()
                 if stage is not None:
                     st["arena"].flat[lo:hi].copy_(stage)           # reduced bf16 sum back into the fp32 master gradient
-            if self.world > 1:
+            if st["post"]:
+                # every bucket of this arena was averaged (and handed to the subscriber) on the post stream
+                torch.cuda.current_stream(st["arena"].flat.device).wait_stream(self._post_stream)
+            elif self.world > 1:
                 st["arena"].flat.mul_(1.0 / self.world)
-            st["sent"], st["works"], st["active"] = 0, [], False
+            self._subs.pop(id(st["arena"]), None)
+            st["sent"], st["works"], st["active"], st["post"] = 0, [], False, False
         grads = [p.grad for p in self._foreign_params if p.requires_grad and p.grad is not None]
         if grads and self.world > 1:
             self._reduce_foreign(grads)

@@ -52,9 +52,11 @@ class ArenaAdam(torch.optim.Adam):
         bookkeeping and disarms.  Returns False (and changes nothing) when something else owns the hook (a gradient
         reducer: the all-reduce has to come first), when the step count lives on the device (graph capture) or the
         arena preconditions do not hold."""
-        if self._dev_step is not None or getattr(self._engine, "grad_ready_hook", None) is not None:
-            return False
         if os.environ.get("PAI_NO_STREAM_ADAM", "0") not in ("", "0"):      # A/B switch
+            return False
+        hook = getattr(self._engine, "grad_ready_hook", None)
+        reducer = getattr(hook, "__self__", None) if hook is not None else None
+        if self._dev_step is not None or (hook is not None and not hasattr(reducer, "subscribe")):
             return False
         group = self.param_groups[0]
         if len(self.param_groups) != 1 or group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
@@ -67,9 +69,14 @@ class ArenaAdam(torch.optim.Adam):
         # between a forward pass and its backward pass would invalidate the filter packs that forward made
         if len(params) != len(arena.params) or not arena.params_adopted():
             return False
+        if reducer is not None:
+            # data parallel: the reducer owns the hook; the update of a bucket follows its all-reduce + average
+            if not reducer.subscribe(arena, self._on_reduced):
+                return False
+        else:
+            self._engine.grad_ready_hook = self._on_ready
         self._streamed = 0
         self._stream_step = self.total_steps + 1
-        self._engine.grad_ready_hook = self._on_ready
         return True
 
     def _adam_range(self, arena, a, b, step):
@@ -82,6 +89,14 @@ class ArenaAdam(torch.optim.Adam):
         with torch.no_grad():
             self._adam_range(arena, self._streamed, int(end_offset), self._stream_step)
         self._streamed = max(self._streamed, int(end_offset))
+
+    def _on_reduced(self, arena, lo, hi):
+        if lo != self._streamed:
+            raise ops.PaiError(f"ArenaAdam: reduced bucket [{lo}, {hi}) does not continue the updated range "
+                               f"[0, {self._streamed})")
+        with torch.no_grad():
+            self._adam_range(arena, lo, hi, self._stream_step)
+        self._streamed = hi
 
     def _disarm(self):
         if getattr(self._engine, "grad_ready_hook", None) == self._on_ready:
