@@ -44,6 +44,8 @@ extern "C" {
 #define PAI_ACT_TANH 3    /* Tanh            models/pix2pix.py:196 */
 
 const char* pai_last_error(void);
+/* 100: round 1.  110: per-device handles, pai_set_tunable, pai_adam_dev, pai_scalar_take / pai_metrics_take,
+ * pai_pack_weights_multi; pai_bn_bwd_reduce accepts du = NULL.  Additions only: a 100 caller runs unchanged. */
 int pai_version(void);
 /* Device properties of the current HIP device (host out-params). */
 int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);

@@ -14,7 +14,7 @@ void pai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pai_last_error(void) { return g_err; }
-extern "C" int pai_version(void) { return 100; }
+extern "C" int pai_version(void) { return 110; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi
 
 extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
