@@ -489,6 +489,7 @@ struct ThinW {
     float* dbias;                 // per wide channel, or null
     int M;                        // N*H*W
     int fast;                     // patch rows by thin_gather8 (set by launch_tw)
+    int pair;                     // 64 wide channels: two 64-pixel chunks share one 256-B-row LDS tile (set by launch_tw)
     float* partial;               // per-workgroup partial sums [grid.x][grid.y][16 T + 1][128] or null (atomics)
 };
 
@@ -503,10 +504,17 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
     const int wc0 = blockIdx.y * 128;          // channel group of this workgroup (WC > 128: single source)
     const int WC = min(p.WC1 + p.WC2 - wc0, 128);
-    const int ntile = WC / 16;                 // column tiles of 16 wide channels (4 or 8)
+    // pair (64 wide channels, one source): the 256-B rows of the LDS tile would be half empty -- instead row r holds
+    // pixel r of TWO consecutive 64-pixel chunks side by side (128 B each), the waves' column halves become the two
+    // chunks, and the step covers 128 pixels: no zero-line fills, half the barriers and the patch gathers of a wave
+    // serve 64 instead of 32 channels.  Columns 64..127 of the partial tile fold onto 0..63 in the reduction.
+    const int pair = p.pair;
+    const int ntile = pair ? 8 : WC / 16;      // column tiles of 16 wide channels (4 or 8)
     const int ks = wid & 1;                    // this wave's 32-pixel K step of the 64-pixel chunk
     const int nt0 = (wid >> 1) * (ntile / 2);  // and its half of the column tiles
     const int ntn = ntile / 2;
+    const int pixh = pair ? (wid >> 1) * 64 : 0;   // pair: first pixel of this wave's chunk within the step
+    const int CH = pair ? 128 : 64;            // pixels per step
     const bf16_t* zero = (const bf16_t*)g_zero_line_thin;
 
     // LDS-DMA map: position (row sr + 16j, slot sc) holds logical chunk sc ^ swz(row)
@@ -514,8 +522,10 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     const int gch = sc ^ tw_swz(sr);
     const bf16_t* wsrc;
     int wstride, wcol;
-    bool wvalid = gch * 8 < WC;
-    if (wc0 + gch * 8 < p.WC1) { wsrc = p.wide1; wstride = p.WC1; wcol = wc0 + gch * 8; }
+    bool wvalid = pair || gch * 8 < WC;
+    const int wpix = pair ? (gch >> 3) * 64 : 0;   // pair: slots 8..15 of a row belong to the second chunk
+    if (pair) { wsrc = p.wide1; wstride = p.WC1; wcol = (gch & 7) * 8; }
+    else if (wc0 + gch * 8 < p.WC1) { wsrc = p.wide1; wstride = p.WC1; wcol = wc0 + gch * 8; }
     else { wsrc = p.wide2; wstride = p.WC2; wcol = gch * 8 - p.WC1; }
 
     // patch row k = 16*tt + fr -> (tap, t)
@@ -548,11 +558,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     float bsum = 0.f;
 
     for (int ci = 0; ci < chunks_per_block; ++ci) {
-        const int p0 = (blockIdx.x * chunks_per_block + ci) * 64;
+        const int p0 = (blockIdx.x * chunks_per_block + ci) * CH;
         if (p0 >= p.M) break;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = p0 + sr + 16 * j;
+            const int m = p0 + wpix + sr + 16 * j;
             const bf16_t* src = (wvalid && m < p.M) ? wsrc + (size_t)m * wstride + wcol : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + (16 * j + wid * 4) * 256),
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
         for (int tt = 0; tt < T; ++tt) {
             us8_t pv;
             if (p.fast) {
-                const int m = p0 + 32 * ks + 8 * fq;        // first of the lane's 8 pixels, all in one image row
+                const int m = p0 + pixh + 32 * ks + 8 * fq;     // first of the lane's 8 pixels, all in one image row
                 int n, ay, bx;
                 if (p.lw >= 0) { bx = m & (p.W - 1); ay = (m >> p.lw) & (p.H - 1); n = m >> (p.lw + p.lh); }
                 else { bx = m % p.W; const int r = m / p.W; ay = r % p.H; n = r / p.H; }
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
             } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int m = p0 + 32 * ks + 8 * fq + j;
+                const int m = p0 + pixh + 32 * ks + 8 * fq + j;
                 int n, ay, bx;
                 if (p.lw >= 0) { bx = m & (p.W - 1); ay = (m >> p.lw) & (p.H - 1); n = m >> (p.lw + p.lh); }
                 else { bx = m % p.W; const int r = m / p.W; ay = r % p.H; n = r / p.H; }
@@ -602,12 +612,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bfr[h * 4 + e] = v[e];
             }
-            if ((wc0 + col0 < p.WC1) ? p.relu1 : p.relu2) bfr = relu8(bfr);
+            if ((pair || wc0 + col0 < p.WC1) ? p.relu1 : p.relu2) bfr = relu8(bfr);
 #pragma unroll
             for (int tt = 0; tt < T; ++tt)
                 acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt], bfr, acc[tt][nt], 0, 0, 0);
         }
-        if (p.dbias && bc < WC) {
+        if (p.dbias && (pair || bc < WC)) {
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) {
                 const int row = bh * 32 + r;
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
                 } else {
                     const int tap = k / T, t = k - tap * T;
                     if (tap < p.ntaps)
-                        atomicAdd(p.dw + (size_t)(wc0 + wcl) * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
+                        atomicAdd(p.dw + (size_t)(wc0 + (pair ? (wcl & 63) : wcl)) * p.s_wc + tap * p.s_tap + t * p.s_t, acc[tt][nt][r]);
                 }
             }
         }
@@ -642,12 +652,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
         float* red = (float*)smem;
         red[tid] = bsum;
         __syncthreads();
-        if (tid < WC) {
+        if (tid < (pair ? 128 : WC)) {
             if (part0) {
                 part0[16 * T * 128 + tid] = red[tid] + red[tid + 128];
                 part0[(size_t)gridDim.y * ((16 * T + 1) * 128) + 16 * T * 128 + tid] = 0.f;
             } else {
-                atomicAdd(p.dbias + wc0 + tid, red[tid] + red[tid + 128]);
+                atomicAdd(p.dbias + wc0 + (pair ? (tid & 63) : tid), red[tid] + red[tid + 128]);
             }
         }
     }
@@ -672,7 +682,9 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_k(ThinW p, int T, int n
     __syncthreads();
     if (slice == 0 && gy < groups) {
         sum = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        const int k = le >> 7, wc = gy * 128 + (le & 127);
+        const int k = le >> 7;
+        int wc = gy * 128 + (le & 127);
+        if (p.pair) wc &= 63;          // the second chunk's columns fold onto the channels
         if (wc < p.WC1 + p.WC2) {
             if (k < 16 * T) {
                 const int tap = k / T, t = k - tap * T;
@@ -743,7 +755,10 @@ static int launch_tw(ThinW& p, int T, hipStream_t s) {
     p.lw = ilog2_exact(p.W);
     p.lh = ilog2_exact(p.H);
     if (p.lw < 0 || p.lh < 0) p.lw = p.lh = -1;
-    const int chunks = cdiv(p.M, 64);
+    // measured (scripts/micro/convbench): D block 0 (two thin channels, 2.1 M pixels) 127 -> 98 us, encoders[0] (one thin
+    // channel) 45 -> 48 us -- the pairing pays where the patch gathers are the larger half of the step
+    p.pair = pai_tunable("thin_pair", 1) && p.WC1 == 64 && p.WC2 == 0 && T == 2;
+    const int chunks = cdiv(p.M, p.pair ? 128 : 64);
     const int groups = cdiv(p.WC1 + p.WC2, 128);
     const int64_t need = thin_wgrad_scratch_bytes(p.M, T, p.WC1 + p.WC2);
     static const bool no_two = getenv("PAI_TW_ATOMIC") && atoi(getenv("PAI_TW_ATOMIC")) != 0;
