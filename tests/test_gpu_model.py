@@ -362,8 +362,11 @@ def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch):
     sa, sb = ma.state_dict(), mb.state_dict()
     for k in sa:
         if sa[k].is_floating_point():
+            # two runs differ by fp32-atomics noise, and Adam's first steps turn a sign decided by that noise into
+            # +-lr = 2e-4 on the element (measured: 1.3e-4 of L2 on a 1024-element filter, i.e. one such element);
+            # a range the streaming step missed would be lr * sqrt(numel) away
             err = float((sa[k].double() - sb[k].double()).norm())
-            assert err <= 1e-4 * max(float(sb[k].double().norm()), 1e-3), (k, err)
+            assert err <= 1e-3 * max(float(sb[k].double().norm()), 1e-3), (k, err)
     for oa, ob in zip(ma.optimizers(), mb.optimizers()):
         assert oa.total_steps == ob.total_steps == 3
         for (ka, va), (kb, vb) in zip(oa.state_dict()["state"].items(), ob.state_dict()["state"].items()):
