@@ -1811,8 +1811,14 @@ static int wgrad_mfma_splits(const GG& g, int* rows_out) {
     // that pass, not the MFMA loop, is the cost, so a split never gets fewer than 512 pixels.
     static const int target_env = getenv("PAI_WGRAD_TARGET") ? atoi(getenv("PAI_WGRAD_TARGET")) : 0;
     const int target_tun = pai_tunable("wgrad_target", 0);
-    // gg_wgrad_patch_k fits four workgroups per CU (128 VGPRs), gg_wgrad_mfma_k<128> three
-    const int target = target_tun ? target_tun : (target_env ? target_env : ((big && !wgrad_mfma_uses_patch(g)) ? 768 : 1024));
+    // gg_wgrad_patch_k fits four workgroups per CU (128 VGPRs), gg_wgrad_mfma_k<128> three.  Measured per layer
+    // (scripts/micro/convbench --set wgrad_target=...): the 137-GFLOP layers (decoders[4-6], D blocks 1-3 at 2N) want
+    // four rounds' worth of workgroups (1024: 138-165 us against 145-224 at 512), the 69-GFLOP ones (encoders[1-3]) and
+    // everything on gg_wgrad_mfma_k two (512: 86-88 us against 95-99 at 1024; encoders[4] 62 against 67 at 768) -- there
+    // the extra atomic passes over dW cost more than the better balance buys.
+    const double gflop = 2.0 * (double)g.M * g.nphase * g.Cout * g.ntaps * g.Cin * 1e-9;
+    const int target_def = (wgrad_mfma_uses_patch(g) && gflop >= 100.0) ? 1024 : 512;
+    const int target = target_tun ? target_tun : (target_env ? target_env : target_def);
     int splits = cdiv(target, tiles);
     static const int min_rows = getenv("PAI_WGRAD_MINROWS") ? atoi(getenv("PAI_WGRAD_MINROWS")) : 512;
     const int max_splits = cdiv(g.M, min_rows);
