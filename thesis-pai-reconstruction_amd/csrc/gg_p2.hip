@@ -36,7 +36,9 @@
 // 1024-thread workgroup per CU: 34 % fewer LDS-DMA bytes per FLOP) runs 10-15 % slower than gg_fwd_patch_k on
 // decoders[5], D block 2 and encoders[2]; and the v_mfma_f32_32x32x16_bf16 form of variants 1, 2 and 4 (which a bare
 // MFMA loop favours by 40 % once other instructions sit between the MFMAs, scripts/micro/mfma_issue.hip) ran 3-8 %
-// slower than their 16x16x32 form -- that code was not kept.
+// slower than their 16x16x32 form -- that code was not kept.  Nor was a 16 x 16 pixels x 64 channels tile with four
+// 64 x 64 waves for the 64-channel layers (decoders[6] forward 166 -> 196-207 us, input gradient of encoders[1]
+// 88 -> 116, of D block 1 192 -> 224): gg_fwd_patch_k<128, 64>'s four to five small workgroups per CU win there.
 //
 // Serves the same reference call sites as gg_fwd_patch_k: the Conv2d k4 s2 p1 / ConvTranspose2d k4 s2 p1 layers of
 // EncoderBlock / DecoderBlock (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and
