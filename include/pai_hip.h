@@ -87,11 +87,22 @@ typedef struct pai_conv_desc {
                              is only defined on the 64-channel diagonal blocks that contain the groups (the entries
                              of the structurally zero blocks may be left zero).  Otherwise a hint: every kernel
                              family computes the same result from the dense packs. */
-    int32_t reserved[2];
+    int32_t pack_flags;   /* bit 0: the w_fwd buffer holds the forward pack FOLLOWED BY its fragment-major copy
+                             (pai_pack_frag(w_fwd, Cout, taps * (C1 + C2), w_fwd + Cout * taps * (C1 + C2) elements));
+                             bit 1: the same for w_dgrad (rows = C1 + C2, K = taps * Cout).  With the copy present the
+                             forward / input-gradient call may run the kernel that feeds its weights to the matrix
+                             cores straight from memory (pai_conv_kernel_name says whether it does); 0: row-major
+                             packs only, every earlier caller */
+    int32_t reserved;
 } pai_conv_desc;
 
 /* Output spatial size of the layer. */
 int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW);
+/* Fragment-major copy of a row-major bf16 filter pack [rows][K] (rows % 64 == 0, K % 32 == 0), same size: for every
+ * 64-row tile t and 32-deep K slice s the 4 KB block (t * K/32 + s) holds, for nt = 0..3 and lane = 0..63, the 8
+ * elements  w[64 t + 16 ((lane % 16) / 4) + 4 nt + lane % 4][32 s + 8 (lane / 16) .. + 8]  -- the matrix-core operand
+ * fragments of one wave in lane order.  See pai_conv_desc.pack_flags. */
+int pai_pack_frag(const void* w_rowmajor, int rows, int K, void* w_frag, void* stream);
 /* Number of partial-statistics rows pai_conv_fwd writes when stats != NULL, and the
  * number of rows the caller must allocate for that buffer (the tail is scratch for
  * pai_bn_finalize's two-stage fp64 reduction). */

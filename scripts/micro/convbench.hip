@@ -7,7 +7,7 @@
 //
 // build: hipcc -O2 --offload-arch=gfx950 scripts/micro/convbench.hip -Iinclude -Lthesis-pai-reconstruction_amd
 //              -lpai_hip -Wl,-rpath,'$ORIGIN/../../thesis-pai-reconstruction_amd' -o scripts/micro/convbench
-// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--set name=v,name=v ;...]
+// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--frag] [--set name=v,name=v ;...]
 //        every --set adds one setting (comma-separated tunables); default: the library defaults only.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -94,7 +94,7 @@ static std::vector<float> read3(float* d) {
 int main(int argc, char** argv) {
     const char* filter = "";
     const char* ops = "fdw";
-    int iters = 10, rounds = 3, batch = 64;
+    int iters = 10, rounds = 3, batch = 64, frag = 0;
     std::vector<Setting> settings;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--filter") && i + 1 < argc) filter = argv[++i];
@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--frag")) frag = 1;   // packs followed by their fragment-major copy (pack_flags = 3)
         else if (!strcmp(argv[i], "--set") && i + 1 < argc) {
             Setting s;
             s.label = argv[++i];
@@ -156,7 +157,9 @@ int main(int argc, char** argv) {
         float *dw[2], *stats;
         HCHECK(hipMalloc(&x1, nx1 * 2));
         if (nx2) HCHECK(hipMalloc(&x2, nx2 * 2));
-        HCHECK(hipMalloc(&wf, nw * 2)); HCHECK(hipMalloc(&wd, nw * 2)); HCHECK(hipMalloc(&dy, ny * 2));
+        HCHECK(hipMalloc(&wf, nw * 4)); HCHECK(hipMalloc(&wd, nw * 4)); HCHECK(hipMalloc(&dy, ny * 2));
+        const bool fragok = frag && (L.Cout % 64) == 0 && (Cin % 64) == 0;
+        d.pack_flags = fragok ? 3 : 0;
         for (int k = 0; k < 2; ++k) {
             HCHECK(hipMalloc(&y[k], ny * 2)); HCHECK(hipMalloc(&dx1[k], nx1 * 2));
             if (nx2) HCHECK(hipMalloc(&dx2[k], nx2 * 2));
@@ -173,6 +176,10 @@ int main(int argc, char** argv) {
             fill_bf16<<<1024, 256, 0, st>>>(wf, nw, 13u, 0.05f, mode, 2);
             fill_bf16<<<1024, 256, 0, st>>>(wd, nw, 14u, 0.05f, mode, 2);
             fill_bf16<<<1024, 256, 0, st>>>(dy, ny, 15u, 1.0f, mode, 2);
+            if (fragok) {
+                PCHECK(pai_pack_frag(wf, L.Cout, 16 * Cin, wf + nw, st));
+                PCHECK(pai_pack_frag(wd, Cin, 16 * L.Cout, wd + nw, st));
+            }
             HCHECK(hipStreamSynchronize(st));
         };
         auto run = [&](char op, int k) {

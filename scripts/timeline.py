@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Step timeline from a rocprofv3 --kernel-trace CSV: per hardware queue the busy time, the time no kernel runs on any
 queue, and the kernels in flight beside the long ones -- what a per-kernel --stats table cannot show.
-    python scripts/timeline.py <..._kernel_trace.csv> [steps_to_skip]
-A "step" is delimited by the Adam launches (two per GAN step: discriminator, generator)."""
+    python scripts/timeline.py <..._kernel_trace.csv> [steps_to_skip] [--seq]
+--seq also lists the last step kernel by kernel: start offset, queue, duration, gap to the previous kernel of the same queue.
+A "step" is delimited by the metrics_take_k launch of training_step."""
 import collections
 import csv
 import sys
@@ -13,17 +14,31 @@ def short(name):
     return name.split("(")[0][:48]
 
 
-def main(path, skip=4):
+def sequence(rows, ends):
+    a, b = ends[-2], ends[-1]
+    seg = rows[a + 1:b + 1]
+    t0 = seg[0][0]
+    last_end = {}
+    qs = sorted({r[2] for r in seg})
+    print(f"last step, {len(seg)} kernels, queues {qs}: start us | queue | duration us | gap on that queue us | kernel")
+    for s, e, q, k in seg:
+        gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+        print(f"  {(s - t0) / 1e3:8.1f} q{qs.index(q)} {(e - s) / 1e3:7.1f} {gap:7.1f}  {k}")
+        last_end[q] = max(e, last_end.get(q, 0))
+
+
+def main(path, skip=4, seq=False):
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), short(r["Kernel_Name"])))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if r[3].startswith("adam")]
-    # the generator's Adam (the larger of each pair) ends a step
-    ends = [i for i in adam if rows[i][1] - rows[i][0] > 50_000]
+    # one metrics_take_k per training step (the streamed Adam launches are spread over the backward passes)
+    ends = [i for i, r in enumerate(rows) if r[3].startswith("metrics_take")]
     if len(ends) < skip + 3:
         print("too few steps in the trace")
         return
+    if seq:
+        sequence(rows, ends)
     a, b = ends[skip], ends[-1]
     n = len(ends) - 1 - skip
     seg = rows[a + 1:b + 1]
@@ -41,7 +56,7 @@ def main(path, skip=4):
         conc[min(depth, 3)] += t - last
         last = t
         depth += d
-    print(f"{n} steps, {wall / 1e3:.1f} us per step between generator Adam launches")
+    print(f"{n} steps, {wall / 1e3:.1f} us per step between metrics_take_k launches")
     for q, v in sorted(per_q.items()):
         print(f"  queue {q}: kernels busy {v / n / 1e3:8.1f} us/step")
     print(f"  no kernel running: {idle / n / 1e3:.1f} us/step;  1 / 2 / 3+ kernels in flight: "
@@ -68,4 +83,5 @@ def main(path, skip=4):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+    args = [a for a in sys.argv[1:] if a != "--seq"]
+    main(args[0], int(args[1]) if len(args) > 1 else 4, "--seq" in sys.argv)

@@ -181,6 +181,7 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
     g->D1 = d->Cout; g->D2 = 0;
     g->wtaps = 16;
     g->gslice = d->groups > 1 ? 16 : 0;
+    g->wfrag = (d->pack_flags >> 0) & 1;
     g->relu1 = d->relu1; g->relu2 = d->relu2;
     int OH, OW;
     pai_conv_out_hw(d, &OH, &OW);
@@ -215,6 +216,7 @@ int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
     g->D1 = d->C1; g->D2 = d->C2;
     g->wtaps = 16;
     g->gslice = d->groups > 1 ? 16 : 0;
+    g->wfrag = (d->pack_flags >> 1) & 1;
     g->OH = d->H; g->OW = d->W;
     if (d->kernel == 1) {
         g->OHg = d->H; g->OWg = d->W;

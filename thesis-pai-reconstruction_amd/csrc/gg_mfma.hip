@@ -43,7 +43,7 @@ struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
     FwdCfg c;
-    if (fwd_p2_rows(g)) {   // pipelined one-workgroup-per-CU kernel (gg_p2.hip): never split
+    if (fwd_bd_rows(g) || fwd_p2_rows(g)) {   // gg_bd.hip / gg_p2.hip: never split
         c.bm = 128; c.bn = 128; c.ksplit = 1;
         return c;
     }
@@ -117,6 +117,7 @@ static int fwd_effective_ksplit(const GG& g) {
 static int patch_rows(const GG& g, const FwdCfg& c);
 
 int fwd_mfma_mtiles(const GG& g) {
+    if (const int rows = fwd_bd_rows(g)) return g.M / rows;
     if (const int rows = fwd_p2_rows(g)) return g.M / rows;
     if (fwd_effective_ksplit(g) > 1) return cdiv(g.M, FIN_ROWS);
     const FwdCfg c = fwd_cfg(g);
@@ -1044,6 +1045,7 @@ static size_t fwd_lds_bytes() {
 }
 
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (fwd_bd_rows(g)) return launch_fwd_bd(g, a, s);
     if (fwd_p2_rows(g)) return launch_fwd_p2(g, a, s);
     FwdCfg c = fwd_cfg(g);
     c.ksplit = fwd_effective_ksplit(g);
@@ -1137,6 +1139,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
 
 // rocprofv3-visible symbol of the main kernel launch_fwd_mfma picks for this problem (same decisions, no launch)
 const char* fwd_mfma_kernel_name(const GG& g) {
+    if (fwd_bd_rows(g)) return fwd_bd_kernel_name(g);
     if (fwd_p2_rows(g)) return fwd_p2_kernel_name(g);
     FwdCfg c = fwd_cfg(g);
     c.ksplit = fwd_effective_ksplit(g);

@@ -71,21 +71,6 @@ template <int TH, int NW, int MT> struct P2Dims {      // NW waves of MT pixel r
     }
 };
 
-// Kernel arguments: plain scalars only.  By-value structs with arrays (GG, PatchGeo) indexed by the run-time phase --
-// and even `cond ? a.x2 : a.x1` on neighbouring fields -- made hipcc 7.2 keep every argument in scratch and re-load
-// them inside the K loop (vector loads, each followed by the vmcnt(0) that drains the LDS-DMA pipeline).  The
-// per-phase tables are therefore packed into 64-bit scalars and unpacked with shifts:
-//   wby / wbx  4 bits per (phase, window): source offset of patch pixel (0,0) from (gy0*S, gx0*S), biased by 8
-//   toff       2 bits (ty, tx) per (phase, window, tap)
-//   wt[phase]  4 bits weight tap slot per (window, tap)
-//   poy / pox  1 bit per phase
-struct P2Prob {
-    int H, W, C1, C2, Cin, Cout, S, nphase, OH, OW, OS, D1, D2, wtaps, relu1, relu2;
-    int groups, TY, TX, mtiles, ntiles;
-    unsigned long long wby, wbx, toff[2], wt[4];
-    unsigned poy, pox;
-};
-
 #ifndef P2_DMA_SPREAD
 #define P2_DMA_SPREAD 1     // 1: the step's LDS-DMA instructions in two batches (behind the barrier, two items later), 0: one
 #endif
@@ -491,31 +476,6 @@ static int p2_variant(const GG& g) {
 int fwd_p2_rows(const GG& g) {
     const int v = p2_variant(g);
     return v == 0 ? 0 : ((v == 2 || v == 5) ? 512 : 256);
-}
-
-static void p2_prob(const GG& g, const PatchGeo& pg, int mtiles, int ntiles, P2Prob* o) {
-    memset(o, 0, sizeof(*o));
-    o->H = g.H; o->W = g.W; o->C1 = g.C1; o->C2 = g.C2; o->Cin = g.Cin; o->Cout = g.Cout; o->S = g.S;
-    o->nphase = g.nphase; o->OH = g.OH; o->OW = g.OW; o->OS = g.OS; o->D1 = g.D1; o->D2 = g.D2; o->wtaps = g.wtaps;
-    o->relu1 = g.relu1; o->relu2 = g.relu2;
-    o->groups = pg.groups; o->TY = pg.TY; o->TX = pg.TX; o->mtiles = mtiles; o->ntiles = ntiles;
-    for (int ph = 0; ph < 4; ++ph) {
-        for (int q = 0; q < 4; ++q) {
-            const int e = ph * 4 + q;
-            o->wby |= (unsigned long long)((pg.by[ph][q] + 8) & 15) << (4 * e);
-            o->wbx |= (unsigned long long)((pg.bx[ph][q] + 8) & 15) << (4 * e);
-            unsigned b8 = 0, b16 = 0;
-            for (int t = 0; t < 4; ++t) {
-                const unsigned toff = (pg.toff4[ph][q] >> (8 * t)) & 0xffu, wt = (pg.wt4[ph][q] >> (8 * t)) & 0xffu;
-                b8 |= ((toff / PATCH_W) * 2 + (toff % PATCH_W)) << (2 * t);
-                b16 |= (wt & 15u) << (4 * t);
-            }
-            o->toff[e >> 3] |= (unsigned long long)b8 << (8 * (e & 7));
-            o->wt[ph] |= (unsigned long long)b16 << (16 * q);
-        }
-        o->poy |= (unsigned)(g.poy[ph] & 1) << ph;
-        o->pox |= (unsigned)(g.pox[ph] & 1) << ph;
-    }
 }
 
 template <int TH, int NW, int MT, int NRING>

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ("C1", C.c_int32), ("C2", C.c_int32), ("Cout", C.c_int32),
                 ("kernel", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("relu1", C.c_int32), ("relu2", C.c_int32), ("epilogue_act", C.c_int32),
-                ("groups", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("groups", C.c_int32), ("pack_flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BwdEpilogue(C.Structure):
@@ -75,6 +75,7 @@ SIGNATURES = {
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
+    "pai_pack_frag": (_I, [_P, _I, _I, _P, _P]),
     "pai_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
