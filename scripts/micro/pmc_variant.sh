@@ -1,13 +1,13 @@
 #!/bin/bash
 # Matrix-pipe busy cycles and clock of ONE layer under a variant build of the library (scripts/micro/variants.sh):
-#   scripts/micro/pmc_variant.sh <variant dir name | -> <layer> <ops> <k=v,...>         (GPU box)
+#   [CB_EXTRA=--frag] scripts/micro/pmc_variant.sh <variant dir name | -> <layer> <ops> <k=v,...>         (GPU box)
 # prints per kernel: launch us, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM cycles), clock = GRBM_GUI_ACTIVE / 8 / us
 v=$1; layer=$2; ops=$3; set=$4
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 [ "$v" != "-" ] && export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/variants/$v:$LD_LIBRARY_PATH
 out=gpurun_out/pmcv_${v}_${layer}_${set//[=,]/_}
 rm -rf $out && mkdir -p $out
-B="scripts/micro/convbench --iters 3 --rounds 1 --ops $ops --filter $layer --set $set"
+B="scripts/micro/convbench $CB_EXTRA --iters 3 --rounds 1 --ops $ops --filter $layer --set $set"
 timeout -k 10 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $out/a -- $B > $out/a.log 2>&1 || echo pass a failed
 timeout -k 10 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/b -- $B > $out/b.log 2>&1 || echo pass b failed
 python3 - $out <<'PY'

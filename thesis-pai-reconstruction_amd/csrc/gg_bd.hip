@@ -15,7 +15,30 @@
 //   * a wave's eight pixel-row fragments are one LDS base address + immediates (the swizzle depends on the patch
 //     column only): 8 ds_read_b128 + 4 buffer loads per 32 MFMAs.
 // The two waves of a workgroup that share a channel half fetch the same weights (L1 / L2 hits): 25-31 B/clk/CU of
-// vector-memory return traffic at full matrix rate, under the 64 B/clk of the path.
+// vector-memory return traffic at full matrix rate, under the 64 B/clk of the path.  A second form (WIDE, tunable
+// fwd_bd = 2) puts the four waves side by side along the channels (256 pixels x 32 channels each): no weight byte is
+// fetched twice, every wave reads the whole patch.
+//
+// STATUS (round 2, scripts/micro/convbench --frag, one MI355X, bit-exact against gg_fwd_patch_k on integer data and in
+// tests/test_gpu_conv_exact.py): OPT-IN (needs the fragment-major pack copy, pai_conv_desc.pack_flags) and NOT faster:
+//   us, gg_fwd_patch_k / this kernel 2 x 2 / WIDE     forward            input gradient
+//   decoders[4]  (137 GFLOP)                          117.1 122.8 122.9  108.5 110.9 110.7
+//   D block 3                                         113.0 115.0 114.2  111.5 115.6 113.9
+//   decoders[5]                                       122.7 130.5 132.8  113.4 119.7 115.7
+// Three very different operand paths end within 5 % of each other.  What was learnt on the way:
+//   * ablations (input gradient of decoders[4], a slower box): everything 125 us, no weight loads 106, no patch fill
+//     113, no fragment reads 120, MFMAs + epilogue alone 92: with the weights out of the LDS the fragment reads are
+//     cheap (5 us) and the cost moves to the vector-memory path;
+//   * counters (scripts/micro/pmc_variant.sh): this kernel keeps the matrix pipe 46 % busy at a 14 % HIGHER clock than
+//     gg_fwd_patch_k (54 % busy): the chip trades clock for activity, the product is the same 1.1-1.15;
+//   * scripts/micro/mfma_mix.hip: the instruction mix of a tap (32 MFMAs + 8 ds_read_b128 + 4 buffer loads, two waves
+//     per SIMD, everything L1-resident) sustains 1.43 PFLOP/s with the reads behind consecutive MFMAs, 1.55-1.56 with
+//     reads and loads clustered, 1.64 with one of them behind every third MFMA (bare MFMAs 1.86; the 32x32x16 form
+//     1.43-1.50 / 1.69): the mix is not what holds the kernel at 1.2;
+//   * hipcc: builtin MFMAs / loads in a hand-pipelined loop of 128 accumulator registers get renamed through the loop
+//     body and spill (each reload behind a vmcnt(0)); inline-asm MFMAs with "+a" accumulators and "+v" in-place loads
+//     give exactly the intended loop in 128 + 100 registers; loop-invariant per-lane values are better kept in LDS;
+//   * LDS-DMA and register loads do NOT retire in order with respect to each other (see the waits in the K loop).
 //
 // Serves the same reference call sites as gg_fwd_patch_k: the Conv2d k4 s2 p1 / ConvTranspose2d k4 s2 p1 layers of
 // EncoderBlock / DecoderBlock (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and
@@ -43,17 +66,20 @@ constexpr size_t BD_LDS = BD_LDS_LOOP > BD_LDS_EPI ? BD_LDS_LOOP : BD_LDS_EPI;
 #define BD_ABL 0            // timing ablations (results WRONG): 1 no patch fill, 2 no MFMA, 4 no fragment reads, 8 no weight loads
 #endif
 
-template <bool RELU>
+// WIDE: the four waves side by side along the channels, each over all 256 pixels x 32 channels (16 x 2 MFMA tiles)
+// instead of 2 x 2 waves of 128 pixels x 64 channels (8 x 4): no two waves fetch the same weights (half the
+// vector-memory bytes per FLOP), twice the pixel-fragment reads from LDS.
+template <bool WIDE, bool RELU>
 __global__ __launch_bounds__(BD_NTHR, 2) void gg_fwd_bd_k(P2Prob g, FwdArgs a) {
-    constexpr int MT = BD_MT, NT = BD_NT, BM = BD_BM, BN = BD_BN, NTHR = BD_NTHR, PJ = BD_PJ, PPI = BD_PPI;
+    constexpr int MT = WIDE ? 16 : BD_MT, NT = WIDE ? 2 : BD_NT, BM = BD_BM, BN = BD_BN, NTHR = BD_NTHR, PJ = BD_PJ, PPI = BD_PPI;
     constexpr int PBYTES = BD_PBYTES, PIX = BD_PIX, PIXR = BD_PIXR;
-    constexpr int WMW = 2, NW = BD_NW;
+    constexpr int WMW = WIDE ? 1 : 2, NW = BD_NW;
     const int mtiles = g.mtiles, ntiles = g.ntiles;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = WIDE ? 0 : wid >> 1, wn = WIDE ? wid : wid & 1;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bn = bid % ntiles;
     bid /= ntiles;
@@ -105,7 +131,9 @@ __global__ __launch_bounds__(BD_NTHR, 2) void gg_fwd_bd_k(P2Prob g, FwdArgs a) {
                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wfa >> 32)) & 0xffffu,
                       (unsigned)__builtin_amdgcn_readfirstlane((int)wbytes), 0x00020000u};
     const unsigned nsub = kelems >> 5, csub = (unsigned)g.Cin >> 5;
-    const unsigned wtile = (unsigned)(bn * 2 + wn) * nsub;
+    // WIDE: wave wn takes fragments 2 (wn % 2) + {0, 1} of 64-channel tile wn / 2
+    const unsigned wtile = (unsigned)(bn * 2 + (WIDE ? wn >> 1 : wn)) * nsub;
+    const unsigned wfrag0 = WIDE ? (unsigned)(wn & 1) * 2048u : 0u;
     const unsigned wv = (unsigned)lane * 16u;
 
     const int fr = lane & 15, fq = lane >> 4;
@@ -158,7 +186,7 @@ __global__ __launch_bounds__(BD_NTHR, 2) void gg_fwd_bd_k(P2Prob g, FwdArgs a) {
     auto slice_off = [&](int gi, int k) __attribute__((always_inline)) -> unsigned {
         const int q = gi & (groups - 1);
         const unsigned wt = (unsigned)(wpk >> (16 * q + 4 * k)) & 15u;
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)((wtile + wt * csub + (unsigned)(gi >> gsh)) << 12));
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)(((wtile + wt * csub + (unsigned)(gi >> gsh)) << 12) + wfrag0));
     };
     // LDS address of this lane's fragment piece (patch row wm * MT, tap offset (ty, tx)) in buffer b
     auto patch_base = [&](int b, unsigned t2) __attribute__((always_inline)) -> unsigned {
@@ -188,18 +216,22 @@ __global__ __launch_bounds__(BD_NTHR, 2) void gg_fwd_bd_k(P2Prob g, FwdArgs a) {
     // Weight loads and their waits are inline asm: a builtin load gets fresh registers from hipcc (the K loop then
     // needs > 256 and spills, each reload behind a vmcnt(0) that drains every load in flight); "+v" loads IN PLACE,
     // and the wait carries the register as an operand so that no MFMA using it can be scheduled in front of it.
-    // Counts: loads retire in order; behind fragment nt of tap s the wave issues 3 - nt + 4 + nt = 7 more weight
-    // loads before pass nt of tap s + 2 needs it, plus the PJ pieces of a patch fill when one was issued in between
-    // (taps k = 3 -- at its start -- and k = 0): the fill is ALWAYS issued (past the last group: out-of-range lanes
-    // into the dump area) so that the counts are compile-time constants.
+    // Counts: behind fragment nt of tap s the wave issues 3 - nt + 4 + nt = 7 more weight loads before pass nt of tap
+    // s + 2 needs it.
+    // NO WAIT MAY COUNT AN LDS-DMA AND A REGISTER LOAD TOGETHER.  vmcnt counts both, but the two kinds do not retire
+    // in order WITH RESPECT TO EACH OTHER on gfx950: with "7 + PJ" where a patch fill (PJ LDS-DMA instructions) had been
+    // issued between a weight load and its wait, and "2 NT" in front of the group barrier, one wave in ~10^4 read a
+    // weight fragment before it had landed -- only on grids of several rounds, where the two workgroups of a CU are
+    // out of phase (scripts/micro/bd_race.sh: 37 mismatching runs of 54 against 0 of 54 with the waits below).  So a
+    // weight wait is vmcnt(7) whatever lies in between (register loads retire in order among themselves; an LDS-DMA
+    // that is still outstanding only makes the wait longer), and "this wave's patch pieces have landed" is vmcnt(0).
     auto load_w1 = [&](u4_t& wf, unsigned soff, int nt) __attribute__((always_inline)) {
         if (BD_ABL & 8) { wf = (u4_t){soff, wv, (unsigned)nt, 1u}; return; }
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(wf) : "v"(wv), "s"(wrs), "s"(soff + nt * 1024u));
     };
-    auto wait_w = [&](u4_t& wf, bool fill_between) __attribute__((always_inline)) {
+    auto wait_w = [&](u4_t& wf) __attribute__((always_inline)) {
         if (BD_ABL & 8) return;
-        if (fill_between) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf) : "n"(7 + ((BD_ABL & 1) ? 0 : PJ)));
-        else asm volatile("s_waitcnt vmcnt(7)" : "+v"(wf));
+        asm volatile("s_waitcnt vmcnt(7)" : "+v"(wf));
     };
 
     // A tap (one 32-deep K slice) is 32 MFMAs per wave, issued CHANNEL-FRAGMENT-MAJOR: for nt: for mt.
@@ -209,72 +241,136 @@ __global__ __launch_bounds__(BD_NTHR, 2) void gg_fwd_bd_k(P2Prob g, FwdArgs a) {
     //   pixels    the wave's eight fragments of a tap stay in registers for its four passes (two sets: the fragments of
     //             the next tap are read during the second pass);
     //   patches   three LDS buffers: patch gi + 2 is requested in the last tap of group gi, behind the group's barrier.
-    // That ONE barrier per group (128 MFMAs per wave) says (1) patch gi + 1 has landed -- requested a group ago; the
-    // counted vmcnt leaves only the two newest weight slices outstanding -- before the read-ahead crosses into it,
-    // and (2) every wave is done with patch gi - 1, whose buffer patch gi + 2 overwrites.  Vector-memory operations
-    // retire in order, so a wait for a weight fragment also waits for a patch requested before it: with the
-    // fragments two taps ahead a patch has two taps' time before any wave can stall on it.
+    // That ONE barrier per group (128 MFMAs per wave) says (1) patch gi + 1 has landed -- requested a group ago --
+    // before the read-ahead crosses into it, and (2) every wave is done with patch gi - 1, whose buffer patch gi + 2
+    // overwrites.
     const int S = 4 * ngroups;
     auto slice_of = [&](int s) __attribute__((always_inline)) -> unsigned {
         const int sc = s < S ? s : S - 1;
         return slice_off(sc >> 2, sc & 3);
     };
-    u4_t wB[2][NT];
-    bf8_t pf[2][MT];
+    if constexpr (WIDE) {
+        // Item-major: a tap is 16 items (pixel row mt) of 2 MFMAs; pixel fragments in a ring of eight (the fragment of item
+        // i + 8 is read behind the MFMAs of item i), weights in a ring of four sets of two fragments, the set of tap
+        // s + 2 requested at the start of tap s.  Counts: behind the set of tap s the wave issues the sets of taps s + 1
+        // and s + 2 (4 loads) before it needs it.
+        u4_t wB[4][NT];
+        bf8_t pf[8];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wB[0][nt] = wB[1][nt] = (u4_t){0u, 0u, 0u, 0u};
-    // prologue in the order the counts above assume: patch 0, tap 0, patch 1, tap 1
-    fire_patch(0, 0, true);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) load_w1(wB[0][nt], slice_of(0), nt);
-    fire_patch(ngroups > 1 ? 1 : 0, 1, ngroups > 1);
+            for (int nt = 0; nt < NT; ++nt) wB[i][nt] = (u4_t){0u, 0u, 0u, 0u};
+        fire_patch(0, 0, true);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) load_w1(wB[1][nt], slice_of(1), nt);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((BD_ABL & 8) ? 0 : 2 * NT) + ((BD_ABL & 1) ? 0 : PJ)) : "memory");   // patch 0 has landed
-    __builtin_amdgcn_s_barrier();
-    unsigned pb_cur = patch_base(0, tap2(0, 0));
+        for (int nt = 0; nt < NT; ++nt) load_w1(wB[0][nt], slice_of(0), nt);
+        fire_patch(ngroups > 1 ? 1 : 0, 1, ngroups > 1);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) pf[0][mt] = read_p(pb_cur, mt);
-    int bufc = 0;
-    for (int gi = 0; gi < ngroups; ++gi) {
-        const int relu = relu_of(gi);
-        const bool more = gi + 1 < ngroups;
-        const int bufn = bufc == 2 ? 0 : bufc + 1, bufp = bufc == 0 ? 2 : bufc - 1;
+        for (int nt = 0; nt < NT; ++nt) load_w1(wB[1][nt], slice_of(1), nt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch 0 has landed
+        __builtin_amdgcn_s_barrier();
+        unsigned pb_cur = patch_base(0, tap2(0, 0));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k == 3) {
-                if (more) {
-                    // patch gi + 1 (requested a group ago) has landed: only the weight loads of the last two taps may be outstanding
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BD_ABL & 8) ? 0 : 2 * NT) : "memory");
-                    __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < 8; ++i) pf[i] = read_p(pb_cur, i);
+        int bufc = 0;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int relu = relu_of(gi);
+            const bool more = gi + 1 < ngroups;
+            const int bufn = bufc == 2 ? 0 : bufc + 1, bufp = bufc == 0 ? 2 : bufc - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 3) {
+                    if (more) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory");   // this wave's pieces of patch gi + 1 have landed
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    fire_patch(gi + 2 < ngroups ? gi + 2 : gi, bufp, gi + 2 < ngroups);
                 }
-                fire_patch(gi + 2 < ngroups ? gi + 2 : gi, bufp, gi + 2 < ngroups);
-            }
-            // (behind the last tap the read-ahead re-reads the current patch: no branch in the MFMA stream)
-            const unsigned pb_next = k < 3 ? patch_base(bufc, tap2(gi, k + 1)) : (more ? patch_base(bufn, tap2(gi + 1, 0)) : pb_cur);
-            const unsigned soff2 = slice_of(4 * gi + k + 2);
-            __builtin_amdgcn_sched_barrier(0);
+                const unsigned pb_next = k < 3 ? patch_base(bufc, tap2(gi, k + 1)) : (more ? patch_base(bufn, tap2(gi + 1, 0)) : pb_cur);
+                const unsigned soff2 = slice_of(4 * gi + k + 2);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                wait_w(wB[k & 1][nt], k == 3 || k == 0);
+                for (int nt = 0; nt < NT; ++nt) load_w1(wB[(k + 2) & 3][nt], soff2, nt);
+                if (!(BD_ABL & 8)) {
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wB[k][0]), "+v"(wB[k][1]) : "n"(2 * NT));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    if (RELU && nt == 0) pf[k & 1][mt] = relu_frag_s(pf[k & 1][mt], relu);
-                    if (BD_ABL & 2) acc[mt][nt][0] += (float)pf[k & 1][mt][0] + __uint_as_float(wB[k & 1][nt][mt & 3]);
-                    else
-                        // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr.  asm with the
-                        // accumulator tied in place in the ACCUMULATION registers ("+a"): as a builtin hipcc 7.2 renames the
-                        // 128 accumulator registers through the loop body and spills
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wB[k & 1][nt]), "v"(pf[k & 1][mt]));
-                    if (nt == 1) pf[(k & 1) ^ 1][mt] = read_p(pb_next, mt);    // the next tap's fragment, 2 1/2 passes ahead
-                    if (nt == 1 || (RELU && nt == 0)) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every read to its first use
+                    bf8_t x = pf[mt & 7];
+                    if (RELU) x = relu_frag_s(x, relu);
+                    if (BD_ABL & 2) acc[mt][0][0] += (float)x[0] + __uint_as_float(wB[k][mt & 1][mt & 3]);
+                    else {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wB[k][nt]), "v"(x));
+                    }
+                    pf[mt & 7] = read_p(mt < 8 ? pb_cur : pb_next, mt < 8 ? mt + 8 : mt - 8);
+                    __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every read to its first use
                 }
-                load_w1(wB[k & 1][nt], soff2, nt);
-                __builtin_amdgcn_sched_barrier(0);
+                pb_cur = pb_next;
             }
-            pb_cur = pb_next;
+            bufc = bufn;
         }
-        bufc = bufn;
+    } else {
+        u4_t wB[2][NT];
+        bf8_t pf[2][MT];
+    #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wB[0][nt] = wB[1][nt] = (u4_t){0u, 0u, 0u, 0u};
+        // prologue in the order the counts above assume: patch 0, tap 0, patch 1, tap 1
+        fire_patch(0, 0, true);
+    #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) load_w1(wB[0][nt], slice_of(0), nt);
+        fire_patch(ngroups > 1 ? 1 : 0, 1, ngroups > 1);
+    #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) load_w1(wB[1][nt], slice_of(1), nt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch 0 has landed
+        __builtin_amdgcn_s_barrier();
+        unsigned pb_cur = patch_base(0, tap2(0, 0));
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pf[0][mt] = read_p(pb_cur, mt);
+        int bufc = 0;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int relu = relu_of(gi);
+            const bool more = gi + 1 < ngroups;
+            const int bufn = bufc == 2 ? 0 : bufc + 1, bufp = bufc == 0 ? 2 : bufc - 1;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 3) {
+                    if (more) {
+                        // patch gi + 1 (requested a group ago) has landed: only the weight loads of the last two taps may be outstanding
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of patch gi + 1 have landed
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    fire_patch(gi + 2 < ngroups ? gi + 2 : gi, bufp, gi + 2 < ngroups);
+                }
+                // (behind the last tap the read-ahead re-reads the current patch: no branch in the MFMA stream)
+                const unsigned pb_next = k < 3 ? patch_base(bufc, tap2(gi, k + 1)) : (more ? patch_base(bufn, tap2(gi + 1, 0)) : pb_cur);
+                const unsigned soff2 = slice_of(4 * gi + k + 2);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wait_w(wB[k & 1][nt]);
+    #pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (RELU && nt == 0) pf[k & 1][mt] = relu_frag_s(pf[k & 1][mt], relu);
+                        if (BD_ABL & 2) acc[mt][nt][0] += (float)pf[k & 1][mt][0] + __uint_as_float(wB[k & 1][nt][mt & 3]);
+                        else
+                            // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr.  asm with the
+                            // accumulator tied in place in the ACCUMULATION registers ("+a"): as a builtin hipcc 7.2 renames the
+                            // 128 accumulator registers through the loop body and spills
+                            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(wB[k & 1][nt]), "v"(pf[k & 1][mt]));
+                        // the next tap's fragments, one read behind every third MFMA of the first three passes: spread
+                        // evenly the 12 other vector-memory / LDS instructions of a tap cost the matrix pipe least
+                        // (scripts/micro/mfma_mix.hip: 1.64 PFLOP/s against 1.43 with the eight reads behind consecutive MFMAs)
+                        if ((nt * MT + mt) % 3 == 2 && (nt * MT + mt) / 3 < MT) pf[(k & 1) ^ 1][(nt * MT + mt) / 3] = read_p(pb_next, (nt * MT + mt) / 3);
+                        if ((nt * MT + mt) % 3 == 2 || (RELU && nt == 0)) __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks every read to its first use
+                    }
+                    load_w1(wB[k & 1][nt], soff2, nt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pb_cur = pb_next;
+            }
+            bufc = bufn;
+        }
     }
     // (the compiler does not know the asm above are MFMAs: their results are read after the pipeline has drained)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -288,7 +384,8 @@ __global__ __launch_bounds__(BD_NTHR, 2) void gg_fwd_bd_k(P2Prob g, FwdArgs a) {
     // lane (fq, fr) holds, for each of its MT pixel rows mt (pixel fr of the row), the 16 consecutive channels
     // wn*64 + 16 fq + (4 nt + r)
     constexpr int CL = 4 * NT;
-    const int col0 = wn * 64 + CL * fq;
+    // (WIDE: the 8 channels 16 fq + 8 (wn % 2) + (4 nt + r) of tile wn / 2)
+    const int col0 = WIDE ? (wn >> 1) * 64 + 16 * fq + 8 * (wn & 1) : wn * 64 + CL * fq;
     float csum[CL], csq[CL];
     {
         float bias_v[CL];
@@ -423,7 +520,7 @@ extern "C" int pai_pack_frag(const void* w_rowmajor, int rows, int K, void* w_fr
 }
 
 // ---- host side --------------------------------------------------------------------------------------------
-// tunable "fwd_bd": 0 off, 1 on for every problem it accepts; "fwd_bd_min_wgs": smallest grid it takes
+// tunable "fwd_bd": 0 off, 1 the 2 x 2-wave form, 2 the four-waves-side-by-side form, for every problem it accepts; "fwd_bd_min_wgs": smallest grid it takes
 int fwd_bd_rows(const GG& g) {
     if (!g.wfrag || !pai_tunable("fwd_bd", 1)) return 0;
     if ((g.C1 % BD_CK) || (g.C2 % BD_CK) || g.Cin < 64) return 0;
@@ -442,8 +539,9 @@ int launch_fwd_bd(const GG& g, const FwdArgs& a, hipStream_t s) {
     PAI_CHECK(fwd_bd_rows(g) && patch_geo(g, BD_TH, &pg), "launch_fwd_bd: problem not eligible");
     static bool attr = false;
     if (!attr) {
-        const void* fns[2] = {reinterpret_cast<const void*>(&gg_fwd_bd_k<false>), reinterpret_cast<const void*>(&gg_fwd_bd_k<true>)};
-        for (int i = 0; i < 2; ++i) {
+        const void* fns[4] = {reinterpret_cast<const void*>(&gg_fwd_bd_k<false, false>), reinterpret_cast<const void*>(&gg_fwd_bd_k<false, true>),
+                              reinterpret_cast<const void*>(&gg_fwd_bd_k<true, false>), reinterpret_cast<const void*>(&gg_fwd_bd_k<true, true>)};
+        for (int i = 0; i < 4; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS);
             PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
         }
@@ -453,10 +551,20 @@ int launch_fwd_bd(const GG& g, const FwdArgs& a, hipStream_t s) {
     P2Prob pr;
     p2_prob(g, pg, mtiles, ntiles, &pr);
     const dim3 grid(mtiles * ntiles * g.nphase), block(BD_NTHR);
-    if (g.relu1 || g.relu2) hipLaunchKernelGGL((gg_fwd_bd_k<true>), grid, block, BD_LDS, s, pr, a);
-    else hipLaunchKernelGGL((gg_fwd_bd_k<false>), grid, block, BD_LDS, s, pr, a);
+    const bool relu = g.relu1 || g.relu2;
+    if (pai_tunable("fwd_bd", 1) == 2) {
+        if (relu) hipLaunchKernelGGL((gg_fwd_bd_k<true, true>), grid, block, BD_LDS, s, pr, a);
+        else hipLaunchKernelGGL((gg_fwd_bd_k<true, false>), grid, block, BD_LDS, s, pr, a);
+    } else {
+        if (relu) hipLaunchKernelGGL((gg_fwd_bd_k<false, true>), grid, block, BD_LDS, s, pr, a);
+        else hipLaunchKernelGGL((gg_fwd_bd_k<false, false>), grid, block, BD_LDS, s, pr, a);
+    }
     PAI_LAUNCH_CHECK();
     return 0;
 }
 
-const char* fwd_bd_kernel_name(const GG& g) { return (g.relu1 || g.relu2) ? "gg_fwd_bd_k<true>" : "gg_fwd_bd_k<false>"; }
+const char* fwd_bd_kernel_name(const GG& g) {
+    const bool relu = g.relu1 || g.relu2;
+    if (pai_tunable("fwd_bd", 1) == 2) return relu ? "gg_fwd_bd_k<true, true>" : "gg_fwd_bd_k<true, false>";
+    return relu ? "gg_fwd_bd_k<false, true>" : "gg_fwd_bd_k<false, false>";
+}

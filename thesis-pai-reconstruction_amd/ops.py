@@ -260,6 +260,11 @@ def pack_weights(dtype, w_master, Cout, taps, Cin, w_fwd=None, w_dgrad=None):
                                       _p(w_dgrad), _stream()), "pai_pack_weights")
 
 
+def pack_frag(w_rowmajor, rows, K, w_frag):
+    """Fragment-major copy of a row-major bf16 filter pack [rows][K] (pai_pack_frag; see pai_conv_desc.pack_flags)."""
+    L.check(L.load().pai_pack_frag(_p(w_rowmajor, torch.bfloat16), rows, K, _p(w_frag, torch.bfloat16), _stream()), "pai_pack_frag")
+
+
 def pack_weights_multi(items):
     """items: [(w_master fp32, Cout, taps, Cin, w_fwd | None, w_dgrad | None)], bf16 packs, Cin and Cout multiples of
     64: every layer in one launch."""
