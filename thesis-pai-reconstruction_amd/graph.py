@@ -62,6 +62,8 @@ class GraphedStep:
             if self.calls <= self.warmup:
                 return m.training_step(batch, batch_idx)
             self._capture(batch)
+            if self.graph is None:       # capture refused (self.disabled says why): that call ran the step eagerly
+                return None
         for s, b in zip(self.static, batch):
             s.copy_(b, non_blocking=True)
         self.graph.replay()
