@@ -15,12 +15,17 @@ typedef __attribute__((ext_vector_type(4))) float f4_t;
 typedef __attribute__((ext_vector_type(16))) float f16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 
-#define MFMA16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define MFMA16(acc, a, b)                                                                                  \
+    do {                                                                                                   \
+        if (ACCV) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));     \
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));          \
+    } while (0)
 #define MFMA32(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define BLD(dst, vo, rs, so) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rs), "s"(so))
 
-template <int SHAPE, int PAT>
+// ACCV: accumulators in the vector registers ("+v") instead of the accumulation registers ("+a")
+template <int SHAPE, int PAT, int ACCV = 0>
 __global__ __launch_bounds__(256, 2) void k(const uint4* src, float* out, int iters) {
     __shared__ uint4 lds[2048];
     const int tid = threadIdx.x;
@@ -71,32 +76,39 @@ __global__ __launch_bounds__(256, 2) void k(const uint4* src, float* out, int it
     out[blockIdx.x * 256 + tid] = t + __uint_as_float(w[0][0] ^ p[0][0]);
 }
 
-template <int SHAPE, int PAT>
+static int g_iters = 2000;   // argv[1]: iterations per launch (a long launch to watch power / clock beside it)
+template <int SHAPE, int PAT, int ACCV = 0>
 static void run(const uint4* src, float* out) {
-    const int iters = 2000, grid = 256 * 2;
+    const int iters = g_iters, grid = 256 * 2;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<SHAPE, PAT>), dim3(grid), dim3(256), 0, 0, src, out, 100);
+    hipLaunchKernelGGL((k<SHAPE, PAT, ACCV>), dim3(grid), dim3(256), 0, 0, src, out, 100);
     float best = 1e9f;
     for (int r = 0; r < 3; ++r) {
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k<SHAPE, PAT>), dim3(grid), dim3(256), 0, 0, src, out, iters);
+        hipLaunchKernelGGL((k<SHAPE, PAT, ACCV>), dim3(grid), dim3(256), 0, 0, src, out, iters);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
     const double flop = (double)grid * 4 * iters * 32.0 * 16 * 16 * 32 * 2;
-    printf("mfma %2dx%2d  2 waves/SIMD  arrangement %d: %7.1f us  %6.0f TFLOP/s\n", SHAPE, SHAPE, PAT, best * 1e3, flop / (best * 1e-3) * 1e-12);
+    printf("mfma %2dx%2d  2 waves/SIMD  %s accumulators  arrangement %d: %7.1f us  %6.0f TFLOP/s\n", SHAPE, SHAPE, ACCV ? "VGPR" : "AGPR", PAT,
+           best * 1e3, flop / (best * 1e-3) * 1e-12);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_iters = atoi(argv[1]);
     uint4* src; float* out;
     (void)hipMalloc(&src, 1024 * 16); (void)hipMalloc(&out, 256 * 8 * 256 * 4);
     unsigned short h[8192];
     srand(1);
     for (int i = 0; i < 8192; ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));   // bf16 around +-1
     (void)hipMemcpy(src, h, sizeof(h), hipMemcpyHostToDevice);
+    if (argc > 2) {   // argv[2]: only the 16x16x32 loops, bare and with the evenly spread mix, both accumulator homes
+        run<16, 0, 0>(src, out); run<16, 0, 1>(src, out); run<16, 4, 0>(src, out); run<16, 4, 1>(src, out);
+        return 0;
+    }
     run<16, 0>(src, out); run<16, 1>(src, out); run<16, 2>(src, out); run<16, 3>(src, out); run<16, 4>(src, out);
     run<32, 0>(src, out); run<32, 1>(src, out); run<32, 2>(src, out); run<32, 3>(src, out); run<32, 4>(src, out);
     return 0;

@@ -590,11 +590,13 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 // kernel it is within +-3 % of the 16x16x32 form on every layer, because neither issue slots nor the matrix pipe
 // bound it.  Compile-time ablations on decoders[4] (137 GFLOP; 16x16x32 / 32x32x16 form, forward us):
 //   everything 128 / 123;  no epilogue 120 / 113;  no patch fill 122 / 115;  no weight-tile fill 106 / 102;
-//   no LDS-DMA fill at all 91 / 86;  neither fills nor fragment reads 77 (1.79 PFLOP/s: this device's matrix ceiling
-//   under load -- bare MFMA loops reach 1.72-1.80, not the 2.5 of the data sheet)
+//   no LDS-DMA fill at all 91 / 86;  neither fills nor fragment reads 77 (1.79 PFLOP/s; a bare MFMA loop sustains 2.07
+//   on this board -- not the 2.5 of the data sheet -- with the clock throttled to ~2.07 GHz at the 1400 W power cap)
 // i.e. the matrix pipe waits for the LDS: per two co-resident workgroup-steps (1024 matrix cycles per SIMD) the LDS
-// serves 2 x 8 waves x 16 ds_read_b128 (1024 cycles) plus 2 x 26 KB of LDS-DMA writes, and only what reduces those
-// bytes per FLOP can move this kernel -- wider wave tiles (gg_p2.hip, at the price of occupancy) did not pay either.
+// serves 2 x 8 waves x 16 ds_read_b128 (1024 cycles) plus 2 x 26 KB of LDS-DMA writes.  And the launch runs AT the
+// power cap (1385 W, 2.02 GHz): 0.36 of its 0.90 pJ per FLOP move operands, so only fewer operand
+// bytes per FLOP at every level can move this kernel -- wider wave tiles (gg_p2.hip, at the price of occupancy and an
+// exposed epilogue) and register-direct weights (gg_bd.hip, more L2 bytes for fewer LDS bytes) did not pay.
 template <int BM, int BN, bool DBB, bool M32>   // DBB: two weight-tile buffers
 __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a, const PatchGeo& pg, int mtiles, int ntiles) {
     static_assert(!M32 || BN == 128, "the 32x32x16 path covers 64-channel wave tiles");
