@@ -92,3 +92,29 @@ def test_handle_api_host_side(pai):
     assert lib.pai_bind(None) != 0
     assert lib.pai_destroy(h2) == 0 and lib.pai_destroy(h1) == 0
     assert lib.pai_destroy(None) != 0
+
+
+def test_kernel_dispatch_table_without_gpu(pai):
+    """Which kernel a layer runs is host logic: the family of every bf16 case of tests/test_gpu_conv.py and the kernel
+    names of the BASELINE configs[1] layers (what bench.py keys its roofline on) are pinned here, without a GPU and
+    without a split-K workspace (the un-split names)."""
+    import importlib.util
+    import torch
+    from thesis_pai_reconstruction_amd import ops
+    spec = importlib.util.spec_from_file_location("_gpu_conv_cases", os.path.join(ROOT, "tests", "test_gpu_conv.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, tr, s, N, H, W, C1, C2, Cout, r1, r2 in mod.CASES:
+        d = ops.make_desc(torch.bfloat16, tr, N, H, W, C1, C2, Cout, s, r1, r2, ops.ACT_LRELU)
+        assert tuple(ops.conv_kernel_id(d, op) for op in (0, 1, 2)) == mod.BF16_FAMILY[name], name
+    big = "gg_fwd_patch_k<256, 128, true>"
+    cfg2 = {   # (transposed, N, H, C1, C2, Cout) -> (forward, input gradient, weight gradient)
+        "encoders[2]": ((0, 64, 64, 128, 0, 256), (big, big, "gg_wgrad_patch_k<128>")),
+        "decoders[4]": ((1, 64, 16, 512, 512, 256), (big, big, "gg_wgrad_patch_k<128>")),
+        "decoders[5]": ((1, 64, 32, 256, 256, 128), (big, big, "gg_wgrad_patch_k<128>")),
+        "decoders[6]": ((1, 64, 64, 128, 128, 64), ("gg_fwd_patch_k<128, 64, false>", big, "gg_wgrad_patch_k<64>")),
+        "D block 3": ((0, 128, 32, 256, 0, 512), (big, big, "gg_wgrad_patch_k<128>")),
+    }
+    for layer, ((tr, N, H, C1, C2, Cout), want) in cfg2.items():
+        d = ops.make_desc(torch.bfloat16, tr, N, H, H, C1, C2, Cout, 2, tr, tr if C2 else 0)
+        assert tuple(ops.conv_kernel_name(d, op) for op in (0, 1, 2)) == want, layer

@@ -51,6 +51,19 @@ CASES = [
 ]
 
 
+# Kernel family (pai_conv_kernel_id: 0 vector-ALU tile, 1 row-dot, 2 / 3 bf16 matrix-core tile 128- / 64-wide, 4 thin-layer
+# matrix-core kernels) every bf16 case runs for forward / input gradient / weight gradient: a silent dispatch change
+# must not leave this test green on another kernel.  (tests/test_abi.py checks the same table without a GPU.)
+BF16_FAMILY = {
+    "enc0_cin1": (4, 1, 4), "disc0_cin1x2": (4, 1, 4), "enc_mid": (2, 3, 2), "enc_wide": (2, 2, 2),
+    "enc_bottleneck": (2, 2, 2), "dec0": (2, 2, 2), "dec_skip": (3, 3, 3), "dec_skip_wide": (2, 2, 2),
+    "head_cout1": (1, 4, 4), "patch_final": (1, 4, 1), "patch_final_wide": (1, 0, 4), "head_relu_skip": (1, 4, 4),
+    "odd_batch_rgb": (0, 0, 0), "enc_patch": (2, 3, 2), "dec_patch": (2, 3, 2), "enc_patch256": (2, 3, 2),
+    "dec_patch256": (2, 2, 2), "enc0_wide": (4, 1, 4), "disc0_wide": (4, 1, 4), "head_wide": (1, 4, 4),
+    "dec_patch256x64": (3, 2, 3), "enc_dgrad256": (2, 2, 2), "enc_splitk": (2, 2, 2), "dec_splitk": (2, 2, 2),
+}
+
+
 def _ref(case, x1, x2, w, b):
     name, tr, s, N, H, W, C1, C2, Cout, r1, r2 = case
     a1 = F.relu(x1) if r1 else x1
@@ -82,6 +95,8 @@ def test_conv_family(pai, case, dtype):
 
     d = ops.make_desc(dtype, tr, N, H, W, C1, C2, Cout, s, r1, r2, ops.ACT_LRELU)
     assert ops.conv_out_hw(d) == (OH, OW)
+    if dtype == torch.bfloat16:
+        assert tuple(ops.conv_kernel_id(d, op) for op in (0, 1, 2)) == BF16_FAMILY[name], name
     # split-K scratch: small-M / long-K layers take the split path only when it is registered
     ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
     ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
