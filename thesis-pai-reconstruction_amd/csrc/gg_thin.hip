@@ -148,6 +148,12 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
     const bf16_t* w = (const bf16_t*)a.w;
     const int mtiles = g.Cout / 16;
     const int KT = g.ntaps * T;      // 16 T, or 9 for the 3x3 layers (zero-padded to the 32 of the MFMA)
+    // bit 1 of fast_ok: every store INSTRUCTION covers whole 64-B sectors.  A lane holds 16 channels of one pixel; as
+    // one 32-B run (two stores to consecutive addresses) each instruction writes 16 of every 32 bytes -- half of every
+    // sector.  With the lane's channels split into the 8 at 8 fq and the 8 at 32 + 8 fq, the four lanes of a pixel
+    // write its first 64 B with the first instruction and its second 64 B with the second.
+    const bool sect = (fast_ok & 2) != 0;
+    fast_ok &= 1;
 
     // A operand: W[co][k], k = tap*T + t, zero beyond 16*T.  MFMA row i of tile mt computes output
     // channel co(mt, i) = 64*(mt>>2) + 16*(i>>2) + 4*(mt&3) + (i&3): after the four tiles of a group a
@@ -157,7 +163,9 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int co = 64 * (mt >> 2) + 16 * (fr >> 2) + 4 * (mt & 3) + (fr & 3);
+        // (sect: the lane's 16 channels are two 8-channel pieces 64 B apart -- see the stores)
+        const int co = sect ? 64 * (mt >> 2) + 32 * ((mt & 3) >> 1) + 8 * (fr >> 2) + 4 * (mt & 1) + (fr & 3)
+                            : 64 * (mt >> 2) + 16 * (fr >> 2) + 4 * (mt & 3) + (fr & 3);
         if (mt < mtiles) {
             if ((KT & 7) == 0) {
                 if (8 * fq < KT) z = *(const us8_t*)(w + (size_t)co * KT + 8 * fq);
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
     for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            bias[gq][e] = (a.bias && gq * 4 < mtiles) ? a.bias[64 * gq + 16 * fq + e] : 0.f;
+            bias[gq][e] = (a.bias && gq * 4 < mtiles) ? a.bias[64 * gq + (sect ? 32 * (e >> 3) + 8 * fq + (e & 7) : 16 * fq + e)] : 0.f;
     // this lane's 8 patch elements: (tap, t) pairs
     int pdy[8], pdx[8];
 #pragma unroll
@@ -273,7 +281,8 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
             }
             if (m >= g.M) continue;
             if ((THIN_ABL & 2) && v[0] != 12345.f) continue;   // ablation: no stores
-            const int co = 64 * gq + 16 * fq;   // first of this lane's 16 channels
+            const int co = 64 * gq + (sect ? 8 : 16) * fq;   // first of this lane's 16 channels
+            const int hop = sect ? 32 : 8;                   // channel distance of the lane's second 8-channel piece
             const size_t pix = (size_t)m;
             if (a.y1 || a.y2) {
                 unsigned pk[8];
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
                 for (int e = 0; e < 8; ++e) pk[e] = pk2bf(v[2 * e], v[2 * e + 1]);
                 bf16_t* dst = (co < g.D1) ? (bf16_t*)a.y1 + pix * g.D1 + co : (bf16_t*)a.y2 + pix * g.D2 + (co - g.D1);
                 *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                *(uint4*)(dst + hop) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
             if (a.yact) {
                 unsigned pk[8];
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
                 }
                 bf16_t* dst = (bf16_t*)a.yact + pix * g.Cout + co;
                 *(uint4*)dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                *(uint4*)(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                *(uint4*)(dst + hop) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
         }
         pv = pnext;
@@ -306,7 +315,11 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
     static const int cap = getenv("PAI_TF_BLOCKS") ? atoi(getenv("PAI_TF_BLOCKS")) : 4096;
     if (blocks > cap) blocks = cap;
     // thin_gather4: even row length, 32-bit byte offsets
-    const int fast_ok = pai_tunable("thin_fast", 1) && (g.W % 2) == 0 && (int64_t)g.N * g.H * g.W * 2 < (1ll << 31);
+    int fast_ok = pai_tunable("thin_fast", 1) && (g.W % 2) == 0 && (int64_t)g.N * g.H * g.W * 2 < (1ll << 31);
+    // whole-sector stores need both 8-channel pieces of a lane in the same output tensor: 64-channel groups
+    // (scripts/micro/convbench, thin_sect = 0 / 1: encoders[0] forward 43.7 -> 42.8 us, D block 0 forward 76.9 -> 75.2,
+    // input gradient of decoders[7] 56.6 -> 54.0; bit-identical outputs)
+    if (pai_tunable("thin_sect", 1) && (g.D2 == 0 || (g.D1 % 64) == 0)) fast_ok |= 2;
     if (g.C2 == 0) hipLaunchKernelGGL(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
     else hipLaunchKernelGGL(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
     PAI_LAUNCH_CHECK();
