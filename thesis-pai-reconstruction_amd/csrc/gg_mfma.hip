@@ -1546,8 +1546,13 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 // (measured and dropped: two LDS stages with a counted vmcnt + raw barrier, 48 KB per workgroup, still three per CU:
 //  10-50 % SLOWER -- decoders[6] 194 -> 306 us, decoders[5] 145 -> 169 us; this kernel's latency is hidden across
 //  workgroups, and the second stage only adds LDS-DMA pressure)
-// Compile-time timing ablations of gg_wgrad_patch_k (results WRONG; scripts/micro/variants.sh):
-// 1 no dW accumulation (atomics / stores), 2 no MFMA, 4 no LDS-DMA fills, 8 no fragment reads
+// Compile-time timing ablations of gg_wgrad_patch_k (results WRONG; scripts/micro/variants.sh, scripts/micro/wg_abl.sh):
+// 1 no dW accumulation (atomics / stores), 2 no MFMA, 4 no LDS-DMA fills, 8 no fragment reads.  Measured (round 2, one box,
+// weight gradient of decoders[4] / D block 3 / decoders[6], us): everything 156 / 150 / 184; no dW accumulation
+// 127 / 127 / 177; no fills 116 / 117 / 127; no fragment reads 154 / 148 / 182; neither fills nor reads 117 / 115 / 126;
+// MFMAs and loop alone 104 / 105 / 124 -- the transposed fragment reads are hidden, the fp32 atomics of the eight pixel
+// splits cost 19 %, the fills (10 B per kFLOP, 1.7 x the forward kernel's) 26 %, and the bare loop still runs a third
+// behind the forward kernel's (two vector instructions per MFMA: 32 of the 66 are the 8-byte transposed reads).
 #ifndef WGRAD_ABL
 #define WGRAD_ABL 0
 #endif
