@@ -52,7 +52,11 @@ def test_graphed_step_matches_eager(pai, dtype):
         if k.endswith("num_batches_tracked"):
             assert int(p) == int(q) == 2 * steps, k
         else:
-            assert float((p.float() - q.float()).norm()) <= 2e-2 * max(float(p.float().norm()), 1e-3), k
+            # noise-amplified divergence of two runs (see above): relative for the filters; for small vectors
+            # (BatchNorm weights / biases) an absolute floor of half of what Adam can move an element in `steps`
+            # steps (+-lr per step, lr = 2e-4) on every element
+            bound = 2e-2 * float(p.float().norm()) + 2e-4 * steps * p.numel() ** 0.5
+            assert float((p.float() - q.float()).norm()) <= bound, k
     for oe, og in zip(eager._all_optimizers(), graphed._all_optimizers()):
         assert og.total_steps == oe.total_steps == steps and int(og._dev_step) == steps
         se, sg = oe.state_dict()["state"], og.state_dict()["state"]
