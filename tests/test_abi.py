@@ -112,7 +112,7 @@ def test_kernel_dispatch_table_without_gpu(pai):
         "encoders[2]": ((0, 64, 64, 128, 0, 256), (big, big, "gg_wgrad_patch_k<128>")),
         "decoders[4]": ((1, 64, 16, 512, 512, 256), (big, big, "gg_wgrad_patch_k<128>")),
         "decoders[5]": ((1, 64, 32, 256, 256, 128), (big, big, "gg_wgrad_patch_k<128>")),
-        "decoders[6]": ((1, 64, 64, 128, 128, 64), ("gg_fwd_patch_k<128, 64, false>", big, "gg_wgrad_patch_k<64>")),
+        "decoders[6]": ((1, 64, 64, 128, 128, 64), ("gg_fwd_patch1_k<256, 64, false>", big, "gg_wgrad_patch_k<64>")),
         "D block 3": ((0, 128, 32, 256, 0, 512), (big, big, "gg_wgrad_patch_k<128>")),
     }
     for layer, ((tr, N, H, C1, C2, Cout), want) in cfg2.items():

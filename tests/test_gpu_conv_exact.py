@@ -36,7 +36,7 @@ CASES = [
     ("cfg2_dec3", 1, 64, 8, 512, 512, 512, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
     ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
-    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<64>")),
+    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<64>")),
     ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch_k<128>")),
     ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
     ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),

@@ -568,6 +568,13 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
     PatchGeo pg;
     // 16 x 16 tiles when the layer still fills the chip with them (two 8-wave workgroups per CU)
     if (!no_256 && c.bn == 128 && (int64_t)(g.M / 256) * (g.Cout / 128) * g.nphase >= 512 && patch_geo(g, 16, &pg)) return 256;
+    // 64-wide layers on 16 x 16 tiles with ONE wave column (gg_fwd_patch1_k, four waves of 64 x 64, three workgroups per
+    // CU): pays where the reduction is long -- decoders[6] forward (two 128-channel sources, ReLU on load) 170 -> 158 us;
+    // the input gradients of encoders[1] / D block 1 (128 channels deep) 91 -> 94 and 188 -> 189: left on the 8 x 16 tile.
+    // With two weight-tile buffers (two workgroups per CU) every one of them is 5-25 % slower.  tunable fwd_w1 (default 1)
+    if (!no_256 && c.bn == 64 && g.Cin >= 256 && pai_tunable("fwd_w1", 1) &&
+        (int64_t)(g.M / 256) * (g.Cout / 64) * g.nphase >= pai_tunable("fwd_w1_min", 768) && patch_geo(g, 16, &pg))
+        return 256;
     // (measured and dropped: a 16 x 16 tile for the 64-wide layers -- decoders[6], input gradients of encoders[1] /
     // D block 1, whose LDS fill rather than the matrix pipe is the bound, scripts/abl.sh -- ran 10-25 % SLOWER than
     // the 8 x 16 tile at 4-5 workgroups per CU: 185 vs 166 us on decoders[6] forward)
@@ -597,12 +604,17 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 // power cap (1385 W, 2.02 GHz): 0.36 of its 0.90 pJ per FLOP move operands, so only fewer operand
 // bytes per FLOP at every level can move this kernel -- wider wave tiles (gg_p2.hip, at the price of occupancy and an
 // exposed epilogue) and register-direct weights (gg_bd.hip, more L2 bytes for fewer LDS bytes) did not pay.
-template <int BM, int BN, bool DBB, bool M32>   // DBB: two weight-tile buffers
+// WN: waves side by side along the channels.  2: (BM / 64) x 2 waves of 64 pixels x BN / 2 channels.  1 (BN = 64 only):
+// BM / 64 waves of 64 pixels x 64 channels -- the 64-channel layers with the 64 x 64 wave tile of the 128-channel
+// kernels (8 fragment reads per 16 MFMAs instead of 6 per 8) and one weight tile per 256 pixels.
+template <int BM, int BN, bool DBB, bool M32, int WN = 2>   // DBB: two weight-tile buffers
 __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a, const PatchGeo& pg, int mtiles, int ntiles) {
-    static_assert(!M32 || BN == 128, "the 32x32x16 path covers 64-channel wave tiles");
+    static_assert(!M32 || (BN == 128 && WN == 2), "the 32x32x16 path covers 64-channel wave tiles");
+    static_assert(WN == 2 || BN == 64, "one wave column: 64 output channels");
     constexpr int abl = PATCH_ABL;
-    typedef PatchDims<BM> PD;
-    constexpr int NTHR = BM * 2, MT = 4, NT = BN / 32;
+    typedef PatchDims<BM, WN> PD;
+    constexpr int NTHR = BM * WN, MT = 4, NT = BN / (16 * WN);
+    constexpr int BNW = BN / WN;             // channels per wave column
     constexpr int RPP = PD::RPP, PJ = PD::PJ, PATCH_PIX = PD::PIX, PATCH_BYTES = PD::BYTES;
     constexpr int BJ = BN / RPP;             // weight tile fill instructions per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -610,7 +622,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = WN == 2 ? wid >> 1 : wid, wn = WN == 2 ? wid & 1 : 0;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bn = bid % ntiles;
     bid /= ntiles;
@@ -674,12 +686,12 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     unsigned wrow[BJ];                       // byte offset of this lane's chunk of weight row j (tap 0, channel 0)
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int lr = sr + RPP * j, half = lr / (BN / 2), rho = lr % (BN / 2);
+        const int lr = sr + RPP * j, half = lr / BNW, rho = lr % BNW;
         // M32: MFMA row m = rho % 32 of channel group rho / 32 produces accumulator register r of lane half h with
         // m = 8 (r >> 2) + 4 h + (r & 3); that row holds channel 16 h + r: 16 consecutive channels per lane again
         const int m32 = rho & 31;
-        const int ch = M32 ? half * (BN / 2) + (rho & 32) + 16 * ((m32 >> 2) & 1) + 4 * (m32 >> 3) + (m32 & 3)
-                           : half * (BN / 2) + (4 * NT) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+        const int ch = M32 ? half * BNW + (rho & 32) + 16 * ((m32 >> 2) & 1) + 4 * (m32 >> 3) + (m32 & 3)
+                           : half * BNW + (4 * NT) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
         wrow[j] = (unsigned)((n0 + ch) * g.wtaps * g.Cin + gchB) * 2u;
     }
 
@@ -688,7 +700,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     int pbase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) pbase[mt] = (wm * 4 + mt) * PATCH_W + fr;
-    const unsigned b_base = (unsigned)(PATCH_BYTES + (wn * (BN / 2) + fr) * 128);
+    const unsigned b_base = (unsigned)(PATCH_BYTES + (wn * BNW + fr) * 128);
     const int fswz = fr >> 1;
     // M32 fragments: lane (n = lane % 32, h = lane / 32) reads chunk 2 ks + h of pixel (row n / 16, column n % 16) of a
     // 32-pixel group and of weight row n of a 32-channel group.  chunk ^ swizzle = (2 ks ^ (s & 6)) | (h ^ (s & 1)):
@@ -700,7 +712,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         const unsigned px = (unsigned)((n32 & 15) + tx);
         pa32[tx] = ((unsigned)((wm * 4 + (n32 >> 4)) * PATCH_W) + px) * 128u + ((((unsigned)h32) ^ (px & 7u)) << 4);
     }
-    const unsigned wa32 = (unsigned)(PATCH_BYTES + (wn * (BN / 2) + n32) * 128) + ((((unsigned)h32) ^ ((unsigned)(n32 >> 1) & 7u)) << 4);
+    const unsigned wa32 = (unsigned)(PATCH_BYTES + (wn * BNW + n32) * 128) + ((((unsigned)h32) ^ ((unsigned)(n32 >> 1) & 7u)) << 4);
 
     typedef __attribute__((ext_vector_type(16))) float f16_t;
     f4_t acc[M32 ? 1 : MT][M32 ? 1 : NT];
@@ -878,12 +890,12 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     // lane (fq, fr) holds, for each of its 4 pixel rows mt*16 + fr, the 4 NT consecutive channels
     // wn*(BN/2) + 4 NT fq + (4 nt + r): bias, statistics, activation, then one or two 16-B LDS stores per row
     constexpr int CL = 4 * NT;               // channels per lane
-    const int col0 = wn * (BN / 2) + CL * fq;
+    const int col0 = wn * BNW + CL * fq;
     if constexpr (M32) {
         // lane (n32, h32): accumulator acc32[gq][j][r] = channel wn*64 + 32 j + 16 h32 + r of tile pixel wm*64 + 32 gq + n32
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int c0l = wn * (BN / 2) + 32 * j + 16 * h32;
+            const int c0l = wn * BNW + 32 * j + 16 * h32;
             float bv[16], cs[16], cq[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) { bv[c] = a.bias ? a.bias[n0 + c0l + c] : 0.f; cs[c] = cq[c] = 0.f; }
@@ -1033,6 +1045,11 @@ template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
     gg_fwd_patch_body<BM, BN, DBB, false>(g, a, pg, mtiles, ntiles);
 }
+// 64 output channels, one wave column: BM / 64 waves of 64 x 64 (see gg_fwd_patch_body, WN = 1)
+template <int BM, int BN, bool DBB>
+__global__ __launch_bounds__(BM, 3) void gg_fwd_patch1_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+    gg_fwd_patch_body<BM, BN, DBB, false, 1>(g, a, pg, mtiles, ntiles);
+}
 // the 32x32x16 form (two weight-tile buffers, 128-channel tiles)
 template <int BM, int BN>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void gg_fwd_patch32_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
@@ -1089,7 +1106,17 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         // second weight-tile buffer: pays on the 128-wide tiles (bit 0: 256-row, bit 1: 128-row), not on the
         // 64-wide ones (bit 2), whose 8 KB weight tile is cheap to wait for and which lose a workgroup per CU to it
         static const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
-        if (prow == 256 && patch_geo(g, 16, &pg)) {
+        if (prow == 256 && c.bn == 64 && patch_geo(g, 16, &pg)) {
+            typedef PatchDims<256, 1> PD;
+            const bool db = (dbb & 4) != 0;
+            const size_t lds = PD::BYTES + (size_t)64 * 128 * (db ? 2 : 1);
+            const size_t epi = 256 * ((size_t)64 * 2 + 16) + 4 * 2 * 64 * sizeof(float);
+            const size_t need = lds > epi ? lds : epi;
+            const int mt256 = g.M / 256;
+            const dim3 grid256(mt256 * ntiles * g.nphase);
+            if (db) hipLaunchKernelGGL((gg_fwd_patch1_k<256, 64, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
+            else hipLaunchKernelGGL((gg_fwd_patch1_k<256, 64, false>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
+        } else if (prow == 256 && patch_geo(g, 16, &pg)) {
             typedef PatchDims<256> PD;
             const bool db = (dbb & 1) != 0;
             const size_t lds = PD::BYTES + (size_t)128 * 128 * (db ? 2 : 1);
@@ -1154,6 +1181,7 @@ const char* fwd_mfma_kernel_name(const GG& g) {
                            : "gg_fwd_mfma_k<128, 64, true, false, 64>";
     const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
     const int prow = patch_rows(g, c);
+    if (prow == 256 && c.bn == 64) return (dbb & 4) ? "gg_fwd_patch1_k<256, 64, true>" : "gg_fwd_patch1_k<256, 64, false>";
     if (prow == 256 && pai_tunable("fwd_m32", 0)) return "gg_fwd_patch32_k<256, 128>";
     if (prow == 128 && c.bn == 128 && pai_tunable("fwd_m32", 0)) return "gg_fwd_patch32_k<128, 128>";
     if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";

@@ -132,10 +132,10 @@ constexpr int PATCH_W = 17;
 // BM = 128: 8 x 16 output pixels, 4 waves;  BM = 256: 16 x 16 output pixels, 8 waves (4 x 2) -- the weight
 // tile fill is then shared by twice the rows: 25 KB of fill and 128 KB of fragment reads per 2 x 512
 // MFMA cycles, the first configuration whose LDS time (916 cycles) is below its matrix time (1024).
-template <int BM> struct PatchDims {
+template <int BM, int WN = 2> struct PatchDims {            // WN: waves side by side along the channels (threads = BM x WN)
     static constexpr int TH = BM / 16;
     static constexpr int PIX = (TH + 1) * PATCH_W;
-    static constexpr int RPP = BM / 4;                       // pixels per block-wide fill instruction
+    static constexpr int RPP = BM * WN / 8;                  // pixels per block-wide fill instruction
     static constexpr int PJ = (PIX + RPP - 1) / RPP;
     static constexpr int BYTES = PJ * RPP * 128;
 };
