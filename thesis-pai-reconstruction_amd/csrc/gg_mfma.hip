@@ -571,7 +571,8 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
     // 64-wide layers on 16 x 16 tiles with ONE wave column (gg_fwd_patch1_k, four waves of 64 x 64, three workgroups per
     // CU): pays where the reduction is long -- decoders[6] forward (two 128-channel sources, ReLU on load) 170 -> 158 us;
     // the input gradients of encoders[1] / D block 1 (128 channels deep) 91 -> 94 and 188 -> 189: left on the 8 x 16 tile.
-    // With two weight-tile buffers (two workgroups per CU) every one of them is 5-25 % slower.  tunable fwd_w1 (default 1)
+    // With two weight-tile buffers (two workgroups per CU) every one of them is 5-25 % slower; two waves of 64 x 64 on the
+    // 8 x 16 tile (128-thread workgroups) run those input gradients 13-22 % slower.  tunable fwd_w1 (default 1)
     if (!no_256 && c.bn == 64 && g.Cin >= 256 && pai_tunable("fwd_w1", 1) &&
         (int64_t)(g.M / 256) * (g.Cout / 64) * g.nphase >= pai_tunable("fwd_w1_min", 768) && patch_geo(g, 16, &pg))
         return 256;
