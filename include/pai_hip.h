@@ -136,12 +136,14 @@ int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_le
  *   scratch    forward / input-gradient calls of the thin layers use its HEAD, weight-gradient calls its
  *              TAIL: calls within each class must be ordered, the two classes may run concurrently
  *              (the engine runs weight gradients on a second stream).
+ *   wgrad workspace  weight-gradient calls of the dense layers: ordered with respect to each other.
  * ------------------------------------------------------------------------- */
 int pai_create(int device_id, void** handle_out);
 int pai_bind(void* handle);
 int pai_destroy(void* handle);
 int pai_handle_set_workspace(void* handle, void* zeroed_device_memory, int64_t bytes);
 int pai_handle_set_scratch(void* handle, void* device_memory, int64_t bytes);
+int pai_handle_set_wgrad_workspace(void* handle, void* device_memory, int64_t bytes);
 
 /* Split-K workspace.  Layers whose GEMM has few output tiles but a long reduction (the U-Net
  * bottleneck: M <= 1024 rows, K up to 8192) are split over K; every split writes its fp32 partial
@@ -162,6 +164,14 @@ int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op);
  * Without it those layers fall back to the slower row-dot kernel / to fp32 atomics. */
 int pai_set_scratch(void* device_memory, int64_t bytes);
 int64_t pai_conv_scratch_bytes(const pai_conv_desc* d, int op);
+/* Weight-gradient workspace (dirty, fp32).  The dense k4 s2 weight gradients are split over the pixels so that the
+ * chip is full; every split stores its partial dW into its own slab of this buffer (plain stores) and a second kernel
+ * adds the slabs in split order -- deterministic, and without the ~1.3 TB/s memory-side float atomics that the splits
+ * otherwise meet through.  Register at least max(pai_conv_wgrad_workspace_bytes(desc)) over the layers; a call that
+ * would need more than is registered falls back to atomics.  Stream contract: weight-gradient calls that use it must
+ * be ordered with respect to each other (the engine issues them on one side stream). */
+int pai_set_wgrad_workspace(void* device_memory, int64_t bytes);
+int64_t pai_conv_wgrad_workspace_bytes(const pai_conv_desc* d);
 
 /* y = conv(act(x1|x2), w) + bias.
  *   w_fwd   : fwd pack, storage dtype

@@ -19,6 +19,8 @@ Layouts covered (file: the function the formula is taken from):
   wg_dy       gg_mfma.hip gg_wgrad_patch_k   dY rows of 256 B read transposed, chunk ch at slot ch ^ tr_swz(row)
   wg_x        gg_mfma.hip gg_wgrad_patch_k   X patch pixels of 64 B read transposed, halves swapped on bit 3 of p
   wg2_x       gg_wg2.hip  gg_wgrad_patch2_k  X patch pixels of 128 B read transposed, 32-B segment ^ xseg_swz(p)
+  wg3_dy      gg_wg3.hip  gg_wgrad_patch3_k  dY rows of 256 B / 128 B read transposed (128- / 64-channel tiles)
+  wg3_x       gg_wg3.hip  gg_wgrad_patch3_k  X patch pixels of 128 B / 256 B read transposed, 32-B segment ^ f(p)
 """
 import itertools
 import sys
@@ -146,11 +148,47 @@ def wg2_x():
     return worst
 
 
+def wg3_dy():
+    """gg_wg3.hip: dY rows of 256 B (BMC = 128, all 8 channel tiles in one wave) and of 128 B (BMC = 64)."""
+    def yswz(bmc, row):
+        return tr_swz(row) if bmc == 128 else ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)
+    worst = 1
+    for bmc in (128, 64):
+        yrow = 2 * bmc
+        for h, mt, kk, st in itertools.product(range(2), range(bmc // 16), range(2), range(2)):
+            def addr(lane):
+                fi, fg = lane & 15, lane >> 4
+                tq, tp = fi >> 2, fi & 3
+                rowl = fg * 8 + tq + 4 * h
+                base = yrow * rowl + 16 * ((tp >> 1) ^ yswz(bmc, rowl)) + 8 * (tp & 1)
+                return (base ^ (mt << 5)) + st * 32768 + kk * 32 * yrow
+            worst = max(worst, ways(addr, HALF_GROUPS, 8))
+    return worst
+
+
+def wg3_x():
+    """gg_wg3.hip: X patch pixels of 128 B (CI = 64) and 256 B (CI = 128), 32-B segment s stored at s ^ f(p)."""
+    def f(ci, p):
+        return (((p >> 1) & 1) | (((p >> 3) & 1) << 1)) if ci == 64 else ((p & 3) | (((p >> 3) & 1) << 2))
+    worst = 1
+    for ci in (64, 128):
+        xpb = 2 * ci
+        for kk, h, toff, nt in itertools.product(range(2), range(2), (0, 1, PATCH_W, PATCH_W + 1), range(ci // 16)):
+            def addr(lane):
+                fi, fg = lane & 15, lane >> 4
+                tq, tp = fi >> 2, fi & 3
+                r = kk * 32 + fg * 8 + tq + 4 * h
+                p = (r >> 4) * PATCH_W + (r & 15) + toff
+                return (p * xpb + (f(ci, p) << 5) + tp * 8) ^ (nt << 5)
+            worst = max(worst, ways(addr, HALF_GROUPS, 8))
+    return worst
+
+
 def main():
     bad = 0
     for name, fn in (("fwd_patch", fwd_patch), ("fwd_weight", fwd_weight), ("fwd_patch32", fwd_patch32),
                      ("fwd_weight32", fwd_weight32), ("p2_patch", p2_patch), ("wg_dy", wg_dy),
-                     ("wg_x", wg_x), ("wg2_x", wg2_x)):
+                     ("wg_x", wg_x), ("wg2_x", wg2_x), ("wg3_dy", wg3_dy), ("wg3_x", wg3_x)):
         w = fn()
         print(f"{name:11s} worst {w}-way" + ("" if w == 1 else "   <-- conflicts"))
         bad += w != 1

@@ -7,7 +7,7 @@
 //
 // build: hipcc -O2 --offload-arch=gfx950 scripts/micro/convbench.hip -Iinclude -Lthesis-pai-reconstruction_amd
 //              -lpai_hip -Wl,-rpath,'$ORIGIN/../../thesis-pai-reconstruction_amd' -o scripts/micro/convbench
-// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--frag] [--set name=v,name=v ;...]
+// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--frag] [--bias] [--set name=v,name=v ;...]
 //        every --set adds one setting (comma-separated tunables); default: the library defaults only.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -94,7 +94,7 @@ static std::vector<float> read3(float* d) {
 int main(int argc, char** argv) {
     const char* filter = "";
     const char* ops = "fdw";
-    int iters = 10, rounds = 3, batch = 64, frag = 0;
+    int iters = 10, rounds = 3, batch = 64, frag = 0, bias = 0;
     std::vector<Setting> settings;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--filter") && i + 1 < argc) filter = argv[++i];
@@ -102,6 +102,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--bias")) bias = 1;   // weight gradients also produce (and compare) the bias gradient
         else if (!strcmp(argv[i], "--frag")) frag = 1;   // packs followed by their fragment-major copy (pack_flags = 3)
         else if (!strcmp(argv[i], "--set") && i + 1 < argc) {
             Setting s;
@@ -132,6 +133,10 @@ int main(int argc, char** argv) {
     HCHECK(hipMalloc(&scratch, sc_bytes));
     PCHECK(pai_set_workspace(ws, ws_bytes));
     PCHECK(pai_set_scratch(scratch, sc_bytes));
+    void* wslab = nullptr;
+    const int64_t wslab_bytes = 256ll << 20;    // weight-gradient slabs: 512 workgroup tiles of 128 KB = 64 MB per launch
+    HCHECK(hipMalloc(&wslab, wslab_bytes));
+    PCHECK(pai_set_wgrad_workspace(wslab, wslab_bytes));
     float* dstat;
     HCHECK(hipMalloc(&dstat, 12));
     hipStream_t st;
@@ -154,7 +159,7 @@ int main(int argc, char** argv) {
         const size_t nx1 = (size_t)n * L.H * L.H * L.C1, nx2 = (size_t)n * L.H * L.H * L.C2, ny = (size_t)n * OH * OW * L.Cout;
         const size_t nw = (size_t)L.Cout * 16 * Cin;
         unsigned short *x1, *x2 = nullptr, *wf, *wd, *dy, *y[2], *dx1[2], *dx2[2] = {nullptr, nullptr};
-        float *dw[2], *stats;
+        float *dw[2], *db[2], *stats;
         HCHECK(hipMalloc(&x1, nx1 * 2));
         if (nx2) HCHECK(hipMalloc(&x2, nx2 * 2));
         HCHECK(hipMalloc(&wf, nw * 4)); HCHECK(hipMalloc(&wd, nw * 4)); HCHECK(hipMalloc(&dy, ny * 2));
@@ -164,6 +169,7 @@ int main(int argc, char** argv) {
             HCHECK(hipMalloc(&y[k], ny * 2)); HCHECK(hipMalloc(&dx1[k], nx1 * 2));
             if (nx2) HCHECK(hipMalloc(&dx2[k], nx2 * 2));
             HCHECK(hipMalloc(&dw[k], nw * 4));
+            HCHECK(hipMalloc(&db[k], (size_t)L.Cout * 4));
         }
         const int srows = pai_bn_stats_buffer_rows(pai_conv_fwd_stats_rows_max(&d));
         HCHECK(hipMalloc(&stats, (size_t)srows * 2 * L.Cout * 4));
@@ -187,7 +193,8 @@ int main(int argc, char** argv) {
             else if (op == 'd') PCHECK(pai_conv_dgrad(&d, dy, wd, dx1[k], dx2[k], 0, st));
             else {
                 HCHECK(hipMemsetAsync(dw[k], 0, nw * 4, st));
-                PCHECK(pai_conv_wgrad(&d, x1, x2, dy, dw[k], nullptr, st));
+                HCHECK(hipMemsetAsync(db[k], 0, (size_t)L.Cout * 4, st));
+                PCHECK(pai_conv_wgrad(&d, x1, x2, dy, dw[k], bias ? db[k] : nullptr, st));
             }
         };
         auto compare = [&](char op, const char* what, bool exact, const char* label) {
@@ -196,7 +203,10 @@ int main(int argc, char** argv) {
             else if (op == 'd') {
                 diff_bf16<<<1024, 256, 0, st>>>(dx1[0], dx1[1], nx1, dstat);
                 if (nx2) diff_bf16<<<1024, 256, 0, st>>>(dx2[0], dx2[1], nx2, dstat);
-            } else diff_f32<<<1024, 256, 0, st>>>(dw[0], dw[1], nw, dstat);
+            } else {
+                diff_f32<<<1024, 256, 0, st>>>(dw[0], dw[1], nw, dstat);
+                if (bias) diff_f32<<<64, 256, 0, st>>>(db[0], db[1], (size_t)L.Cout, dstat);
+            }
             HCHECK(hipStreamSynchronize(st));
             const auto r = read3(dstat);
             const bool ok = exact ? (r[2] == 0.f) : (r[1] <= 0.02f * r[0] + 1e-6f);
@@ -230,7 +240,7 @@ int main(int argc, char** argv) {
                     run(op, 0);   // warm
                     HCHECK(hipEventRecord(e0, st));
                     for (int it = 0; it < iters; ++it) {
-                        if (op == 'w') PCHECK(pai_conv_wgrad(&d, x1, x2, dy, dw[0], nullptr, st));
+                        if (op == 'w') PCHECK(pai_conv_wgrad(&d, x1, x2, dy, dw[0], bias ? db[0] : nullptr, st));
                         else run(op, 0);
                     }
                     HCHECK(hipEventRecord(e1, st));
@@ -252,7 +262,7 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
         (void)hipFree(x1); if (x2) (void)hipFree(x2); (void)hipFree(wf); (void)hipFree(wd); (void)hipFree(dy); (void)hipFree(stats);
-        for (int k = 0; k < 2; ++k) { (void)hipFree(y[k]); (void)hipFree(dx1[k]); if (dx2[k]) (void)hipFree(dx2[k]); (void)hipFree(dw[k]); }
+        for (int k = 0; k < 2; ++k) { (void)hipFree(y[k]); (void)hipFree(dx1[k]); if (dx2[k]) (void)hipFree(dx2[k]); (void)hipFree(dw[k]); (void)hipFree(db[k]); }
     }
     for (int s = 0; s < NS; ++s)
         printf("total [%s]: fwd %.1f us, dgrad %.1f us, wgrad %.1f us\n", settings[s].label.c_str(), total[s * 3], total[s * 3 + 1], total[s * 3 + 2]);

@@ -105,6 +105,7 @@ class AttentionUnetEngine(UnetEngine):
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["dec_desc"] + P["gate_desc"][1:]
                                  for op in (0, 1)), device)
         ops.ensure_scratch(ops.scratch_bytes_for(P["enc_desc"] + P["dec_desc"]), device)
+        ops.ensure_wgrad_workspace(P["enc_desc"] + P["dec_desc"], device)
         return P
 
     def _new_slot(self, P):

@@ -14,7 +14,7 @@ void pai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pai_last_error(void) { return g_err; }
-extern "C" int pai_version(void) { return 110; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi
+extern "C" int pai_version(void) { return 120; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace
 
 extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -268,7 +268,7 @@ static void finish_gg(GG* g) {
 // below only maps device -> active handle.  Threading contract: one host thread drives a device at a time.
 constexpr int PAI_MAX_DEVICES = 64;
 static pai_handle_s* g_active[PAI_MAX_DEVICES];
-static const pai_handle_s g_empty_handle = {-1, nullptr, 0, nullptr, 0};
+static const pai_handle_s g_empty_handle = {-1, nullptr, 0, nullptr, 0, nullptr, 0};
 
 static int current_device() {
     int dev = 0;
@@ -283,7 +283,7 @@ const pai_handle_s* pai_ctx() {
 extern "C" int pai_create(int device_id, void** handle_out) {
     PAI_CHECK(handle_out != nullptr, "pai_create: null handle_out");
     PAI_CHECK(device_id >= 0 && device_id < PAI_MAX_DEVICES, "pai_create: device id %d out of range", device_id);
-    pai_handle_s* h = new pai_handle_s{device_id, nullptr, 0, nullptr, 0};
+    pai_handle_s* h = new pai_handle_s{device_id, nullptr, 0, nullptr, 0, nullptr, 0};
     if (!g_active[device_id]) g_active[device_id] = h;      // the first handle of a device is active at once
     *handle_out = h;
     return 0;
@@ -320,12 +320,25 @@ extern "C" int pai_handle_set_scratch(void* handle, void* device_memory, int64_t
     return 0;
 }
 
+extern "C" int pai_handle_set_wgrad_workspace(void* handle, void* device_memory, int64_t bytes) {
+    PAI_CHECK(handle != nullptr, "pai_handle_set_wgrad_workspace: null handle");
+    pai_handle_s* h = (pai_handle_s*)handle;
+    h->wslab = (float*)device_memory;
+    h->wslab_bytes = device_memory ? bytes : 0;
+    return 0;
+}
+
+float* wgrad_slab_acquire(int64_t bytes) {
+    const pai_handle_s* h = pai_ctx();
+    return (h->wslab && h->wslab_bytes >= bytes) ? h->wslab : nullptr;
+}
+
 // The active handle of the current device, created on first use: convenience for single-model callers
 // (pai_set_workspace / pai_set_scratch without an explicit pai_create).
 static pai_handle_s* active_or_new() {
     const int dev = current_device();
     if (dev < 0) return nullptr;
-    if (!g_active[dev]) g_active[dev] = new pai_handle_s{dev, nullptr, 0, nullptr, 0};
+    if (!g_active[dev]) g_active[dev] = new pai_handle_s{dev, nullptr, 0, nullptr, 0, nullptr, 0};
     return g_active[dev];
 }
 
@@ -339,6 +352,19 @@ extern "C" int pai_set_scratch(void* device_memory, int64_t bytes) {
     pai_handle_s* h = active_or_new();
     PAI_CHECK(h != nullptr, "pai_set_scratch: no current HIP device");
     return pai_handle_set_scratch(h, device_memory, bytes);
+}
+
+extern "C" int pai_set_wgrad_workspace(void* device_memory, int64_t bytes) {
+    pai_handle_s* h = active_or_new();
+    PAI_CHECK(h != nullptr, "pai_set_wgrad_workspace: no current HIP device");
+    return pai_handle_set_wgrad_workspace(h, device_memory, bytes);
+}
+
+extern "C" int64_t pai_conv_wgrad_workspace_bytes(const pai_conv_desc* d) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return -1;
+    if (!wgrad_mfma_ok(d->dtype, g)) return 0;
+    return wgrad3_slab_bytes(g);
 }
 
 extern "C" int64_t pai_conv_workspace_bytes(const pai_conv_desc* d, int op) {
@@ -579,7 +605,7 @@ static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x
     PAI_CHECK(x1 && dy && dw, "pai_conv_wgrad: null pointer");
     PAI_CHECK(d->C2 == 0 || x2, "pai_conv_wgrad: C2 > 0 but x2 is null");
     WgradArgs a;
-    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0;
+    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0; a.slab = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (overwrite) {
         const bool thin = thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) ||

@@ -184,6 +184,8 @@ struct pai_handle_s {
     int64_t workspace_bytes;
     float* scratch;            // thin layers: skinny-GEMM output (head of the buffer), weight-gradient partial tiles (tail)
     int64_t scratch_bytes;
+    float* wslab;              // weight gradients split over the pixels: one fp32 dW slab per split (gg_wg3.hip)
+    int64_t wslab_bytes;
 };
 // active handle of the calling thread's current HIP device; never null (a device without a handle has an empty one:
 // no workspace, no scratch -> un-split / fallback kernels)
@@ -218,7 +220,17 @@ struct WgradArgs {
     float* dw;
     float* dbias;
     int overwrite;   // dw = / dbias = instead of +=; honoured by gg_wgrad_mfma_k when wgrad_mfma_can_overwrite(g)
+    float* slab;     // set by the launcher: pixel split `s` stores its tile into slab + s * |dW| (plain stores, no atomics)
 };
+// the handle's weight-gradient workspace if it holds `bytes`, else NULL (the launch then adds with fp32 atomics)
+float* wgrad_slab_acquire(int64_t bytes);
+int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, int overwrite, hipStream_t s);
+// patch-resident weight gradient with 128 x 64 / 64 x 128 wave tiles (gg_wg3.hip)
+bool wgrad3_ok(const GG& g);
+int launch_wgrad3(const GG& g, const WgradArgs& a, hipStream_t s);
+const char* wgrad3_kernel_name(const GG& g);
+int64_t wgrad3_slab_bytes(const GG& g);
+bool wgrad3_overwrites(const GG& g);
 // un-split, single-phase launch of gg_wgrad_mfma_k: every dW element has exactly one writer
 bool wgrad_mfma_can_overwrite(const GG& g);
 int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);

@@ -1837,6 +1837,7 @@ static bool wgrad_mfma_uses_patch(const GG& g) {
 bool wgrad_mfma_can_overwrite(const GG& g) {
     int rows;
     if (wgrad2_ok(g)) return false;
+    if (wgrad3_ok(g)) return wgrad3_overwrites(g);
     return g.nphase == 1 && !wgrad_mfma_uses_patch(g) && wgrad_mfma_splits(g, &rows) == 1;
 }
 
@@ -1876,6 +1877,7 @@ static int wgrad_mfma_splits(const GG& g, int* rows_out) {
 
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     if (wgrad2_ok(g)) return launch_wgrad2(g, a, s);
+    if (wgrad3_ok(g)) return launch_wgrad3(g, a, s);
     const bool big = (g.Cout % 128) == 0;
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
     const int jtiles = cdiv(g.ntaps * g.Cin, 128);
@@ -1909,6 +1911,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
 
 const char* wgrad_mfma_kernel_name(const GG& g) {
     if (wgrad2_ok(g)) return "gg_wgrad_patch2_k<128>";
+    if (wgrad3_ok(g)) return wgrad3_kernel_name(g);
     const bool big = (g.Cout % 128) == 0;
     const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;

@@ -1,0 +1,445 @@
+// Patch-resident weight gradient with 128 x 64 WAVE tiles ("wgrad3"):
+//   dW[co][tap][ci] = sum_pixels dY[pix][co] * X[pix + tap][ci]
+//
+// What bounds gg_wgrad_patch_k (gg_mfma.hip) is the LDS port, not the matrix pipe and not the fill volume (round 2:
+// fills alone and MFMAs alone take ~110 us each on decoders[4] and do not overlap; gg_wg2.hip halved the fill per FLOP
+// with the SAME 64 x 64 wave tile and was not faster): per 64-pixel step its four 64 x 64 waves read 64 KB of
+// transposed fragments and receive 21 KB of LDS-DMA for 512 matrix cycles per SIMD = 166 B per cycle of a port that
+// peaks at 256.  The lever is LDS bytes per FLOP, and only the WAVE tile changes the fragment share of it.
+// Here a workgroup is four waves side by side along the columns; wave t owns tap t of the 2 x 2 window x CI input
+// channels and ALL BMC output channels of the tile:
+//   BMC = 128, CI = 64:  wave tile 128 x 64 (8 + 4 fragments per 32 MFMAs instead of 4 + 4 per 16), workgroup tile
+//                        128 x 256.  Per 64-pixel step: 96 KB of fragment reads + 27 KB of fills for 1024 matrix
+//                        cycles per SIMD = 120 B per cycle (-28 %).
+//   BMC = 64, CI = 128:  wave tile 64 x 128 (4 + 8 fragments per 32 MFMAs), workgroup tile 64 x 512: the layers with 64
+//                        output channels (decoders[6]) read dY once per 128 input channels instead of once per 32 --
+//                        gg_wgrad_patch_k<64> moved 820 MB of HBM traffic for 268 MB of operands there.
+// 128 accumulator registers per lane, two workgroups per CU, two LDS stages (the tiles of step k + 1 are in flight
+// while step k is multiplied, one barrier per step), LDS-DMA through buffer descriptors as in gg_wgrad_patch_k.
+//
+// Pixel splits no longer ADD their partial tiles with fp32 atomics (the memory-side atomic rate is ~1.3 TB/s and one
+// round of workgroups flushes 32-64 MB at the same moment: 19 % of gg_wgrad_patch_k): every split stores its tile into
+// its own slab of the handle's weight-gradient workspace with plain stores and wgrad_slab_sum_k adds the slabs in
+// split order (deterministic) into dW.
+//
+// Serves the weight-gradient half of aten::convolution_backward of the dense Conv2d / ConvTranspose2d k4 s2 p1 layers
+// (reference models/pix2pix.py:58-111, models/wrapper.py:229-232).
+#include <type_traits>
+
+#include "gg_tile.h"
+
+__device__ __forceinline__ int tr_swz3(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ unsigned tr_off3(int row, int ch) { return (unsigned)(256 * row + 16 * (ch ^ tr_swz3(row))); }
+// X patch image: pixel p = py * 17 + px at byte XPB * p (XPB = 2 CI bytes); its 32-B segments (16 channels) are stored
+// at segment s ^ f(p), f(p) = bit 1 of p | bit 3 of p << 1 (gg_wg2.hip): the eight pixel rows a half-wave of a
+// ds_read_b64_tr_b16 touches (p0 .. p0+3 and p0+8 .. p0+11, any p0) then cover the 64 banks once, for 128-B and for
+// 256-B pixels alike (scripts/lds_swizzle_check.py wg3_x)
+//   128-B pixels (CI = 64):  4 segments, bank half = bit 0 of p, f(p) = bit 1 | bit 3 << 1
+//   256-B pixels (CI = 128): 8 segments,                        f(p) = bit 0 | bit 1 << 1 | bit 3 << 2
+template <int CI> __device__ __forceinline__ unsigned xseg_swz3(unsigned p) {
+    return CI == 64 ? (((p >> 1) & 1u) | (((p >> 3) & 1u) << 1)) : ((p & 3u) | (((p >> 3) & 1u) << 2));
+}
+// dY tile image: K row r (64 per step) x BMC channels, 16-B chunk c of the row stored at slot c ^ yswz(r).  The 16 rows
+// a ds_read_b64_tr_b16 touches per 32-lane half ({0-3, 8-11} + 4 h of a 32-row half step, 32 B each) must cover the
+// 64 banks once:
+//   256-B rows (BMC = 128): the guide's T10 layout (b), as gg_wgrad_mfma_k
+//   128-B rows (BMC = 64):  bank half = bit 0 of r, 32-B segment ^ (bit 1 | bit 3 << 1)
+template <int BMC> __device__ __forceinline__ int yswz3(int row) {
+    return BMC == 128 ? tr_swz3(row) : ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
+}
+
+#ifndef WG3_ABL
+#define WG3_ABL 0     // timing ablations (results WRONG): 1 no dW store, 2 no MFMA, 4 no fills, 8 no fragment reads
+#endif
+
+template <int BMC, int CI>
+__global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
+                                                            int splits, int blocks_per_split) {
+    static_assert((BMC == 128 && CI == 64) || (BMC == 64 && CI == 128), "wave tile 128 x 64 or 64 x 128");
+    constexpr int MT = BMC / 16;                 // 16-row MFMA tiles along the output channels
+    constexpr int NT = CI / 16;                  // 16-column MFMA tiles along the input channels
+    constexpr int YROW = BMC * 2;                // bytes per pixel row of the dY tile (256 or 128)
+    constexpr int YBUF = 64 * YROW;
+    constexpr int XPB = CI * 2;                  // bytes per patch pixel
+    constexpr int XSLOTS = 96;                   // pixel slots filled (85 used)
+    constexpr int XBUF = XSLOTS * XPB;
+    constexpr int STAGE = YBUF + XBUF;
+    constexpr int YJ = YBUF / 4096;              // dY fill instructions per thread (256 threads x 16 B each)
+    constexpr int XJ = XBUF / 4096;              // X fill instructions per thread
+    constexpr int XCH = XPB / 16;                // 16-B chunks per patch pixel
+    constexpr int XPPI = 256 / XCH;              // patch pixels per block-wide fill instruction
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = tap of the window
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = bid % jtiles; bid /= jtiles;
+    const int cot = bid % cotiles; bid /= cotiles;
+    const int split = bid % splits;
+    const int ph = bid / splits;
+    const int co0 = cot * BMC;
+    const int q = jt & (pg.groups - 1);
+    const int ci0 = (jt >> (pg.groups == 4 ? 2 : 0)) * CI;
+
+    // CI-channel column tiles never straddle the two sources (host: C1 % CI == 0)
+    const bool second = ci0 >= g.C1;
+    const bf16_t* xsrc = second ? (const bf16_t*)a.x2 : (const bf16_t*)a.x1;
+    const int xcs = second ? g.C2 : g.C1;
+    const int xrelu = second ? g.relu2 : g.relu1;
+    constexpr unsigned OOB = 0x80000000u;        // beyond every buffer: the LDS-DMA writes zeros
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.dy), 0, (unsigned)((g.N << (g.ldh + g.ldw)) * g.Cout) * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>((const void*)xsrc), 0, (unsigned)(g.N * g.H * g.W * xcs) * 2u, 0x00020000);
+
+    const int los = g.OS == 2 ? 1 : 0;
+    const int poy = g.poy[ph], pox = g.pox[ph];
+    // dY tile fill map: K row r of the step = pixel (gy0 + (r >> 4), gx0 + (r & 15)) of its 4 x 16 block.
+    //   BMC = 128: 256-B rows, 16 chunks; thread -> (row 16 j + tid / 16, slot tid % 16), slot holds chunk slot ^ swz(row)
+    //   BMC = 64:  128-B rows,  8 chunks; thread -> (row 32 j + tid / 8,  slot tid % 8)
+    constexpr int YCH = YROW / 16, YRPI = 256 / YCH;   // chunks per row, rows per block-wide fill instruction
+    const int ysr = tid / YCH, ysc = tid % YCH;
+    const int ygch = ysc ^ yswz3<BMC>(ysr);      // the swizzle only looks at row bits 0-3: the same for every j
+    const unsigned ythr = (unsigned)(((((ysr >> 4) << los) << g.ldw) + ((ysr & 15) << los)) * g.Cout + co0 + ygch * 8) * 2u;
+    const unsigned yjstep = (unsigned)(((((YRPI >> 4) << los) << g.ldw)) * g.Cout) * 2u;   // YRPI rows = YRPI / 16 pixel rows further
+    // X patch fill map: thread -> (pixel XPPI jj + tid / XCH, 16-B chunk tid % XCH)
+    const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
+    int xty[XJ], xtx[XJ];
+    unsigned xthr[XJ];
+#pragma unroll
+    for (int jj = 0; jj < XJ; ++jj) {
+        const int p = jj * XPPI + tid / XCH;
+        const int py_ = p / PATCH_W, px_ = p - py_ * PATCH_W;
+        xty[jj] = p >= 5 * PATCH_W ? 0x40000000 : py_ * g.S + wby;      // beyond the patch: a row no image has
+        xtx[jj] = px_ * g.S + wbx;
+        const int c = tid % XCH;                 // physical chunk: segment c >> 1 holds source segment (c >> 1) ^ f(p)
+        const int xch = (second ? ci0 - g.C1 : ci0) + (((((c >> 1) ^ (int)xseg_swz3<CI>((unsigned)p)) << 1) | (c & 1)) * 8);
+        xthr[jj] = (unsigned)(((py_ * g.S + wby) * g.W + px_ * g.S + wbx) * xcs + xch) * 2u;
+    }
+
+    const int lbx = g.lw - 4, lby = g.lh - 2;
+    const int kb0 = split * blocks_per_split;
+    const int kb1 = min(g.M >> 6, kb0 + blocks_per_split);
+
+    const int fi = lane & 15, fg = lane >> 4;
+    const int tq = fi >> 2, tp = fi & 3;
+    // fragment addresses (integer LDS addresses: the dynamic LDS block starts at 0, checked below)
+    //   dY: K row rl = fg * 8 + tq (+ 4 h) of a 32-row half step, channel tile mt: chunk (2 mt + (tp >> 1)) ^ swz(rl), the tile
+    //       index is an XOR of address bits 5.. (the swizzle only touches the chunk bits)
+    //   X:  patch pixel of K row r + tap shift, segment nt ^ f(p): the tile index is an XOR of address bits 5..
+    const unsigned toff = (pg.toff4[ph][q] >> (8 * wid)) & 0xffu;
+    unsigned ybase[2], xbase[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rowl = fg * 8 + tq + 4 * h;
+        ybase[h] = (unsigned)(YROW * rowl + 16 * ((tp >> 1) ^ yswz3<BMC>(rowl)) + 8 * (tp & 1));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int r = kk * 32 + fg * 8 + tq + 4 * h;
+            const unsigned p = (unsigned)((r >> 4) * PATCH_W + (r & 15)) + toff;
+            xbase[kk][h] = (unsigned)YBUF + p * XPB + (xseg_swz3<CI>(p) << 5) + tp * 8;
+        }
+    }
+#define WG3_XOR(dst, src, imm) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(dst) : "v"(src), "s"(imm))
+#define WG3_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(size_t)(unsigned)(addr))
+#define WG3_BLDS16(rs, voff, soff, laddr) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + (laddr)), 16, (int)(voff), (int)(soff), 0, 0)
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
+
+    f4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    // Bias gradient = column sums of dY.  Every wave holds the dY fragments of its tile anyway: wave w adds up the
+    // fragments of channel tiles w * MT/4 .. of the steps with kb % jtiles == jt, so the jtiles workgroups that read the
+    // same dY share the work (a few vector instructions per step each) and no workgroup is slower than the others.
+    constexpr int BT = MT / 4;
+    const bool do_bias = a.dbias != nullptr;
+    float bsum[BT];
+#pragma unroll
+    for (int i = 0; i < BT; ++i) bsum[i] = 0.f;
+
+    unsigned ysof = 0, xofs[XJ];
+    auto prepare = [&](int kb) {
+        const int gx0 = (kb & ((1 << lbx) - 1)) << 4;
+        const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << 2;
+        const int n = kb >> (lbx + lby);
+        ysof = (unsigned)(((((n << g.ldh) + (gy0 << los) + poy) << g.ldw) + (gx0 << los) + pox) * g.Cout) * 2u;
+        const int oy = gy0 * g.S, ox = gx0 * g.S;
+        const unsigned xsof = (unsigned)(((((n << g.lsh) + oy) << g.lsw) + ox) * xcs) * 2u;
+#pragma unroll
+        for (int jj = 0; jj < XJ; ++jj) {
+            const bool inb = (unsigned)(xty[jj] + oy) < (unsigned)g.H && (unsigned)(xtx[jj] + ox) < (unsigned)g.W;
+            xofs[jj] = inb ? xthr[jj] + xsof : OOB;
+        }
+    };
+    auto fire = [&](int st) {
+        if (WG3_ABL & 4) return;
+#pragma unroll
+        for (int j = 0; j < YJ; ++j) WG3_BLDS16(yrs, ythr, ysof + (unsigned)j * yjstep, st * STAGE + (YRPI * j + wid * (YRPI / 4)) * YROW);
+#pragma unroll
+        for (int jj = 0; jj < XJ; ++jj) WG3_BLDS16(xrs, xofs[jj], 0, st * STAGE + YBUF + (jj * XPPI + wid * (XPPI / 4)) * XPB);
+    };
+    if (kb0 < kb1) {
+        prepare(kb0);
+        fire(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // The K loop is scheduled by hand.  hipcc puts an s_waitcnt vmcnt(0) in front of the first LDS read it can see behind
+    // an LDS-DMA (the DMA is a pending LDS write as far as it knows, and it cannot tell the two stages apart): with the
+    // fragment reads as compiler-visible loads the "two stages" of gg_wg2.hip were fire -> wait -> multiply, i.e. no
+    // overlap at all.  Here the fragment reads and the MFMAs are inline asm, the waits are explicit:
+    //   step(ST):  reads of k-half 0 -> set 0;  fire the NEXT step's tiles into the other stage;  lgkmcnt(0);
+    //              32 MFMAs on set 0 with the reads of k-half 1 -> set 1 between them;  lgkmcnt(0);  32 MFMAs on set 1;
+    //              vmcnt(0) (the next tiles have had a whole step to land);  barrier.
+    // (asm volatile statements keep their order; a sched_barrier behind every wait keeps compiler-scheduled code -- the
+    //  ReLU of the fragments, the bias sums -- from moving above it, guide rule 18.)
+    typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+#define WG3_RD(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+    auto step = [&](auto st_tag, int kb) {
+        constexpr int ST = decltype(st_tag)::value;
+        constexpr unsigned SB = (unsigned)(ST * STAGE);
+        bf8_t fa[2][MT], fb[2][NT];
+        // fragment `i` of k-half KK: i < NT: X tile i, else dY tile i - NT (X first: every MFMA row needs all of them)
+        auto read_frag = [&](auto kk_tag, int i) {
+            constexpr int KK = decltype(kk_tag)::value;
+            u2_t lo, hi;
+            if (i < NT) {
+                unsigned o0 = xbase[KK][0], o1 = xbase[KK][1];
+                if (i) { WG3_XOR(o0, xbase[KK][0], i << 5); WG3_XOR(o1, xbase[KK][1], i << 5); }
+                WG3_RD(lo, o0, SB);
+                WG3_RD(hi, o1, SB);
+                fb[KK][i] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            } else {
+                const int mt = i - NT;
+                unsigned a0 = ybase[0], a1 = ybase[1];
+                if (mt) { WG3_XOR(a0, ybase[0], mt << 5); WG3_XOR(a1, ybase[1], mt << 5); }
+                WG3_RD(lo, a0, SB + KK * (32 * YROW));
+                WG3_RD(hi, a1, SB + KK * (32 * YROW));
+                fa[KK][mt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+        };
+        typedef std::integral_constant<int, 0> K0;
+        typedef std::integral_constant<int, 1> K1;
+        if (!(WG3_ABL & 8)) {
+#pragma unroll
+            for (int i = 0; i < NT + MT; ++i) read_frag(K0{}, i);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) fa[kk][mt] = __builtin_bit_cast(bf8_t, make_uint4(ybase[0], SB, mt, kk));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[kk][nt] = __builtin_bit_cast(bf8_t, make_uint4(xbase[kk][0], SB, nt, kk));
+            }
+        }
+        if (kb + 1 < kb1) {
+            prepare(kb + 1);
+            fire(ST ^ 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const bool bias_step = do_bias && (kb % jtiles) == jt;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (xrelu) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[kk][nt] = relu_frag(fb[kk][nt]);
+            }
+            if (bias_step) {
+#pragma unroll
+                for (int i = 0; i < BT; ++i) {
+                    const uint4 v = BT == 2 ? (wid == 0 ? __builtin_bit_cast(uint4, fa[kk][0 + i]) : wid == 1 ? __builtin_bit_cast(uint4, fa[kk][2 + i])
+                                               : wid == 2 ? __builtin_bit_cast(uint4, fa[kk][4 + i]) : __builtin_bit_cast(uint4, fa[kk][6 + i]))
+                                            : (wid == 0 ? __builtin_bit_cast(uint4, fa[kk][0]) : wid == 1 ? __builtin_bit_cast(uint4, fa[kk][1])
+                                               : wid == 2 ? __builtin_bit_cast(uint4, fa[kk][2]) : __builtin_bit_cast(uint4, fa[kk][3]));
+                    const unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(d[e] << 16) + __uint_as_float(d[e] & 0xffff0000u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (WG3_ABL & 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][0][0] += (float)fa[kk][mt][0] + (float)fb[kk][mt % NT][0];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(fa[kk][mt]), "v"(fb[kk][nt]));
+                        // the other k-half's fragments, one between two MFMAs (its X tiles first)
+                        if (kk == 0 && !(WG3_ABL & 8) && (mt * NT + nt) < NT + MT) read_frag(K1{}, mt * NT + nt);
+                    }
+            }
+            if (kk == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    typedef std::integral_constant<int, 0> St0;
+    typedef std::integral_constant<int, 1> St1;
+    int kb = kb0;
+    for (; kb + 1 < kb1; kb += 2) {
+        step(St0{}, kb);
+        step(St1{}, kb + 1);
+    }
+    if (kb < kb1) step(St0{}, kb);
+    // MFMA results are read by vector instructions below: the hazard distance is the compiler's job for ITS MFMAs only
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (do_bias) {
+        // lanes fg = 0..3 of a wave hold the same channel fi over different K rows
+#pragma unroll
+        for (int i = 0; i < BT; ++i) {
+            float t = bsum[i];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (fg == 0) atomicAdd(a.dbias + co0 + (wid * BT + i) * 16 + fi, t);
+        }
+    }
+    // ---- the wave's BMC x CI tile: into this split's slab (plain stores), or into dW ----------------------------
+    const int wt = (int)((pg.wt4[ph][q] >> (8 * wid)) & 0xffu);
+    float* out = a.slab ? a.slab + (size_t)split * ((size_t)g.Cout * g.wtaps * g.Cin) : a.dw;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const size_t cbase = (size_t)wt * g.Cin + ci0 + nt * 16 + fi;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + mt * 16 + fg * 4 + r;
+                float* pw = out + (size_t)co * g.wtaps * g.Cin + cbase;
+                if (WG3_ABL & 1) { if (acc[mt][nt][r] == 123.456f) *pw = 0.f; }
+                else if (a.slab) *pw = acc[mt][nt][r];
+                else if (splits == 1) {
+                    if (a.overwrite) *pw = acc[mt][nt][r];
+                    else *pw += acc[mt][nt][r];
+                } else {
+                    atomicAdd(pw, acc[mt][nt][r]);
+                }
+            }
+        }
+    }
+}
+
+// dW (+)= sum over the splits' slabs, in split order (deterministic); 16 B per thread and slab
+__global__ __launch_bounds__(256) void wgrad_slab_sum_k(float* __restrict__ dw, const float* __restrict__ slab, int nsplits,
+                                                        long n4, long slab_stride4, int overwrite) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* s = (const float4*)slab + i;
+    float4 v = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)dw)[i];
+#pragma unroll 4
+    for (int k = 0; k < nsplits; ++k) {
+        const float4 t = s[(long)k * slab_stride4];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    ((float4*)dw)[i] = v;
+}
+
+int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, int overwrite, hipStream_t s) {
+    PAI_CHECK((n % 4) == 0, "wgrad slab sum: %lld elements are not a multiple of 4", (long long)n);
+    const long n4 = (long)(n / 4);
+    hipLaunchKernelGGL(wgrad_slab_sum_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dw, slab, nsplits, n4, n4, overwrite);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+static int wg3_variant(const GG& g) {   // 0: not eligible, 1: <128, 64>, 2: <64, 128>
+    const int mode = pai_tunable("wgrad3", 1);
+    if (!mode) return 0;
+    PatchGeo pg;
+    // 32-bit byte offsets into buffer descriptors: every tensor below 2 GB
+    if ((int64_t)g.N * g.H * g.W * (g.C1 > g.C2 ? g.C1 : g.C2) * 2 >= (1ll << 31) || (int64_t)g.N * g.OH * g.OW * g.Cout * 2 >= (1ll << 31))
+        return 0;
+    if (!(g.lsw >= 0 && g.lw >= 4 && g.lh >= 2 && patch_geo(g, 4, &pg))) return 0;
+    if ((g.Cout % 128) == 0 && (g.C1 % 64) == 0 && (g.C2 % 64) == 0 && g.Cin >= 64) return (mode & 1) ? 1 : 0;
+    if ((g.Cout % 64) == 0 && (g.C1 % 128) == 0 && (g.C2 % 128) == 0 && g.Cin >= 128) return (mode & 2) ? 2 : 0;
+    return 0;
+}
+
+bool wgrad3_ok(const GG& g) { return wg3_variant(g) != 0; }
+
+struct Wg3Cfg { int bmc, ci, cotiles, jtiles, tiles, psplits, per; };
+
+static Wg3Cfg wg3_cfg(const GG& g) {
+    PatchGeo pg;
+    patch_geo(g, 4, &pg);
+    Wg3Cfg c;
+    const int v = wg3_variant(g);
+    c.bmc = v == 1 ? 128 : 64;
+    c.ci = v == 1 ? 64 : 128;
+    c.cotiles = g.Cout / c.bmc;
+    c.jtiles = (g.Cin / c.ci) * pg.groups;
+    c.tiles = c.cotiles * c.jtiles * g.nphase;
+    const int kblocks = g.M / 64;
+    // pixel splits: two workgroups per CU fill the chip with 512; a split never gets fewer than 512 pixels
+    int splits = cdiv(pai_tunable("wgrad3_target", 512), c.tiles);
+    const int max_splits = cdiv(g.M, pai_tunable("wgrad3_minrows", 512));
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    c.per = cdiv(kblocks, splits);
+    c.psplits = cdiv(kblocks, c.per);
+    return c;
+}
+
+int64_t wgrad3_slab_bytes(const GG& g) {
+    if (!wgrad3_ok(g)) return 0;
+    const Wg3Cfg c = wg3_cfg(g);
+    return c.psplits > 1 ? (int64_t)c.psplits * g.Cout * g.wtaps * g.Cin * 4 : 0;
+}
+
+// pai_conv_wgrad_overwrite needs no zero fill: every dW element has one writer (un-split: the taps of different phases
+// are disjoint) or the slab sum writes it
+bool wgrad3_overwrites(const GG& g) {
+    if (!wgrad3_ok(g)) return false;
+    const Wg3Cfg c = wg3_cfg(g);
+    if (c.psplits == 1) return true;
+    return pai_tunable("wgrad_slab", 1) && wgrad_slab_acquire((int64_t)c.psplits * g.Cout * g.wtaps * g.Cin * 4) != nullptr;
+}
+
+const char* wgrad3_kernel_name(const GG& g) { return wg3_variant(g) == 1 ? "gg_wgrad_patch3_k<128, 64>" : "gg_wgrad_patch3_k<64, 128>"; }
+
+int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
+    PatchGeo pg;
+    PAI_CHECK(wgrad3_ok(g) && patch_geo(g, 4, &pg), "launch_wgrad3: problem not eligible");
+    const Wg3Cfg c = wg3_cfg(g);
+    WgradArgs a = a0;
+    const int64_t dwn = (int64_t)g.Cout * g.wtaps * g.Cin;
+    const int64_t need = (int64_t)c.psplits * dwn * 4;
+    float* slab = nullptr;
+    if (c.psplits > 1 && pai_tunable("wgrad_slab", 1)) slab = wgrad_slab_acquire(need);
+    a.slab = slab;
+    if (a.overwrite && a.dbias) {   // the bias sums of the workgroups meet by atomics
+        hipError_t e = hipMemsetAsync(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
+        PAI_CHECK(e == hipSuccess, "launch_wgrad3: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+        attr = true;
+    }
+    const dim3 grid(c.tiles * c.psplits);
+    if (c.bmc == 128) {
+        const size_t lds = 2 * (64 * 256 + 96 * 128);
+        hipLaunchKernelGGL((gg_wgrad_patch3_k<128, 64>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+    } else {
+        const size_t lds = 2 * (64 * 128 + 96 * 256);
+        hipLaunchKernelGGL((gg_wgrad_patch3_k<64, 128>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+    }
+    PAI_LAUNCH_CHECK();
+    if (slab) return launch_wgrad_slab_sum(a.dw, slab, c.psplits, dwn, a.overwrite, s);
+    return 0;
+}

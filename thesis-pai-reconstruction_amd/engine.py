@@ -447,6 +447,7 @@ class UnetEngine:
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["enc_desc"] + P["dec_desc"]
                                  for op in (0, 1)), device)
         ops.ensure_scratch(ops.scratch_bytes_for(P["enc_desc"] + P["dec_desc"]), device)
+        ops.ensure_wgrad_workspace(P["enc_desc"] + P["dec_desc"], device)
         self._plans[key] = P
         return P
 
@@ -765,6 +766,7 @@ class DiscEngine:
         P["oh"], P["ow"] = (H >> 4) - 1, (W >> 4) - 1
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["desc"] for op in (0, 1)), device)
         ops.ensure_scratch(ops.scratch_bytes_for(P["desc"]), device)
+        ops.ensure_wgrad_workspace(P["desc"], device)
         self._plans[key] = P
         return P
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "pai_destroy": (_I, [C.c_void_p]),
     "pai_handle_set_workspace": (_I, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pai_handle_set_scratch": (_I, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pai_handle_set_wgrad_workspace": (_I, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pai_conv_out_hw": (_I, [_D, C.POINTER(_I), C.POINTER(_I)]),
     "pai_conv_fwd_stats_rows": (_I, [_D]),
     "pai_conv_fwd_stats_rows_max": (_I, [_D]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "pai_conv_workspace_bytes": (_L, [_D, _I]),
     "pai_set_scratch": (_I, [_P, _L]),
     "pai_conv_scratch_bytes": (_L, [_D, _I]),
+    "pai_set_wgrad_workspace": (_I, [_P, _L]),
+    "pai_conv_wgrad_workspace_bytes": (_L, [_D]),
     "pai_conv_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_conv_dgrad": (_I, [_D, _P, _P, _P, _P, _I, _P]),
     "pai_conv_dgrad_act": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),

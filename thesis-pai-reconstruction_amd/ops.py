@@ -130,6 +130,7 @@ class Handle:
         L.check(L.load().pai_create(self.device.index, C.byref(self._h)), "pai_create")
         self.workspace = None
         self.scratch = None
+        self.wgrad_workspace = None
 
     def bind(self):
         L.check(L.load().pai_bind(self._h), "pai_bind")
@@ -152,6 +153,18 @@ class Handle:
             self.scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
             L.check(L.load().pai_handle_set_scratch(self._h, self.scratch.data_ptr(), self.scratch.numel() * 4),
                     "pai_handle_set_scratch")
+
+    def ensure_wgrad_workspace(self, nbytes: int) -> None:
+        """Register (grow) the weight-gradient slab buffer (pai_handle_set_wgrad_workspace)."""
+        if nbytes <= 0:
+            return
+        if self.wgrad_workspace is None or self.wgrad_workspace.numel() * 4 < nbytes:
+            if self.wgrad_workspace is not None:
+                torch.cuda.synchronize(self.device)     # side-stream launches may still be writing the old buffer
+            self.wgrad_workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            L.check(L.load().pai_handle_set_wgrad_workspace(self._h, self.wgrad_workspace.data_ptr(),
+                                                           self.wgrad_workspace.numel() * 4),
+                    "pai_handle_set_wgrad_workspace")
 
     def close(self):
         if self._h:
@@ -197,6 +210,15 @@ def scratch_bytes_for(descs) -> int:
 def ensure_scratch(nbytes: int, device) -> None:
     """Grow the general scratch buffer of the device's default handle."""
     handle_for(device).ensure_scratch(nbytes)
+
+
+def conv_wgrad_workspace_bytes(d: ConvDesc) -> int:
+    return L.load().pai_conv_wgrad_workspace_bytes(C.byref(d))
+
+
+def ensure_wgrad_workspace(descs, device) -> None:
+    """Grow the weight-gradient slab buffer of the device's default handle to what the layers `descs` need."""
+    handle_for(device).ensure_wgrad_workspace(max((conv_wgrad_workspace_bytes(d) for d in descs), default=0))
 
 
 def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None):
