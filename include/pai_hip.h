@@ -45,14 +45,22 @@ extern "C" {
 
 const char* pai_last_error(void);
 /* 100: round 1.  110: per-device handles, pai_set_tunable, pai_adam_dev, pai_scalar_take / pai_metrics_take,
- * pai_pack_weights_multi; pai_bn_bwd_reduce accepts du = NULL.  Additions only: a 100 caller runs unchanged. */
+ * pai_pack_weights_multi; pai_bn_bwd_reduce accepts du = NULL.  120: weight-gradient workspace
+ * (pai_set_wgrad_workspace), pai_build_flags, PAI_TUNABLE_UNSET; pai_conv_desc.pack_flags bits other than 0-1 and
+ * .reserved are CHECKED to be zero (descriptors must be zero-initialised; a 100 caller that did so runs unchanged). */
 int pai_version(void);
+/* bit 0: the library was built with PAI_EXPERIMENTAL=1 and carries the experiment kernels of round 2 (gg_p2.hip,
+ * gg_bd.hip + pai_pack_frag, gg_wg2.hip: bit-exact, slower than the defaults, off unless a tunable selects them).
+ * The default build returns 0 and pai_pack_frag fails. */
+int pai_build_flags(void);
 /* Device properties of the current HIP device (host out-params). */
 int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
 
-/* Kernel-selection switches (host side, process-wide), e.g. "fwd_p2" = 0 routes the layers of the pipelined
- * one-workgroup-per-CU forward kernel back to the two-workgroup patch kernel.  For tests that pin the kernel a
- * call runs and for A/B timing in one process; production code never needs it. */
+/* Kernel-selection switches (host side, process-wide), e.g. "wgrad3" = 0 routes the dense weight gradients back to
+ * gg_wgrad_patch_k, "wgrad_slab" = 0 makes their pixel splits meet through fp32 atomics again.  Every switch has a
+ * built-in default (the experiment kernels default to OFF); value PAI_TUNABLE_UNSET returns a switch to it.  For
+ * tests that pin the kernel a call runs and for A/B timing in one process; production code never needs it. */
+#define PAI_TUNABLE_UNSET (-2147483647 - 1)
 int pai_set_tunable(const char* name, int value);
 
 /* ---------------------------------------------------------------------------
@@ -91,9 +99,9 @@ typedef struct pai_conv_desc {
                              (pai_pack_frag(w_fwd, Cout, taps * (C1 + C2), w_fwd + Cout * taps * (C1 + C2) elements));
                              bit 1: the same for w_dgrad (rows = C1 + C2, K = taps * Cout).  With the copy present the
                              forward / input-gradient call may run the kernel that feeds its weights to the matrix
-                             cores straight from memory (pai_conv_kernel_name says whether it does); 0: row-major
-                             packs only, every earlier caller */
-    int32_t reserved;
+                             cores straight from memory (pai_conv_kernel_name says whether it does; PAI_EXPERIMENTAL
+                             builds only, pai_build_flags); 0: row-major packs only.  Bits 2-31 MUST be zero. */
+    int32_t reserved;     /* MUST be zero (checked) */
 } pai_conv_desc;
 
 /* Output spatial size of the layer. */

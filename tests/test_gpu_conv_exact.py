@@ -22,24 +22,24 @@ pytestmark = pytest.mark.gpu
 SPLIT = ("gg_fwd_mfma_k<128, 128, true, true, 64>", "gg_fwd_mfma_k<128, 128, false, false, 64>")
 # (name, transposed, N, H, C1, C2, Cout, relu, (forward, input-gradient, weight-gradient kernel))
 CASES = [
-    ("enc_patch", 0, 4, 128, 64, 0, 256, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch_k<128>")),
-    ("dec_patch", 1, 4, 64, 64, 64, 128, 1, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch_k<128>")),
-    ("enc_patch256", 0, 8, 256, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch_k<128>")),
-    ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch_k<128>")),
-    ("dec_patch256x64", 1, 8, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch_k<64>")),
-    ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
+    ("enc_patch", 0, 4, 128, 64, 0, 256, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
+    ("dec_patch", 1, 4, 64, 64, 64, 128, 1, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
+    ("enc_patch256", 0, 8, 256, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
+    ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("dec_patch256x64", 1, 8, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
+    ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
     ("enc_splitk", 0, 4, 8, 256, 0, 256, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     ("dec_splitk", 1, 4, 4, 256, 256, 256, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     # BASELINE configs[1] layer shapes at the benchmark batch (64; the discriminator sees 2 x 64 in its own phase)
-    ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
+    ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
     ("cfg2_enc4", 0, 64, 16, 512, 0, 512, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     ("cfg2_dec3", 1, 64, 8, 512, 512, 512, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
-    ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
-    ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
-    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<64>")),
-    ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch_k<128>")),
-    ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
-    ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch_k<128>")),
+    ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
+    ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
 ]
 
 
@@ -54,14 +54,14 @@ def _named(ops, d, op, want):
     return got
 
 
-def _reference(tr, x1, x2, w, dy, relu):
+def _reference(tr, x1, x2, w, dy, relu, bias=None):
     """PyTorch-CPU fp32 (exact on this data): y, dx (w.r.t. the relu'd, concatenated input), dw."""
     xs = [F.relu(x1) if relu else x1]
     if x2 is not None:
         xs.append(F.relu(x2) if relu else x2)
     x = torch.cat(xs, 1).requires_grad_(True)
     wr = w.clone().requires_grad_(True)
-    y = F.conv_transpose2d(x, wr, None, stride=2, padding=1) if tr else F.conv2d(x, wr, None, stride=2, padding=1)
+    y = F.conv_transpose2d(x, wr, bias, stride=2, padding=1) if tr else F.conv2d(x, wr, bias, stride=2, padding=1)
     y.backward(dy)
     return y.detach(), x.grad, wr.grad
 
@@ -79,7 +79,8 @@ def _run_case(pai, case, tunables=(), workspace=True, frag=False):
     w = _ints((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4), 3)
     OH = H * 2 if tr else H // 2
     dy = _ints((N, Cout, OH, OH), 5)
-    y_ref, dx_ref, dw_ref = _reference(tr, x1, x2, w, dy, relu)
+    bias = _ints((Cout,), 7, -3, 3)           # the bias add of the epilogue is part of what is pinned
+    y_ref, dx_ref, dw_ref = _reference(tr, x1, x2, w, dy, relu, bias)
     assert float(y_ref.abs().max()) < 2 ** 24 and float(dw_ref.abs().max()) < 2 ** 24     # exact in fp32
 
     d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, relu, relu if C2 else 0, ops.ACT_NONE)
@@ -89,12 +90,12 @@ def _run_case(pai, case, tunables=(), workspace=True, frag=False):
     if workspace:
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
         ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
+        ops.ensure_wgrad_workspace([d], dev())      # pixel splits of the weight gradient: slabs + ordered sum, no atomics
     else:
         bare = ops.Handle(dev()).bind()
     check_names = not tunables and not workspace
-    lib = pai.lib.load()
     for k, v in tunables:
-        assert lib.pai_set_tunable(k.encode(), v) == 0
+        ops.set_tunable(k, v)
     try:
         wm = fwd_pack(w, bool(tr))
         wf = torch.empty(wm.numel() * (2 if frag else 1), dtype=dt, device=dev())
@@ -109,7 +110,7 @@ def _run_case(pai, case, tunables=(), workspace=True, frag=False):
         used.append(_named(ops, d, 0, names[0]) if check_names else ops.conv_kernel_name(d, 0))
         y = torch.empty(N * OH * OH * Cout, dtype=dt, device=dev())
         stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, device=dev())
-        ops.conv_fwd(d, X1, X2, wf, None, y_raw=y, stats=stats)
+        ops.conv_fwd(d, X1, X2, wf, bias.to(dev()), y_raw=y, stats=stats)
         torch.cuda.synchronize()
         assert torch.equal(from_nhwc(y, N, OH, OH, Cout), y_ref.bfloat16().float()), (name, "forward")
         rows = ops.conv_fwd_stats_rows(d)
@@ -135,7 +136,7 @@ def _run_case(pai, case, tunables=(), workspace=True, frag=False):
         return used
     finally:
         for k, _ in tunables:
-            lib.pai_set_tunable(k.encode(), 0)
+            ops.set_tunable(k)          # back to the built-in default
         if bare is not None:
             default.bind()
             bare.close()
@@ -159,17 +160,11 @@ P2_CASES = [c for c in CASES if c[0] in ("enc_patch256", "dec_patch256", "enc_dg
 @pytest.mark.parametrize("mode", [1, 2], ids=["8wave", "4wave"])
 @pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
 def test_pipelined_p2_kernels_bit_exact(pai, case, mode):
-    """gg_p2.hip (off by default, tunable fwd_p2): the one-workgroup-per-CU pipelined variants give the same bits."""
+    """gg_p2.hip (PAI_EXPERIMENTAL builds, tunable fwd_p2): the one-workgroup-per-CU pipelined variants give the same bits."""
+    if not pai.ops.experimental_built():
+        pytest.skip("library built without PAI_EXPERIMENTAL=1")
     used = _run_case(pai, case, tunables=(("fwd_p2", mode),))
     assert any(u.startswith("gg_fwd_p2_k<") for u in used[:2]), used
-
-
-@pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
-def test_mfma_32x32x16_form_bit_exact(pai, case):
-    """gg_fwd_patch32_k (off by default, tunable fwd_m32): the v_mfma_f32_32x32x16_bf16 form of the patch-resident
-    kernel -- other LDS image, other accumulator layout, other epilogue mapping -- gives the same bits."""
-    used = _run_case(pai, case, tunables=(("fwd_m32", 1),))
-    assert any(u.startswith("gg_fwd_patch32_k<") for u in used[:2]), used
 
 
 # layers whose forward or input gradient gives gg_fwd_bd_k >= 512 workgroups; cfg2_D1 / cfg2_D2: grids of several rounds,
@@ -184,10 +179,73 @@ def test_register_direct_weight_kernel_bit_exact(pai, case, mode):
     """gg_bd.hip: the patch-resident kernel that feeds the matrix cores their weights straight from a fragment-major
     copy of the filter pack (pai_pack_frag) -- other operand path, other tile split, accumulators in the accumulation
     registers -- gives the same bits; without the copy (pack_flags = 0) the default kernels run."""
+    if not pai.ops.experimental_built():
+        pytest.skip("library built without PAI_EXPERIMENTAL=1")
     used = _run_case(pai, case, tunables=(("fwd_bd", mode),), frag=True)
     want = "gg_fwd_bd_k<true, " if mode == 2 else "gg_fwd_bd_k<false, "
     assert any(u.startswith(want) for u in used[:2]), used
     assert not any(u.startswith("gg_fwd_bd_k") for u in _run_case(pai, case, tunables=(("fwd_bd", mode),))[:2])
+
+
+OLD_WGRAD = {"enc_patch": "gg_wgrad_patch_k<128>", "dec_patch": "gg_wgrad_patch_k<128>", "dec_patch256x64": "gg_wgrad_patch_k<64>",
+             "cfg2_dec5": "gg_wgrad_patch_k<128>"}
+
+
+@pytest.mark.parametrize("name", sorted(OLD_WGRAD))
+def test_previous_weight_gradient_kernels_stay_exact(pai, name):
+    """gg_wgrad_patch_k (round 1-2; still the kernel of layers gg_wgrad_patch3_k does not take, e.g. 32-channel
+    multiples): tunable wgrad3 = 0 routes the same cases back to it."""
+    from thesis_pai_reconstruction_amd import ops
+    case = next(c for c in CASES if c[0] == name)
+    used = _run_case(pai, case, tunables=(("wgrad3", 0),))
+    assert used[2] == OLD_WGRAD[name], used
+    ops.set_tunable("wgrad3", 0)
+    ops.set_tunable("wgrad_slab", 0)
+    try:
+        d = ops.make_desc(torch.bfloat16, case[1], case[2], case[3], case[3], case[4], case[5], case[6], 2, 0, 0, ops.ACT_NONE)
+        assert ops.conv_wgrad_workspace_bytes(d) >= 0
+    finally:
+        ops.set_tunable("wgrad3")
+        ops.set_tunable("wgrad_slab")
+
+
+@pytest.mark.parametrize("slab", [1, 0], ids=["slabs", "atomics"])
+@pytest.mark.parametrize("name", ["enc_patch256", "dec_patch256x64", "cfg2_D1", "cfg2_dec4"])
+def test_weight_gradient_bias_and_overwrite(pai, name, slab):
+    """gg_wgrad_patch3_k with a bias gradient (column sums of dY taken from the fragments every wave holds, spread over
+    the workgroups that share a dY tile) and through pai_conv_wgrad_overwrite (dW / dbias need no zero fill: the slab sum,
+    or the single writer of an un-split tile, stores them) -- exact on integer data, with the pixel splits meeting through
+    slabs and through fp32 atomics."""
+    from thesis_pai_reconstruction_amd import ops
+    case = next(c for c in CASES if c[0] == name)
+    _, tr, N, H, C1, C2, Cout, relu, names = case
+    Cin, dt = C1 + C2, torch.bfloat16
+    x1 = _ints((N, C1, H, H), 1)
+    x2 = _ints((N, C2, H, H), 2) if C2 else None
+    OH = H * 2 if tr else H // 2
+    dy = _ints((N, Cout, OH, OH), 5)
+    w = torch.zeros((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4))
+    _, _, dw_ref = _reference(tr, x1, x2, w, dy, relu)
+    db_ref = dy.sum((0, 2, 3))
+    assert float(dw_ref.abs().max()) < 2 ** 24 and float(db_ref.abs().max()) < 2 ** 24
+    d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, relu, relu if C2 else 0, ops.ACT_NONE)
+    ops.ensure_wgrad_workspace([d], dev())
+    ops.set_tunable("wgrad_slab", slab)
+    try:
+        assert ops.conv_kernel_name(d, 2) == names[2]
+        X1, X2, DY = nhwc(x1, dt), (nhwc(x2, dt) if C2 else None), nhwc(dy, dt)
+        n = Cout * 16 * Cin
+        for overwrite in (False, True):
+            # accumulate: starts from a known integer offset; overwrite: starts from garbage
+            dw = torch.full((n,), 3.0, device=dev()) if not overwrite else torch.full((n,), float("nan"), device=dev())
+            db = torch.full((Cout,), 5.0, device=dev()) if not overwrite else torch.full((Cout,), float("nan"), device=dev())
+            (ops.conv_wgrad_overwrite if overwrite else ops.conv_wgrad)(d, X1, X2, DY, dw, db)
+            torch.cuda.synchronize()
+            off_w, off_b = (0.0, 0.0) if overwrite else (3.0, 5.0)
+            assert torch.equal(unpack_fwd(dw, Cout, Cin, bool(tr)), dw_ref + off_w), (name, "dw", overwrite)
+            assert torch.equal(db.cpu(), db_ref + off_b), (name, "dbias", overwrite)
+    finally:
+        ops.set_tunable("wgrad_slab")
 
 
 def test_two_handles_keep_their_own_buffers(pai):
@@ -229,3 +287,135 @@ def test_two_handles_keep_their_own_buffers(pai):
         default.bind()
         for h in (ha, hb, hc):
             h.close()
+
+
+# ---- the fused producer backward of the input-gradient store (pai_conv_dgrad_bn) -----------------------------------
+# (case of CASES, act1, act2, affine): decoder form (producer read through ReLU, no second gradient) and encoder form
+# (LeakyReLU on the encoder path + the skip decoder's gradient through ReLU), on the kernels the benchmark runs
+DGRAD_BN = [("dec_patch256", 2, 0, True), ("enc_dgrad256", 1, 2, True), ("cfg2_enc2", 1, 2, True), ("dec_splitk", 2, 0, True),
+            ("enc_patch256", 1, 0, False)]
+
+
+@pytest.mark.parametrize("cfg", DGRAD_BN, ids=[c[0] for c in DGRAD_BN])
+def test_fused_producer_backward_bit_exact(pai, cfg):
+    """pai_conv_dgrad_bn on integer data: du = act1'(pre) * g + act2'(pre) * add with pre = z * scale + shift, g the
+    bf16-rounded input gradient; the stored du and (for ReLU producers, whose du stay integers) the BatchNorm-backward
+    partial sums must equal the PyTorch-CPU restatement BIT FOR BIT -- the round-2 tests only held this store to its own
+    two-pass form.  reference models/pix2pix.py:63-70,99-106 (the BatchNorm / activation backward aten runs as its own
+    kernels)."""
+    from thesis_pai_reconstruction_amd import ops
+    name, act1, act2, affine = cfg
+    case = next(c for c in CASES if c[0] == name)
+    _, tr, N, H, C1, C2, Cout, relu, _ = case
+    Cin, dt = C1 + C2, torch.bfloat16
+    OH = H * 2 if tr else H // 2
+    w = _ints((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4), 3)
+    dy = _ints((N, Cout, OH, OH), 5)
+    # input gradient w.r.t. the layer's (concatenated) input, exact integers
+    x = torch.zeros(N, Cin, H, H, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, stride=2, padding=1) if tr else F.conv2d(x, w, None, stride=2, padding=1)
+    y.backward(dy)
+    g = x.grad[:, :C1].bfloat16().float()                      # what the kernel holds when the store runs
+    z = _ints((N, C1, H, H), 11, -3, 3)
+    add = _ints((N, C1, H, H), 12) if act2 else None
+    scale = torch.tensor([1.0, 2.0, 0.5, -1.0]).repeat(C1 // 4) if affine else None
+    shift = torch.tensor([0.0, 1.0, -1.0, 2.0, -2.0, 0.5, 3.0, -0.5]).repeat(C1 // 8) if affine else None
+    mean = torch.tensor([1.0, -1.0, 0.0, 2.0]).repeat(C1 // 4)
+    rstd = torch.tensor([0.5, 1.0, 2.0, 0.25]).repeat(C1 // 4)
+    pre = z * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) if affine else z
+    pos = pre > 0
+
+    def sel(v, act):
+        return torch.where(pos, v, 0.2 * v if act == 1 else torch.zeros_like(v)) if act else v
+    du = sel(g, act1) + (sel(add, act2) if add is not None else 0.0)
+    du_bf = du.bfloat16().float()
+
+    d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, 0, 0, ops.ACT_NONE)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    wm = fwd_pack(w, bool(tr))
+    wd = torch.empty(wm.numel(), dtype=dt, device=dev())
+    ops.pack_weights(dt, wm, Cout, 16, Cin, None, wd)
+    dx1 = torch.empty(N * H * H * C1, dtype=dt, device=dev())
+    dx2 = torch.empty(N * H * H * C2, dtype=dt, device=dev()) if C2 else None
+    part = torch.full((ops.conv_dgrad_bn_rows_max(d) * 2 * C1,), float("nan"), device=dev())
+    f = lambda t: None if t is None else t.to(dev())
+    rows = ops.conv_dgrad_bn(d, nhwc(dy, dt), wd, dx1, dx2, nhwc(z, dt), act1, nhwc(add, dt) if add is not None else None, act2,
+                             f(scale), f(shift), f(mean), f(rstd), part)
+    torch.cuda.synchronize()
+    assert ops.conv_kernel_id(d, 1) in (2, 3) and rows > 0                  # the matrix-core kernels: the store IS fused
+    assert torch.equal(from_nhwc(dx1, N, H, H, C1), du_bf), (name, "du")
+    if C2:
+        assert torch.equal(from_nhwc(dx2, N, H, H, C2), x.grad[:, C1:].bfloat16().float()), (name, "skip half")
+    P = part[: rows * 2 * C1].view(rows, 2, C1).double().sum(0).cpu()
+    s1 = du_bf.double().sum((0, 2, 3))
+    s2 = (du_bf.double() * ((z.double() - mean.view(1, -1, 1, 1).double()) * rstd.view(1, -1, 1, 1).double())).sum((0, 2, 3))
+    if act1 != 1:       # integers all the way: exact
+        assert torch.equal(P[0], s1) and torch.equal(P[1], s2), name
+    else:               # 0.2 * g rounded to bf16 is no integer: fp32 sums in the tile's order
+        assert float((P[0] - s1).abs().max()) <= 1e-5 * float(du_bf.abs().double().sum((0, 2, 3)).max())
+        assert float((P[1] - s2).abs().max()) <= 1e-5 * float((du_bf.abs() * 8).double().sum((0, 2, 3)).max())
+
+
+# ---- the thin layers at the benchmark's own shapes (BASELINE configs[1]) --------------------------------------------
+# (name, transposed, N, H, C1, C2, Cout): encoders[0], discriminator block 0 at the 2 x 64 batch of its own phase, and
+# decoders[7] (reference models/pix2pix.py:141-147,185-193, models/wrapper.py:229)
+THIN = [("cfg2_enc0", 0, 64, 256, 1, 0, 64), ("cfg2_D0", 0, 128, 256, 1, 1, 64), ("cfg2_dec7", 1, 64, 128, 64, 64, 1)]
+
+
+@pytest.mark.parametrize("case", THIN, ids=[c[0] for c in THIN])
+def test_thin_layers_bit_exact_at_config2_shapes(pai, case):
+    """thin_fwd_k, thin_dgrad_gemm_k + thin_col2im_k and thin_wgrad_k on integer data at full size: every partial sum is
+    an exact fp32 integer, so forward (+ bias, + LeakyReLU copy), input gradient and weight / bias gradient must equal
+    PyTorch-CPU bit for bit -- byte-permute gathers, edge-lane masks and the col2im tap tables included.  The family is
+    asserted strictly (4 = thin matrix-core kernels) with the scratch registered."""
+    from thesis_pai_reconstruction_amd import ops
+    name, tr, N, H, C1, C2, Cout = case
+    Cin, dt = C1 + C2, torch.bfloat16
+    OH = H * 2 if tr else H // 2
+    x1 = _ints((N, C1, H, H), 1)
+    x2 = _ints((N, C2, H, H), 2) if C2 else None
+    w = _ints((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4), 3)
+    bias = _ints((Cout,), 7, -3, 3)
+    dy = _ints((N, Cout, OH, OH), 5)
+    y_ref, dx_ref, dw_ref = _reference(tr, x1, x2, w, dy, 0, bias)
+    db_ref = dy.sum((0, 2, 3))
+    assert max(float(t.abs().max()) for t in (y_ref, dx_ref, dw_ref, db_ref)) < 2 ** 24
+    d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, 0, 0, ops.ACT_LRELU if not tr else ops.ACT_NONE)
+    ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
+    want_ops = (0, 1, 2) if tr else (0, 2)
+    assert all(ops.conv_kernel_id(d, op) == 4 for op in want_ops), [ops.conv_kernel_id(d, op) for op in (0, 1, 2)]
+    wm = fwd_pack(w, bool(tr))
+    wf = torch.empty(wm.numel(), dtype=dt, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dt, device=dev())
+    ops.pack_weights(dt, wm, Cout, 16, Cin, wf, wd)
+    X1, X2, DY, B = nhwc(x1, dt), (nhwc(x2, dt) if C2 else None), nhwc(dy, dt), bias.to(dev())
+    if tr:      # decoders[7]: fp32 output (the engine adds tanh; the exact test leaves it out), both source gradients
+        y32 = torch.empty(N * OH * OH * Cout, dtype=torch.float32, device=dev())
+        ops.conv_fwd(d, X1, X2, wf, B, y_f32=y32)
+        torch.cuda.synchronize()
+        assert torch.equal(y32.cpu().view(N, OH, OH, Cout).permute(0, 3, 1, 2), y_ref), (name, "forward")
+        dx1 = torch.empty(N * H * H * C1, dtype=dt, device=dev())
+        dx2 = torch.empty(N * H * H * C2, dtype=dt, device=dev())
+        ops.conv_dgrad(d, DY, wd, dx1, dx2)
+        torch.cuda.synchronize()
+        assert torch.equal(from_nhwc(dx1, N, H, H, C1), dx_ref[:, :C1].bfloat16().float()), (name, "dgrad x1")
+        assert torch.equal(from_nhwc(dx2, N, H, H, C2), dx_ref[:, C1:].bfloat16().float()), (name, "dgrad x2")
+    else:
+        y = torch.empty(N * OH * OH * Cout, dtype=dt, device=dev())
+        ya = torch.empty_like(y)
+        ops.conv_fwd(d, X1, X2, wf, B, y_raw=y, y_act=ya)
+        torch.cuda.synchronize()
+        assert torch.equal(from_nhwc(y, N, OH, OH, Cout), y_ref.bfloat16().float()), (name, "forward")
+        assert torch.equal(from_nhwc(ya, N, OH, OH, Cout), F.leaky_relu(y_ref, 0.2).bfloat16().float()), (name, "forward act")
+        del y, ya
+        if C2:  # discriminator block 0: the gradient w.r.t. the image half only (what the generator phase asks for)
+            dx2 = torch.empty(N * H * H * C2, dtype=dt, device=dev())
+            ops.conv_dgrad(d, DY, wd, None, dx2, only_c2=True)
+            torch.cuda.synchronize()
+            assert torch.equal(from_nhwc(dx2, N, H, H, C2), dx_ref[:, C1:].bfloat16().float()), (name, "dgrad x2")
+    dw = torch.zeros(wm.numel(), dtype=torch.float32, device=dev())
+    db = torch.zeros(Cout, dtype=torch.float32, device=dev())
+    ops.conv_wgrad(d, X1, X2, DY, dw, db)
+    torch.cuda.synchronize()
+    assert torch.equal(unpack_fwd(dw, Cout, Cin, bool(tr)), dw_ref), (name, "wgrad")
+    assert torch.equal(db.cpu(), db_ref), (name, "dbias")

@@ -71,6 +71,7 @@ def _worker(rank, world, port, precision, family, q):
         os.environ["PAI_NO_STREAM_ADAM"] = "1"
         m.training_step((x, t), 0)             # the first fused step moves the parameters into the arena
         os.environ["PAI_NO_STREAM_ADAM"] = "0"
+        os.environ["PAI_DDP_STREAM_ADAM"] = "1"     # the streamed update under a reducer is opt-in (optim.ArenaAdam.arm_streaming)
         if twin is not None:
             twin.training_step((x, t), 0)
             twin.load_state_dict(m.state_dict())

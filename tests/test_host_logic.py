@@ -201,6 +201,12 @@ def test_trainer_fit_logs_and_keeps_best_checkpoint(pai, tmp_path):
     tr3.fit(m3, train_dataloaders=data, ckpt_path=best)
     # the best checkpoint was written after epoch index 1 or 3; training continues with the NEXT epoch up to max_epochs = 6
     assert tr3.batches_seen == ck["batches_seen"] + 5 * (6 - ck["epoch"] - 1) and tr3.global_step == 2 * tr3.batches_seen
+    # ... and so does the score to beat: a resumed run must not overwrite best.ckpt with a worse first validation
+    assert ck["callbacks"]["ModelCheckpoint"]["best_model_score"] == pytest.approx(float(ckpt.best_model_score))
+    ckpt4 = ModelCheckpoint(save_top_k=1, monitor="val_ssim", mode="max", filename="best", dirpath=str(tmp_path / "resumed"))
+    tr4 = Trainer(max_epochs=ck["epoch"] + 1, enable_progress_bar=False, logger=None, callbacks=[ckpt4])
+    tr4.restore(ToyGAN(), best)
+    assert ckpt4.best_model_score == pytest.approx(float(ckpt.best_model_score)) and ckpt4.best_model_path == str(best)
 
 
 def test_precision_strings(pai):

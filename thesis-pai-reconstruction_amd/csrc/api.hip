@@ -16,6 +16,15 @@ void pai_set_error(const char* fmt, ...) {
 extern "C" const char* pai_last_error(void) { return g_err; }
 extern "C" int pai_version(void) { return 120; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace
 
+// bit 0: the experiment kernels (gg_p2.hip, gg_bd.hip, gg_wg2.hip; PAI_EXPERIMENTAL=1 at build time) are present
+extern "C" int pai_build_flags(void) {
+#ifdef PAI_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -48,7 +57,12 @@ int pai_tunable(const char* name, int def) {
 extern "C" int pai_set_tunable(const char* name, int value) {
     PAI_CHECK(name && strlen(name) < sizeof(g_tunables[0].name), "pai_set_tunable: bad name");
     for (int i = 0; i < g_ntunables; ++i)
-        if (!strcmp(g_tunables[i].name, name)) { g_tunables[i].value = value; return 0; }
+        if (!strcmp(g_tunables[i].name, name)) {
+            if (value == PAI_TUNABLE_UNSET) g_tunables[i] = g_tunables[--g_ntunables];   // back to the built-in default
+            else g_tunables[i].value = value;
+            return 0;
+        }
+    if (value == PAI_TUNABLE_UNSET) return 0;
     PAI_CHECK(g_ntunables < 32, "pai_set_tunable: table full");
     strcpy(g_tunables[g_ntunables].name, name);
     g_tunables[g_ntunables++].value = value;
@@ -82,6 +96,8 @@ static int check_desc(const pai_conv_desc* d) {
             PAI_CHECK(d->H >= 2 && d->W >= 2, "k4 s1 p1 Conv2d needs H, W >= 2");
     }
     PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
+    PAI_CHECK((d->pack_flags & ~3) == 0 && d->reserved == 0, "pai_conv_desc: pack_flags bits other than 0-1 / reserved must be zero (got %d, %d)",
+              d->pack_flags, d->reserved);
     if (d->groups > 1) {
         PAI_CHECK(d->kernel == 3 && d->C2 == 0 && d->C1 == d->Cout && (d->C1 % d->groups) == 0 && (d->C1 % 16) == 0 &&
                       (16 % (d->C1 / d->groups)) == 0,

@@ -590,27 +590,19 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 #ifndef PATCH_SETPRIO
 #define PATCH_SETPRIO 0   // 1: raise the wave's issue priority over its MFMA cluster (guide T5)
 #endif
-// M32: v_mfma_f32_32x32x16_bf16 on 2 x 2 accumulator tiles instead of v_mfma_f32_16x16x32_bf16 on 4 x 4.  Same
-// FLOPs per matrix-pipe cycle, but in a bare register-operand loop the 16x16x32 form loses a third of its rate to ANY
-// other instruction issued between two MFMAs of a SIMD (one v_pk_max or one ds_read_b128 per MFMA: 1.72 -> 1.15
-// PFLOP/s, scripts/micro/mfma_issue.hip), the 32x32x16 form a tenth (1.80 -> 1.65 with two v_pk_max per
-// 16x16x32-equivalent).  BN == 128 only.  STATUS (round 2): bit-exact, NOT the default (tunable fwd_m32): in this
-// kernel it is within +-3 % of the 16x16x32 form on every layer, because neither issue slots nor the matrix pipe
-// bound it.  Compile-time ablations on decoders[4] (137 GFLOP; 16x16x32 / 32x32x16 form, forward us):
-//   everything 128 / 123;  no epilogue 120 / 113;  no patch fill 122 / 115;  no weight-tile fill 106 / 102;
-//   no LDS-DMA fill at all 91 / 86;  neither fills nor fragment reads 77 (1.79 PFLOP/s; a bare MFMA loop sustains 2.07
-//   on this board -- not the 2.5 of the data sheet -- with the clock throttled to ~2.07 GHz at the 1400 W power cap)
-// i.e. the matrix pipe waits for the LDS: per two co-resident workgroup-steps (1024 matrix cycles per SIMD) the LDS
-// serves 2 x 8 waves x 16 ds_read_b128 (1024 cycles) plus 2 x 26 KB of LDS-DMA writes.  And the launch runs AT the
-// power cap (1385 W, 2.02 GHz): 0.36 of its 0.90 pJ per FLOP move operands, so only fewer operand
-// bytes per FLOP at every level can move this kernel -- wider wave tiles (gg_p2.hip, at the price of occupancy and an
-// exposed epilogue) and register-direct weights (gg_bd.hip, more L2 bytes for fewer LDS bytes) did not pay.
+// (A v_mfma_f32_32x32x16_bf16 form of this body -- 2 x 2 accumulator tiles of 32 x 32, other LDS swizzle and epilogue
+// mapping -- was built and measured in round 2: bit-exact and within +-3 % of this one on every layer, because neither
+// issue slots nor the matrix pipe bound the kernel; removed in round 3, numbers in DESIGN.md section 9.)
+// Compile-time ablations on decoders[4] (137 GFLOP, forward us): everything 128; no epilogue 120; no patch fill 122; no
+// weight-tile fill 106; no LDS-DMA fill at all 91; neither fills nor fragment reads 77 (1.79 PFLOP/s; a bare MFMA loop
+// sustains 2.07 on this board with the clock throttled to ~2.07 GHz at the 1400 W power cap): the matrix pipe waits for
+// the LDS -- per two co-resident workgroup-steps (1024 matrix cycles per SIMD) the LDS serves 2 x 8 waves x 16
+// ds_read_b128 (1024 cycles) plus 2 x 26 KB of LDS-DMA writes.
 // WN: waves side by side along the channels.  2: (BM / 64) x 2 waves of 64 pixels x BN / 2 channels.  1 (BN = 64 only):
 // BM / 64 waves of 64 pixels x 64 channels -- the 64-channel layers with the 64 x 64 wave tile of the 128-channel
 // kernels (8 fragment reads per 16 MFMAs instead of 6 per 8) and one weight tile per 256 pixels.
-template <int BM, int BN, bool DBB, bool M32, int WN = 2>   // DBB: two weight-tile buffers
+template <int BM, int BN, bool DBB, int WN = 2>   // DBB: two weight-tile buffers
 __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a, const PatchGeo& pg, int mtiles, int ntiles) {
-    static_assert(!M32 || (BN == 128 && WN == 2), "the 32x32x16 path covers 64-channel wave tiles");
     static_assert(WN == 2 || BN == 64, "one wave column: 64 output channels");
     constexpr int abl = PATCH_ABL;
     typedef PatchDims<BM, WN> PD;
@@ -659,13 +651,10 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 
     // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
     const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
-    // 16x16x32: slot c of pixel p holds chunk c ^ (p & 6) (p & 6 == sr & 6: RPP j does not touch bits 1-2).
-    // 32x32x16: a ds_read_b128 lane group spans two patch rows (columns 0-3, 12-15 of one, 4-11 of the next): slot c
-    // holds chunk c ^ (px & 7), px the patch COLUMN -- conflict-free for both tap shifts, and row-independent, so
-    // a wave's pixel rows are one base address + immediates (scripts/lds_swizzle_check.py fwd_patch32)
+    // slot c of pixel p holds chunk c ^ (p & 6) (p & 6 == sr & 6: RPP j does not touch bits 1-2)
     const int gchA = (sc ^ (sr & 6)) * 8;
     int pixb[PJ];                            // source pixel index of the patch pixel for window offset (0,0)
-    unsigned vmask[PJ];                      // bit q: inside the image for window q of this phase; M32: bits 8-.. channel offset
+    unsigned vmask[PJ];                      // bit q: inside the image for window q of this phase
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int p = j * RPP + sr;
@@ -678,7 +667,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
             const int yy = y + (int)((wby16 >> (4 * q)) & 15u) - 8, xx = x + (int)((wbx16 >> (4 * q)) & 15u) - 8;
             if (q < pg.groups && p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
         }
-        vmask[j] = M32 ? (m | ((unsigned)((sc ^ (px & 7)) * 8) << 8)) : m;
+        vmask[j] = m;
     }
     const int gchB = (sc ^ ((sr >> 1) & 7)) * 8;
     // LDS row rho = 16 nt + i of a wave's half of the weight tile holds output channel
@@ -688,11 +677,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int lr = sr + RPP * j, half = lr / BNW, rho = lr % BNW;
-        // M32: MFMA row m = rho % 32 of channel group rho / 32 produces accumulator register r of lane half h with
-        // m = 8 (r >> 2) + 4 h + (r & 3); that row holds channel 16 h + r: 16 consecutive channels per lane again
-        const int m32 = rho & 31;
-        const int ch = M32 ? half * BNW + (rho & 32) + 16 * ((m32 >> 2) & 1) + 4 * (m32 >> 3) + (m32 & 3)
-                           : half * BNW + (4 * NT) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+        const int ch = half * BNW + (4 * NT) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
         wrow[j] = (unsigned)((n0 + ch) * g.wtaps * g.Cin + gchB) * 2u;
     }
 
@@ -703,31 +688,11 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     for (int mt = 0; mt < MT; ++mt) pbase[mt] = (wm * 4 + mt) * PATCH_W + fr;
     const unsigned b_base = (unsigned)(PATCH_BYTES + (wn * BNW + fr) * 128);
     const int fswz = fr >> 1;
-    // M32 fragments: lane (n = lane % 32, h = lane / 32) reads chunk 2 ks + h of pixel (row n / 16, column n % 16) of a
-    // 32-pixel group and of weight row n of a 32-channel group.  chunk ^ swizzle = (2 ks ^ (s & 6)) | (h ^ (s & 1)):
-    // the k-step is an XOR of address bits 5-6, pixel-row pair and channel group are immediates.
-    const int n32 = lane & 31, h32 = lane >> 5;
-    unsigned pa32[2];
+    f4_t acc[MT][NT];
 #pragma unroll
-    for (int tx = 0; tx < 2; ++tx) {
-        const unsigned px = (unsigned)((n32 & 15) + tx);
-        pa32[tx] = ((unsigned)((wm * 4 + (n32 >> 4)) * PATCH_W) + px) * 128u + ((((unsigned)h32) ^ (px & 7u)) << 4);
-    }
-    const unsigned wa32 = (unsigned)(PATCH_BYTES + (wn * BNW + n32) * 128) + ((((unsigned)h32) ^ ((unsigned)(n32 >> 1) & 7u)) << 4);
-
-    typedef __attribute__((ext_vector_type(16))) float f16_t;
-    f4_t acc[M32 ? 1 : MT][M32 ? 1 : NT];
-    f16_t acc32[M32 ? 2 : 1][M32 ? 2 : 1];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int i = 0; i < (M32 ? 1 : MT); ++i)
-#pragma unroll
-        for (int j = 0; j < (M32 ? 1 : NT); ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < (M32 ? 2 : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < (M32 ? 2 : 1); ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
     // One step = one tap of one window: 64 channels of the patch against one weight tile.  The weight tile
     // of step i+1 is in flight (second buffer) while step i is multiplied; the patch is replaced every 4
@@ -741,13 +706,13 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
         const bool second = c0 >= g.C1;
         const int C = second ? g.C2 : g.C1;
-        const int cofs = (second ? c0 - g.C1 : c0) + (M32 ? 0 : gchA);
+        const int cofs = (second ? c0 - g.C1 : c0) + gchA;
         const int dpix = ((int)((wby16 >> (4 * q)) & 15u) - 8) * g.W + (int)((wbx16 >> (4 * q)) & 15u) - 8;
         if (abl & 2) return;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
             const unsigned vo = ((vmask[j] >> q) & 1u)
-                                    ? (unsigned)((pixb[j] + dpix) * C + cofs + (M32 ? (int)(vmask[j] >> 8) : 0)) * 2u : OOB;
+                                    ? (unsigned)((pixb[j] + dpix) * C + cofs) * 2u : OOB;
             if (second) FP_BLDS16(x2rs, vo, 0, smem + (j * RPP + wid * 8) * 128);
             else FP_BLDS16(x1rs, vo, 0, smem + (j * RPP + wid * 8) * 128);
         }
@@ -783,42 +748,6 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
                 else if (more) fire_b(gi + 1, 0, buf ^ 1);
             }
             const unsigned bb = b_base + (DBB ? buf * (BN * 128) : 0);
-            if constexpr (M32) {
-                // toff = ty * 17 + tx
-                const int ty = toff >= PATCH_W ? 1 : 0, tx = toff - ty * PATCH_W;
-                const unsigned pcur = (tx ? pa32[1] : pa32[0]) + (unsigned)(ty * PATCH_W * 128);
-                const unsigned wcur = wa32 + (DBB ? (unsigned)(buf * (BN * 128)) : 0u);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    bf8_t pf[2], wf[2];
-                    const unsigned pk = pcur ^ (unsigned)(ks << 5), wk = wcur ^ (unsigned)(ks << 5);
-#pragma unroll
-                    for (int gq = 0; gq < 2; ++gq) pf[gq] = *(const bf8_t*)(smem + pk + gq * (2 * PATCH_W * 128));
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) wf[j] = *(const bf8_t*)(smem + wk + j * (32 * 128));
-                    if (relu) {
-                        // volatile: keeps this a branch (as a select hipcc spends a v_cndmask per v_pk_max)
-                        typedef __attribute__((ext_vector_type(4))) int i4_t;
-#pragma unroll
-                        for (int gq = 0; gq < 2; ++gq) {
-                            i4_t xi = __builtin_bit_cast(i4_t, pf[gq]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                int t = xi[e];
-                                asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(t));
-                                xi[e] = t;
-                            }
-                            pf[gq] = __builtin_bit_cast(bf8_t, xi);
-                        }
-                    }
-#pragma unroll
-                    for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            // D[i = channel slot][j = pixel]
-                            acc32[gq][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[gq], acc32[gq][j], 0, 0, 0);
-                }
-            } else
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
@@ -875,8 +804,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if constexpr (M32) t += acc32[i & 1][j & 1][(i >> 1) * 4 + (j >> 1)];
-                else t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+                t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
             }
         if (t == 123.456f) *(float*)a.y1 = t;
         return;
@@ -892,53 +820,6 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     // wn*(BN/2) + 4 NT fq + (4 nt + r): bias, statistics, activation, then one or two 16-B LDS stores per row
     constexpr int CL = 4 * NT;               // channels per lane
     const int col0 = wn * BNW + CL * fq;
-    if constexpr (M32) {
-        // lane (n32, h32): accumulator acc32[gq][j][r] = channel wn*64 + 32 j + 16 h32 + r of tile pixel wm*64 + 32 gq + n32
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c0l = wn * BNW + 32 * j + 16 * h32;
-            float bv[16], cs[16], cq[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { bv[c] = a.bias ? a.bias[n0 + c0l + c] : 0.f; cs[c] = cq[c] = 0.f; }
-#pragma unroll
-            for (int gq = 0; gq < 2; ++gq) {
-                const int row = wm * 64 + gq * 32 + n32;
-                unsigned pk[8];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    float v0 = acc32[gq][j][r] + bv[r], v1 = acc32[gq][j][r + 1] + bv[r + 1];
-                    cs[r] += v0; cq[r] = fmaf(v0, v0, cq[r]);
-                    cs[r + 1] += v1; cq[r + 1] = fmaf(v1, v1, cq[r + 1]);
-                    if (eact == PAI_ACT_LRELU) { v0 = fmaxf(v0, 0.2f * v0); v1 = fmaxf(v1, 0.2f * v1); }
-                    else if (eact == PAI_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                    pk[r >> 1] = pk2bf(v0, v1);
-                }
-                *(uint4*)(Cs + row * CROW + c0l * 2) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                *(uint4*)(Cs + row * CROW + c0l * 2 + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-            }
-            if (a.stats) {
-                // sum over the 16 lanes of each DPP row (pixels of one patch row); the wave's two rows per lane half
-                // land in their own sstat rows: [2 wm + n32 / 16][2][BN]
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    float sv = cs[c], qv = cq[c];
-                    sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0xB1, 0xF, 0xF, false));
-                    qv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0xB1, 0xF, 0xF, false));
-                    sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x4E, 0xF, 0xF, false));
-                    qv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0x4E, 0xF, 0xF, false));
-                    sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x141, 0xF, 0xF, false));
-                    qv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0x141, 0xF, 0xF, false));
-                    sv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv), 0x140, 0xF, 0xF, false));
-                    qv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv), 0x140, 0xF, 0xF, false));
-                    if (fr == 0) {
-                        const int sr2 = 2 * wm + (n32 >> 4);
-                        sstat[(sr2 * 2 + 0) * BN + c0l + c] = sv;
-                        sstat[(sr2 * 2 + 1) * BN + c0l + c] = qv;
-                    }
-                }
-            }
-        }
-    } else {
     float bias_v[CL], csum[CL], csq[CL];
 #pragma unroll
     for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
@@ -983,13 +864,12 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
             }
         }
     }
-    }
     __syncthreads();
     if (a.stats && tid < BN) {
         float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + n0 + tid;
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < (M32 ? 2 * WM : WM); ++i) { s += sstat[(i * 2 + 0) * BN + tid]; q += sstat[(i * 2 + 1) * BN + tid]; }
+        for (int i = 0; i < WM; ++i) { s += sstat[(i * 2 + 0) * BN + tid]; q += sstat[(i * 2 + 1) * BN + tid]; }
         dst[0] = s;
         dst[g.Cout] = q;
     }
@@ -1044,19 +924,13 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 
 template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
-    gg_fwd_patch_body<BM, BN, DBB, false>(g, a, pg, mtiles, ntiles);
+    gg_fwd_patch_body<BM, BN, DBB>(g, a, pg, mtiles, ntiles);
 }
 // 64 output channels, one wave column: BM / 64 waves of 64 x 64 (see gg_fwd_patch_body, WN = 1)
 template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM, 3) void gg_fwd_patch1_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
-    gg_fwd_patch_body<BM, BN, DBB, false, 1>(g, a, pg, mtiles, ntiles);
+    gg_fwd_patch_body<BM, BN, DBB, 1>(g, a, pg, mtiles, ntiles);
 }
-// the 32x32x16 form (two weight-tile buffers, 128-channel tiles)
-template <int BM, int BN>
-__global__ __launch_bounds__(BM * 2, BM == 128 ? 3 : 4) void gg_fwd_patch32_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
-    gg_fwd_patch_body<BM, BN, true, true>(g, a, pg, mtiles, ntiles);
-}
-
 template <int BM, int BN, bool DB, int WR = 64>
 static size_t fwd_lds_bytes() {
     const size_t main_loop = (size_t)(DB ? 2 : 1) * (BM * 128 + BN * 128);
@@ -1135,16 +1009,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             }
             const int mt256 = g.M / 256;
             const dim3 grid256(mt256 * ntiles * g.nphase);
-            if (pai_tunable("fwd_m32", 0)) {
-                static bool attr32 = false;
-                if (!attr32) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patch32_k<256, 128>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                    PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-                    attr32 = true;
-                }
-                hipLaunchKernelGGL((gg_fwd_patch32_k<256, 128>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
-            } else if (db) hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+            if (db) hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
             else hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, false>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
         } else if (prow == 128 && patch_geo(g, 8, &pg)) {
             typedef PatchDims<128> PD;
@@ -1153,8 +1018,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 4 * 2 * c.bn * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
             if (c.bn == 128) {
-                if (pai_tunable("fwd_m32", 0)) hipLaunchKernelGGL((gg_fwd_patch32_k<128, 128>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
-                else if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
                 else hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
             } else {
                 if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 64, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
@@ -1183,8 +1047,6 @@ const char* fwd_mfma_kernel_name(const GG& g) {
     const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
     const int prow = patch_rows(g, c);
     if (prow == 256 && c.bn == 64) return (dbb & 4) ? "gg_fwd_patch1_k<256, 64, true>" : "gg_fwd_patch1_k<256, 64, false>";
-    if (prow == 256 && pai_tunable("fwd_m32", 0)) return "gg_fwd_patch32_k<256, 128>";
-    if (prow == 128 && c.bn == 128 && pai_tunable("fwd_m32", 0)) return "gg_fwd_patch32_k<128, 128>";
     if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";
     if (prow == 128) {
         if (c.bn == 128) return (dbb & 2) ? "gg_fwd_patch_k<128, 128, true>" : "gg_fwd_patch_k<128, 128, false>";

@@ -353,7 +353,7 @@ int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, 
 
 // ---- host side ----------------------------------------------------------------------------------------------
 static int wg3_variant(const GG& g) {   // 0: not eligible, 1: <128, 64>, 2: <64, 128>
-    const int mode = pai_tunable("wgrad3", 1);
+    const int mode = pai_tunable("wgrad3", 3);   // bit 0: the 128 x 64 wave tile, bit 1: the 64 x 128 one; 0: gg_wgrad_patch_k
     if (!mode) return 0;
     PatchGeo pg;
     // 32-bit byte offsets into buffer descriptors: every tensor below 2 GB

@@ -106,6 +106,10 @@ class GradReducer:
         self._subs[id(arena)] = fn
         return True
 
+    def unsubscribe(self, arena) -> None:
+        """Drop a subscription that has not fired (the subscriber gave up: ``ArenaAdam._disarm``)."""
+        self._subs.pop(id(arena), None)
+
     def _launch(self, st, lo, hi):
         if hi <= lo:
             return

@@ -61,9 +61,9 @@ class GraphedStep:
         if self.graph is None:
             if self.calls <= self.warmup:
                 return m.training_step(batch, batch_idx)
-            self._capture(batch)
+            eager = self._capture(batch)
             if self.graph is None:       # capture refused (self.disabled says why): that call ran the step eagerly
-                return None
+                return eager
         for s, b in zip(self.static, batch):
             s.copy_(b, non_blocking=True)
         self.graph.replay()
@@ -78,10 +78,11 @@ class GraphedStep:
     def _capture(self, batch):
         m = self.model
         opts = m._all_optimizers()
-        for opt in opts:
+        for opt in opts:       # all or nothing: no optimizer is switched to device-side counting unless every one can be
             if not hasattr(opt, "enable_device_step"):
                 self.disabled = f"{type(opt).__name__} keeps its step count on the host"
                 return m.training_step(batch, 0)
+        for opt in opts:
             opt.enable_device_step()
         # the engines' cross-stream events recorded by earlier (un-captured) steps must not be waited on inside the capture
         for mod in m.modules():

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
     "pai_pack_frag": (_I, [_P, _I, _I, _P, _P]),
+    "pai_build_flags": (_I, []),
     "pai_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),

@@ -241,6 +241,18 @@ class ModelCheckpoint(Callback):
         self.best_model_score = None
         self.best_model_path = ""
 
+    def state_dict(self):
+        """Carried in checkpoints (Trainer.save_checkpoint) so that a resumed run does not overwrite best.ckpt with a
+        worse first validation."""
+        score = self.best_model_score
+        return {"monitor": self.monitor, "best_model_score": None if score is None else float(score),
+                "best_model_path": self.best_model_path}
+
+    def load_state_dict(self, state):
+        if state.get("monitor") == self.monitor:
+            self.best_model_score = state.get("best_model_score")
+            self.best_model_path = state.get("best_model_path", "")
+
     def _dir(self, trainer):
         if self.dirpath:
             return self.dirpath

@@ -27,6 +27,7 @@ class ArenaAdam(torch.optim.Adam):
         self._dev_coeff = None
         self._streamed = None          # streaming step armed: elements of the arena already updated by the hook
         self._stream_step = 0
+        self._reducer = None           # the GradReducer the armed step subscribed to (data parallel)
 
     # ---- hipGraph support -----------------------------------------------------------------------------
     def enable_device_step(self):
@@ -70,9 +71,15 @@ class ArenaAdam(torch.optim.Adam):
         if len(params) != len(arena.params) or not arena.params_adopted():
             return False
         if reducer is not None:
-            # data parallel: the reducer owns the hook; the update of a bucket follows its all-reduce + average
+            # data parallel: the reducer owns the hook; the update of a bucket follows its all-reduce + average.
+            # OPT-IN (PAI_DDP_STREAM_ADAM=1): this path updates parameters on a third stream while the backward pass
+            # is still running and has only been exercised with two ranks on ONE GPU over gloo (tests/test_gpu_ddp.py),
+            # never over RCCL on several GPUs; until it has, the default under a reducer is the update in step().
+            if os.environ.get("PAI_DDP_STREAM_ADAM", "0") in ("", "0"):
+                return False
             if not reducer.subscribe(arena, self._on_reduced):
                 return False
+            self._reducer = reducer
         else:
             self._engine.grad_ready_hook = self._on_ready
         self._streamed = 0
@@ -86,6 +93,12 @@ class ArenaAdam(torch.optim.Adam):
                      float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), step)
 
     def _on_ready(self, arena, end_offset):
+        if int(end_offset) < self._streamed:
+            # a SECOND backward pass into this arena before step(): its gradients would be added behind an update that
+            # has already consumed the first pass (GradArena.begin_backward allows accumulation; a streaming step
+            # cannot honour it) -- same guard as GradReducer._on_ready
+            raise ops.PaiError("ArenaAdam: a streaming step is armed and a second backward pass reached this arena "
+                               "before step(); use one backward pass per optimizer step or do not arm_streaming()")
         with torch.no_grad():
             self._adam_range(arena, self._streamed, int(end_offset), self._stream_step)
         self._streamed = max(self._streamed, int(end_offset))
@@ -101,6 +114,11 @@ class ArenaAdam(torch.optim.Adam):
     def _disarm(self):
         if getattr(self._engine, "grad_ready_hook", None) == self._on_ready:
             self._engine.grad_ready_hook = None
+        reducer = getattr(self, "_reducer", None)
+        if reducer is not None:
+            # a subscription whose backward pass never activated the arena must not fire in a later pass
+            reducer.unsubscribe(self._engine.arena())
+            self._reducer = None
         self._streamed = None
 
     # ---- helpers --------------------------------------------------------------------------------
@@ -196,6 +214,9 @@ class ArenaAdam(torch.optim.Adam):
                 st["exp_avg"], st["exp_avg_sq"] = m, v
                 st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32)   # host scalar, as _mirror_state keeps it
         self._arena_steps = 0
+        if self._dev_step is not None:
+            # graph mode: the bias correction continues from the LOADED step count, not from the one captured before
+            self._dev_step.fill_(self.total_steps)
 
 
 class MultiAdam(torch.optim.Adam):
