@@ -71,10 +71,11 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(attention=False, b4_steps=20, b64_steps=1):
+def cpu_baseline(attention=False, b4_steps=20, b64_steps=3):
     """The oracle's CPU restatement of the same GAN step (fp32, the ATen kernels the reference dispatches to) on this
     box's host cores, at BOTH batch sizes BASELINE.md section 4 asks for: batch 4 (BASELINE configs[0], the headline
-    `value`) and batch 64 (the GPU workload's batch; one step, no warm-up -- it takes ~15 s)."""
+    `value`: 1 warm-up + 20 timed steps) and batch 64 (the GPU workload's batch: 1 warm-up + 3 timed steps of ~7 s each,
+    bounded so that the default run still ends within minutes)."""
     import oracle
     torch.set_num_threads(host_cores())
     make = oracle.make_attention_unet_state if attention else oracle.make_unet_state
@@ -94,11 +95,39 @@ def cpu_baseline(attention=False, b4_steps=20, b64_steps=1):
         return batch * steps / (time.perf_counter() - t0)
 
     v4 = run(4, 1, b4_steps)
-    v64 = run(64, 0, b64_steps) if b64_steps > 0 else None
+    v64 = run(64, 1, b64_steps) if b64_steps > 0 else None
     return {"value": round(v4, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{b4_steps} fp32 GAN steps at batch 4 (BASELINE configs[0]), 1 warm-up, oracle/step_ref.py on "
-                      f"torch-CPU; value_b64: {b64_steps} step at batch 64, no warm-up",
+                      f"torch-CPU; value_b64: {b64_steps} timed steps at batch 64 after 1 warm-up step, same cores",
             "value_b64": None if v64 is None else round(v64, 3)}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N worker processes (one rank each, torchrun-style
+    environment, rendezvous on 127.0.0.1) and wait for them.  This parent never touches the GPU -- it runs before
+    any HIP call and only counts devices -- and nothing is re-exec'ed: the workers are ordinary children whose exit
+    codes it returns.  On a box with fewer GPUs than ranks (the one-GPU development box) the ranks share device 0
+    and talk over gloo (RCCL wants one GPU per rank); rank 0's single JSON line says which."""
+    import socket
+    import subprocess
+    ngpu = torch.cuda.device_count()          # no context is created by counting
+    if ngpu < 1:
+        raise SystemExit("bench.py needs a GPU: there is no CPU path")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PAI_BENCH_SPAWNED="1")
+    if ngpu < n:
+        env.setdefault("PAI_DIST_BACKEND", "gloo")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r % ngpu))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -134,6 +163,8 @@ def main():
                     help="name=value,... launch-configuration switches (pai_set_tunable) for A/B runs on one box; the "
                          "line then carries them under config.tunables")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))        # before anything touches the GPU
 
     import pai_bootstrap
     pai = pai_bootstrap.load()
@@ -337,7 +368,8 @@ def main():
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "channel_mults": list(mults), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}",
-                   "grad_bucket_dtype": args.grad_dtype},
+                   "grad_bucket_dtype": args.grad_dtype,
+                   **({"backend": torch.distributed.get_backend(), "gpus_visible": torch.cuda.device_count()} if world > 1 else {})},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "launch_mode": ("hipGraph replay (one launch per step)" if graphed is not None and graphed.graph is not None else
                         "eager" + (f" ({graphed.disabled})" if graphed is not None and graphed.disabled else "")),

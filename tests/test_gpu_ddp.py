@@ -214,3 +214,25 @@ def test_reduced_gradients_equal_mean_of_local(family):
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two worker ranks before it
+    touches the GPU (here both on the one GPU of the box, over gloo), rank 0 prints the ONE JSON line with n_gpus = 2,
+    for the weak (64 images per rank in production, 4 here) and the strong (--global-batch) form.  reference
+    main.py:123-136 gets its ranks from pl.Trainer."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for extra, scaling, per_gpu in ((["--batch", "4"], "weak", 4), (["--global-batch", "8"], "strong", 4)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--no-cpu-baseline", "--no-kernel-events"] + extra, env=env, capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["config"]["per_gpu_batch"] == per_gpu
+        assert rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2" and rec["value"] > 0

@@ -1700,7 +1700,9 @@ bool wgrad_mfma_can_overwrite(const GG& g) {
     int rows;
     if (wgrad2_ok(g)) return false;
     if (wgrad3_ok(g)) return wgrad3_overwrites(g);
-    return g.nphase == 1 && !wgrad_mfma_uses_patch(g) && wgrad_mfma_splits(g, &rows) == 1;
+    // un-split gg_wgrad_mfma_k: one writer per dW element (the taps of different phases are disjoint); the bias sums of
+    // several phases meet by atomics, launch_wgrad_mfma clears dbias for them
+    return !wgrad_mfma_uses_patch(g) && wgrad_mfma_splits(g, &rows) == 1;
 }
 
 static int wgrad_mfma_splits(const GG& g, int* rows_out) {
@@ -1763,6 +1765,10 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     }
     const size_t lds = 2 * 64 * 256;
     dim3 grid(tiles * splits);
+    if (a.overwrite && a.dbias && g.nphase > 1) {
+        hipError_t e = hipMemsetAsync(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
+        PAI_CHECK(e == hipSuccess, "launch_wgrad_mfma: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
     if (big)
         hipLaunchKernelGGL(gg_wgrad_mfma_k<128>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
     else

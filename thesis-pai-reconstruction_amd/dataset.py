@@ -19,13 +19,17 @@ from .lightning import LightningDataModule
 
 def load_gray_256(path: str, size: int = 256, normalize: bool = True) -> torch.Tensor:
     """read_image(GRAY) -> Resize((256,256), antialias=True) on uint8 -> float32/255 -> [-1,1]
-    (reference dataset.py:51-59,129-132).  PIL's BILINEAR resize is the antialiased bilinear
-    filter torchvision's antialias=True reproduces."""
+    (reference dataset.py:51-59,129-132).  The resize is the reference's own operator: torchvision 0.15 casts the
+    uint8 tensor to float32, runs aten's antialiased bilinear kernel (``interpolate(..., mode="bilinear",
+    antialias=True, align_corners=False)``), rounds (half to even) and casts back to uint8 BEFORE the division by
+    255 -- byte work, reproduced bit for bit (PIL's BILINEAR filter accumulates with 8-bit fixed-point weights and is
+    one uint8 step off on ~1 % of the pixels; PIL only decodes here)."""
     from PIL import Image
-    img = Image.open(path).convert("L")
-    if img.size != (size, size):
-        img = img.resize((size, size), Image.BILINEAR)
-    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(torch.float32).div_(255).unsqueeze(0)
+    img = torch.from_numpy(np.asarray(Image.open(path).convert("L"), dtype=np.uint8).copy())
+    if tuple(img.shape) != (size, size):
+        img = torch.nn.functional.interpolate(img[None, None].to(torch.float32), size=(size, size), mode="bilinear",
+                                              antialias=True, align_corners=False).round_().to(torch.uint8)[0, 0]
+    x = img.to(torch.float32).div_(255).unsqueeze(0)
     return x * 2 - 1 if normalize else x
 
 

@@ -84,6 +84,8 @@ class GradArena:
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.views = {}
         self.params = []
+        self._small = []      # segments that are ACCUMULATED into (BatchNorm gamma / beta) or never written (conv biases in
+        #                       front of a BatchNorm): cleared per backward pass; the conv weights are overwritten instead
         for p, mod in entries:
             o, n = self.offsets[id(p)]
             seg = self.flat[o:o + n]
@@ -92,6 +94,7 @@ class GradArena:
                 v = seg.view(cout, 4, 4, cin).permute(_logical_perm(mod))
             else:
                 v = seg.view(p.shape)
+                self._small.append(seg)
             self.views[id(p)] = v
             self.params.append(p)
 
@@ -106,17 +109,24 @@ class GradArena:
         o, n = self.offsets[id(p)]
         return (o + n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
 
-    def begin_backward(self, params) -> None:
-        """Zero the arena unless ``params`` already carry this arena's views (gradient
-        accumulation across several backward passes)."""
+    def begin_backward(self, params, overwrite_weights: bool = False) -> bool:
+        """Prepare the arena for a backward pass; returns True for the FIRST pass since ``zero_grad`` (``params`` carry
+        no gradients yet), False when they already carry this arena's views (gradient accumulation across several
+        backward passes: nothing is cleared).  First pass: the arena is zeroed -- or, with ``overwrite_weights``, only
+        its small segments are (one multi-tensor launch instead of a 218 MB fill for the Pix2Pix generator): the caller
+        then promises to OVERWRITE every conv-weight segment (``pai_conv_wgrad_overwrite``) in that pass."""
         grads = [p.grad for p in params if p.requires_grad]
         if all(g is None for g in grads):
-            self.flat.zero_()
-            return
+            if overwrite_weights and self._small:
+                torch._foreach_zero_(self._small)
+            else:
+                self.flat.zero_()
+            return True
         for p in params:
             if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.view(p).data_ptr()):
                 raise ops.PaiError("gradient arena: parameters carry foreign .grad tensors; call "
                                    "zero_grad(set_to_none=True) before backward")
+        return False
 
     def attach(self, params) -> None:
         for p in params:
@@ -592,8 +602,11 @@ class UnetEngine:
         return pred, S
 
     # ---- backward ---------------------------------------------------------------------------
-    def backward(self, S, gpred: torch.Tensor):
-        """Accumulates every parameter gradient into the arena.  gpred: fp32, pred's shape."""
+    def backward(self, S, gpred: torch.Tensor, fresh: bool = False):
+        """Accumulates every parameter gradient into the arena.  gpred: fp32, pred's shape.  ``fresh``: this is the first
+        backward pass since zero_grad and ``GradArena.begin_backward(..., overwrite_weights=True)`` left the conv-weight
+        segments un-cleared: every weight (and non-BatchNorm bias) gradient is then WRITTEN (pai_conv_wgrad_overwrite: no
+        zero fill, no read of dW) instead of added."""
         P = S["P"]
         L, N, dtype = self.L, P["N"], P["dtype"]
         eh, ew = P["eh"], P["ew"]
@@ -612,10 +625,12 @@ class UnetEngine:
 
         side = self._side
 
+        conv_wgrad = ops.conv_wgrad_overwrite if fresh else ops.conv_wgrad
+
         def wgrad(d, x1, x2, dz, conv, with_bias):
             """Weight (and bias) gradient of one layer on the side stream."""
             with torch.cuda.stream(side.fork(d)):
-                ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
+                conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
                 done(conv.bias)
 
         # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
@@ -715,7 +730,7 @@ class UnetEngine:
         # encoder 0 (its dz came out of encoder 1's input gradient): on the tail stream, beside encoder 1's
         conv0 = self.enc_conv[0]
         with torch.cuda.stream(side.fork_tail()):
-            ops.conv_wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
+            conv_wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
         side.join()
         done(conv0.bias)      # both side streams have been joined: the whole arena is final
 
@@ -831,7 +846,9 @@ class DiscEngine:
         ops.conv_fwd(P["desc"][4], S["a"][3], None, wf, None, y_f32=S["logits"])
         return S["logits"], S
 
-    def backward(self, S, glogits, need_params: bool, need_dy: bool):
+    def backward(self, S, glogits, need_params: bool, need_dy: bool, fresh: bool = False):
+        """``fresh``: see UnetEngine.backward."""
+        conv_wgrad = ops.conv_wgrad_overwrite if fresh else ops.conv_wgrad
         P = S["P"]
         N, H, W, dtype, dev = P["N"], P["H"], P["W"], P["dtype"], P["device"]
         if S["grads"] is None:
@@ -852,7 +869,7 @@ class DiscEngine:
         side = self._side
         if need_params:
             with torch.cuda.stream(side.fork(d)):
-                ops.conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
+                conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
                 if hook is not None:
                     hook(A, A.end_of(self.convs[4].weight))
             side.mark_scratch()
@@ -865,10 +882,10 @@ class DiscEngine:
             if need_params and k == 0:
                 # thin first layer: tail stream, beside block 1's weight gradient; its hook fires after the join
                 with torch.cuda.stream(side.fork_tail()):
-                    ops.conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
+                    conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
             elif need_params:
                 with torch.cuda.stream(side.fork(d)):
-                    ops.conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                    conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
                     if hook is not None:
                         hook(A, A.end_of(conv.bias))
             if k > 0:

@@ -62,8 +62,8 @@ class UnetFunction(torch.autograd.Function):
     def backward(ctx, gpred):
         engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
         arena = engine.arena()
-        arena.begin_backward(params)
-        engine.backward(slot, gpred)
+        fresh = arena.begin_backward(params, overwrite_weights=True)
+        engine.backward(slot, gpred, fresh)
         arena.attach(params)
         engine.release(slot)
         return (None,) * (5 + len(params))
@@ -86,10 +86,11 @@ class DiscFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, glogits):
         engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
+        fresh = False
         if ctx.need_params:
             arena = engine.arena()
-            arena.begin_backward(params)
-        gy = engine.backward(slot, glogits, ctx.need_params, ctx.need_dy)
+            fresh = arena.begin_backward(params, overwrite_weights=True)
+        gy = engine.backward(slot, glogits, ctx.need_params, ctx.need_dy, fresh)
         if ctx.need_params:
             arena.attach(params)
         engine.release(slot)
@@ -116,8 +117,8 @@ class DiscPairsFunction(torch.autograd.Function):
     def backward(ctx, glogits):
         engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
         arena = engine.arena()
-        arena.begin_backward(params)
-        engine.backward(slot, glogits, True, False)
+        fresh = arena.begin_backward(params, overwrite_weights=True)
+        engine.backward(slot, glogits, True, False, fresh)
         arena.attach(params)
         engine.release(slot)
         return (None,) * (5 + len(params))
