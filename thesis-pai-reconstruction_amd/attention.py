@@ -42,6 +42,8 @@ class _Gate:
 
 
 class AttentionUnetEngine(UnetEngine):
+    overwrites_weight_grads = False    # the gate gradients are added into a cleared arena
+
     def __init__(self, unet: nn.Module):
         super().__init__(unet)
         # attention_blocks[k] gates the skip of decoder k+1 (reference :199-203)

@@ -329,6 +329,8 @@ class _SideStream:
 # generator
 # --------------------------------------------------------------------------------------
 class UnetEngine:
+    overwrites_weight_grads = True     # backward(..., fresh=True) writes every conv-weight gradient (see GradArena.begin_backward)
+
     def __init__(self, unet: nn.Module):
         self.unet = unet
         encs, decs = list(unet.encoders), list(unet.decoders)

@@ -62,8 +62,12 @@ class UnetFunction(torch.autograd.Function):
     def backward(ctx, gpred):
         engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
         arena = engine.arena()
-        fresh = arena.begin_backward(params, overwrite_weights=True)
-        engine.backward(slot, gpred, fresh)
+        if getattr(engine, "overwrites_weight_grads", False):
+            fresh = arena.begin_backward(params, overwrite_weights=True)
+            engine.backward(slot, gpred, fresh)
+        else:       # engines that ADD every gradient (attention U-Net): the whole arena is cleared
+            arena.begin_backward(params)
+            engine.backward(slot, gpred)
         arena.attach(params)
         engine.release(slot)
         return (None,) * (5 + len(params))
