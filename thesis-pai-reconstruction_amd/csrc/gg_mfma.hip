@@ -112,6 +112,8 @@ static int fwd_effective_ksplit(const GG& g) {
     return ks;
 }
 
+int fwd_mfma_ksplit_effective(const GG& g) { return fwd_effective_ksplit(g); }
+
 // number of BN partial-statistics rows per phase this launch configuration writes
 // rows per workgroup of the patch-resident kernel for this problem: 0 (not applicable), 128 or 256
 static int patch_rows(const GG& g, const FwdCfg& c);
@@ -972,6 +974,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             if (pai_tunable("fwd_splitk_db", 1)) FWD_LAUNCH(128, 128, true, true); else FWD_LAUNCH(128, 128, true, false);
         } else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
+        if (a.skip_finish) return 0;      // the caller finishes the slabs itself (gg_finish.hip)
         const int ftiles = cdiv(g.M, FIN_ROWS);
         hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
                            pai_ctx()->workspace, ftiles, c.ksplit);

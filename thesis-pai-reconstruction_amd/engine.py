@@ -255,6 +255,14 @@ class _BNState:
         self.sums = torch.empty(2 * C, dtype=torch.float32, device=device)
 
 
+def _conv_bn_train(d, x1, x2, wf, bias, z, a, act, bn: nn.BatchNorm2d, st: _BNState, n_updates, stats):
+    """Convolution + BatchNorm2d(train) + activation (pai_conv_fwd_bn: one fused finish launch for the bottleneck
+    layers, conv -> finalize -> apply for the others)."""
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    ops.conv_fwd_bn(d, x1, x2, wf, bias, z, a, act, bn.weight, bn.bias, float(bn.eps), float(mom), n_updates,
+                    bn.running_mean, bn.running_var, bn.num_batches_tracked, st.mean, st.rstd, st.scale, st.shift, stats)
+
+
 def _bn_forward(bn: nn.BatchNorm2d, st: _BNState, stats, rows, count, training, n_updates):
     C = bn.num_features
     if training:
@@ -549,15 +557,13 @@ class UnetEngine:
             if bn is not None:
                 M = N * eh[i] * ew[i]
                 if training:
-                    rows = ops.conv_fwd_stats_rows(d)
-                    ops.conv_fwd(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, y_raw=S["z"][i],
-                                 stats=P["stats"])
-                    _bn_forward(bn, S["ebn"][i], P["stats"], rows, M, True, bn_updates)
+                    _conv_bn_train(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, S["z"][i], S["a"][i], ACT_LRELU,
+                                   bn, S["ebn"][i], bn_updates, P["stats"])
                 else:
                     ops.conv_fwd(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, y_raw=S["z"][i])
                     _bn_forward(bn, S["ebn"][i], None, 0, M, False, 0)
-                ops.bn_apply(dtype, S["z"][i], M, self.enc_c[i], S["ebn"][i].scale, S["ebn"][i].shift,
-                             ACT_LRELU, S["a"][i])
+                    ops.bn_apply(dtype, S["z"][i], M, self.enc_c[i], S["ebn"][i].scale, S["ebn"][i].shift,
+                                 ACT_LRELU, S["a"][i])
             else:
                 ops.conv_fwd(d, S["a"][i - 1], None, wf, self.enc_conv[i].bias, y_raw=S["z"][i])
                 if i < L - 1:
@@ -578,16 +584,15 @@ class UnetEngine:
             if j < L - 1:
                 bn = self.dec_bn[j]
                 M = N * S["dh"][j] * S["dw"][j]
+                act = ACT_RELU if j < L - 2 else ACT_NONE
                 if training:
-                    rows = ops.conv_fwd_stats_rows(d)
-                    ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_raw=S["w"][j], stats=P["stats"])
-                    _bn_forward(bn, S["dbn"][j], P["stats"], rows, M, True, bn_updates)
+                    _conv_bn_train(d, x1, x2, wf, self.dec_conv[j].bias, S["w"][j], S["r"][j], act, bn, S["dbn"][j],
+                                   bn_updates, P["stats"])
                 else:
                     ops.conv_fwd(d, x1, x2, wf, self.dec_conv[j].bias, y_raw=S["w"][j])
                     _bn_forward(bn, S["dbn"][j], None, 0, M, False, 0)
-                act = ACT_RELU if j < L - 2 else ACT_NONE
-                ops.bn_apply(dtype, S["w"][j], M, self.dec_c[j], S["dbn"][j].scale, S["dbn"][j].shift, act,
-                             S["r"][j])
+                    ops.bn_apply(dtype, S["w"][j], M, self.dec_c[j], S["dbn"][j].scale, S["dbn"][j].shift, act,
+                                 S["r"][j])
                 if training and self.dec_drop[j] > 0:
                     # ReLU(Dropout2d(y)) == Dropout2d(ReLU(y)) (mask >= 0): applied to the stored activation
                     self._dropout(S, j, M, self.dec_c[j], dtype)
@@ -669,11 +674,10 @@ class UnetEngine:
                 ops.bn_bwd_reduce(dtype, G["gr"][j], act, None, ACT_NONE, S["r"][j] if act != ACT_NONE else None,
                                   S["w"][j], M, C, st.mean, st.rstd, du if act != ACT_NONE else None, part, st.sums,
                                   A.seg(bn.weight), A.seg(bn.bias))
-            else:
-                du = G["gr"][j]
-                ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
-            ops.bn_bwd_apply(dtype, du, S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
-            self._dbg(f"dec{j}.du", du); self._dbg(f"dec{j}.dz", dz)
+                ops.bn_bwd_apply(dtype, du, S["w"][j], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
+            # else: the input-gradient call of decoder j+1 carried this layer's BatchNorm backward through to dz
+            # (pai_conv_dgrad_bn_apply: sums, dgamma / dbeta and dz are written)
+            self._dbg(f"dec{j}.dz", dz)
             d = P["dec_desc"][j]
             if j == 0:
                 x1, x2 = S["z"][L - 1], None
@@ -694,10 +698,11 @@ class UnetEngine:
                               self.dec_c[j - 1], G["gr"][j - 1])
                 fused_rows = None
             else:
-                pst = S["dbn"][j - 1]   # producer: decoder j-1 (BatchNorm, read through ReLU)
-                fused_rows = ops.conv_dgrad_bn(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j], S["w"][j - 1],
-                                               ACT_RELU, None, ACT_NONE, pst.scale, pst.shift, pst.mean, pst.rstd,
-                                               part)
+                pst, pbn = S["dbn"][j - 1], self.dec_bn[j - 1]   # producer: decoder j-1 (BatchNorm, read through ReLU)
+                ops.conv_dgrad_bn_apply(d, dz, wd, G["gr"][j - 1], G["gskip"][L - 1 - j], S["w"][j - 1], ACT_RELU, None,
+                                        ACT_NONE, pst.scale, pst.shift, pst.mean, pst.rstd, part, pbn.weight, pst.sums,
+                                        A.seg(pbn.weight), A.seg(pbn.bias), G["dz_dec"][j - 1])
+                fused_rows = -1
         # last encoder (no norm)
         i = L - 1
         conv = self.enc_conv[i]
@@ -712,9 +717,11 @@ class UnetEngine:
             d = P["enc_desc"][i]
             if i - 1 == 0:   # bare Conv2d: no norm; the gradient written IS dz of encoder 0
                 return ops.conv_dgrad_bn(d, dz, wd, G["dz_enc"][0], None, S["z"][0], ACT_LRELU, G["gskip"][0], ACT_NONE)
-            pst = S["ebn"][i - 1]
-            return ops.conv_dgrad_bn(d, dz, wd, G["ga"][i - 1], None, S["z"][i - 1], ACT_LRELU, G["gskip"][i - 1],
-                                     ACT_RELU, pst.scale, pst.shift, pst.mean, pst.rstd, part)
+            pst, pbn = S["ebn"][i - 1], self.enc_bn[i - 1]
+            ops.conv_dgrad_bn_apply(d, dz, wd, G["ga"][i - 1], None, S["z"][i - 1], ACT_LRELU, G["gskip"][i - 1], ACT_RELU,
+                                    pst.scale, pst.shift, pst.mean, pst.rstd, part, pbn.weight, pst.sums,
+                                    A.seg(pbn.weight), A.seg(pbn.bias), G["dz_enc"][i - 1])
+            return -1
 
         fused_rows = enc_dgrad(i, dz, wd)
         # BN encoders
@@ -722,9 +729,7 @@ class UnetEngine:
             bn, st, conv = self.enc_bn[i], S["ebn"][i], self.enc_conv[i]
             M = N * eh[i] * ew[i]
             C = self.enc_c[i]
-            du, dz = G["ga"][i], G["dz_enc"][i]
-            ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
-            ops.bn_bwd_apply(dtype, du, S["z"][i], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
+            dz = G["dz_enc"][i]       # written by encoder i+1's input-gradient call (pai_conv_dgrad_bn_apply)
             d = P["enc_desc"][i]
             wgrad(d, S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)

@@ -38,6 +38,14 @@ class BwdEpilogue(C.Structure):
                 ("act1", C.c_int32), ("act2", C.c_int32)]
 
 
+class BnTrain(C.Structure):
+    """struct pai_bn_train (include/pai_hip.h)."""
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("n_updates", C.c_int32), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -75,6 +83,9 @@ SIGNATURES = {
     "pai_conv_dgrad_bn_rows_max": (_I, [_D]),
     "pai_conv_dgrad_bn": (_I, [_D, _P, _P, _P, _P, C.POINTER(BwdEpilogue), C.POINTER(_I), _P]),
     "pai_bn_bwd_finalize": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "pai_conv_fwd_bn": (_I, [_D, _P, _P, _P, _P, _P, _P, _I, C.POINTER(BnTrain), _P, _P]),
+    "pai_conv_dgrad_bn_apply": (_I, [_D, _P, _P, _P, _P, C.POINTER(BwdEpilogue), _P, _P, _P, _P, _P, _P]),
+    "pai_conv_bn_fused": (_I, [_D, _I]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),

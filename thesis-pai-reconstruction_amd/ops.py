@@ -258,6 +258,35 @@ def conv_dgrad_bn(d, dy, w_dgrad, dx1, dx2, z, act1, add=None, act2=ACT_NONE, sc
     return rows.value
 
 
+def conv_fwd_bn(d, x1, x2, w, bias, z, a, act, gamma, beta, eps, momentum, n_updates, running_mean, running_var,
+                num_batches_tracked, mean, rstd, scale, shift, stats):
+    """Convolution + BatchNorm2d(train) + activation in one call (pai_conv_fwd_bn)."""
+    f32 = torch.float32
+    bn = L.BnTrain(_p(gamma, f32), _p(beta, f32), float(eps), float(momentum), int(n_updates), _p(running_mean, f32),
+                   _p(running_var, f32), _p(num_batches_tracked, torch.int64), _p(mean, f32), _p(rstd, f32),
+                   _p(scale, f32), _p(shift, f32))
+    with _Timed(d, 0):
+        L.check(L.load().pai_conv_fwd_bn(C.byref(d), _p(x1), _p(x2), _p(w), _p(bias, f32), _p(z), _p(a), int(act),
+                                         C.byref(bn), _p(stats, f32), _stream()), "pai_conv_fwd_bn")
+
+
+def conv_bn_fused(d, op: int) -> bool:
+    return L.load().pai_conv_bn_fused(C.byref(d), op) == 1
+
+
+def conv_dgrad_bn_apply(d, dy, w_dgrad, du_scratch, dx2, z, act1, add, act2, scale, shift, mean, rstd, partials, gamma,
+                        sums, dgamma, dbeta, dz):
+    """Input gradient + the producer's complete BatchNorm backward (pai_conv_dgrad_bn_apply): writes dz, sums and adds
+    dgamma / dbeta."""
+    f32 = torch.float32
+    e = L.BwdEpilogue(_p(z), _p(add), _p(scale, f32), _p(shift, f32), _p(mean, f32), _p(rstd, f32), _p(partials, f32),
+                      int(act1), int(act2))
+    with _Timed(d, 1):
+        L.check(L.load().pai_conv_dgrad_bn_apply(C.byref(d), _p(dy), _p(w_dgrad), _p(du_scratch), _p(dx2), C.byref(e),
+                                                 _p(gamma, f32), _p(sums, f32), _p(dgamma, f32), _p(dbeta, f32), _p(dz),
+                                                 _stream()), "pai_conv_dgrad_bn_apply")
+
+
 def bn_bwd_finalize(partials, rows, C_, sums, dgamma, dbeta):
     L.check(L.load().pai_bn_bwd_finalize(_p(partials, torch.float32), rows, C_, _p(sums, torch.float32),
                                          _p(dgamma, torch.float32), _p(dbeta, torch.float32), _stream()),
