@@ -11,7 +11,7 @@
 // thread sums the K-split slabs of its <= 16 rows (two 16-B loads per row and slab), the 8 channel statistics meet in
 // the workgroup (fp64, deterministic), and the same threads normalise / back-propagate the values they still hold in
 // registers.  One launch instead of three, no intermediate tensor (z is written once, du never), 14 launches fewer on
-// the critical path of a training step.
+// the critical path of a training step.  STATUS (round 3): correct and tested, NOT faster -- see finish_fused_ok below.
 //
 // Serves nn.BatchNorm2d(train) + activation behind the bottleneck convolutions (reference models/pix2pix.py:63-70,99-106)
 // and the matching half of aten::native_batch_norm_backward.
@@ -37,29 +37,78 @@ __device__ __forceinline__ void fb_block_sums(const float* s1, const float* s2, 
     }
 }
 
-__global__ __launch_bounds__(256) void splitk_finish_bn_k(GG g, FinishBnArgs f) {
+// Sum of the K-split slabs for the rows of this workgroup's 8 channels (slab layout [split][channel group][row][8],
+// written by gg_fwd_mfma_k when FwdArgs.skip_finish is set: 32 B per thread, contiguous across the threads).  Thread (rl = tid % RL, sl = tid / RL): RL =
+// min(256, rows rounded up to a power of two) row lanes, SL = 256 / RL split lanes.  A thread owns rows rl + RL i and the
+// splits sl, sl + SL, ..; per split ALL its rows are requested before any is added (up to 32 independent 16-B loads in
+// flight per thread: with the split loop innermost a thread waited for memory once per four splits and row, and the
+// launch was a chain of ~30 memory round trips).  With SL > 1 (fewer than 256 rows: the 2 x 2 and 1 x 1 layers, whose
+// cost model picks 32-64 splits) the split lanes meet through LDS, in lane order (deterministic); the result is then
+// valid in the threads sl == 0 only.
+template <int NR>
+__device__ __forceinline__ void fb_slab_sum(const float* ws, int ksplit, int rows, int Cout, int c0, int tid, int RL,
+                                            float (*v)[8], float* xch /* LDS [256][8] or NULL when SL == 1 */) {
+    const int SL = 256 / RL, rl = tid & (RL - 1), sl = tid / RL;
+    const size_t slab = (size_t)rows * Cout;
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+    constexpr int NB = NR < 8 ? NR : 8;               // rows requested together (16 independent 16-B loads per thread)
+    for (int s = sl; s < ksplit; s += SL) {
+#pragma unroll
+        for (int i0 = 0; i0 < NR; i0 += NB) {
+            float4 t0[NB], t1[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = rl + RL * (i0 + i);
+                if (r < rows) {
+                    const float* src = ws + (size_t)s * slab + ((size_t)(c0 >> 3) * rows + r) * 8;   // [split][group][row][8]
+                    t0[i] = *(const float4*)src;
+                    t1[i] = *(const float4*)(src + 4);
+                } else {
+                    t0[i] = t1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float* o = v[i0 + i];
+                o[0] += t0[i].x; o[1] += t0[i].y; o[2] += t0[i].z; o[3] += t0[i].w;
+                o[4] += t1[i].x; o[5] += t1[i].y; o[6] += t1[i].z; o[7] += t1[i].w;
+            }
+        }
+    }
+    if (SL > 1) {      // NR == 1 here: one row per row lane
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xch[tid * 8 + k] = v[0][k];
+        __syncthreads();
+        if (sl == 0) {
+            for (int q = 1; q < SL; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[0][k] += xch[(q * RL + rl) * 8 + k];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_finish_bn_k(GG g, FinishBnArgs f, int RL) {
     __shared__ double red[2][4][8];
     __shared__ float coef[2][8];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * 8;
     const int rows = g.nphase * g.M;
     const size_t slab = (size_t)rows * g.Cout;
+    __shared__ float xch[256 * 8];
     float v[FB_ROWS][8], s1[8], s2[8], bv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = s2[k] = 0.f; bv[k] = f.bias ? f.bias[c0 + k] : 0.f; }
+    const bool owner = tid < RL;                       // threads that hold finished rows (all of them when RL == 256)
+    if (RL == 256) fb_slab_sum<FB_ROWS>(f.ws, f.ksplit, rows, g.Cout, c0, tid, 256, v, nullptr);
+    else fb_slab_sum<1>(f.ws, f.ksplit, rows, g.Cout, c0, tid, RL, v, xch);
 #pragma unroll
     for (int i = 0; i < FB_ROWS; ++i) {
-        const int r = tid + 256 * i;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
-        if (r < rows) {
-            const float* src = f.ws + (size_t)r * g.Cout + c0;
-#pragma unroll 4
-            for (int s = 0; s < f.ksplit; ++s) {
-                const float4 v0 = *(const float4*)(src + s * slab), v1 = *(const float4*)(src + s * slab + 4);
-                v[i][0] += v0.x; v[i][1] += v0.y; v[i][2] += v0.z; v[i][3] += v0.w;
-                v[i][4] += v1.x; v[i][5] += v1.y; v[i][6] += v1.z; v[i][7] += v1.w;
-            }
+        const int r = tid + 256 * i;                   // RL < 256: only i == 0 holds a row (r = tid < RL)
+        if ((RL == 256 || i == 0) && owner && r < rows) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 v[i][k] += bv[k];
@@ -105,7 +154,7 @@ __global__ __launch_bounds__(256) void splitk_finish_bn_k(GG g, FinishBnArgs f) 
 #pragma unroll
     for (int i = 0; i < FB_ROWS; ++i) {
         const int r = tid + 256 * i;
-        if (r >= rows) continue;
+        if (r >= rows || !owner || (RL < 256 && i > 0)) continue;
         const int ph = r / g.M, m = r - ph * g.M;
         int n, gy, gx;
         decode_row(g, m, n, gy, gx);
@@ -125,12 +174,11 @@ __global__ __launch_bounds__(256) void splitk_finish_bn_k(GG g, FinishBnArgs f) 
 
 // blockIdx.x < D1 / 8: 8 channels of the first destination, through the producer's activation and BatchNorm backward;
 // the rest: 8 channels of the second destination (the skip path), plain bf16 store.
-__global__ __launch_bounds__(256) void splitk_finish_bnbwd_k(GG g, FwdArgs a, FinishBwdArgs f) {
+__global__ __launch_bounds__(256) void splitk_finish_bnbwd_k(GG g, FwdArgs a, FinishBwdArgs f, int RL) {
     __shared__ double red[2][4][8];
     __shared__ float coef[2][8];
     const int tid = threadIdx.x;
     const int rows = g.nphase * g.M;
-    const size_t slab = (size_t)rows * g.Cout;
     const bool first = (int)blockIdx.x * 8 < g.D1;
     const int c0 = blockIdx.x * 8;                       // column of the slab
     const int cd = first ? c0 : c0 - g.D1;               // column of the destination tensor
@@ -139,26 +187,21 @@ __global__ __launch_bounds__(256) void splitk_finish_bnbwd_k(GG g, FwdArgs a, Fi
     const bf16_t* bap = (const bf16_t*)a.badd;
     BwdParams BP;
     if (first) bwd_load_params(a, cd, BP);
+    __shared__ float xch[256 * 8];
     uint4 du[FB_ROWS], zq[FB_ROWS];
     float s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
+    float v[FB_ROWS][8];
+    const bool owner = tid < RL;
+    if (RL == 256) fb_slab_sum<FB_ROWS>(f.ws, f.ksplit, rows, g.Cout, c0, tid, 256, v, nullptr);
+    else fb_slab_sum<1>(f.ws, f.ksplit, rows, g.Cout, c0, tid, RL, v, xch);
 #pragma unroll
     for (int i = 0; i < FB_ROWS; ++i) {
         const int r = tid + 256 * i;
         du[i] = zq[i] = make_uint4(0, 0, 0, 0);
-        if (r >= rows) continue;
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 0.f;
-        const float* src = f.ws + (size_t)r * g.Cout + c0;
-#pragma unroll 4
-        for (int s = 0; s < f.ksplit; ++s) {
-            const float4 v0 = *(const float4*)(src + s * slab), v1 = *(const float4*)(src + s * slab + 4);
-            v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w;
-            v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
-        }
-        const uint4 o = make_uint4(pk2bf(v[0], v[1]), pk2bf(v[2], v[3]), pk2bf(v[4], v[5]), pk2bf(v[6], v[7]));
+        if (r >= rows || !owner || (RL < 256 && i > 0)) continue;
+        const uint4 o = make_uint4(pk2bf(v[i][0], v[i][1]), pk2bf(v[i][2], v[i][3]), pk2bf(v[i][4], v[i][5]), pk2bf(v[i][6], v[i][7]));
         const int ph = r / g.M, m = r - ph * g.M;
         int n, gy, gx;
         decode_row(g, m, n, gy, gx);
@@ -200,7 +243,7 @@ __global__ __launch_bounds__(256) void splitk_finish_bnbwd_k(GG g, FwdArgs a, Fi
 #pragma unroll
     for (int i = 0; i < FB_ROWS; ++i) {
         const int r = tid + 256 * i;
-        if (r >= rows) continue;
+        if (r >= rows || !owner || (RL < 256 && i > 0)) continue;
         const int ph = r / g.M, m = r - ph * g.M;
         int n, gy, gx;
         decode_row(g, m, n, gy, gx);
@@ -227,19 +270,33 @@ __global__ __launch_bounds__(256) void splitk_finish_bnbwd_k(GG g, FwdArgs a, Fi
 // ---- host ---------------------------------------------------------------------------------------------------------
 // the split-K launch of this problem is followed by a column-owner finish: few rows, 8-channel groups
 bool finish_fused_ok(const GG& g, int d1_cols) {
-    if (!pai_tunable("finish_fused", 1)) return false;
+    // OFF by default (tunable finish_fused = 1 turns it on): measured in the BASELINE configs[1] step on one box, three
+    // interleaved pairs: 6.64 / 6.65 / 6.65 ms per step with the fused finish against 6.55 / 6.56 / 6.52 with the three
+    // launches (first version, row-major slabs read 32 B per row: 7.02 against 6.70).  A column owner is 64 workgroups
+    // (Cout / 8), one per CU at 290 registers: the 8-33 MB of slabs of a bottleneck layer then stream through a quarter
+    // of the chip, while splitk_finish_k spreads them over 1024 workgroups; the two launch boundaries saved (~3 us) do
+    // not pay for that.  Kept: bit-exact (tests/test_gpu_finish.py), and the two entry points are the right place for
+    // a better fusion.
+    if (!pai_tunable("finish_fused", 0)) return false;
     if (fwd_mfma_ksplit_effective(g) <= 1) return false;
     return (int64_t)g.nphase * g.M <= FB_MAX_ROWS && (g.Cout % 8) == 0 && (d1_cols % 8) == 0;
 }
 
+static int fb_row_lanes(const GG& g) {      // row lanes of a workgroup: the rows rounded up to a power of two, at most 256
+    const int rows = g.nphase * g.M;
+    int rl = 1;
+    while (rl < rows && rl < 256) rl <<= 1;
+    return rl;
+}
+
 int launch_finish_bn(const GG& g, const FinishBnArgs& f, hipStream_t s) {
-    hipLaunchKernelGGL(splitk_finish_bn_k, dim3(g.Cout / 8), dim3(256), 0, s, g, f);
+    hipLaunchKernelGGL(splitk_finish_bn_k, dim3(g.Cout / 8), dim3(256), 0, s, g, f, fb_row_lanes(g));
     PAI_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_finish_bnbwd(const GG& g, const FwdArgs& a, const FinishBwdArgs& f, hipStream_t s) {
-    hipLaunchKernelGGL(splitk_finish_bnbwd_k, dim3(g.Cout / 8), dim3(256), 0, s, g, a, f);
+    hipLaunchKernelGGL(splitk_finish_bnbwd_k, dim3(g.Cout / 8), dim3(256), 0, s, g, a, f, fb_row_lanes(g));
     PAI_LAUNCH_CHECK();
     return 0;
 }

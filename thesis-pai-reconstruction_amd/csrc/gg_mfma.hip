@@ -322,6 +322,27 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
         // run at ~1.3 TB/s chip-wide against ~6 TB/s for stores, and at 16-64 splits the added bytes
         // (splits x output) were the whole cost of the bottleneck layers.  splitk_finish_k sums the slabs
         // in a fixed order (deterministic) and applies the epilogue.
+        if (a.skip_finish) {
+            // the caller's column-owner finish (gg_finish.hip) reads 8-channel groups over ALL rows: slab layout
+            // [split][channel group][phase * M + m][8] -- a 16 x 16 accumulator tile is two contiguous 512-B blocks, and
+            // the finish reads 32 B per thread, contiguous across its threads
+            const size_t rows_all = (size_t)g.nphase * g.M;
+            float* sl = ws + (size_t)ks * rows_all * g.Cout;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * WR + mt * 16 + fq * 4 + r;
+                    if (m0 + row < g.M) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int col = n0 + wn * (BN / 2) + nt * 16 + fr;
+                            sl[((size_t)(col >> 3) * rows_all + (size_t)ph * g.M + m0 + row) * 8 + (col & 7)] = acc[mt][nt][r];
+                        }
+                    }
+                }
+            return;
+        }
         float* dst = ws + ((size_t)(ks * g.nphase + ph) * g.M + m0) * g.Cout + n0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
