@@ -19,6 +19,8 @@
 // aten::convolution_backward calls.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gg_tile.h"
 
 
@@ -39,6 +41,7 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
 // double-buffered, one 512-thread workgroup per CU) when that still gives every CU a workgroup,
 // else 128 x 128 / 128 x 64 (single buffer, 3-4 workgroups per CU), split over K when even that
 // leaves CUs idle.
+constexpr int FWD_WIDE_DEFAULT = 1;   // gg_fwd_patchw_k (128 x 64 wave tiles) for the 256-row tiles: tunable fwd_wide
 struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
@@ -624,12 +627,16 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 // WN: waves side by side along the channels.  2: (BM / 64) x 2 waves of 64 pixels x BN / 2 channels.  1 (BN = 64 only):
 // BM / 64 waves of 64 pixels x 64 channels -- the 64-channel layers with the 64 x 64 wave tile of the 128-channel
 // kernels (8 fragment reads per 16 MFMAs instead of 6 per 8) and one weight tile per 256 pixels.
-template <int BM, int BN, bool DBB, int WN = 2>   // DBB: two weight-tile buffers
+// WPX: output pixels per wave.  64: 64 x 64 wave tiles (4 + 4 fragment reads per 16 MFMAs).  128: 128 x 64 wave tiles
+// (8 + 4 per 32: a quarter fewer LDS fragment bytes per FLOP, the lever that took the weight gradient from 0.75 to 1.0
+// PFLOP/s, gg_wg3.hip), 128 accumulator registers, half the waves -- 256 x 128 tiles are then four waves, two
+// workgroups per CU at up to 256 registers.
+template <int BM, int BN, bool DBB, int WN = 2, int WPX = 64>   // DBB: two weight-tile buffers
 __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a, const PatchGeo& pg, int mtiles, int ntiles) {
     static_assert(WN == 2 || BN == 64, "one wave column: 64 output channels");
     constexpr int abl = PATCH_ABL;
-    typedef PatchDims<BM, WN> PD;
-    constexpr int NTHR = BM * WN, MT = 4, NT = BN / (16 * WN);
+    typedef PatchDims<BM, WN, WPX> PD;
+    constexpr int NTHR = PD::NTHR, MT = WPX / 16, NT = BN / (16 * WN);
     constexpr int BNW = BN / WN;             // channels per wave column
     constexpr int RPP = PD::RPP, PJ = PD::PJ, PATCH_PIX = PD::PIX, PATCH_BYTES = PD::BYTES;
     constexpr int BJ = BN / RPP;             // weight tile fill instructions per thread
@@ -674,23 +681,26 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 
     // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
     const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
-    // slot c of pixel p holds chunk c ^ (p & 6) (p & 6 == sr & 6: RPP j does not touch bits 1-2)
-    const int gchA = (sc ^ (sr & 6)) * 8;
-    int pixb[PJ];                            // source pixel index of the patch pixel for window offset (0,0)
-    unsigned vmask[PJ];                      // bit q: inside the image for window q of this phase
+    // slot c of patch pixel (py, px) holds chunk c ^ (px & 6): the swizzle looks at the patch COLUMN only, so the pixel
+    // rows a wave reads (its four 16-pixel rows, shifted down by the tap's ty) are ONE base address + immediates
+    // (scripts/lds_swizzle_check.py fwd_patch: conflict-free for both tx shifts)
+    // per fill instruction ONE register: bits 0-23 source pixel index of the patch pixel for window offset (0, 0) (every
+    // tensor is below 2 GB and has >= 64 channels: < 2^24 pixels), bits 24-27 "inside the image" for window q of this
+    // phase, bits 28-30 this thread's chunk.  (The kernel sits at the 128-register line of four waves per SIMD.)
+    unsigned pfill[PJ];
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
         const int p = j * RPP + sr;
         const int py = p / PATCH_W, px = p - py * PATCH_W;
         const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
-        pixb[j] = (img * g.H + y) * g.W + x;
+        const int pixb = (img * g.H + y) * g.W + x;
         unsigned m = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int yy = y + (int)((wby16 >> (4 * q)) & 15u) - 8, xx = x + (int)((wbx16 >> (4 * q)) & 15u) - 8;
             if (q < pg.groups && p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
         }
-        vmask[j] = m;
+        pfill[j] = ((unsigned)pixb & 0xffffffu) | (m << 24) | ((unsigned)(sc ^ (px & 6)) << 28);
     }
     const int gchB = (sc ^ ((sr >> 1) & 7)) * 8;
     // LDS row rho = 16 nt + i of a wave's half of the weight tile holds output channel
@@ -705,12 +715,24 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     }
 
     // ---- fragment read addresses -----------------------------------------------------------------
+    // Every fragment address of the K loop is one of these six registers + a compile-time immediate: the patch offset
+    // (ty, tx) of tap slot k is (k >> 1, k & 1) by construction (patch_geo), so ty and the wave's pixel row mt are
+    // immediates ((mt + ty) x 17 pixels), and so are the weight buffer (k & 1) and channel tile nt.  (Until round 3 the
+    // loop rebuilt four pixel addresses per tap from a run-time offset: ~30 vector instructions per 32 MFMAs.)
     const int fr = lane & 15, fq = lane >> 4;
-    int pbase[MT];
+    unsigned a_addr[2][2];                   // [tx][kk]
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) pbase[mt] = (wm * 4 + mt) * PATCH_W + fr;
-    const unsigned b_base = (unsigned)(PATCH_BYTES + (wn * BNW + fr) * 128);
+    for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned px = (unsigned)(fr + tx);
+            a_addr[tx][kk] = ((unsigned)(wm * MT * PATCH_W) + px) * 128u + ((((unsigned)(kk * 4 + fq)) ^ (px & 6u)) << 4);
+        }
     const int fswz = fr >> 1;
+    unsigned b_addr[2];                      // [kk]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+        b_addr[kk] = (unsigned)(PATCH_BYTES + (wn * BNW + fr) * 128) + (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
     f4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -729,13 +751,17 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
         const bool second = c0 >= g.C1;
         const int C = second ? g.C2 : g.C1;
-        const int cofs = (second ? c0 - g.C1 : c0) + gchA;
+        const int cofs = second ? c0 - g.C1 : c0;
         const int dpix = ((int)((wby16 >> (4 * q)) & 15u) - 8) * g.W + (int)((wbx16 >> (4 * q)) & 15u) - 8;
         if (abl & 2) return;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const unsigned vo = ((vmask[j] >> q) & 1u)
-                                    ? (unsigned)((pixb[j] + dpix) * C + cofs) * 2u : OOB;
+            // (opaque copy: hipcc otherwise hoists the three fields of every pfill[j] out of the K loop as fifteen
+            //  loop invariants and spills them -- five scratch round trips in front of every patch fill)
+            unsigned pf = pfill[j];
+            asm volatile("" : "+v"(pf));
+            const unsigned vo = ((pf >> (24 + q)) & 1u)
+                                    ? (unsigned)(((int)(pf & 0xffffffu) + dpix) * C + cofs + (int)((pf >> 28) & 7u) * 8) * 2u : OOB;
             if (second) FP_BLDS16(x2rs, vo, 0, smem + (j * RPP + wid * 8) * 128);
             else FP_BLDS16(x1rs, vo, 0, smem + (j * RPP + wid * 8) * 128);
         }
@@ -749,75 +775,72 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     };
     fire_patch(0);
     fire_b(0, 0, 0);
-    int buf = 0;
+    // one tap (slot K of the window, patch offset (K >> 1, K & 1)); the weight buffer of step K is K & 1 (four steps per
+    // patch: the parity restarts with every patch)
+    auto step = [&](auto k_tag, int gi, int relu, bool more) {
+        constexpr int K = decltype(k_tag)::value;
+        constexpr int TY = K >> 1, TX = K & 1;
+        constexpr int BUF = DBB ? (K & 1) : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // this step's tiles have landed; everyone is done with the other weight buffer
+        if (DBB) {
+            if (K < 3) fire_b(gi, K + 1, BUF ^ 1);
+            else if (more) fire_b(gi + 1, 0, BUF ^ 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf8_t af[MT], bfr[NT];
+            if (!(abl & 8)) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    af[mt] = *(const bf8_t*)(smem + (a_addr[TX][kk] & 0xffffu) + (mt + TY) * (PATCH_W * 128));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bfr[nt] = *(const bf8_t*)(smem + (b_addr[kk] & 0x3ffffu) + BUF * (BN * 128) + nt * 16 * 128);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(bf8_t, make_uint4(a_addr[TX][kk], b_addr[kk], mt, kk));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(b_addr[kk], a_addr[TX][kk], nt, kk));
+            }
+            if (relu) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
+            }
+            if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
+            if (!(abl & 4)) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            } else {
+                acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];
+            }
+            if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        }
+        if (DBB) {
+            if (K == 3 && more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // every wave is done reading the patch
+                fire_patch(gi + 1);
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // every wave is done reading before the next fill overwrites
+            if (K < 3) fire_b(gi, K + 1, 0);
+            else if (more) { fire_patch(gi + 1); fire_b(gi + 1, 0, 0); }
+        }
+    };
     for (int gi = 0; gi < ngroups; ++gi) {
         const int c0g = (gi >> gsh) * MBK;
         const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
-        const unsigned toff4 = pg.toff4[ph][gi & (pg.groups - 1)];
         const bool more = gi + 1 < ngroups;
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const int toff = (int)((toff4 >> (8 * k)) & 0xffu);
-            unsigned abase[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const unsigned pp = (unsigned)(pbase[mt] + toff);
-                abase[mt] = (pp << 7) ^ ((pp & 6u) << 4);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // this step's tiles have landed; everyone is done with the other weight buffer
-            if (DBB) {
-                if (k < 3) fire_b(gi, k + 1, buf ^ 1);
-                else if (more) fire_b(gi + 1, 0, buf ^ 1);
-            }
-            const unsigned bb = b_base + (DBB ? buf * (BN * 128) : 0);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
-                const unsigned cb = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
-                bf8_t af[MT], bfr[NT];
-                if (!(abl & 8)) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + bb + nt * 16 * 128 + cb);
-                } else {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(bf8_t, make_uint4(ca, cb, mt, kk));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(cb, ca, nt, kk));
-                }
-                if (relu) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
-                }
-                if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
-                if (!(abl & 4)) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
-                } else {
-                    acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];
-                }
-                if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
-            }
-            if (DBB) {
-                buf ^= 1;
-                if (k == 3 && more) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();   // every wave is done reading the patch
-                    fire_patch(gi + 1);
-                }
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();       // every wave is done reading before the next fill overwrites
-                if (k < 3) fire_b(gi, k + 1, 0);
-                else if (more) { fire_patch(gi + 1); fire_b(gi + 1, 0, 0); }
-            }
-        }
+        step(std::integral_constant<int, 0>{}, gi, relu, more);
+        step(std::integral_constant<int, 1>{}, gi, relu, more);
+        step(std::integral_constant<int, 2>{}, gi, relu, more);
+        step(std::integral_constant<int, 3>{}, gi, relu, more);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the epilogue reuses the tile memory
@@ -835,7 +858,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 
     // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
     constexpr int CROW = BN * 2 + 16;
-    constexpr int WM = BM / 64;
+    constexpr int WM = BM / WPX;
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
@@ -848,7 +871,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int row = wm * 64 + mt * 16 + fr;
+        const int row = wm * WPX + mt * 16 + fr;
         unsigned pk[CL / 2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -949,6 +972,11 @@ template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
     gg_fwd_patch_body<BM, BN, DBB>(g, a, pg, mtiles, ntiles);
 }
+// 128 x 64 wave tiles: BM / 128 x 2 waves (see gg_fwd_patch_body, WPX = 128)
+template <int BM, int BN, bool DBB>
+__global__ __launch_bounds__(BM, 2) void gg_fwd_patchw_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+    gg_fwd_patch_body<BM, BN, DBB, 2, 128>(g, a, pg, mtiles, ntiles);
+}
 // 64 output channels, one wave column: BM / 64 waves of 64 x 64 (see gg_fwd_patch_body, WN = 1)
 template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM, 3) void gg_fwd_patch1_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
@@ -1033,7 +1061,16 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             }
             const int mt256 = g.M / 256;
             const dim3 grid256(mt256 * ntiles * g.nphase);
-            if (db) hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+            if (pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) {
+                static bool attrw = false;
+                if (!attrw) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patchw_k<256, 128, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                    PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+                    attrw = true;
+                }
+                hipLaunchKernelGGL((gg_fwd_patchw_k<256, 128, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
+            } else if (db) hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
             else hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, false>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
         } else if (prow == 128 && patch_geo(g, 8, &pg)) {
             typedef PatchDims<128> PD;
@@ -1071,6 +1108,7 @@ const char* fwd_mfma_kernel_name(const GG& g) {
     const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
     const int prow = patch_rows(g, c);
     if (prow == 256 && c.bn == 64) return (dbb & 4) ? "gg_fwd_patch1_k<256, 64, true>" : "gg_fwd_patch1_k<256, 64, false>";
+    if (prow == 256 && pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) return "gg_fwd_patchw_k<256, 128, true>";
     if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";
     if (prow == 128) {
         if (c.bn == 128) return (dbb & 2) ? "gg_fwd_patch_k<128, 128, true>" : "gg_fwd_patch_k<128, 128, false>";

@@ -132,10 +132,11 @@ constexpr int PATCH_W = 17;
 // BM = 128: 8 x 16 output pixels, 4 waves;  BM = 256: 16 x 16 output pixels, 8 waves (4 x 2) -- the weight
 // tile fill is then shared by twice the rows: 25 KB of fill and 128 KB of fragment reads per 2 x 512
 // MFMA cycles, the first configuration whose LDS time (916 cycles) is below its matrix time (1024).
-template <int BM, int WN = 2> struct PatchDims {            // WN: waves side by side along the channels (threads = BM x WN)
+template <int BM, int WN = 2, int WPX = 64> struct PatchDims {   // WN: waves side by side along the channels; WPX: pixels per wave
     static constexpr int TH = BM / 16;
     static constexpr int PIX = (TH + 1) * PATCH_W;
-    static constexpr int RPP = BM * WN / 8;                  // pixels per block-wide fill instruction
+    static constexpr int NTHR = BM / WPX * 64 * WN;          // threads of the workgroup
+    static constexpr int RPP = NTHR / 8;                     // pixels per block-wide fill instruction
     static constexpr int PJ = (PIX + RPP - 1) / RPP;
     static constexpr int BYTES = PJ * RPP * 128;
 };
@@ -154,9 +155,13 @@ static inline bool patch_geo(const GG& g, int th, PatchGeo* pg) {
             for (int t = 0; t < 4; ++t) {
                 const int ty = g.dy[ph][t] - by, tx = g.dx[ph][t] - bx;
                 if (ty > 1 || tx > 1) return false;
-                seen |= 1u << (ty * 2 + tx);
-                pg->toff4[ph][0] |= (unsigned)(ty * PATCH_W + tx) << (8 * t);
-                pg->wt4[ph][0] |= (unsigned)g.wt[ph][t] << (8 * t);
+                // canonical slot order: slot k of a window is its tap at patch offset (ty, tx) = (k >> 1, k & 1) -- the
+                // forward kernel unrolls the four taps of a window with compile-time patch offsets
+                const int k = ty * 2 + tx;
+                if (seen & (1u << k)) return false;
+                seen |= 1u << k;
+                pg->toff4[ph][0] |= (unsigned)(ty * PATCH_W + tx) << (8 * k);
+                pg->wt4[ph][0] |= (unsigned)g.wt[ph][t] << (8 * k);
             }
             if (seen != 15u) return false;
             pg->by[ph][0] = (signed char)by;
@@ -170,19 +175,21 @@ static inline bool patch_geo(const GG& g, int th, PatchGeo* pg) {
         for (int t = 0; t < 16; ++t) { ymin = g.dy[0][t] < ymin ? g.dy[0][t] : ymin; xmin = g.dx[0][t] < xmin ? g.dx[0][t] : xmin; }
         for (int q = 0; q < 4; ++q) {
             const int by = ymin + (q >> 1), bx = xmin + (q & 1);
-            int k = 0;
+            int n = 0;
             unsigned seen = 0;
             for (int t = 0; t < 16; ++t) {
                 const int ry = g.dy[0][t] - by, rx = g.dx[0][t] - bx;
                 if (ry < 0 || rx < 0 || (ry & 1) || (rx & 1)) continue;
                 const int ty = ry / 2, tx = rx / 2;
-                if (ty > 1 || tx > 1 || k == 4) return false;
-                seen |= 1u << (ty * 2 + tx);
+                if (ty > 1 || tx > 1 || n == 4) return false;
+                const int k = ty * 2 + tx;           // canonical slot order, see above
+                if (seen & (1u << k)) return false;
+                seen |= 1u << k;
                 pg->toff4[0][q] |= (unsigned)(ty * PATCH_W + tx) << (8 * k);
                 pg->wt4[0][q] |= (unsigned)g.wt[0][t] << (8 * k);
-                ++k;
+                ++n;
             }
-            if (k != 4 || seen != 15u) return false;
+            if (n != 4 || seen != 15u) return false;
             pg->by[0][q] = (signed char)by;
             pg->bx[0][q] = (signed char)bx;
         }
