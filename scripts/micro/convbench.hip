@@ -7,7 +7,7 @@
 //
 // build: hipcc -O2 --offload-arch=gfx950 scripts/micro/convbench.hip -Iinclude -Lthesis-pai-reconstruction_amd
 //              -lpai_hip -Wl,-rpath,'$ORIGIN/../../thesis-pai-reconstruction_amd' -o scripts/micro/convbench
-// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--frag] [--bias] [--set name=v,name=v ;...]
+// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--frag] [--bias] [--bnbwd] [--zeros PCT] [--set name=v,name=v ;...]
 //        every --set adds one setting (comma-separated tunables); default: the library defaults only.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -34,12 +34,15 @@ __device__ __forceinline__ unsigned short f2bf_rne(float f) {
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 // mode 0: uniform [-scale, scale); mode 1: integers in [-imax, imax]
-__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale, int mode, int imax) {
+// zero_pct: that share of the elements is exactly zero (post-ReLU activations of a trained network are ~half zeros: the
+// chip draws less power on them and holds a higher clock than on dense random operands, guide rule 25)
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale, int mode, int imax, int zero_pct = 0) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned h = hash32((unsigned)i * 2654435761u + seed);
         float v;
         if (mode == 0) v = ((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale;
         else v = (float)((int)(h % (unsigned)(2 * imax + 1)) - imax);
+        if (zero_pct && (int)(hash32(h ^ 0x9e3779b9u) % 100u) < zero_pct) v = 0.f;
         p[i] = f2bf_rne(v);
     }
 }
@@ -94,7 +97,7 @@ static std::vector<float> read3(float* d) {
 int main(int argc, char** argv) {
     const char* filter = "";
     const char* ops = "fdw";
-    int iters = 10, rounds = 3, batch = 64, frag = 0, bias = 0;
+    int iters = 10, rounds = 3, batch = 64, frag = 0, bias = 0, bnbwd = 0, zero_pct = 0;
     std::vector<Setting> settings;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--filter") && i + 1 < argc) filter = argv[++i];
@@ -102,6 +105,9 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--bnbwd")) bnbwd = 1; // input gradients run pai_conv_dgrad_bn: producer BatchNorm / activation backward
+                                                         // (affine pre-activation, second gradient, partial sums) fused into the store
+        else if (!strcmp(argv[i], "--zeros") && i + 1 < argc) zero_pct = atoi(argv[++i]);   // percent of exact zeros in x1 / x2 / dy
         else if (!strcmp(argv[i], "--bias")) bias = 1;   // weight gradients also produce (and compare) the bias gradient
         else if (!strcmp(argv[i], "--frag")) frag = 1;   // packs followed by their fragment-major copy (pack_flags = 3)
         else if (!strcmp(argv[i], "--set") && i + 1 < argc) {
@@ -159,7 +165,8 @@ int main(int argc, char** argv) {
         const size_t nx1 = (size_t)n * L.H * L.H * L.C1, nx2 = (size_t)n * L.H * L.H * L.C2, ny = (size_t)n * OH * OW * L.Cout;
         const size_t nw = (size_t)L.Cout * 16 * Cin;
         unsigned short *x1, *x2 = nullptr, *wf, *wd, *dy, *y[2], *dx1[2], *dx2[2] = {nullptr, nullptr};
-        float *dw[2], *db[2], *stats;
+        float *dw[2], *db[2], *stats, *bnp = nullptr, *bnpart = nullptr;
+        unsigned short *bz = nullptr, *badd = nullptr;
         HCHECK(hipMalloc(&x1, nx1 * 2));
         if (nx2) HCHECK(hipMalloc(&x2, nx2 * 2));
         HCHECK(hipMalloc(&wf, nw * 4)); HCHECK(hipMalloc(&wd, nw * 4)); HCHECK(hipMalloc(&dy, ny * 2));
@@ -173,15 +180,25 @@ int main(int argc, char** argv) {
         }
         const int srows = pai_bn_stats_buffer_rows(pai_conv_fwd_stats_rows_max(&d));
         HCHECK(hipMalloc(&stats, (size_t)srows * 2 * L.Cout * 4));
+        if (bnbwd && L.C1 > 2) {
+            HCHECK(hipMalloc(&bz, nx1 * 2)); HCHECK(hipMalloc(&badd, nx1 * 2));
+            HCHECK(hipMalloc(&bnp, (size_t)4 * L.C1 * 4));
+            HCHECK(hipMalloc(&bnpart, (size_t)pai_conv_dgrad_bn_rows_max(&d) * 2 * L.C1 * 4));
+            fill_bf16<<<1024, 256, 0, st>>>(bz, nx1, 21u, 1.0f, 1, 3);
+            fill_bf16<<<1024, 256, 0, st>>>(badd, nx1, 22u, 1.0f, 1, 2);
+            std::vector<float> hp(4 * L.C1);
+            for (int c = 0; c < L.C1; ++c) { hp[c] = (c & 1) ? 1.f : 2.f; hp[L.C1 + c] = (float)((c % 5) - 2); hp[2 * L.C1 + c] = (float)(c % 3) - 1.f; hp[3 * L.C1 + c] = (c & 2) ? 0.5f : 1.f; }
+            HCHECK(hipMemcpy(bnp, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+        }
         const double gflop = 2.0 * (double)n * L.H * L.H * (L.tr ? 1.0 : 0.25) * 16.0 * Cin * L.Cout / 1e9;
 
         auto fill_all = [&](int mode) {
             // integer mode: |x| <= 2, |w| <= 2, K <= 16384 terms -> |sum| <= 65536 < 2^24: exact in fp32
-            fill_bf16<<<1024, 256, 0, st>>>(x1, nx1, 11u, 1.0f, mode, 2);
-            if (nx2) fill_bf16<<<1024, 256, 0, st>>>(x2, nx2, 12u, 1.0f, mode, 2);
+            fill_bf16<<<1024, 256, 0, st>>>(x1, nx1, 11u, 1.0f, mode, 2, zero_pct);
+            if (nx2) fill_bf16<<<1024, 256, 0, st>>>(x2, nx2, 12u, 1.0f, mode, 2, zero_pct);
             fill_bf16<<<1024, 256, 0, st>>>(wf, nw, 13u, 0.05f, mode, 2);
             fill_bf16<<<1024, 256, 0, st>>>(wd, nw, 14u, 0.05f, mode, 2);
-            fill_bf16<<<1024, 256, 0, st>>>(dy, ny, 15u, 1.0f, mode, 2);
+            fill_bf16<<<1024, 256, 0, st>>>(dy, ny, 15u, 1.0f, mode, 2, zero_pct);
             if (fragok) {
                 PCHECK(pai_pack_frag(wf, L.Cout, 16 * Cin, wf + nw, st));
                 PCHECK(pai_pack_frag(wd, Cin, 16 * L.Cout, wd + nw, st));
@@ -190,7 +207,13 @@ int main(int argc, char** argv) {
         };
         auto run = [&](char op, int k) {
             if (op == 'f') PCHECK(pai_conv_fwd(&d, x1, x2, wf, nullptr, y[k], nullptr, nullptr, (L.C1 > 2 && L.Cout > 2) ? stats : nullptr, st));
-            else if (op == 'd') PCHECK(pai_conv_dgrad(&d, dy, wd, dx1[k], dx2[k], 0, st));
+            else if (op == 'd' && bz) {
+                pai_bwd_epilogue e;
+                e.z = bz; e.add = L.tr ? nullptr : badd; e.scale = bnp; e.shift = bnp + L.C1; e.mean = bnp + 2 * L.C1; e.rstd = bnp + 3 * L.C1;
+                e.partials = bnpart; e.act1 = L.tr ? PAI_ACT_RELU : PAI_ACT_LRELU; e.act2 = L.tr ? PAI_ACT_NONE : PAI_ACT_RELU;
+                int rows = 0;
+                PCHECK(pai_conv_dgrad_bn(&d, dy, wd, dx1[k], dx2[k], &e, &rows, st));
+            } else if (op == 'd') PCHECK(pai_conv_dgrad(&d, dy, wd, dx1[k], dx2[k], 0, st));
             else {
                 HCHECK(hipMemsetAsync(dw[k], 0, nw * 4, st));
                 HCHECK(hipMemsetAsync(db[k], 0, (size_t)L.Cout * 4, st));
@@ -261,6 +284,7 @@ int main(int argc, char** argv) {
             printf(" | last: %s\n", kname[oi]);
             fflush(stdout);
         }
+        if (bz) { (void)hipFree(bz); (void)hipFree(badd); (void)hipFree(bnp); (void)hipFree(bnpart); }
         (void)hipFree(x1); if (x2) (void)hipFree(x2); (void)hipFree(wf); (void)hipFree(wd); (void)hipFree(dy); (void)hipFree(stats);
         for (int k = 0; k < 2; ++k) { (void)hipFree(y[k]); (void)hipFree(dx1[k]); if (dx2[k]) (void)hipFree(dx2[k]); (void)hipFree(dw[k]); (void)hipFree(db[k]); }
     }

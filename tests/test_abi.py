@@ -107,7 +107,7 @@ def test_kernel_dispatch_table_without_gpu(pai):
     for name, tr, s, N, H, W, C1, C2, Cout, r1, r2 in mod.CASES:
         d = ops.make_desc(torch.bfloat16, tr, N, H, W, C1, C2, Cout, s, r1, r2, ops.ACT_LRELU)
         assert tuple(ops.conv_kernel_id(d, op) for op in (0, 1, 2)) == mod.BF16_FAMILY[name], name
-    big = "gg_fwd_patchw_k<256, 128, true>"
+    big = "gg_fwd_patch_k<256, 128, true>"
     cfg2 = {   # (transposed, N, H, C1, C2, Cout) -> (forward, input gradient, weight gradient)
         "encoders[2]": ((0, 64, 64, 128, 0, 256), (big, big, "gg_wgrad_patch3_k<128, 64>")),
         "decoders[4]": ((1, 64, 16, 512, 512, 256), (big, big, "gg_wgrad_patch3_k<128, 64>")),

@@ -24,22 +24,22 @@ SPLIT = ("gg_fwd_mfma_k<128, 128, true, true, 64>", "gg_fwd_mfma_k<128, 128, fal
 CASES = [
     ("enc_patch", 0, 4, 128, 64, 0, 256, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
     ("dec_patch", 1, 4, 64, 64, 64, 128, 1, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("enc_patch256", 0, 8, 256, 64, 0, 128, 0, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("enc_patch256", 0, 8, 256, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
+    ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
     ("dec_patch256x64", 1, 8, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
-    ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
     ("enc_splitk", 0, 4, 8, 256, 0, 256, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     ("dec_splitk", 1, 4, 4, 256, 256, 256, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     # BASELINE configs[1] layer shapes at the benchmark batch (64; the discriminator sees 2 x 64 in its own phase)
-    ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
     ("cfg2_enc4", 0, 64, 16, 512, 0, 512, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     ("cfg2_dec3", 1, 64, 8, 512, 512, 512, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
-    ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
-    ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patchw_k<256, 128, true>", "gg_fwd_patchw_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
+    ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
 ]
 
 
@@ -158,11 +158,12 @@ P2_CASES = [c for c in CASES if c[0] in ("enc_patch256", "dec_patch256", "enc_dg
 
 
 @pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
-def test_eight_wave_form_of_the_256_row_tile_bit_exact(pai, case):
-    """gg_fwd_patch_k<256, 128> (eight waves of 64 x 64; the default until round 3, tunable fwd_wide = 0) against the
-    same cases as gg_fwd_patchw_k<256, 128> (four waves of 128 x 64), which the named run above pins."""
-    used = _run_case(pai, case, tunables=(("fwd_wide", 0),))
-    assert any(u == "gg_fwd_patch_k<256, 128, true>" for u in used[:2]), used
+def test_wide_wave_tile_form_of_the_256_row_tile_bit_exact(pai, case):
+    """gg_fwd_patchw_k<256, 128> (four waves of 128 x 64, round-3 operand addressing; tunable fwd_wide = 1: faster than the
+    default alone on the chip, slower beside the weight-gradient stream of the training step) against the same cases as
+    gg_fwd_patch_k<256, 128> (eight waves of 64 x 64), which the named run above pins."""
+    used = _run_case(pai, case, tunables=(("fwd_wide", 1),))
+    assert any(u == "gg_fwd_patchw_k<256, 128, true>" for u in used[:2]), used
 
 
 @pytest.mark.parametrize("mode", [1, 2], ids=["8wave", "4wave"])

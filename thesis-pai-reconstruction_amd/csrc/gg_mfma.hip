@@ -41,7 +41,7 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
 // double-buffered, one 512-thread workgroup per CU) when that still gives every CU a workgroup,
 // else 128 x 128 / 128 x 64 (single buffer, 3-4 workgroups per CU), split over K when even that
 // leaves CUs idle.
-constexpr int FWD_WIDE_DEFAULT = 1;   // gg_fwd_patchw_k (128 x 64 wave tiles) for the 256-row tiles: tunable fwd_wide
+constexpr int FWD_WIDE_DEFAULT = 0;   // gg_fwd_patchw_k (128 x 64 wave tiles) for the 256-row tiles: tunable fwd_wide
 struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
@@ -631,7 +631,12 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 // (8 + 4 per 32: a quarter fewer LDS fragment bytes per FLOP, the lever that took the weight gradient from 0.75 to 1.0
 // PFLOP/s, gg_wg3.hip), 128 accumulator registers, half the waves -- 256 x 128 tiles are then four waves, two
 // workgroups per CU at up to 256 registers.
-template <int BM, int BN, bool DBB, int WN = 2, int WPX = 64>   // DBB: two weight-tile buffers
+// COLSWZ: the round-3 operand addressing (patch chunks swizzled by the patch COLUMN, taps unrolled: every fragment address
+// a register + immediate).  false: the round-1/2 addressing (swizzle by the pixel index, four pixel addresses rebuilt per
+// tap, ~30 vector instructions per 32 MFMAs) -- kept for the two configurations of eight / four 64 x 64 waves that sit AT
+// their occupancy's register line (128): unrolled, hipcc spills 12-15 registers there and reloads the fill constants from
+// scratch in front of every patch fill (same-box step: 6.68-6.74 ms against 6.55-6.59 with this form).
+template <int BM, int BN, bool DBB, int WN = 2, int WPX = 64, bool COLSWZ = true>   // DBB: two weight-tile buffers
 __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a, const PatchGeo& pg, int mtiles, int ntiles) {
     static_assert(WN == 2 || BN == 64, "one wave column: 64 output channels");
     constexpr int abl = PATCH_ABL;
@@ -700,7 +705,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
             const int yy = y + (int)((wby16 >> (4 * q)) & 15u) - 8, xx = x + (int)((wbx16 >> (4 * q)) & 15u) - 8;
             if (q < pg.groups && p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
         }
-        pfill[j] = ((unsigned)pixb & 0xffffffu) | (m << 24) | ((unsigned)(sc ^ (px & 6)) << 28);
+        pfill[j] = ((unsigned)pixb & 0xffffffu) | (m << 24) | ((unsigned)(sc ^ ((COLSWZ ? px : sr) & 6)) << 28);
     }
     const int gchB = (sc ^ ((sr >> 1) & 7)) * 8;
     // LDS row rho = 16 nt + i of a wave's half of the weight tile holds output channel
@@ -733,6 +738,10 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
         b_addr[kk] = (unsigned)(PATCH_BYTES + (wn * BNW + fr) * 128) + (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
+    int pbase[MT];                           // !COLSWZ: patch pixel of the wave's row mt (tap offset added per step)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) pbase[mt] = (wm * MT + mt) * PATCH_W + fr;
+    const unsigned b_base = (unsigned)(PATCH_BYTES + (wn * BNW + fr) * 128);
     f4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -775,72 +784,146 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     };
     fire_patch(0);
     fire_b(0, 0, 0);
-    // one tap (slot K of the window, patch offset (K >> 1, K & 1)); the weight buffer of step K is K & 1 (four steps per
-    // patch: the parity restarts with every patch)
-    auto step = [&](auto k_tag, int gi, int relu, bool more) {
-        constexpr int K = decltype(k_tag)::value;
-        constexpr int TY = K >> 1, TX = K & 1;
-        constexpr int BUF = DBB ? (K & 1) : 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // this step's tiles have landed; everyone is done with the other weight buffer
-        if (DBB) {
-            if (K < 3) fire_b(gi, K + 1, BUF ^ 1);
-            else if (more) fire_b(gi + 1, 0, BUF ^ 1);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf8_t af[MT], bfr[NT];
-            if (!(abl & 8)) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    af[mt] = *(const bf8_t*)(smem + (a_addr[TX][kk] & 0xffffu) + (mt + TY) * (PATCH_W * 128));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bfr[nt] = *(const bf8_t*)(smem + (b_addr[kk] & 0x3ffffu) + BUF * (BN * 128) + nt * 16 * 128);
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(bf8_t, make_uint4(a_addr[TX][kk], b_addr[kk], mt, kk));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(b_addr[kk], a_addr[TX][kk], nt, kk));
+    if constexpr (COLSWZ) {
+        // one tap (slot K of the window, patch offset (K >> 1, K & 1)); the weight buffer of step K is K & 1 (four steps per
+        // patch: the parity restarts with every patch)
+        auto step = [&](auto k_tag, int gi, int relu, bool more) {
+            constexpr int K = decltype(k_tag)::value;
+            constexpr int TY = K >> 1, TX = K & 1;
+            constexpr int BUF = DBB ? (K & 1) : 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // this step's tiles have landed; everyone is done with the other weight buffer
+            if (DBB) {
+                if (K < 3) fire_b(gi, K + 1, BUF ^ 1);
+                else if (more) fire_b(gi + 1, 0, BUF ^ 1);
             }
-            if (relu) {
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf8_t af[MT], bfr[NT];
+                if (!(abl & 8)) {
+                    const unsigned aa = a_addr[TX][kk], ba = b_addr[kk];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
-            }
-            if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
-            if (!(abl & 4)) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        af[mt] = *(const bf8_t*)(smem + (aa & 0xffffu) + (mt + TY) * (PATCH_W * 128));
+    #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                        bfr[nt] = *(const bf8_t*)(smem + (ba & 0x3ffffu) + BUF * (BN * 128) + nt * 16 * 128);
+                } else {
+    #pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(bf8_t, make_uint4(a_addr[TX][kk], b_addr[kk], mt, kk));
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(b_addr[kk], a_addr[TX][kk], nt, kk));
+                }
+                if (relu) {
+    #pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
+                }
+                if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                if (!(abl & 4)) {
+    #pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                } else {
+                    acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];
+                }
+                if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            }
+            if (DBB) {
+                if (K == 3 && more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // every wave is done reading the patch
+                    fire_patch(gi + 1);
+                }
             } else {
-                acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];
-            }
-            if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
-        }
-        if (DBB) {
-            if (K == 3 && more) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();   // every wave is done reading the patch
-                fire_patch(gi + 1);
+                __builtin_amdgcn_s_barrier();       // every wave is done reading before the next fill overwrites
+                if (K < 3) fire_b(gi, K + 1, 0);
+                else if (more) { fire_patch(gi + 1); fire_b(gi + 1, 0, 0); }
             }
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();       // every wave is done reading before the next fill overwrites
-            if (K < 3) fire_b(gi, K + 1, 0);
-            else if (more) { fire_patch(gi + 1); fire_b(gi + 1, 0, 0); }
+        };
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int c0g = (gi >> gsh) * MBK;
+            const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
+            const bool more = gi + 1 < ngroups;
+            step(std::integral_constant<int, 0>{}, gi, relu, more);
+            step(std::integral_constant<int, 1>{}, gi, relu, more);
+            step(std::integral_constant<int, 2>{}, gi, relu, more);
+            step(std::integral_constant<int, 3>{}, gi, relu, more);
         }
-    };
-    for (int gi = 0; gi < ngroups; ++gi) {
-        const int c0g = (gi >> gsh) * MBK;
-        const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
-        const bool more = gi + 1 < ngroups;
-        step(std::integral_constant<int, 0>{}, gi, relu, more);
-        step(std::integral_constant<int, 1>{}, gi, relu, more);
-        step(std::integral_constant<int, 2>{}, gi, relu, more);
-        step(std::integral_constant<int, 3>{}, gi, relu, more);
+    } else {
+        int buf = 0;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int c0g = (gi >> gsh) * MBK;
+            const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
+            const unsigned toff4 = pg.toff4[ph][gi & (pg.groups - 1)];
+            const bool more = gi + 1 < ngroups;
+    #pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int toff = (int)((toff4 >> (8 * k)) & 0xffu);
+                unsigned abase[MT];
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const unsigned pp = (unsigned)(pbase[mt] + toff);
+                    abase[mt] = (pp << 7) ^ ((pp & 6u) << 4);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // this step's tiles have landed; everyone is done with the other weight buffer
+                if (DBB) {
+                    if (k < 3) fire_b(gi, k + 1, buf ^ 1);
+                    else if (more) fire_b(gi + 1, 0, buf ^ 1);
+                }
+                const unsigned bb = b_base + (DBB ? buf * (BN * 128) : 0);
+    #pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const unsigned ca = (unsigned)((kk * 4 + fq) << 4);
+                    const unsigned cb = (unsigned)(((kk * 4 + fq) ^ fswz) << 4);
+                    bf8_t af[MT], bfr[NT];
+                    if (!(abl & 8)) {
+    #pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf8_t*)(smem + (abase[mt] ^ ca));
+    #pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bfr[nt] = *(const bf8_t*)(smem + bb + nt * 16 * 128 + cb);
+                    } else {
+    #pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(bf8_t, make_uint4(ca, cb, mt, kk));
+    #pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(cb, ca, nt, kk));
+                    }
+                    if (relu) {
+    #pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
+                    }
+                    if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                    if (!(abl & 4)) {
+    #pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                // D[i = channel slot][j = pixel]: acc[mt][nt][r] = channel slot 4 fq + r of pixel fr
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];
+                    }
+                    if (PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
+                }
+                if (DBB) {
+                    buf ^= 1;
+                    if (k == 3 && more) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();   // every wave is done reading the patch
+                        fire_patch(gi + 1);
+                    }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();       // every wave is done reading before the next fill overwrites
+                    if (k < 3) fire_b(gi, k + 1, 0);
+                    else if (more) { fire_patch(gi + 1); fire_b(gi + 1, 0, 0); }
+                }
+            }
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the epilogue reuses the tile memory
@@ -970,7 +1053,8 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 
 template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
-    gg_fwd_patch_body<BM, BN, DBB>(g, a, pg, mtiles, ntiles);
+    // (BM, BN, DBB) = (256, 128, *) and (128, 128, false) are the configurations at the register line, see COLSWZ
+    gg_fwd_patch_body<BM, BN, DBB, 2, 64, !(BN == 128 && (BM == 256 || !DBB))>(g, a, pg, mtiles, ntiles);
 }
 // 128 x 64 wave tiles: BM / 128 x 2 waves (see gg_fwd_patch_body, WPX = 128)
 template <int BM, int BN, bool DBB>
