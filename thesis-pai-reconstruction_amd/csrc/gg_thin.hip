@@ -454,9 +454,118 @@ __global__ __launch_bounds__(256) void thin_col2im_k(GG g, FwdArgs a, const floa
     }
 }
 
+// Both steps in ONE kernel for the 4-phase form (decoders[7] + tanh, input gradient of D block 0): a workgroup owns a
+// 16 x 16 block of SOURCE pixels of one image.  It runs the skinny GEMM over the block and its one-pixel halo (18 x 18
+// pixels = 21 groups of 16, 1.27 x the block: the halo rows are L2 hits, the neighbouring workgroups read them too),
+// keeps the 16 tap values per pixel in LDS (fp32, rows padded to 17 floats) and gathers the 32 x 32 output pixels from
+// there -- the 67 MB (decoders[7]) of fp32 scratch written by thin_dgrad_gemm_k and re-read ~2 x by thin_col2im_k never
+// exist.  Halo pixels beyond the image hold zeros (zero fragments), so the gather needs no bounds test.
+constexpr int TU_HW = 18, TU_PIX = TU_HW * TU_HW, TU_GROUPS = (TU_PIX + 15) / 16, TU_LD = 17;
+template <int T, int KS>
+__global__ __launch_bounds__(256) void thin_up_k(GG g, FwdArgs a, int t0, int tiles_x, int tiles_y) {
+    __shared__ float Ys[T][TU_GROUPS * 16][TU_LD];
+    __shared__ int tab[4][4];     // dy | dx << 8 | wt << 16 per (phase, tap)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* x1 = (const bf16_t*)a.x1;
+    const bf16_t* x2 = (const bf16_t*)a.x2;
+    const bf16_t* w = (const bf16_t*)a.w;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * 16; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * 16;
+    const int n = bid / tiles_y;
+    if (tid < 16) {
+        const int p = tid >> 2, k = tid & 3;
+        tab[p][k] = (g.dy[p][k] & 0xff) | ((g.dx[p][k] & 0xff) << 8) | ((g.wt[p][k] & 0xff) << 16);
+    }
+    // A operand: Wp[(t, tap)][c]
+    bf8_t af[T][KS];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            af[tt][s] = *(const bf8_t*)(w + (size_t)((t0 + tt) * g.wtaps + fr) * g.Cin + 32 * s + 8 * fq);
+    for (int gi = wid; gi < TU_GROUPS; gi += 4) {
+        const int p = gi * 16 + fr;
+        const int hy = p / TU_HW, hx = p - hy * TU_HW;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const bool inb = p < TU_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        const size_t m = inb ? (size_t)(n * g.H + iy) * g.W + ix : 0;
+        bf8_t bfr[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * fq;
+            bfr[s] = __builtin_bit_cast(bf8_t, make_uint4(0, 0, 0, 0));
+            if (inb) {
+                if (c < g.C1) {
+                    bfr[s] = *(const bf8_t*)(x1 + m * g.C1 + c);
+                    if (g.relu1) bfr[s] = relu8(bfr[s]);
+                } else {
+                    bfr[s] = *(const bf8_t*)(x2 + m * g.C2 + (c - g.C1));
+                    if (g.relu2) bfr[s] = relu8(bfr[s]);
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+            f4_t acc = (f4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][s], bfr[s], acc, 0, 0, 0);
+            // D[i = tap 4 fq + r][j = pixel fr]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ys[tt][p][4 * fq + r] = acc[r];
+        }
+    }
+    __syncthreads();
+    // 32 x 32 output pixels, lanes along ox
+    for (int i = tid; i < 1024; i += 256) {
+        const int oyl = i >> 5, oxl = i & 31;
+        const int oy = 2 * ty0 + oyl, ox = 2 * tx0 + oxl;
+        const int ph = (oyl & 1) * 2 + (oxl & 1);
+        const int hy0 = (oyl >> 1) + 1, hx0 = (oxl >> 1) + 1;
+        const size_t o = ((size_t)n * g.OH + oy) * g.OW + ox;
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+            const int t = t0 + tt;
+            float v = a.bias ? a.bias[t] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = tab[ph][k];
+                const int hy = hy0 + (int)(signed char)(e & 0xff), hx = hx0 + (int)(signed char)((e >> 8) & 0xff);
+                v += Ys[tt][hy * TU_HW + hx][(e >> 16) & 0xff];
+            }
+            if (t < g.D1) {
+                if (a.y1 && !a.skip_d1) ((bf16_t*)a.y1)[o * g.D1 + t] = f2bf(v);
+            } else if (a.y2) {
+                ((bf16_t*)a.y2)[o * g.D2 + (t - g.D1)] = f2bf(v);
+            }
+            if (a.yact || a.yf32) {
+                const float av = act_apply(v, a.eact);
+                if (a.yact) ((bf16_t*)a.yact)[o * g.Cout + t] = f2bf(av);
+                if (a.yf32) a.yf32[o * g.Cout + t] = av;
+            }
+        }
+    }
+}
+
+static bool thin_up_ok(const GG& g) {
+    return pai_tunable("thin_up", 1) && g.nphase == 4 && g.ntaps == 4 && g.OS == 2 && g.wtaps == 16 && (g.H % 16) == 0 &&
+           (g.W % 16) == 0 && (g.Cin == 64 || g.Cin == 128);
+}
+
 int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int T = thin_dgrad_T(g, a);
     const int t0 = (g.Cout == 2 && a.skip_d1) ? 1 : 0;
+    if (thin_up_ok(g)) {
+        const int tx = g.W / 16, ty = g.H / 16;
+        const dim3 grid(g.N * tx * ty);
+        if (T == 1 && g.Cin == 128) hipLaunchKernelGGL((thin_up_k<1, 4>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        else if (T == 1) hipLaunchKernelGGL((thin_up_k<1, 2>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        else if (g.Cin == 128) hipLaunchKernelGGL((thin_up_k<2, 4>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        else hipLaunchKernelGGL((thin_up_k<2, 2>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     // every wave keeps the whole filter in registers: give it >= 4 pixel groups to amortise that
     int blocks = cdiv((int64_t)g.N * g.H * g.W, 256);
     if (blocks > 4096) blocks = 4096;
@@ -688,8 +797,18 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_k(ThinW p, int T, int n
     const int b0 = blockIdx.y * per, b1 = min(ntiles, b0 + per);
     float sum = 0.f;
     if (gy < groups) {
+        // eight independent loads in flight per thread: as a plain loop this was a chain of ~32 dependent memory round
+        // trips per thread and the launch took 21 us for 18 MB
         const float* src = p.partial + (size_t)gy * pst + le;
-        for (int b = b0 + slice; b < b1; b += 4) sum += src[(size_t)b * groups * pst];
+        const size_t bstride = (size_t)groups * pst;
+        int b = b0 + slice;
+        for (; b + 28 < b1; b += 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(b + 4 * u) * bstride];
+            sum += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        for (; b < b1; b += 4) sum += src[(size_t)b * bstride];
     }
     red[slice][threadIdx.x & 63] = sum;
     __syncthreads();
