@@ -272,6 +272,9 @@ int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2, const
  * plainly -- no zero-fill pass, no read of dW; the others clear the buffers themselves and accumulate. */
 int pai_conv_wgrad_overwrite(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
                              float* dw, float* dbias, void* stream);
+/* dw = ..., dbias += ...: as above for the weights; the bias gradient is added to what the caller cleared. */
+int pai_conv_wgrad_overwrite_w(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
+                               float* dw, float* dbias, void* stream);
 
 /* fp32 master weights (fwd pack) -> storage-dtype fwd pack and/or dgrad pack. */
 int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,

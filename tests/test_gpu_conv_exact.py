@@ -244,13 +244,14 @@ def test_weight_gradient_bias_and_overwrite(pai, name, slab):
         assert ops.conv_kernel_name(d, 2) == names[2]
         X1, X2, DY = nhwc(x1, dt), (nhwc(x2, dt) if C2 else None), nhwc(dy, dt)
         n = Cout * 16 * Cin
-        for overwrite in (False, True):
-            # accumulate: starts from a known integer offset; overwrite: starts from garbage
+        for overwrite in (0, 1, 2):
+            # 0 accumulate: starts from a known integer offset; 1 overwrite: starts from garbage; 2 pai_conv_wgrad_overwrite_w:
+            # the weights start from garbage, the bias gradient is added
             dw = torch.full((n,), 3.0, device=dev()) if not overwrite else torch.full((n,), float("nan"), device=dev())
-            db = torch.full((Cout,), 5.0, device=dev()) if not overwrite else torch.full((Cout,), float("nan"), device=dev())
-            (ops.conv_wgrad_overwrite if overwrite else ops.conv_wgrad)(d, X1, X2, DY, dw, db)
+            db = torch.full((Cout,), 5.0, device=dev()) if overwrite != 1 else torch.full((Cout,), float("nan"), device=dev())
+            (ops.conv_wgrad, ops.conv_wgrad_overwrite, ops.conv_wgrad_overwrite_w)[overwrite](d, X1, X2, DY, dw, db)
             torch.cuda.synchronize()
-            off_w, off_b = (0.0, 0.0) if overwrite else (3.0, 5.0)
+            off_w, off_b = (0.0 if overwrite else 3.0), (0.0 if overwrite == 1 else 5.0)
             assert torch.equal(unpack_fwd(dw, Cout, Cin, bool(tr)), dw_ref + off_w), (name, "dw", overwrite)
             assert torch.equal(db.cpu(), db_ref + off_b), (name, "dbias", overwrite)
     finally:

@@ -703,6 +703,13 @@ extern "C" int pai_conv_wgrad_overwrite(const pai_conv_desc* d, const void* x1, 
     return conv_wgrad_impl(d, x1, x2, dy, dw, dbias, 1, stream);
 }
 
+// dw = ..., dbias += ...: the weights need no caller zeroing, the bias gradient is ADDED to what the caller cleared (one
+// multi-tensor clear of all small gradient segments per backward pass instead of one fill launch per layer)
+extern "C" int pai_conv_wgrad_overwrite_w(const pai_conv_desc* d, const void* x1, const void* x2,
+                                          const void* dy, float* dw, float* dbias, void* stream) {
+    return conv_wgrad_impl(d, x1, x2, dy, dw, dbias, 2, stream);
+}
+
 static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
                            float* dbias, int overwrite, void* stream) {
     GG g;
@@ -710,7 +717,7 @@ static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x
     PAI_CHECK(x1 && dy && dw, "pai_conv_wgrad: null pointer");
     PAI_CHECK(d->C2 == 0 || x2, "pai_conv_wgrad: C2 > 0 but x2 is null");
     WgradArgs a;
-    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0; a.slab = nullptr;
+    a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0; a.overwrite_bias = 0; a.slab = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (overwrite) {
         const bool thin = thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) ||
@@ -719,10 +726,11 @@ static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x
         const bool rowdot = g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0;
         if (!thin && !rowdot && wgrad_mfma_ok(d->dtype, g) && wgrad_mfma_can_overwrite(g)) {
             a.overwrite = 1;       // every element has exactly one writer: plain stores, nothing to clear
+            a.overwrite_bias = overwrite == 1;
         } else {                   // the accumulating kernels: clear first
             hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * g.wtaps * g.Cin * sizeof(float), s);
             PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_overwrite: hipMemsetAsync: %s", hipGetErrorString(e));
-            if (dbias) {
+            if (dbias && overwrite == 1) {
                 e = hipMemsetAsync(dbias, 0, (size_t)g.Cout * sizeof(float), s);
                 PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_overwrite: hipMemsetAsync: %s", hipGetErrorString(e));
             }

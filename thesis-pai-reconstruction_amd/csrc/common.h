@@ -247,7 +247,8 @@ struct WgradArgs {
     const void *x1, *x2, *dy;
     float* dw;
     float* dbias;
-    int overwrite;   // dw = / dbias = instead of +=; honoured by gg_wgrad_mfma_k when wgrad_mfma_can_overwrite(g)
+    int overwrite;   // dw = instead of +=; honoured by gg_wgrad_mfma_k when wgrad_mfma_can_overwrite(g)
+    int overwrite_bias;   // dbias = instead of += (pai_conv_wgrad_overwrite; 0 for pai_conv_wgrad_overwrite_w: the caller cleared dbias)
     float* slab;     // set by the launcher: pixel split `s` stores its tile into slab + s * |dW| (plain stores, no atomics)
 };
 // the handle's weight-gradient workspace if it holds `bytes`, else NULL (the launch then adds with fp32 atomics)

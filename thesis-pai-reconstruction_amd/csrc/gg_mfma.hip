@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 #pragma unroll
             for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
             if (splits == 1 && g.nphase == 1) {
-                if (a.overwrite) a.dbias[co0 + tid] = t;
+                if (a.overwrite_bias) a.dbias[co0 + tid] = t;
                 else a.dbias[co0 + tid] += t;
             } else {
                 atomicAdd(a.dbias + co0 + tid, t);
@@ -1792,7 +1792,7 @@ __global__ __launch_bounds__(256, 4) void gg_wgrad_patch_k(GG g, WgradArgs a, Pa
 #pragma unroll
             for (int h = 0; h < 256 / BMC; ++h) t += red[tid + h * BMC];
             if (splits == 1 && g.nphase == 1) {
-                if (a.overwrite) a.dbias[co0 + tid] = t;
+                if (a.overwrite_bias) a.dbias[co0 + tid] = t;
                 else a.dbias[co0 + tid] += t;
             } else {
                 atomicAdd(a.dbias + co0 + tid, t);
@@ -1911,7 +1911,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     }
     const size_t lds = 2 * 64 * 256;
     dim3 grid(tiles * splits);
-    if (a.overwrite && a.dbias && g.nphase > 1) {
+    if (a.overwrite_bias && a.dbias && g.nphase > 1) {
         hipError_t e = hipMemsetAsync(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
         PAI_CHECK(e == hipSuccess, "launch_wgrad_mfma: hipMemsetAsync: %s", hipGetErrorString(e));
     }

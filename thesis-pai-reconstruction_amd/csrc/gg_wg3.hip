@@ -328,25 +328,48 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     }
 }
 
-// dW (+)= sum over the splits' slabs, in split order (deterministic); 16 B per thread and slab
+// dW (+)= sum over the splits' slabs (deterministic: fixed association).  Block = 64 float4 elements x 4 split lanes:
+// lane q adds the splits q, q + 4, ... with eight 16-B loads in flight, the four lanes meet in LDS in lane order.  (One
+// thread per element with the split loop inside it was a chain of dependent loads: the layers with a small dW and many
+// splits -- encoders[1] / D block 1: 0.5 MB x 128 -- ran 128 workgroups for 30 us.)
 __global__ __launch_bounds__(256) void wgrad_slab_sum_k(float* __restrict__ dw, const float* __restrict__ slab, int nsplits,
                                                         long n4, long slab_stride4, int overwrite) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const float4* s = (const float4*)slab + i;
-    float4 v = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)dw)[i];
-#pragma unroll 4
-    for (int k = 0; k < nsplits; ++k) {
-        const float4 t = s[(long)k * slab_stride4];
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    __shared__ float4 red[3][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + e;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4* s = (const float4*)slab + i;
+        int k = q;
+        for (; k + 28 < nsplits; k += 32) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = s[(long)(k + 4 * u) * slab_stride4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+        }
+        for (; k < nsplits; k += 4) {
+            const float4 t = s[(long)k * slab_stride4];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
     }
-    ((float4*)dw)[i] = v;
+    if (q) red[q - 1][e] = v;
+    __syncthreads();
+    if (q == 0 && i < n4) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { v.x += red[j][e].x; v.y += red[j][e].y; v.z += red[j][e].z; v.w += red[j][e].w; }
+        if (!overwrite) {
+            const float4 o = ((const float4*)dw)[i];
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        ((float4*)dw)[i] = v;
+    }
 }
 
 int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, int overwrite, hipStream_t s) {
     PAI_CHECK((n % 4) == 0, "wgrad slab sum: %lld elements are not a multiple of 4", (long long)n);
     const long n4 = (long)(n / 4);
-    hipLaunchKernelGGL(wgrad_slab_sum_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dw, slab, nsplits, n4, n4, overwrite);
+    hipLaunchKernelGGL(wgrad_slab_sum_k, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, dw, slab, nsplits, n4, n4, overwrite);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -417,7 +440,7 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     float* slab = nullptr;
     if (c.psplits > 1 && pai_tunable("wgrad_slab", 1)) slab = wgrad_slab_acquire(need);
     a.slab = slab;
-    if (a.overwrite && a.dbias) {   // the bias sums of the workgroups meet by atomics
+    if (a.overwrite_bias && a.dbias) {   // the bias sums of the workgroups meet by atomics
         hipError_t e = hipMemsetAsync(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
         PAI_CHECK(e == hipSuccess, "launch_wgrad3: hipMemsetAsync: %s", hipGetErrorString(e));
     }

@@ -92,6 +92,8 @@ class GradArena:
             if mod is not None and p.dim() == 4:
                 cin, cout = _cin_cout(mod)
                 v = seg.view(cout, 4, 4, cin).permute(_logical_perm(mod))
+                if min(cin, cout) <= 2:       # thin layers: their kernels ADD partial tiles -- cleared with the small segments
+                    self._small.append(seg)
             else:
                 v = seg.view(p.shape)
                 self._small.append(seg)
@@ -632,12 +634,15 @@ class UnetEngine:
 
         side = self._side
 
-        conv_wgrad = ops.conv_wgrad_overwrite if fresh else ops.conv_wgrad
+        # first pass: dense weight gradients are WRITTEN; bias gradients and the thin layers' weights are added to
+        # segments GradArena.begin_backward cleared in one launch
+        conv_wgrad = ops.conv_wgrad_overwrite_w if fresh else ops.conv_wgrad
 
         def wgrad(d, x1, x2, dz, conv, with_bias):
             """Weight (and bias) gradient of one layer on the side stream."""
             with torch.cuda.stream(side.fork(d)):
-                conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
+                fn = ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad
+                fn(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
                 done(conv.bias)
 
         # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
@@ -737,7 +742,8 @@ class UnetEngine:
         # encoder 0 (its dz came out of encoder 1's input gradient): on the tail stream, beside encoder 1's
         conv0 = self.enc_conv[0]
         with torch.cuda.stream(side.fork_tail()):
-            conv_wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
+            (ops.conv_wgrad if min(_cin_cout(conv0)) <= 2 else conv_wgrad)(
+                P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
         side.join()
         done(conv0.bias)      # both side streams have been joined: the whole arena is final
 
@@ -855,7 +861,7 @@ class DiscEngine:
 
     def backward(self, S, glogits, need_params: bool, need_dy: bool, fresh: bool = False):
         """``fresh``: see UnetEngine.backward."""
-        conv_wgrad = ops.conv_wgrad_overwrite if fresh else ops.conv_wgrad
+        conv_wgrad = ops.conv_wgrad_overwrite_w if fresh else ops.conv_wgrad
         P = S["P"]
         N, H, W, dtype, dev = P["N"], P["H"], P["W"], P["dtype"], P["device"]
         if S["grads"] is None:
@@ -876,7 +882,7 @@ class DiscEngine:
         side = self._side
         if need_params:
             with torch.cuda.stream(side.fork(d)):
-                conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)
+                ops.conv_wgrad(d, S["a"][3], None, dl, A.seg(self.convs[4].weight), None)     # thin (one output channel): added
                 if hook is not None:
                     hook(A, A.end_of(self.convs[4].weight))
             side.mark_scratch()
@@ -889,7 +895,8 @@ class DiscEngine:
             if need_params and k == 0:
                 # thin first layer: tail stream, beside block 1's weight gradient; its hook fires after the join
                 with torch.cuda.stream(side.fork_tail()):
-                    conv_wgrad(d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
+                    (ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad)(
+                        d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
             elif need_params:
                 with torch.cuda.stream(side.fork(d)):
                     conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pai_conv_bn_fused": (_I, [_D, _I]),
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "pai_conv_wgrad_overwrite_w": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
     "pai_pack_frag": (_I, [_P, _I, _I, _P, _P]),
     "pai_build_flags": (_I, []),

@@ -306,6 +306,13 @@ def conv_wgrad_overwrite(d, x1, x2, dy, dw, dbias=None):
                                                   _p(dbias, torch.float32), _stream()), "pai_conv_wgrad_overwrite")
 
 
+def conv_wgrad_overwrite_w(d, x1, x2, dy, dw, dbias=None):
+    """dw = conv_backward_weight(...) into an uninitialised buffer, dbias += ... (pai_conv_wgrad_overwrite_w)."""
+    with _Timed(d, 2):
+        L.check(L.load().pai_conv_wgrad_overwrite_w(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw, torch.float32),
+                                                    _p(dbias, torch.float32), _stream()), "pai_conv_wgrad_overwrite_w")
+
+
 def pack_weights(dtype, w_master, Cout, taps, Cin, w_fwd=None, w_dgrad=None):
     L.check(L.load().pai_pack_weights(code_of(dtype), _p(w_master, torch.float32), Cout, taps, Cin, _p(w_fwd),
                                       _p(w_dgrad), _stream()), "pai_pack_weights")
