@@ -184,11 +184,27 @@ def wg3_x():
     return worst
 
 
+def wg3_x8():
+    """gg_wg3.hip, 8 x 8-pixel K steps (BW = 8): patch rows of 9 pixels at a pitch of 12, 128-B pixels, f(p) = bit 1 | bit 2 << 1."""
+    pw = 12
+    worst = 1
+    for kk, h, toff, nt in itertools.product(range(2), range(2), (0, 1, pw, pw + 1), range(4)):
+        def addr(lane):
+            fi, fg = lane & 15, lane >> 4
+            tq, tp = fi >> 2, fi & 3
+            r = kk * 32 + fg * 8 + tq + 4 * h
+            p = (r >> 3) * pw + (r & 7) + toff
+            f = ((p >> 1) & 1) | (((p >> 2) & 1) << 1)
+            return (p * 128 + (f << 5) + tp * 8) ^ (nt << 5)
+        worst = max(worst, ways(addr, HALF_GROUPS, 8))
+    return worst
+
+
 def main():
     bad = 0
     for name, fn in (("fwd_patch", fwd_patch), ("fwd_weight", fwd_weight), ("fwd_patch32", fwd_patch32),
                      ("fwd_weight32", fwd_weight32), ("p2_patch", p2_patch), ("wg_dy", wg_dy),
-                     ("wg_x", wg_x), ("wg2_x", wg2_x), ("wg3_dy", wg3_dy), ("wg3_x", wg3_x)):
+                     ("wg_x", wg_x), ("wg2_x", wg2_x), ("wg3_dy", wg3_dy), ("wg3_x", wg3_x), ("wg3_x8", wg3_x8)):
         w = fn()
         print(f"{name:11s} worst {w}-way" + ("" if w == 1 else "   <-- conflicts"))
         bad += w != 1

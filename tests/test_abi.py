@@ -109,11 +109,11 @@ def test_kernel_dispatch_table_without_gpu(pai):
         assert tuple(ops.conv_kernel_id(d, op) for op in (0, 1, 2)) == mod.BF16_FAMILY[name], name
     big = "gg_fwd_patch_k<256, 128, true>"
     cfg2 = {   # (transposed, N, H, C1, C2, Cout) -> (forward, input gradient, weight gradient)
-        "encoders[2]": ((0, 64, 64, 128, 0, 256), (big, big, "gg_wgrad_patch3_k<128, 64>")),
-        "decoders[4]": ((1, 64, 16, 512, 512, 256), (big, big, "gg_wgrad_patch3_k<128, 64>")),
-        "decoders[5]": ((1, 64, 32, 256, 256, 128), (big, big, "gg_wgrad_patch3_k<128, 64>")),
-        "decoders[6]": ((1, 64, 64, 128, 128, 64), ("gg_fwd_patch1_k<256, 64, false>", big, "gg_wgrad_patch3_k<64, 128>")),
-        "D block 3": ((0, 128, 32, 256, 0, 512), (big, big, "gg_wgrad_patch3_k<128, 64>")),
+        "encoders[2]": ((0, 64, 64, 128, 0, 256), (big, big, "gg_wgrad_patch3_k<128, 64, 16>")),
+        "decoders[4]": ((1, 64, 16, 512, 512, 256), (big, big, "gg_wgrad_patch3_k<128, 64, 16>")),
+        "decoders[5]": ((1, 64, 32, 256, 256, 128), (big, big, "gg_wgrad_patch3_k<128, 64, 16>")),
+        "decoders[6]": ((1, 64, 64, 128, 128, 64), ("gg_fwd_patch1_k<256, 64, false>", big, "gg_wgrad_patch3_k<64, 128, 16>")),
+        "D block 3": ((0, 128, 32, 256, 0, 512), (big, big, "gg_wgrad_patch3_k<128, 64, 16>")),
     }
     for layer, ((tr, N, H, C1, C2, Cout), want) in cfg2.items():
         d = ops.make_desc(torch.bfloat16, tr, N, H, H, C1, C2, Cout, 2, tr, tr if C2 else 0)

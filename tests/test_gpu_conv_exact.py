@@ -22,24 +22,24 @@ pytestmark = pytest.mark.gpu
 SPLIT = ("gg_fwd_mfma_k<128, 128, true, true, 64>", "gg_fwd_mfma_k<128, 128, false, false, 64>")
 # (name, transposed, N, H, C1, C2, Cout, relu, (forward, input-gradient, weight-gradient kernel))
 CASES = [
-    ("enc_patch", 0, 4, 128, 64, 0, 256, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("dec_patch", 1, 4, 64, 64, 64, 128, 1, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("enc_patch256", 0, 8, 256, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("dec_patch256x64", 1, 8, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
-    ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("enc_patch", 0, 4, 128, 64, 0, 256, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("dec_patch", 1, 4, 64, 64, 64, 128, 1, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("enc_patch256", 0, 8, 256, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("dec_patch256x64", 1, 8, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<64, 128, 16>")),
+    ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
     ("enc_splitk", 0, 4, 8, 256, 0, 256, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     ("dec_splitk", 1, 4, 4, 256, 256, 256, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
     # BASELINE configs[1] layer shapes at the benchmark batch (64; the discriminator sees 2 x 64 in its own phase)
-    ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_enc4", 0, 64, 16, 512, 0, 512, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
-    ("cfg2_dec3", 1, 64, 8, 512, 512, 512, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
-    ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<64, 128>")),
-    ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
-    ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64>")),
+    ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("cfg2_enc4", 0, 64, 16, 512, 0, 512, 0, (SPLIT, SPLIT, "gg_wgrad_patch3_k<128, 64, 8>")),
+    ("cfg2_dec3", 1, 64, 8, 512, 512, 512, 1, (SPLIT, SPLIT, "gg_wgrad_patch3_k<128, 64, 8>")),
+    ("cfg2_dec4", 1, 64, 16, 512, 512, 256, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("cfg2_dec5", 1, 64, 32, 256, 256, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("cfg2_dec6", 1, 64, 64, 128, 128, 64, 1, ("gg_fwd_patch1_k<256, 64, false>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<64, 128, 16>")),
+    ("cfg2_D1", 0, 128, 128, 64, 0, 128, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 64, false>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("cfg2_D2", 0, 128, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
+    ("cfg2_D3", 0, 128, 32, 256, 0, 512, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
 ]
 
 
@@ -219,7 +219,7 @@ def test_previous_weight_gradient_kernels_stay_exact(pai, name):
 
 
 @pytest.mark.parametrize("slab", [1, 0], ids=["slabs", "atomics"])
-@pytest.mark.parametrize("name", ["enc_patch256", "dec_patch256x64", "cfg2_D1", "cfg2_dec4"])
+@pytest.mark.parametrize("name", ["enc_patch256", "dec_patch256x64", "cfg2_D1", "cfg2_dec4", "cfg2_enc4", "cfg2_dec3"])
 def test_weight_gradient_bias_and_overwrite(pai, name, slab):
     """gg_wgrad_patch3_k with a bias gradient (column sums of dY taken from the fragments every wave holds, spread over
     the workgroups that share a dY tile) and through pai_conv_wgrad_overwrite (dW / dbias need no zero fill: the slab sum,

@@ -141,11 +141,11 @@ template <int BM, int WN = 2, int WPX = 64> struct PatchDims {   // WN: waves si
     static constexpr int BYTES = PJ * RPP * 128;
 };
 
-static inline bool patch_geo(const GG& g, int th, PatchGeo* pg) {
-    if ((g.OWg % 16) || (g.OHg % th)) return false;
+static inline bool patch_geo(const GG& g, int th, PatchGeo* pg, int tw = 16) {   // th x tw: output pixels of a tile
+    if ((g.OWg % tw) || (g.OHg % th)) return false;
     memset(pg, 0, sizeof(*pg));
     pg->TY = g.OHg / th;
-    pg->TX = g.OWg / 16;
+    pg->TX = g.OWg / tw;
     if (g.S == 1 && g.ntaps == 4) {
         pg->groups = 1;
         for (int ph = 0; ph < g.nphase; ++ph) {

@@ -36,7 +36,11 @@ __device__ __forceinline__ unsigned tr_off3(int row, int ch) { return (unsigned)
 // 256-B pixels alike (scripts/lds_swizzle_check.py wg3_x)
 //   128-B pixels (CI = 64):  4 segments, bank half = bit 0 of p, f(p) = bit 1 | bit 3 << 1
 //   256-B pixels (CI = 128): 8 segments,                        f(p) = bit 0 | bit 1 << 1 | bit 3 << 2
-template <int CI> __device__ __forceinline__ unsigned xseg_swz3(unsigned p) {
+//   BW = 8 (8 x 8-pixel K steps: the 8 x 8 images of encoders[4] / decoders[3]): patch rows of 9 pixels at a pitch of
+//   12, the half-wave's rows are p0 .. p0+3 and p0+12 .. p0+15: f(p) = bit 1 | bit 2 << 1 (128-B pixels; pitches 9, 10
+//   and 17 admit no XOR swizzle at all -- scripts/lds_swizzle_check.py wg3_x8)
+template <int CI, int BW> __device__ __forceinline__ unsigned xseg_swz3(unsigned p) {
+    if (BW == 8) return ((p >> 1) & 1u) | (((p >> 2) & 1u) << 1);
     return CI == 64 ? (((p >> 1) & 1u) | (((p >> 3) & 1u) << 1)) : ((p & 3u) | (((p >> 3) & 1u) << 2));
 }
 // dY tile image: K row r (64 per step) x BMC channels, 16-B chunk c of the row stored at slot c ^ yswz(r).  The 16 rows
@@ -52,16 +56,21 @@ template <int BMC> __device__ __forceinline__ int yswz3(int row) {
 #define WG3_ABL 0     // timing ablations (results WRONG): 1 no dW store, 2 no MFMA, 4 no fills, 8 no fragment reads
 #endif
 
-template <int BMC, int CI>
+// BW: width of the K step's pixel block: 16 (4 x 16 pixels, images >= 16 wide) or 8 (8 x 8 pixels: 8 x 8 images)
+template <int BMC, int CI, int BW = 16>
 __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
                                                             int splits, int blocks_per_split) {
     static_assert((BMC == 128 && CI == 64) || (BMC == 64 && CI == 128), "wave tile 128 x 64 or 64 x 128");
+    static_assert(BW == 16 || (BW == 8 && CI == 64), "8-wide blocks: 128-B patch pixels only");
+    constexpr int LBW = BW == 16 ? 4 : 3;        // log2 BW
+    constexpr int BH = 64 / BW, LBH = BW == 16 ? 2 : 3;   // rows of the block
+    constexpr int PW = BW == 16 ? PATCH_W : 12;  // pitch of a patch row in pixels (BW + 1 used)
     constexpr int MT = BMC / 16;                 // 16-row MFMA tiles along the output channels
     constexpr int NT = CI / 16;                  // 16-column MFMA tiles along the input channels
     constexpr int YROW = BMC * 2;                // bytes per pixel row of the dY tile (256 or 128)
     constexpr int YBUF = 64 * YROW;
     constexpr int XPB = CI * 2;                  // bytes per patch pixel
-    constexpr int XSLOTS = 96;                   // pixel slots filled (85 used)
+    constexpr int XSLOTS = BW == 16 ? 96 : 128;  // pixel slots filled (5 x 17 = 85 / 9 rows at pitch 12 = 108 used)
     constexpr int XBUF = XSLOTS * XPB;
     constexpr int STAGE = YBUF + XBUF;
     constexpr int YJ = YBUF / 4096;              // dY fill instructions per thread (256 threads x 16 B each)
@@ -100,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     constexpr int YCH = YROW / 16, YRPI = 256 / YCH;   // chunks per row, rows per block-wide fill instruction
     const int ysr = tid / YCH, ysc = tid % YCH;
     const int ygch = ysc ^ yswz3<BMC>(ysr);      // the swizzle only looks at row bits 0-3: the same for every j
-    const unsigned ythr = (unsigned)(((((ysr >> 4) << los) << g.ldw) + ((ysr & 15) << los)) * g.Cout + co0 + ygch * 8) * 2u;
-    const unsigned yjstep = (unsigned)(((((YRPI >> 4) << los) << g.ldw)) * g.Cout) * 2u;   // YRPI rows = YRPI / 16 pixel rows further
+    const unsigned ythr = (unsigned)(((((ysr >> LBW) << los) << g.ldw) + ((ysr & (BW - 1)) << los)) * g.Cout + co0 + ygch * 8) * 2u;
+    const unsigned yjstep = (unsigned)(((((YRPI >> LBW) << los) << g.ldw)) * g.Cout) * 2u;   // YRPI rows = YRPI / BW pixel rows further
     // X patch fill map: thread -> (pixel XPPI jj + tid / XCH, 16-B chunk tid % XCH)
     const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
     int xty[XJ], xtx[XJ];
@@ -109,15 +118,15 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
 #pragma unroll
     for (int jj = 0; jj < XJ; ++jj) {
         const int p = jj * XPPI + tid / XCH;
-        const int py_ = p / PATCH_W, px_ = p - py_ * PATCH_W;
-        xty[jj] = p >= 5 * PATCH_W ? 0x40000000 : py_ * g.S + wby;      // beyond the patch: a row no image has
+        const int py_ = p / PW, px_ = p - py_ * PW;
+        xty[jj] = (py_ > BH || px_ > BW) ? 0x40000000 : py_ * g.S + wby;      // beyond the patch: a row no image has
         xtx[jj] = px_ * g.S + wbx;
         const int c = tid % XCH;                 // physical chunk: segment c >> 1 holds source segment (c >> 1) ^ f(p)
-        const int xch = (second ? ci0 - g.C1 : ci0) + (((((c >> 1) ^ (int)xseg_swz3<CI>((unsigned)p)) << 1) | (c & 1)) * 8);
+        const int xch = (second ? ci0 - g.C1 : ci0) + (((((c >> 1) ^ (int)xseg_swz3<CI, BW>((unsigned)p)) << 1) | (c & 1)) * 8);
         xthr[jj] = (unsigned)(((py_ * g.S + wby) * g.W + px_ * g.S + wbx) * xcs + xch) * 2u;
     }
 
-    const int lbx = g.lw - 4, lby = g.lh - 2;
+    const int lbx = g.lw - LBW, lby = g.lh - LBH;
     const int kb0 = split * blocks_per_split;
     const int kb1 = min(g.M >> 6, kb0 + blocks_per_split);
 
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     //   dY: K row rl = fg * 8 + tq (+ 4 h) of a 32-row half step, channel tile mt: chunk (2 mt + (tp >> 1)) ^ swz(rl), the tile
     //       index is an XOR of address bits 5.. (the swizzle only touches the chunk bits)
     //   X:  patch pixel of K row r + tap shift, segment nt ^ f(p): the tile index is an XOR of address bits 5..
-    const unsigned toff = (pg.toff4[ph][q] >> (8 * wid)) & 0xffu;
+    const unsigned toff = (unsigned)((wid >> 1) * PW + (wid & 1));     // tap slot k sits at patch offset (k >> 1, k & 1) (patch_geo)
     unsigned ybase[2], xbase[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -136,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int r = kk * 32 + fg * 8 + tq + 4 * h;
-            const unsigned p = (unsigned)((r >> 4) * PATCH_W + (r & 15)) + toff;
-            xbase[kk][h] = (unsigned)YBUF + p * XPB + (xseg_swz3<CI>(p) << 5) + tp * 8;
+            const unsigned p = (unsigned)((r >> LBW) * PW + (r & (BW - 1))) + toff;
+            xbase[kk][h] = (unsigned)YBUF + p * XPB + (xseg_swz3<CI, BW>(p) << 5) + tp * 8;
         }
     }
 #define WG3_XOR(dst, src, imm) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(dst) : "v"(src), "s"(imm))
@@ -163,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
 
     unsigned ysof = 0, xofs[XJ];
     auto prepare = [&](int kb) {
-        const int gx0 = (kb & ((1 << lbx) - 1)) << 4;
-        const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << 2;
+        const int gx0 = (kb & ((1 << lbx) - 1)) << LBW;
+        const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << LBH;
         const int n = kb >> (lbx + lby);
         ysof = (unsigned)(((((n << g.ldh) + (gy0 << los) + poy) << g.ldw) + (gx0 << los) + pox) * g.Cout) * 2u;
         const int oy = gy0 * g.S, ox = gx0 * g.S;
@@ -375,13 +384,15 @@ int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, 
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
-static int wg3_variant(const GG& g) {   // 0: not eligible, 1: <128, 64>, 2: <64, 128>
-    const int mode = pai_tunable("wgrad3", 3);   // bit 0: the 128 x 64 wave tile, bit 1: the 64 x 128 one; 0: gg_wgrad_patch_k
+static int wg3_variant(const GG& g) {   // 0: not eligible, 1: <128, 64>, 2: <64, 128>, 3: <128, 64> on 8 x 8-pixel K steps
+    const int mode = pai_tunable("wgrad3", 7);   // bit 0: the 128 x 64 wave tile, bit 1: the 64 x 128 one, bit 2: 8 x 8-pixel K steps; 0: round-2 kernels
     if (!mode) return 0;
     PatchGeo pg;
     // 32-bit byte offsets into buffer descriptors: every tensor below 2 GB
     if ((int64_t)g.N * g.H * g.W * (g.C1 > g.C2 ? g.C1 : g.C2) * 2 >= (1ll << 31) || (int64_t)g.N * g.OH * g.OW * g.Cout * 2 >= (1ll << 31))
         return 0;
+    if (g.lsw >= 0 && g.lw == 3 && g.lh >= 3 && patch_geo(g, 8, &pg, 8))    // 8-wide images (encoders[4], decoders[3])
+        return ((mode & 4) && (g.Cout % 128) == 0 && (g.C1 % 64) == 0 && (g.C2 % 64) == 0 && g.Cin >= 64) ? 3 : 0;
     if (!(g.lsw >= 0 && g.lw >= 4 && g.lh >= 2 && patch_geo(g, 4, &pg))) return 0;
     if ((g.Cout % 128) == 0 && (g.C1 % 64) == 0 && (g.C2 % 64) == 0 && g.Cin >= 64) return (mode & 1) ? 1 : 0;
     if ((g.Cout % 64) == 0 && (g.C1 % 128) == 0 && (g.C2 % 128) == 0 && g.Cin >= 128) return (mode & 2) ? 2 : 0;
@@ -394,11 +405,11 @@ struct Wg3Cfg { int bmc, ci, cotiles, jtiles, tiles, psplits, per; };
 
 static Wg3Cfg wg3_cfg(const GG& g) {
     PatchGeo pg;
-    patch_geo(g, 4, &pg);
-    Wg3Cfg c;
     const int v = wg3_variant(g);
-    c.bmc = v == 1 ? 128 : 64;
-    c.ci = v == 1 ? 64 : 128;
+    if (v == 3) patch_geo(g, 8, &pg, 8); else patch_geo(g, 4, &pg);
+    Wg3Cfg c;
+    c.bmc = v == 2 ? 64 : 128;
+    c.ci = v == 2 ? 128 : 64;
     c.cotiles = g.Cout / c.bmc;
     c.jtiles = (g.Cin / c.ci) * pg.groups;
     c.tiles = c.cotiles * c.jtiles * g.nphase;
@@ -428,11 +439,15 @@ bool wgrad3_overwrites(const GG& g) {
     return pai_tunable("wgrad_slab", 1) && wgrad_slab_acquire((int64_t)c.psplits * g.Cout * g.wtaps * g.Cin * 4) != nullptr;
 }
 
-const char* wgrad3_kernel_name(const GG& g) { return wg3_variant(g) == 1 ? "gg_wgrad_patch3_k<128, 64>" : "gg_wgrad_patch3_k<64, 128>"; }
+const char* wgrad3_kernel_name(const GG& g) {
+    const int v = wg3_variant(g);
+    return v == 1 ? "gg_wgrad_patch3_k<128, 64, 16>" : (v == 2 ? "gg_wgrad_patch3_k<64, 128, 16>" : "gg_wgrad_patch3_k<128, 64, 8>");
+}
 
 int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     PatchGeo pg;
-    PAI_CHECK(wgrad3_ok(g) && patch_geo(g, 4, &pg), "launch_wgrad3: problem not eligible");
+    const int variant = wg3_variant(g);
+    PAI_CHECK(variant != 0 && (variant == 3 ? patch_geo(g, 8, &pg, 8) : patch_geo(g, 4, &pg)), "launch_wgrad3: problem not eligible");
     const Wg3Cfg c = wg3_cfg(g);
     WgradArgs a = a0;
     const int64_t dwn = (int64_t)g.Cout * g.wtaps * g.Cin;
@@ -446,21 +461,27 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     }
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
         attr = true;
     }
     const dim3 grid(c.tiles * c.psplits);
-    if (c.bmc == 128) {
+    if (variant == 1) {
         const size_t lds = 2 * (64 * 256 + 96 * 128);
-        hipLaunchKernelGGL((gg_wgrad_patch3_k<128, 64>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
-    } else {
+        hipLaunchKernelGGL((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+    } else if (variant == 2) {
         const size_t lds = 2 * (64 * 128 + 96 * 256);
-        hipLaunchKernelGGL((gg_wgrad_patch3_k<64, 128>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        hipLaunchKernelGGL((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+    } else {
+        const size_t lds = 2 * (64 * 256 + 128 * 128);
+        hipLaunchKernelGGL((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
     }
     PAI_LAUNCH_CHECK();
     if (slab) return launch_wgrad_slab_sum(a.dw, slab, c.psplits, dwn, a.overwrite, s);
