@@ -414,8 +414,12 @@ static Wg3Cfg wg3_cfg(const GG& g) {
     c.jtiles = (g.Cin / c.ci) * pg.groups;
     c.tiles = c.cotiles * c.jtiles * g.nphase;
     const int kblocks = g.M / 64;
-    // pixel splits: two workgroups per CU fill the chip with 512; a split never gets fewer than 512 pixels
-    int splits = cdiv(pai_tunable("wgrad3_target", 512), c.tiles);
+    // pixel splits: ONE workgroup per CU (256).  Alone on the chip two per CU (512) are faster (scripts/micro/convbench), but
+    // in the training step the weight gradients run beside the input-gradient chain of the main stream: with 256
+    // workgroups they flush half the slab bytes (32 instead of 64 MB per layer, and wgrad_slab_sum_k reads half) and leave
+    // the other half of every CU to the main stream -- same-box step, two interleaved runs each: 6.36 ms at 256, 6.42-6.44
+    // at 192, 6.49 at 384, 6.55 at 512, 6.67 at 768, 7.05 at 128.  A split never gets fewer than 512 pixels.
+    int splits = cdiv(pai_tunable("wgrad3_target", 256), c.tiles);
     const int max_splits = cdiv(g.M, pai_tunable("wgrad3_minrows", 512));
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
