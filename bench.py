@@ -347,8 +347,13 @@ def main():
     value = world * args.batch * args.steps / dt
     reuse = model._can_reuse_forward()
     gflop = step_gflop_per_image(reuse, args.model == "attention_unet")
+    gflop_src = "SURVEY 8(d) MAC budget"
     if args.model in ("resnext_unet", "trans_unet"):
-        gflop = float("nan")     # SURVEY 8(d) gives the MAC budget of configs[1]/[2] only
+        # SURVEY 8(d) gives the MAC budget of configs[1]/[2] only: for the composable families the figure is what the step
+        # EXECUTED -- ops.conv_flops (2 x M x Cout x taps x Cin of the dense product, grouped convolutions counted with
+        # their block-diagonal zeros removed) summed over the convolution-family launches of the profiled steps
+        gflop = (sum(p[2] for p in prof) / args.steps / args.batch / 1e9) if prof else float("nan")
+        gflop_src = "sum of ops.conv_flops over the executed convolution-family launches (incl. nn.Linear as 1 x 1)"
     out = {
         "metric": ("train images/sec (256x256, bs=64) Pix2Pix step" if args.model == "pix2pix" else
                    f"train images/sec ({args.size}x{args.size}, bs={args.batch}) {args.model} GAN step"),
@@ -375,6 +380,7 @@ def main():
                         "eager" + (f" ({graphed.disabled})" if graphed is not None and graphed.disabled else "")),
         "clock_ramp_steps": prewarm_steps,
         "step_conv_gflop_per_image": None if gflop != gflop else round(gflop, 2),
+        "step_conv_gflop_source": gflop_src,
         "step_mfma_frac": None if gflop != gflop else round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": roofline,
         "roofline_isolated": roofline_isolated,

@@ -512,6 +512,10 @@ int pai_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg
 int pai_adam_multi(int count, void* const* params, const void* const* grads, void* const* exp_avgs,
                    void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2, float eps,
                    int step_count, void* stream);
+/* ... with the step count in device memory (a captured step, see pai_adam_dev): *step_dev is advanced ONCE per call. */
+int pai_adam_multi_dev(int count, void* const* params, const void* const* grads, void* const* exp_avgs,
+                       void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2, float eps,
+                       int64_t* step_dev, float* coeff2_dev, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Gradient exchange (data parallelism, one process per GPU; replaces the all-reduce Lightning's DDP wrapper issues

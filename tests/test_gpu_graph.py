@@ -84,3 +84,38 @@ def test_graph_replay_is_one_launch_of_host_time(pai):
     print(f"host issue per step: graph {host * 1e3:.3f} ms, eager {eager * 1e3:.3f} ms")
     assert host < 1e-3 and host < 0.5 * eager
     assert np.isfinite(float(m.logged["loss"]))
+
+
+@pytest.mark.parametrize("family", ["resnext_unet", "trans_unet"])
+def test_composable_families_capture_and_replay(pai, family):
+    """The residual / Trans U-Nets (op-level path of nnops.py, MultiAdam) as one hipGraph: warm-up and capture on one side
+    stream (autograd's AccumulateGrad nodes), the Adam step count on the device (pai_adam_multi_dev).  Graph against an
+    eager twin from the same weights: same losses step by step, same step counts (reference models/res_unet.py:238-335,
+    models/trans_unet.py:35-117)."""
+    import copy
+    from thesis_pai_reconstruction_amd.graph import GraphedStep
+    torch.manual_seed(0)
+    if family == "resnext_unet":
+        eager = pai.ResUnetGAN(1, 1, "next", (1, 2), 0.0, "gan")
+    else:
+        eager = pai.TransUnetGAN(1, 1, (1, 2), 2, 0.0, "gan")
+    eager.to(DEV)
+    eager.set_precision("bf16-mixed")
+    eager.train()
+    graphed = copy.deepcopy(eager)
+    gs = GraphedStep(graphed, warmup=2)
+    batches = [tuple(t.to(DEV) for t in synth_batch(300 + s, 2, 64)) for s in range(6)]
+    for s, b in enumerate(batches):
+        eager.logged, graphed.logged = {}, {}
+        eager.training_step(b, s)
+        gs(b, s)
+        torch.cuda.synchronize()
+        assert gs.disabled is None, gs.disabled
+        for k, v in eager.logged.items():
+            a, g = float(v), float(graphed.logged[k])
+            assert abs(a - g) <= 5e-2 * max(1.0, abs(a)), (s, k, a, g)
+    assert gs.graph is not None and gs.opt_steps_per_replay == 2
+    for oe, og in zip(eager._all_optimizers(), graphed._all_optimizers()):
+        se, sg = oe.state_dict()["state"], og.state_dict()["state"]
+        assert int(next(iter(sg.values()))["step"]) == int(next(iter(se.values()))["step"]) == len(batches)
+        assert int(og._dev_step) == len(batches)

@@ -390,6 +390,59 @@ __global__ __launch_bounds__(256) void adam_multi_k(AdamChunk c, float lr_over_b
     }
 }
 
+__global__ __launch_bounds__(256) void adam_multi_dev_k(AdamChunk c, const float* coeff, float beta1, float beta2, float omb1,
+                                                        float omb2, float eps) {
+    const float lr_over_bc1 = coeff[0], inv_sqrt_bc2 = coeff[1];
+    const int t = blockIdx.y;
+    const int64_t numel = c.n[t];
+    float* p = c.p[t];
+    const float* g = c.g[t];
+    float* m = c.m[t];
+    float* v = c.v[t];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + omb1 * gi;
+        const float vi = beta2 * v[i] + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+// pai_adam_multi with the step count in DEVICE memory (a step captured into a hipGraph, see pai_adam_dev): ONE
+// adam_coeff_k advances the count and derives the coefficients, every chunk launch reads them.
+extern "C" int pai_adam_multi_dev(int count, void* const* params, const void* const* grads, void* const* exp_avgs,
+                                  void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2,
+                                  float eps, int64_t* step_dev, float* coeff2_dev, void* stream) {
+    PAI_CHECK(count >= 0 && (count == 0 || (params && grads && exp_avgs && exp_avg_sqs && numels)) && step_dev && coeff2_dev,
+              "pai_adam_multi_dev: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_coeff_k, dim3(1), dim3(1), 0, s, (long long*)step_dev, coeff2_dev, lr, beta1, beta2);
+    PAI_LAUNCH_CHECK();
+    for (int i0 = 0; i0 < count; i0 += ADAM_CHUNK) {
+        const int nt = count - i0 < ADAM_CHUNK ? count - i0 : ADAM_CHUNK;
+        AdamChunk c;
+        memset(&c, 0, sizeof(c));
+        int64_t big = 1;
+        for (int i = 0; i < nt; ++i) {
+            PAI_CHECK(params[i0 + i] && grads[i0 + i] && exp_avgs[i0 + i] && exp_avg_sqs[i0 + i] && numels[i0 + i] >= 0,
+                      "pai_adam_multi_dev: null tensor %d", i0 + i);
+            c.p[i] = (float*)params[i0 + i];
+            c.g[i] = (const float*)grads[i0 + i];
+            c.m[i] = (float*)exp_avgs[i0 + i];
+            c.v[i] = (float*)exp_avg_sqs[i0 + i];
+            c.n[i] = numels[i0 + i];
+            if (c.n[i] > big) big = c.n[i];
+        }
+        int64_t bx = (big + 1023) / 1024;
+        if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(adam_multi_dev_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, s, c, (const float*)coeff2_dev,
+                           beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps);
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int pai_adam_multi(int count, void* const* params, const void* const* grads, void* const* exp_avgs,
                               void* const* exp_avg_sqs, const int64_t* numels, float lr, float beta1, float beta2,
                               float eps, int step_count, void* stream) {

@@ -28,6 +28,11 @@ class GraphedStep:
         self.shape = None
         self.opt_steps_per_replay = 0
         self.logs = []                # (name, tensor) pairs the captured step passed to self.log()
+        # Eager warm-up steps AND the capture run on this side stream: autograd's AccumulateGrad nodes (the composable
+        # networks of nnops.py receive their parameter gradients through them) remember the stream they were created on,
+        # and nodes created on the default stream make the backward pass of the capture synchronise with it -- an
+        # illegal operation during capture (the process aborts).  torch's own recipe: warm up on the capture stream.
+        self.stream = None
         self.disabled = None          # reason string when capture is not possible
 
     # ---- eligibility ------------------------------------------------------------------------------------
@@ -59,8 +64,14 @@ class GraphedStep:
             return m.training_step(batch, batch_idx)
         self.calls += 1
         if self.graph is None:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
             if self.calls <= self.warmup:
-                return m.training_step(batch, batch_idx)
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    out = m.training_step(batch, batch_idx)
+                torch.cuda.current_stream().wait_stream(self.stream)
+                return out
             eager = self._capture(batch)
             if self.graph is None:       # capture refused (self.disabled says why): that call ran the step eagerly
                 return eager
@@ -104,7 +115,7 @@ class GraphedStep:
             logs.append((name, value.detach() if torch.is_tensor(value) else value))
         m.log = record
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=self.stream):
                 m.training_step(self.static, 0)
         finally:
             del m.log                 # back to the class's method

@@ -143,6 +143,7 @@ SIGNATURES = {
     "pai_allreduce": (_I, [_P, _P, _L, _I, _P]),
     "pai_comm_destroy": (_I, [_P]),
     "pai_adam_multi": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
+    "pai_adam_multi_dev": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _P]),
 }
 
 _lib = None

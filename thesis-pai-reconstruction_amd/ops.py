@@ -89,12 +89,14 @@ def conv_kernel_name(d: ConvDesc, op: int) -> str:
 
 
 def conv_flops(d: ConvDesc) -> int:
-    """Algorithmic FLOPs (2 x MAC, padding taps included) of one fwd / dgrad / wgrad launch."""
+    """Algorithmic FLOPs (2 x MAC, padding taps included) of one fwd / dgrad / wgrad launch; a grouped convolution
+    (pai_conv_desc.groups) counts the MACs of its groups only, not the structural zeros of the block-diagonal form."""
+    groups = max(1, int(getattr(d, "groups", 1)))
     if d.transposed:
-        return 2 * d.N * d.H * d.W * 16 * (d.C1 + d.C2) * d.Cout
+        return 2 * d.N * d.H * d.W * 16 * (d.C1 + d.C2) * d.Cout // groups
     oh = (d.H + 2 * d.pad - d.kernel) // d.stride + 1
     ow = (d.W + 2 * d.pad - d.kernel) // d.stride + 1
-    return 2 * d.N * oh * ow * d.kernel * d.kernel * (d.C1 + d.C2) * d.Cout
+    return 2 * d.N * oh * ow * d.kernel * d.kernel * (d.C1 + d.C2) * d.Cout // groups
 
 
 class _Timed:
@@ -606,6 +608,19 @@ def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step
     numels = (C.c_int64 * n)(*[p.numel() for p in params])
     L.check(L.load().pai_adam_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numels, lr, beta1, beta2,
                                     eps, step, _stream()), "pai_adam_multi")
+
+
+def adam_multi_dev(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step_dev, coeff_dev):
+    """adam_multi with the step count on the device (pai_adam_multi_dev; hipGraph capture)."""
+    n = len(params)
+    for t in (*params, *grads, *exp_avgs, *exp_avg_sqs):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise PaiError("adam_multi_dev needs contiguous fp32 HIP tensors")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+    numels = (C.c_int64 * n)(*[p.numel() for p in params])
+    L.check(L.load().pai_adam_multi_dev(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numels, lr, beta1,
+                                        beta2, eps, _p(step_dev, torch.int64), _p(coeff_dev, torch.float32), _stream()),
+            "pai_adam_multi_dev")
 
 
 class Comm:

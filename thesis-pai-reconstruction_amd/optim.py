@@ -248,6 +248,40 @@ class MultiAdam(torch.optim.Adam):
 
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-7):
         super().__init__(list(params), lr=lr, betas=betas, eps=eps, foreach=True)
+        self._dev_step = None          # graph mode: int64 device scalar holding the step count (graph.GraphedStep)
+        self._dev_coeff = None
+        self._arena_steps = 0          # replays not yet mirrored into the per-parameter `step` entries
+
+    # ---- hipGraph support (same contract as ArenaAdam) ----------------------------------------------------------
+    def _total_steps(self) -> int:
+        st = next(iter(self.state.values()), None)
+        return (int(st["step"]) if st and "step" in st else 0) + self._arena_steps
+
+    def enable_device_step(self):
+        if self._dev_step is None:
+            dev = self.param_groups[0]["params"][0].device
+            self._dev_step = torch.tensor(self._total_steps(), dtype=torch.int64, device=dev)
+            self._dev_coeff = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def note_replays(self, n: int = 1):
+        self._arena_steps += n
+
+    def _mirror_steps(self):
+        if self._arena_steps:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] += self._arena_steps
+            self._arena_steps = 0
+
+    def state_dict(self):
+        self._mirror_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._arena_steps = 0
+        super().load_state_dict(state_dict)
+        if self._dev_step is not None:
+            self._dev_step.fill_(self._total_steps())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -274,6 +308,15 @@ class MultiAdam(torch.optim.Adam):
             steps.add(int(st["step"]))
         if len(steps) != 1:          # parameters with different histories (e.g. unused in some steps): stock path
             return super().step()
+        if self._dev_step is not None:
+            # captured step: the count lives on the device and advances with every replay (note_replays keeps the host
+            # bookkeeping in step with it)
+            ops.adam_multi_dev([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
+                               [self.state[p]["exp_avg_sq"] for p in ps], float(group["lr"]), float(group["betas"][0]),
+                               float(group["betas"][1]), float(group["eps"]), self._dev_step, self._dev_coeff)
+            self._arena_steps += 1
+            return None
+        self._mirror_steps()
         step = steps.pop() + 1
         ops.adam_multi([p.data for p in ps], [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps],
                        [self.state[p]["exp_avg_sq"] for p in ps], float(group["lr"]), float(group["betas"][0]),
