@@ -104,7 +104,8 @@ def test_composable_families_capture_and_replay(pai, family):
     eager.train()
     graphed = copy.deepcopy(eager)
     gs = GraphedStep(graphed, warmup=2)
-    batches = [tuple(t.to(DEV) for t in synth_batch(300 + s, 2, 64)) for s in range(6)]
+    size = 64 if family == "resnext_unet" else 256        # the TransUNet is built for 256 x 256 inputs
+    batches = [tuple(t.to(DEV) for t in synth_batch(300 + s, 2, size)) for s in range(6)]
     for s, b in enumerate(batches):
         eager.logged, graphed.logged = {}, {}
         eager.training_step(b, s)
