@@ -501,6 +501,14 @@ int pai_reduce_rows(const float* partial, int rows, int C, float* out, int accum
  * decay / amsgrad; models/wrapper.py:98-111).  step_count is the 1-based step. */
 int pai_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
              float lr, float beta1, float beta2, float eps, int step_count, void* stream);
+/* pai_adam over a range of the arena that holds ONE dense conv weight in master order [Cout][taps][Cin] (Cin, Cout
+ * multiples of 64) at element offset w_off, and writes that weight's bf16 filter packs (as pai_pack_weights would: w_fwd
+ * in master order, w_dgrad [Cin][taps][Cout]; either may be NULL) from the block that produced the new values.  The
+ * rest of the range (bias, BatchNorm affine parameters) gets the plain update.  Same result, bit for bit, as pai_adam
+ * followed by pai_pack_weights.  All pointers 16-byte aligned, w_off a multiple of 4. */
+int pai_adam_pack(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t w_off,
+                  int Cout, int taps, int Cin, void* w_fwd, void* w_dgrad, float lr, float beta1, float beta2, float eps,
+                  int step_count, void* stream);
 /* pai_adam with the step count in device memory (*step_dev is advanced by the call; coeff2_dev: two floats of device
  * scratch): what a training step captured into a hipGraph needs -- a host-side step count would be frozen into the
  * graph and every replay would reuse the captured step's bias correction. */

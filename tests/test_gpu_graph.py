@@ -24,39 +24,50 @@ def _build(pai, mults, seed, dtype):
     return m
 
 
+def _sync_training_state(src, dst):
+    """dst <- src, in place (a captured graph holds the addresses): parameters, BatchNorm buffers, Adam moments."""
+    with torch.no_grad():
+        sd = dst.state_dict()
+        for k, v in src.state_dict().items():
+            sd[k].copy_(v)
+        for os_, od in zip(src._all_optimizers(), dst._all_optimizers()):
+            a_s, a_d = os_._engine.arena(), od._engine.arena()
+            if getattr(a_s, "mflat", None) is not None and getattr(a_d, "mflat", None) is not None:
+                a_d.mflat.copy_(a_s.mflat)
+                a_d.vflat.copy_(a_s.vflat)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_graphed_step_matches_eager(pai, dtype):
+    """Every step starts from the SAME state in both models (the eager model's, copied in place after each comparison):
+    a GAN step amplifies last-bit noise (fp32 atomics of the bias / thin-layer gradients order differently from run to
+    run) by 2-3x per step -- two eager runs of seven free-running steps differ by up to 8e-2 in d_loss -- so free-running
+    models can only be held to a bound that says nothing.  Step by step the bound is tight."""
     from thesis_pai_reconstruction_amd.graph import GraphedStep
     mults, n, size, steps = (1, 2, 4, 8), 4, 64, 7
     batches = [tuple(t.to(DEV) for t in synth_batch(100 + s, n, size)) for s in range(steps)]
-    eager, eager2, graphed = (_build(pai, mults, 3, dtype) for _ in range(3))
+    eager, graphed = (_build(pai, mults, 3, dtype) for _ in range(2))
     gs = GraphedStep(graphed, warmup=2)
     for s, b in enumerate(batches):
-        eager.logged, eager2.logged, graphed.logged = {}, {}, {}
+        eager.logged, graphed.logged = {}, {}
         eager.training_step(b, s)
-        eager2.training_step(b, s)
         gs(b, s)
         torch.cuda.synchronize()
         assert gs.disabled is None, gs.disabled
         for k, v in eager.logged.items():
-            a, a2, g = float(v), float(eager2.logged[k]), float(graphed.logged[k])
-            # fp32 atomics of the weight gradients make two runs differ in the last bits and Adam (lr 2e-4 against
-            # weights of std 0.02) amplifies that step by step: two EAGER runs of the same step are held to the same
-            # bound as graph vs eager.  Measured: differences roughly double per step; at step 6 (d_loss) eager vs
-            # eager reaches 2.6e-3 in fp32 and graph vs eager 1.6e-2 in bf16 on some boxes.
-            tol = min(5e-2, 1e-3 * 2 ** s) * max(1.0, abs(a))
-            assert abs(a - a2) <= tol and abs(a - g) <= tol, (s, k, a, a2, g)
+            a, g = float(v), float(graphed.logged[k])
+            assert abs(a - g) <= 1e-4 * max(1.0, abs(a)), (s, k, a, g)
+        for (k, p), (_, q) in zip(eager.state_dict().items(), graphed.state_dict().items()):
+            if k.endswith("num_batches_tracked"):
+                assert int(p) == int(q) == 2 * (s + 1), k
+            else:
+                # one step apart from identical states: +-lr per element at most where noise flips a sign Adam's first
+                # steps normalise (lr = 2e-4), far less in the mean
+                d = (p.float() - q.float()).abs()
+                assert float(d.max()) <= 4.1e-4 and float(d.mean()) <= 1e-5, (s, k, float(d.max()), float(d.mean()))
+        _sync_training_state(eager, graphed)
     assert gs.graph is not None and gs.opt_steps_per_replay == 2
     assert graphed._pai_opt_steps == eager._pai_opt_steps == 2 * steps
-    for (k, p), (_, q) in zip(eager.state_dict().items(), graphed.state_dict().items()):
-        if k.endswith("num_batches_tracked"):
-            assert int(p) == int(q) == 2 * steps, k
-        else:
-            # noise-amplified divergence of two runs (see above): relative for the filters; for small vectors
-            # (BatchNorm weights / biases) an absolute floor of half of what Adam can move an element in `steps`
-            # steps (+-lr per step, lr = 2e-4) on every element
-            bound = 2e-2 * float(p.float().norm()) + 2e-4 * steps * p.numel() ** 0.5
-            assert float((p.float() - q.float()).norm()) <= bound, k
     for oe, og in zip(eager._all_optimizers(), graphed._all_optimizers()):
         assert og.total_steps == oe.total_steps == steps and int(og._dev_step) == steps
         se, sg = oe.state_dict()["state"], og.state_dict()["state"]

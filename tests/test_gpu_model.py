@@ -337,7 +337,8 @@ def test_arena_adam_equals_stock_adam(pai):
     assert arena.params_adopted()
 
 
-def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch, dtype):
     """ArenaAdam.arm_streaming: ranges of the arena are updated from the engine's gradient-ready hook while the backward
     pass is still running (from the second step on: the first fused step moves the parameters into the arena).  Same
     arithmetic as one step() at the end -- checked BIT FOR BIT: the twin model takes the ordinary step, but on the
@@ -347,8 +348,8 @@ def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch):
     mults, seed = (1, 2, 2, 4), 35
     x, t = synth_batch(seed + 100, 4, 32)
     batch = (x.to(DEV), t.to(DEV))
-    ma, _, _ = build(pai, mults, "gan", seed)
-    mb, _, _ = build(pai, mults, "gan", seed)
+    ma, _, _ = build(pai, mults, "gan", seed, dtype=dtype)
+    mb, _, _ = build(pai, mults, "gan", seed, dtype=dtype)
     armed, twin_steps = [], []
     for o in ma.optimizers():
         orig = o.arm_streaming
@@ -360,10 +361,25 @@ def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch):
             twin_steps.append(1)
             return orig(*a, **k)
         ob.step = step
+    from importlib import import_module
+    ops = import_module(pai.__name__ + ".ops")
+    fused = []
+    orig_adam_pack = ops.adam_pack
+    monkeypatch.setattr(ops, "adam_pack", lambda *a, **k: fused.append(1) or orig_adam_pack(*a, **k))
+
+    def packs_of(m):
+        eg, ed = m.unet.engine, m.discriminator.engine
+        return eg.enc_packs + eg.dec_packs + ed.packs
+
     for s in range(3):
         monkeypatch.setenv("PAI_NO_STREAM_ADAM", "0")
         ma.training_step(batch, s)
         assert ma.unet.engine.grad_ready_hook is None and ma.discriminator.engine.grad_ready_hook is None
+        if s >= 1 and dtype == torch.bfloat16:
+            # the streamed update wrote the bf16 filter packs of the dense layers itself (pai_adam_pack): only the thin
+            # layers (1- and 2-channel ends of both networks) are left to re-pack
+            stale = [pk._stale(dtype) for pk in packs_of(ma)]
+            assert fused and sum(stale) <= 4 < len(stale), stale
         monkeypatch.setenv("PAI_NO_STREAM_ADAM", "1")
         mb.training_step(batch, s)
         torch.cuda.synchronize()
@@ -373,6 +389,12 @@ def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch):
         for oa, ob in zip(ma.optimizers(), mb.optimizers()):
             aa, ab = oa._engine.arena(), ob._engine.arena()
             assert torch.equal(aa.mflat, ab.mflat) and torch.equal(aa.vflat, ab.vflat) and torch.equal(aa.pflat, ab.pflat), s
+        # ... and they are the packs a re-pack of the twin's (identical) master weights gives
+        for k, (pa, pb) in enumerate(zip(packs_of(ma), packs_of(mb))):
+            wfa, wda = pa.get(dtype)
+            wfb, wdb = pb.get(dtype)
+            assert torch.equal(wfa, wfb), (s, k)
+            assert (wda is None) == (wdb is None) and (wda is None or torch.equal(wda, wdb)), (s, k)
     assert armed == [False, False, True, True, True, True]        # (D, G) per step; step 0 adopts the parameters
     assert len(twin_steps) == 6
     for oa, ob in zip(ma.optimizers(), mb.optimizers()):

@@ -183,6 +183,38 @@ def test_adam_matches_torch(pai):
     assert float((P.cpu() - ref.detach()).abs().max()) < 1e-7
 
 
+@pytest.mark.parametrize("cout,taps,cin,pre,post", [(128, 16, 64, 192, 384), (64, 4, 192, 0, 0), (64, 16, 64, 64, 5)])
+def test_adam_pack_equals_adam_then_pack(pai, cout, taps, cin, pre, post):
+    """pai_adam_pack (the streamed optimizer step that writes a dense layer's bf16 filter packs from the block that
+    produced the new weights) against pai_adam followed by pai_pack_weights, bit for bit: parameters, both moments,
+    both packs, with neighbours in front of and behind the weight inside the range."""
+    from thesis_pai_reconstruction_amd import ops
+    wn = cout * taps * cin
+    n = pre + wn + post
+    p0, g = rnd((n,), 3).to(dev()), rnd((n,), 4, 0.01).to(dev())
+    m0, v0 = rnd((n,), 5, 0.01).to(dev()), rnd((n,), 6, 0.01).abs().to(dev())
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    bf = torch.bfloat16
+    wfa, wda = torch.empty(wn, dtype=bf, device=dev()), torch.empty(wn, dtype=bf, device=dev())
+    wfb, wdb = torch.full((wn,), 7.0, dtype=bf, device=dev()), torch.full((wn,), 7.0, dtype=bf, device=dev())
+    for step in (1, 2, 5):
+        ops.adam(pa, g, ma, va, 2e-4, 0.5, 0.999, 1e-7, step)
+        ops.pack_weights(bf, pa[pre:pre + wn], cout, taps, cin, wfa, wda)
+        ops.adam_pack(pb, g, mb, vb, pre, cout, taps, cin, wfb, wdb, 2e-4, 0.5, 0.999, 1e-7, step)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), step
+        assert torch.equal(wfa, wfb) and torch.equal(wda, wdb), step
+    # one pack only
+    wdb.fill_(7.0)
+    ops.adam_pack(pb, g, mb, vb, pre, cout, taps, cin, wfb, None, 2e-4, 0.5, 0.999, 1e-7, 6)
+    assert float(wdb.float().min()) == 7.0
+    with pytest.raises(ops.PaiError):
+        ops.adam_pack(pb, g, mb, vb, pre, cout + 1, taps, cin, wfb, wdb, 2e-4, 0.5, 0.999, 1e-7, 1)
+    with pytest.raises(ops.PaiError):
+        ops.adam_pack(pb, g, mb, vb, pre + post + 64, cout, taps, cin, wfb, wdb, 2e-4, 0.5, 0.999, 1e-7, 1)
+
+
 def test_cast_roundtrip(pai):
     from thesis_pai_reconstruction_amd import ops
     x = rnd((1000,), 1).to(dev())

@@ -335,19 +335,9 @@ __global__ __launch_bounds__(8 * FIN_LANES) void bn_bwd_finalize_k(const float* 
     const int c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        // eight rows requested before any is added: as a plain loop this was one memory round trip per row and lane
-        // (the 4096 partial rows of decoders[6]: 32 dependent trips, 11 us on the critical path of the backward pass)
+        // (8 rows in flight per lane were tried twice: faster alone, 11 -> 6 us at 4096 rows, but 7.4 -> 22.9 us on average
+        //  in the training step, where the launch runs beside a weight-gradient kernel -- rocprofv3 traces of round 3)
         int r = rl;
-        for (; r + 7 * FIN_LANES < rows; r += 8 * FIN_LANES) {
-            float a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a[u] = partials[((size_t)(r + u * FIN_LANES) * 2 + 0) * C + c];
-                b[u] = partials[((size_t)(r + u * FIN_LANES) * 2 + 1) * C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
-        }
         for (; r < rows; r += FIN_LANES) {
             s1 += (double)partials[((size_t)r * 2 + 0) * C + c];
             s2 += (double)partials[((size_t)r * 2 + 1) * C + c];

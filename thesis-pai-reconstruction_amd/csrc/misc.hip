@@ -289,16 +289,24 @@ extern "C" int pai_colsum(int dtype, const void* x, int64_t rows, int C, float* 
     return launch_colsum(dtype, x, rows, C, out, (hipStream_t)stream);
 }
 
+// One element of torch.optim.Adam (no weight decay / amsgrad), shared by every Adam kernel of the library so that they
+// agree bit for bit whatever the compiler would contract in each loop: the fused multiply-adds are spelled out and
+// contraction is off.  omb = 1 - beta rounded from double, as torch does.
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float lr_over_bc1, float beta1, float beta2,
+                                      float omb1, float omb2, float eps, float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+    const float mi = __builtin_fmaf(beta1, m, omb1 * g);
+    const float vi = __builtin_fmaf(beta2, v, omb2 * g * g);
+    m = mi;
+    v = vi;
+    p = p - lr_over_bc1 * mi / __builtin_fmaf(sqrtf(vi), inv_sqrt_bc2, eps);
+}
+
 __global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m, float* v, int64_t numel,
                                               float lr_over_bc1, float beta1, float beta2, float omb1, float omb2,
                                               float eps, float inv_sqrt_bc2) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + omb1 * gi;      // omb = 1 - beta rounded from double, as torch does
-        const float vi = beta2 * v[i] + omb2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        adam1(p[i], m[i], v[i], g[i], lr_over_bc1, beta1, beta2, omb1, omb2, eps, inv_sqrt_bc2);
     }
 }
 
@@ -313,6 +321,93 @@ extern "C" int pai_adam(float* param, const float* grad, float* exp_avg, float* 
     hipLaunchKernelGGL(adam_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, numel, (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1),
                        (float)(1.0 - (double)beta2), eps, (float)(1.0 / sqrt(bc2)));
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// Adam over one range of the arena that holds ONE dense conv weight ([Cout][taps][Cin], both multiples of 64) plus a few
+// small neighbours (its bias, BatchNorm gamma / beta): the weight is walked in the 64 x 64 tiles of pack64_k, so the block
+// that has just produced 64 x 64 new fp32 weights also writes their bf16 forward pack and (through LDS) the transposed
+// input-gradient pack -- the separate pack launch and its read of every master weight disappear (Pix2Pix generator:
+// 218 MB read + one launch on the critical path between two training steps).  Blocks behind the tiles take the
+// neighbours elementwise.  Same arithmetic, expression by expression, as adam_k.
+__global__ __launch_bounds__(256) void adam_pack64_k(float* p, const float* g, float* m, float* v, int64_t numel,
+                                                     int64_t w_off, int Cout, int taps, int Cin, bf16_t* wf, bf16_t* wd,
+                                                     int ntiles, float lr_over_bc1, float beta1, float beta2, float omb1,
+                                                     float omb2, float eps, float inv_sqrt_bc2) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= ntiles) {
+        const int64_t wn = (int64_t)Cout * taps * Cin;
+        const int64_t rest = numel - wn;
+        for (int64_t k = (int64_t)(blockIdx.x - ntiles) * 256 + tid; k < rest; k += (int64_t)(gridDim.x - ntiles) * 256) {
+            const int64_t i = k < w_off ? k : k + wn;
+            adam1(p[i], m[i], v[i], g[i], lr_over_bc1, beta1, beta2, omb1, omb2, eps, inv_sqrt_bc2);
+        }
+        return;
+    }
+    const int nci = Cin / 64, nco = Cout / 64;
+    const int lb = blockIdx.x;
+    const int ci0 = (lb % nci) * 64, co0 = ((lb / nci) % nco) * 64, t = lb / (nci * nco);
+    const int q = tid & 15, r0 = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 16 * j;
+        const int64_t i = w_off + ((int64_t)(co0 + r) * taps + t) * Cin + ci0 + 4 * q;
+        const float4 g4 = *(const float4*)(g + i);
+        float4 m4 = *(const float4*)(m + i), v4 = *(const float4*)(v + i), p4 = *(const float4*)(p + i);
+        float* pe = &p4.x; float* me = &m4.x; float* ve = &v4.x; const float* ge = &g4.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            adam1(pe[e], me[e], ve[e], ge[e], lr_over_bc1, beta1, beta2, omb1, omb2, eps, inv_sqrt_bc2);
+            tile[r][4 * q + e] = pe[e];
+        }
+        *(float4*)(m + i) = m4;
+        *(float4*)(v + i) = v4;
+        *(float4*)(p + i) = p4;
+    }
+    __syncthreads();
+    const int c = tid & 7, s0 = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = s0 + 32 * j;
+        if (wf) {
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pk2bf(tile[r][8 * c + 2 * e], tile[r][8 * c + 2 * e + 1]);
+            *(uint4*)(wf + ((size_t)(co0 + r) * taps + t) * Cin + ci0 + 8 * c) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        if (wd) {
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pk2bf(tile[8 * c + 2 * e][r], tile[8 * c + 2 * e + 1][r]);
+            *(uint4*)(wd + ((size_t)(ci0 + r) * taps + t) * Cout + co0 + 8 * c) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+    }
+}
+
+extern "C" int pai_adam_pack(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                             int64_t w_off, int Cout, int taps, int Cin, void* w_fwd, void* w_dgrad, float lr,
+                             float beta1, float beta2, float eps, int step_count, void* stream) {
+    PAI_CHECK(param && grad && exp_avg && exp_avg_sq && step_count >= 1 && (w_fwd || w_dgrad), "pai_adam_pack: bad arguments");
+    PAI_CHECK(Cin > 0 && Cout > 0 && taps > 0 && (Cin % 64) == 0 && (Cout % 64) == 0,
+              "pai_adam_pack: Cin=%d, Cout=%d must be multiples of 64 (bf16 packs)", Cin, Cout);
+    const int64_t wn = (int64_t)Cout * taps * Cin;
+    PAI_CHECK(w_off >= 0 && (w_off % 4) == 0 && w_off + wn <= numel, "pai_adam_pack: weight [%lld, %lld) outside the range of %lld",
+              (long long)w_off, (long long)(w_off + wn), (long long)numel);
+    PAI_CHECK((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)w_fwd | (uintptr_t)w_dgrad) & 15) == 0,
+              "pai_adam_pack: pointers must be 16-byte aligned");
+    const int64_t ntiles = (int64_t)(Cin / 64) * (Cout / 64) * taps;
+    const int64_t rest = numel - wn;
+    int64_t extra = (rest + 1023) / 1024;
+    if (extra > 256) extra = 256;
+    PAI_CHECK(ntiles + extra < (1ll << 31), "pai_adam_pack: too many tiles");
+    const double bc1 = 1.0 - pow((double)beta1, step_count);
+    const double bc2 = 1.0 - pow((double)beta2, step_count);
+    hipLaunchKernelGGL(adam_pack64_k, dim3((unsigned)(ntiles + extra)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, numel, w_off, Cout, taps, Cin, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, (int)ntiles,
+                       (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps,
+                       (float)(1.0 / sqrt(bc2)));
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -335,12 +430,7 @@ __global__ __launch_bounds__(256) void adam_dev_k(float* p, const float* g, floa
                                                   float eps) {
     const float lr_over_bc1 = coeff[0], inv_sqrt_bc2 = coeff[1];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + omb1 * gi;
-        const float vi = beta2 * v[i] + omb2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        adam1(p[i], m[i], v[i], g[i], lr_over_bc1, beta1, beta2, omb1, omb2, eps, inv_sqrt_bc2);
     }
 }
 
@@ -381,12 +471,7 @@ __global__ __launch_bounds__(256) void adam_multi_k(AdamChunk c, float lr_over_b
     float* m = c.m[t];
     float* v = c.v[t];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + omb1 * gi;      // omb = 1 - beta rounded from double, as torch does
-        const float vi = beta2 * v[i] + omb2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        adam1(p[i], m[i], v[i], g[i], lr_over_bc1, beta1, beta2, omb1, omb2, eps, inv_sqrt_bc2);
     }
 }
 
@@ -400,12 +485,7 @@ __global__ __launch_bounds__(256) void adam_multi_dev_k(AdamChunk c, const float
     float* m = c.m[t];
     float* v = c.v[t];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
-        const float mi = beta1 * m[i] + omb1 * gi;
-        const float vi = beta2 * v[i] + omb2 * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        adam1(p[i], m[i], v[i], g[i], lr_over_bc1, beta1, beta2, omb1, omb2, eps, inv_sqrt_bc2);
     }
 }
 

@@ -215,6 +215,22 @@ class _Packs:
         self.version = (w._version, w.data_ptr(), self.gen[0])
         self.dtype = dtype
 
+    # ---- packs written by the optimizer itself (pai_adam_pack) ---------------------------------------------------------
+    def spare(self):
+        """The second set of pack buffers, for an update that runs while the current packs are still being read (the
+        input-gradient kernels of the SAME backward pass use the weights of before the update): None unless the layer
+        has bf16 packs in use.  The optimizer writes them and ``commit``s once the step is complete."""
+        if self.dtype != torch.bfloat16 or self.wf is None or self.wf is self.mod.weight:
+            return None
+        if getattr(self, "_spare", None) is None:
+            self._spare = (torch.empty_like(self.wf), torch.empty_like(self.wd) if self.wd is not None else None)
+        return self._spare
+
+    def commit(self):
+        """The spare buffers now hold the packs of the CURRENT master weights (call after the generation bump)."""
+        (self.wf, self.wd), self._spare = self._spare, (self.wf, self.wd)
+        self._mark(self.dtype)
+
     def get(self, dtype):
         if self._stale(dtype):
             w, cout, taps, cin, wf_out, wd_out = self._prepare(dtype)
@@ -244,6 +260,20 @@ def refresh_packs(packs, dtype) -> None:
         ops.pack_weights_multi(batch)
         for pk in todo:
             pk._mark(dtype)
+
+
+def pack_targets(arena, packs):
+    """The layers whose packs an optimizer may write itself (``pai_adam_pack``): [(arena offset, numel, Cout, taps, Cin,
+    _Packs)] sorted by offset -- dense bf16 layers with channel counts in multiples of 64, as ``refresh_packs`` batches."""
+    out = []
+    for pk in packs:
+        cin, cout = _cin_cout(pk.mod)
+        if cin % 64 or cout % 64 or id(pk.mod.weight) not in arena.offsets:
+            continue
+        o, n = arena.offsets[id(pk.mod.weight)]
+        out.append((o, n, cout, n // (cin * cout), cin, pk))
+    out.sort(key=lambda t: t[0])
+    return out
 
 
 class _BNState:
@@ -409,6 +439,9 @@ class UnetEngine:
                 to_fwd_pack_(c)
             self._arena = GradArena(self.ordered_params(), dev)
         return self._arena
+
+    def pack_targets(self):
+        return pack_targets(self.arena(), self.enc_packs + self.dec_packs)
 
     # ---- plan / buffers ------------------------------------------------------------------
     def _plan(self, N, H, W, dtype, device):
@@ -777,6 +810,9 @@ class DiscEngine:
                 to_fwd_pack_(c)
             self._arena = GradArena(self.ordered_params(), dev)
         return self._arena
+
+    def pack_targets(self):
+        return pack_targets(self.arena(), self.packs)
 
     def _plan(self, N, H, W, dtype, device):
         key = (N, H, W, dtype, str(device))

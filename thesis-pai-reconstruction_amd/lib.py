@@ -138,6 +138,7 @@ SIGNATURES = {
     "pai_reduce_rows": (_I, [_P, _I, _I, _P, _I, _P]),
     "pai_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
     "pai_adam_dev": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P, _P]),
+    "pai_adam_pack": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _F, _F, _F, _F, _I, _P]),
     "pai_comm_unique_id": (_I, [_P]),
     "pai_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "pai_allreduce": (_I, [_P, _P, _L, _I, _P]),

@@ -591,6 +591,17 @@ def adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
                               _stream()), "pai_adam")
 
 
+def adam_pack(param, grad, exp_avg, exp_avg_sq, w_off, cout, taps, cin, w_fwd, w_dgrad, lr, beta1, beta2, eps, step):
+    """pai_adam_pack: Adam over a range holding one dense conv weight (at element ``w_off``) whose bf16 packs are written by
+    the same launch."""
+    dt = torch.bfloat16
+    L.check(L.load().pai_adam_pack(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
+                                   _p(exp_avg_sq, torch.float32), param.numel(), int(w_off), cout, taps, cin,
+                                   _p(w_fwd, dt) if w_fwd is not None else None,
+                                   _p(w_dgrad, dt) if w_dgrad is not None else None, lr, beta1, beta2, eps, step,
+                                   _stream()), "pai_adam_pack")
+
+
 def adam_dev(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_dev, coeff_dev):
     """pai_adam_dev: the step count lives in ``step_dev`` (int64 device scalar, advanced by the call)."""
     L.check(L.load().pai_adam_dev(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),

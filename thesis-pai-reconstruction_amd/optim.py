@@ -34,6 +34,10 @@ class ArenaAdam(torch.optim.Adam):
         self._own_stream = os.environ.get("PAI_ADAM_STREAM", "0") not in ("", "0")
         self._adam_stream = None
         self._adam_pending = False
+        # PAI_ADAM_PACK=0: never write filter packs from the streamed update (A/B switch; default on)
+        self._fuse_packs = os.environ.get("PAI_ADAM_PACK", "1") not in ("", "0")
+        self._pack_targets = None      # armed step without a reducer: the engine's pack_targets()
+        self._packs_written = []       # _Packs whose spare buffers the armed step has filled; committed by step()
 
     # ---- hipGraph support -----------------------------------------------------------------------------
     def enable_device_step(self):
@@ -76,6 +80,7 @@ class ArenaAdam(torch.optim.Adam):
         # between a forward pass and its backward pass would invalidate the filter packs that forward made
         if len(params) != len(arena.params) or not arena.params_adopted():
             return False
+        self._pack_targets = None
         if reducer is not None:
             # data parallel: the reducer owns the hook; the update of a bucket follows its all-reduce + average.
             # OPT-IN (PAI_DDP_STREAM_ADAM=1): this path updates parameters on a third stream while the backward pass
@@ -88,6 +93,9 @@ class ArenaAdam(torch.optim.Adam):
             self._reducer = reducer
         else:
             self._engine.grad_ready_hook = self._on_ready
+            targets = getattr(self._engine, "pack_targets", None)
+            self._pack_targets = targets() if (targets is not None and self._fuse_packs) else None
+        self._packs_written = []
         self._streamed = 0
         self._stream_step = self.total_steps + 1
         return True
@@ -97,6 +105,25 @@ class ArenaAdam(torch.optim.Adam):
         if b > a:
             ops.adam(arena.pflat[a:b], arena.flat[a:b], arena.mflat[a:b], arena.vflat[a:b], float(group["lr"]),
                      float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), step)
+
+    def _adam_range_packing(self, arena, a, b, step):
+        """``_adam_range`` whose launches also write the bf16 filter packs of the dense conv weights inside [a, b)
+        (``pai_adam_pack``), into the layers' SPARE pack buffers: the input-gradient kernels of the running backward pass
+        still read the current ones.  ``step()`` commits them."""
+        inside = [t for t in (self._pack_targets or ()) if a <= t[0] and t[0] + t[1] <= b]
+        group = self.param_groups[0]
+        cur = a
+        for k, (o, n, cout, taps, cin, pk) in enumerate(inside):
+            spare = pk.spare()
+            if spare is None:
+                continue
+            end = inside[k + 1][0] if k + 1 < len(inside) else b
+            ops.adam_pack(arena.pflat[cur:end], arena.flat[cur:end], arena.mflat[cur:end], arena.vflat[cur:end], o - cur,
+                          cout, taps, cin, spare[0], spare[1], float(group["lr"]), float(group["betas"][0]),
+                          float(group["betas"][1]), float(group["eps"]), step)
+            self._packs_written.append(pk)
+            cur = end
+        self._adam_range(arena, cur, b, step)
 
     def _on_ready(self, arena, end_offset):
         if int(end_offset) < self._streamed:
@@ -113,10 +140,10 @@ class ArenaAdam(torch.optim.Adam):
                     self._adam_stream = torch.cuda.Stream(device=arena.flat.device)
                 self._adam_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._adam_stream):
-                    self._adam_range(arena, self._streamed, int(end_offset), self._stream_step)
+                    self._adam_range_packing(arena, self._streamed, int(end_offset), self._stream_step)
                 self._adam_pending = True
             else:
-                self._adam_range(arena, self._streamed, int(end_offset), self._stream_step)
+                self._adam_range_packing(arena, self._streamed, int(end_offset), self._stream_step)
         self._streamed = max(self._streamed, int(end_offset))
 
     def _on_reduced(self, arena, lo, hi):
@@ -192,6 +219,9 @@ class ArenaAdam(torch.optim.Adam):
             self._adam_range(arena, streamed, arena.flat.numel(), self._stream_step)     # what the hook did not reach
             self._arena_steps += 1
             self._engine.weights_generation[0] += 1
+            for pk in self._packs_written:      # their spare buffers hold the packs of the weights as they are now
+                pk.commit()
+            self._packs_written = []
             return None
         if self._dev_step is not None:
             ops.adam_dev(arena.pflat, arena.flat, arena.mflat, arena.vflat, float(group["lr"]), float(group["betas"][0]),
