@@ -41,7 +41,11 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
 // double-buffered, one 512-thread workgroup per CU) when that still gives every CU a workgroup,
 // else 128 x 128 / 128 x 64 (single buffer, 3-4 workgroups per CU), split over K when even that
 // leaves CUs idle.
-constexpr int FWD_WIDE_DEFAULT = 0;   // gg_fwd_patchw_k (128 x 64 wave tiles) for the 256-row tiles: tunable fwd_wide
+// gg_fwd_patchw_k (128 x 64 wave tiles) for the 256-row tiles: tunable fwd_wide.  5-9 % faster when a launch has the GPU to
+// itself, 1 % slower over the step as the default -- and no faster either when only the launches that DO run alone (the
+// forward passes, the generator step's pass through the discriminator) take it: 6.36-6.39 ms/step with and without,
+// three interleaved runs (round 3).
+constexpr int FWD_WIDE_DEFAULT = 0;
 struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
