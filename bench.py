@@ -31,6 +31,7 @@ MULTS = (1, 2, 4, 8, 8, 8, 8, 8)
 TRANS_MULTS = (1, 2, 2, 4, 4)       # TransUnetGAN's class default; the CLI default of 8 levels leaves no patches
 SIZE = 256
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0          # HBM3E, same guide
 PEAK_HBM_GBS = 8000.0
 # conv MACs per image: generator G, discriminator D, first layers G1, D1
 G_MAC, D_MAC, G1_MAC, D1_MAC = 5_947_523_072, 1_646_010_368, 16_777_216, 33_554_432
@@ -277,13 +278,14 @@ def main():
     # taken over a REPEAT of the same K steps, not inside the timed ones: ~150 event records per step
     # put a barrier packet between back-to-back kernels and cost 2-5 ms/step (11.7-15.1 vs 9.9 ms
     # measured), which would make `value` a measurement of the instrumentation.
-    prof = []
+    prof, prof_hbm = [], []
     if not args.no_kernel_events:
-        ops.PROFILE = []
+        ops.PROFILE, ops.PROFILE_HBM = [], []
         for i in range(args.steps):
             model.training_step(batch, i)
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        prof_hbm, ops.PROFILE_HBM = ops.PROFILE_HBM, None
         barrier()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -318,7 +320,28 @@ def main():
                      "gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 3),
                      "kernel_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())}}
 
+    def roofline_hbm_of(prof_hbm, nsteps):
+        """The HBM-bound passes issued through ops (BatchNorm apply / backward passes of the composable networks, Adam):
+        algorithmic bytes over HIP-event time of the family that takes the most time."""
+        fam = {}
+        for name, nbytes, e0, e1 in prof_hbm:
+            f = fam.setdefault(name, {"ms": 0.0, "bytes": 0, "launches": 0})
+            f["ms"] += e0.elapsed_time(e1)
+            f["bytes"] += nbytes
+            f["launches"] += 1
+        if not fam:
+            return None
+        top = max(fam, key=lambda k: fam[k]["ms"])
+        f = fam[top]
+        gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "traffic": None, "kernel": top, "launches_per_step": f["launches"] / nsteps,
+                "ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())},
+                "algorithmic_gb_per_step": {k: round(v["bytes"] / nsteps / 1e9, 3) for k, v in sorted(fam.items())},
+                "note": "co-scheduled with the matrix kernels where the step overlaps them; bytes are algorithmic (tensor sizes)"}
+
     dom, roofline = roofline_of(prof or [], args.steps)
+    roofline_hbm = roofline_hbm_of(prof_hbm or [], args.steps)
     # The timed region co-schedules weight-gradient kernels with the input-gradient chain on a second
     # stream, which stretches every individual launch.  For the kernel's own efficiency the same
     # launches are timed once more with that overlap switched off (3 extra steps, not part of `value`).
@@ -384,6 +407,7 @@ def main():
         "step_mfma_frac": None if gflop != gflop else round(gflop * 1e9 * value / world / 1e12 / PEAK_BF16_TFLOPS, 4),
         "roofline": roofline,
         "roofline_isolated": roofline_isolated,
+        "roofline_hbm": roofline_hbm,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(attention=args.model == "attention_unet") if args.model not in ("resnext_unet", "trans_unet") else None

@@ -119,6 +119,34 @@ class _Timed:
         return False
 
 
+# The HBM-bound passes (BatchNorm apply / backward reduce / backward apply, Adam): when PROFILE_HBM is a list every call
+# is bracketed the same way and (pass family, algorithmic bytes, events) is appended -- bench.py's `roofline_hbm`.
+PROFILE_HBM = None
+
+
+class _TimedBytes:
+    def __init__(self, family, nbytes):
+        self.on = PROFILE_HBM is not None
+        if self.on:
+            self.family, self.nbytes = family, int(nbytes)
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE_HBM.append((self.family, self.nbytes, self.e0, self.e1))
+        return False
+
+
+def _es(dtype) -> int:
+    return 4 if dtype == torch.float32 else 2
+
+
 class Handle:
     """A per-device handle of libpai_hip.so (pai_create / pai_bind / pai_destroy, include/pai_hip.h) together with the
     torch tensors registered as its split-K workspace and scratch (the library never allocates).  One per device is
@@ -367,8 +395,9 @@ def bn_eval_coeffs(C_, gamma, beta, running_mean, running_var, eps, scale, shift
 
 
 def bn_apply(dtype, z, M, C_, scale, shift, act, out):
-    L.check(L.load().pai_bn_apply(code_of(dtype), _p(z), M, C_, _p(scale), _p(shift), act, _p(out), _stream()),
-            "pai_bn_apply")
+    with _TimedBytes("bn_passes", 2 * M * C_ * _es(dtype)):     # read z, write the activation
+        L.check(L.load().pai_bn_apply(code_of(dtype), _p(z), M, C_, _p(scale), _p(shift), act, _p(out), _stream()),
+                "pai_bn_apply")
 
 
 def bn_bwd_partial_rows(M) -> int:
@@ -376,20 +405,25 @@ def bn_bwd_partial_rows(M) -> int:
 
 
 def bn_bwd_reduce(dtype, g1, act1, g2, act2, a, z, M, C_, mean, rstd, du, partials, sums, dgamma, dbeta):
-    L.check(L.load().pai_bn_bwd_reduce(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), _p(z), M, C_, _p(mean),
-                                       _p(rstd), _p(du), _p(partials), _p(sums), _p(dgamma), _p(dbeta),
-                                       _stream()), "pai_bn_bwd_reduce")
+    # reads g1 (+ g2), the stored activation (+ z when it is a separate tensor), writes du
+    streams = 2 + (g2 is not None) + (a is not None and z is not None and a.data_ptr() != z.data_ptr()) + (du is not None)
+    with _TimedBytes("bn_passes", streams * M * C_ * _es(dtype)):
+        L.check(L.load().pai_bn_bwd_reduce(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), _p(z), M, C_, _p(mean),
+                                           _p(rstd), _p(du), _p(partials), _p(sums), _p(dgamma), _p(dbeta),
+                                           _stream()), "pai_bn_bwd_reduce")
 
 
 def bn_bwd_reduce_affine(dtype, g1, act1, g2, act2, z, M, C_, scale, shift, mean, rstd, du, partials, sums, dgamma, dbeta):
-    L.check(L.load().pai_bn_bwd_reduce_affine(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(z), M, C_, _p(scale),
-                                              _p(shift), _p(mean), _p(rstd), _p(du), _p(partials), _p(sums), _p(dgamma),
-                                              _p(dbeta), _stream()), "pai_bn_bwd_reduce_affine")
+    with _TimedBytes("bn_passes", (2 + (g2 is not None) + (du is not None)) * M * C_ * _es(dtype)):
+        L.check(L.load().pai_bn_bwd_reduce_affine(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(z), M, C_, _p(scale),
+                                                  _p(shift), _p(mean), _p(rstd), _p(du), _p(partials), _p(sums), _p(dgamma),
+                                                  _p(dbeta), _stream()), "pai_bn_bwd_reduce_affine")
 
 
 def bn_bwd_apply(dtype, du, z, M, C_, mean, rstd, gamma, sums, dz):
-    L.check(L.load().pai_bn_bwd_apply(code_of(dtype), _p(du), _p(z), M, C_, _p(mean), _p(rstd), _p(gamma),
-                                      _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply")
+    with _TimedBytes("bn_passes", 3 * M * C_ * _es(dtype)):      # read du and z, write dz
+        L.check(L.load().pai_bn_bwd_apply(code_of(dtype), _p(du), _p(z), M, C_, _p(mean), _p(rstd), _p(gamma),
+                                          _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply")
 
 
 def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
@@ -586,20 +620,23 @@ def reduce_rows(partial, rows, C_, out, accumulate=False):
 
 
 def adam(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
-    L.check(L.load().pai_adam(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
-                              _p(exp_avg_sq, torch.float32), param.numel(), lr, beta1, beta2, eps, step,
-                              _stream()), "pai_adam")
+    with _TimedBytes("adam", 28 * param.numel()):      # read g, p, m, v; write p, m, v
+        L.check(L.load().pai_adam(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
+                                  _p(exp_avg_sq, torch.float32), param.numel(), lr, beta1, beta2, eps, step,
+                                  _stream()), "pai_adam")
 
 
 def adam_pack(param, grad, exp_avg, exp_avg_sq, w_off, cout, taps, cin, w_fwd, w_dgrad, lr, beta1, beta2, eps, step):
     """pai_adam_pack: Adam over a range holding one dense conv weight (at element ``w_off``) whose bf16 packs are written by
     the same launch."""
     dt = torch.bfloat16
-    L.check(L.load().pai_adam_pack(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
-                                   _p(exp_avg_sq, torch.float32), param.numel(), int(w_off), cout, taps, cin,
-                                   _p(w_fwd, dt) if w_fwd is not None else None,
-                                   _p(w_dgrad, dt) if w_dgrad is not None else None, lr, beta1, beta2, eps, step,
-                                   _stream()), "pai_adam_pack")
+    packs = 2 * cout * taps * cin * ((w_fwd is not None) + (w_dgrad is not None))
+    with _TimedBytes("adam", 28 * param.numel() + packs):
+        L.check(L.load().pai_adam_pack(_p(param, torch.float32), _p(grad, torch.float32), _p(exp_avg, torch.float32),
+                                       _p(exp_avg_sq, torch.float32), param.numel(), int(w_off), cout, taps, cin,
+                                       _p(w_fwd, dt) if w_fwd is not None else None,
+                                       _p(w_dgrad, dt) if w_dgrad is not None else None, lr, beta1, beta2, eps, step,
+                                       _stream()), "pai_adam_pack")
 
 
 def adam_dev(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_dev, coeff_dev):
@@ -617,8 +654,9 @@ def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step
             raise PaiError("adam_multi needs contiguous fp32 HIP tensors")
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
     numels = (C.c_int64 * n)(*[p.numel() for p in params])
-    L.check(L.load().pai_adam_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numels, lr, beta1, beta2,
-                                    eps, step, _stream()), "pai_adam_multi")
+    with _TimedBytes("adam", 28 * sum(p.numel() for p in params)):
+        L.check(L.load().pai_adam_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), numels, lr, beta1,
+                                        beta2, eps, step, _stream()), "pai_adam_multi")
 
 
 def adam_multi_dev(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step_dev, coeff_dev):
