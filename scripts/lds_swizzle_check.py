@@ -184,6 +184,24 @@ def wg3_x():
     return worst
 
 
+def group_wgrad():
+    """gg_group.hip grouped3_wgrad_k: transposed fragment reads of the dy tile (rows y * 32 + ...) and of the shifted source
+    patch (rows of 34 pixels, any offset), 128-B rows, 16-B chunk c of row p at slot c ^ gsw(p)."""
+    def gsw(p):
+        return ((p & 3) ^ ((p >> 3) & 1)) << 1
+    worst = 1
+    rows0 = [y * 32 for y in range(4)] + [y * 34 + (1 + dy) * 34 + 1 + dx for y in range(4) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    for row0, sl, h in itertools.product(rows0, range(4), range(2)):
+        def addr(lane):
+            fr, fq = lane & 15, lane >> 4
+            tq, tp = fr >> 2, fr & 3
+            row = row0 + fq * 8 + h * 4 + tq
+            chunk = 2 * sl + (tp >> 1)
+            return row * 128 + ((chunk ^ gsw(row)) << 4) + 8 * (tp & 1)
+        worst = max(worst, ways(addr, HALF_GROUPS, 8))
+    return worst
+
+
 def wg3_x8():
     """gg_wg3.hip, 8 x 8-pixel K steps (BW = 8): patch rows of 9 pixels at a pitch of 12, 128-B pixels, f(p) = bit 1 | bit 2 << 1."""
     pw = 12

@@ -366,6 +366,45 @@ def test_grouped_conv3x3(pai, dtype, C, groups, N, H, W):
     assert rel_err(gw.cpu(), w.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 8, 32), (3, 12, 64), (9, 128, 64)])
+def test_grouped_conv3x3_weight_gradient_exact(pai, N, H, W):
+    """The weight gradient of the grouped 3 x 3 convolution on grouped3_wgrad_k (diagonal 16-channel blocks only, partial
+    blocks of the persistent workgroups summed in a fixed order): on small-integer data every sum is exact in fp32, so the
+    group blocks must equal PyTorch-CPU's F.conv2d(groups=32) weight gradient BIT FOR BIT -- accumulating into a non-zero
+    dW and overwriting a dirty one; (9, 128, 64): 576 tiles on 512 workgroups, some take two.  Without the weight-gradient
+    workspace the dense kernel still serves the call."""
+    from thesis_pai_reconstruction_amd import nnops, ops
+    C, groups, dtype = 128, 32, torch.bfloat16
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x = torch.randint(-2, 3, (N, C, H, W), generator=g).float().requires_grad_(True)
+    w = torch.randint(-2, 3, (C, C // groups, 3, 3), generator=g).float().requires_grad_(True)
+    dy = torch.randint(-2, 3, (N, C, H, W), generator=g).float()
+    F.conv2d(x, w, None, padding=1, groups=groups).backward(dy)
+    d = ops.make_desc(dtype, 0, N, H, W, C, 0, C, 1, 0, 0, ops.ACT_NONE, kernel=3, groups=groups)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    ops.ensure_wgrad_workspace([d], dev())
+    assert ops.conv_wgrad_workspace_bytes(d) > 0
+    assert ops.conv_kernel_id(d, 2) == 6 and ops.conv_kernel_name(d, 2) == "grouped3_wgrad_k"
+    X, DY = nhwc(x.detach(), dtype), nhwc(dy, dtype)
+    base = torch.randint(-3, 4, (C * 9 * C,), generator=g).float().to(dev())
+    dw = base.clone()
+    ops.conv_wgrad(d, X, None, DY, dw, None)                    # dW += ...
+    got = nnops._grad_from_fwd_pack(dw, w, groups) - nnops._grad_from_fwd_pack(base, w, groups)
+    assert torch.equal(got.cpu(), w.grad)
+    dw2 = torch.full_like(base, 12345.0)
+    ops.conv_wgrad_overwrite(d, X, None, DY, dw2, None)         # dW = ...
+    assert torch.equal(nnops._grad_from_fwd_pack(dw2, w, groups).cpu(), w.grad)
+    # the dense kernel (tunable off) agrees on the group blocks
+    try:
+        ops.set_tunable("grouped_wgrad", 0)
+        assert ops.conv_kernel_id(d, 2) != 6
+        dw3 = torch.zeros_like(base)
+        ops.conv_wgrad(d, X, None, DY, dw3, None)
+        assert torch.equal(nnops._grad_from_fwd_pack(dw3, w, groups).cpu(), w.grad)
+    finally:
+        ops.set_tunable("grouped_wgrad")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("k,N,H,W,C1,C2,K", [(1, 2, 16, 16, 128, 128, 128), (3, 2, 16, 16, 64, 64, 64), (3, 1, 6, 10, 128, 64, 64),
                                              (1, 3, 8, 8, 256, 256, 64), (3, 2, 8, 16, 64, 128, 128)])

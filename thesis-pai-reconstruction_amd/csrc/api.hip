@@ -379,6 +379,7 @@ extern "C" int pai_set_wgrad_workspace(void* device_memory, int64_t bytes) {
 extern "C" int64_t pai_conv_wgrad_workspace_bytes(const pai_conv_desc* d) {
     GG g;
     if (gg_build_fwd(d, &g)) return -1;
+    if (grouped3_wgrad_ok(d->dtype, g, nullptr)) return grouped3_wgrad_part_bytes(g);
     if (!wgrad_mfma_ok(d->dtype, g)) return 0;
     return wgrad3_slab_bytes(g);
 }
@@ -441,6 +442,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (gg_build_fwd(d, &g)) return -1;
     }
     if (op == 2) {
+        if (grouped3_wgrad_ok(d->dtype, g, nullptr) && wgrad_slab_acquire(grouped3_wgrad_part_bytes(g))) return 6;
         if (thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) || thin_wgrad_conv1_ok(d->dtype, g) ||
             thin_wgrad_conv3_ok(d->dtype, g) || thin_wgrad_conv3t_ok(d->dtype, g)) return 4;
         if (g.Cout <= 2 && (g.ntaps == 4 || g.ntaps == 9 || g.ntaps == 16) && (g.C1 % 8) == 0 && (g.C2 % 8) == 0) {
@@ -463,7 +465,7 @@ extern "C" int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, 
     static const char* fam[7] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16", "small_mfma_bf16", "grouped3_k"};
     const int id = pai_conv_kernel_id(d, op);
     if (id < 0 || !name || name_len <= 0) return -1;
-    const char* n = fam[id];
+    const char* n = (id == 6 && op == 2) ? "grouped3_wgrad_k" : fam[id];
     if (id == 2 || id == 3) {
         GG g;
         if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
@@ -719,6 +721,13 @@ static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x
     WgradArgs a;
     a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0; a.overwrite_bias = 0; a.slab = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    if (grouped3_wgrad_ok(d->dtype, g, dbias)) {      // block-diagonal 3 x 3 filter: the diagonal blocks only (gg_group.hip)
+        float* part = wgrad_slab_acquire(grouped3_wgrad_part_bytes(g));
+        if (part) {
+            a.overwrite = overwrite != 0;
+            return launch_grouped3_wgrad(g, a, part, s);
+        }
+    }
     if (overwrite) {
         const bool thin = thin_wgrad_conv_ok(d->dtype, g) || thin_wgrad_convt_ok(d->dtype, g) ||
                           thin_wgrad_conv1_ok(d->dtype, g) || thin_wgrad_conv3_ok(d->dtype, g) ||

@@ -254,6 +254,10 @@ struct WgradArgs {
 // the handle's weight-gradient workspace if it holds `bytes`, else NULL (the launch then adds with fp32 atomics)
 float* wgrad_slab_acquire(int64_t bytes);
 int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, int overwrite, hipStream_t s);
+// weight gradient of the same layer: diagonal 16-channel blocks only, partial blocks in the weight-gradient workspace
+bool grouped3_wgrad_ok(int dtype, const GG& g, const float* dbias);
+int64_t grouped3_wgrad_part_bytes(const GG& g);
+int launch_grouped3_wgrad(const GG& g, const WgradArgs& a, float* part, hipStream_t s);
 // patch-resident weight gradient with 128 x 64 / 64 x 128 wave tiles (gg_wg3.hip)
 bool wgrad3_ok(const GG& g);
 int launch_wgrad3(const GG& g, const WgradArgs& a, hipStream_t s);

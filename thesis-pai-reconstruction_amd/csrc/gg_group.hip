@@ -213,3 +213,181 @@ int launch_grouped3(const GG& g, const FwdArgs& a, hipStream_t s) {
     PAI_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer.  Until round 3 it went through the dense gg_wgrad_mfma_k (32x the useful MACs on the
+// zero blocks: 1.64 ms at 512 x 512 x 16 images, where reading x and dy once takes 0.36 ms).  Here only the eight diagonal
+// 16 x 16 blocks per tap are formed (4x the useful MACs, 1/8 of the dense work):
+//   dW[co][tap][ci] = sum_pixels dy[p][co] * x[p + (dy_tap, dx_tap)][ci],   co, ci in one 16-channel slice.
+//   * a workgroup owns 4 x 32 output pixels x 64 channels (blockIdx.y picks the half) per step: dy tile (16 KB) and the
+//     6 x 34 source pixels it meets (26 KB) in LDS, 128-B rows, 16-B chunk c of row p at slot c ^ gsw(p);
+//   * wave w = slice w of the half: one K step = one 32-pixel row of the tile; the dy fragment (A: 16 output channels x 32
+//     pixels) and the nine shifted x fragments (B: 32 pixels x 16 input channels) are TRANSPOSED reads of the pixel-major
+//     tiles (ds_read_b64_tr_b16, as thin_wgrad_k), nine MFMAs per K step into nine accumulators;
+//   * the next tile's 42 KB are fetched into registers while this one is multiplied (as grouped3_k);
+//   * persistent workgroups store their 4 x 9 x 16 x 16 partial blocks into the weight-gradient workspace, a second
+//     launch sums them in a fixed order (deterministic) and assigns / adds the diagonal blocks of dW.
+// Only the diagonal 16-channel blocks of dW are written (the rest of a block-diagonal filter's gradient is not defined;
+// the dense kernel used to leave cross-group products there).  No bias gradient (the layer feeds a BatchNorm).
+namespace {
+constexpr int WTH = 4, WTW = 32;              // output pixels per step
+constexpr int WPW = WTW + 2, WPH = WTH + 2;   // source patch 6 x 34
+constexpr int WPATCH = WPW * WPH;             // 204 pixels
+constexpr int WDY = WTH * WTW;                // 128 pixels
+constexpr int WG_MAX_BLOCKS = 512;
+constexpr int WPART = 2 * HS * 9 * 256;       // floats per persistent workgroup PAIR (both channel halves)
+
+// 16-B chunk c of row p sits at slot c ^ gsw(p): the four consecutive rows a 16-lane group of a transposed read touches
+// land in four different 32-B bank ranges, and the group eight rows further on in the complementary four
+__device__ __forceinline__ int gsw(int p) { return ((p & 3) ^ ((p >> 3) & 1)) << 1; }
+
+// fragment "16 channels x 32 rows" of a pixel-major tile (128-B rows): lane (fr = channel, fq = k quarter) ends up with
+// rows row0 + 8 fq + 0..7 of channel 16 * (chunk0 / 2) + fr
+__device__ __forceinline__ bf8_t tr_frag16(const unsigned char* tile, int row0, int chunk0, int lane) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
+    const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+    bf8_t f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = row0 + fq * 8 + h * 4 + tq;
+        const int chunk = chunk0 + (tp >> 1);
+        bf4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (bf4_t __attribute__((address_space(3)))*)(tile + row * 128 + ((chunk ^ gsw(row)) << 4) + 8 * (tp & 1)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[h * 4 + e] = v[e];
+    }
+    return f;
+}
+}  // namespace
+
+bool grouped3_wgrad_ok(int dtype, const GG& g, const float* dbias) {
+    if (dtype != PAI_BF16 || g.gslice != 16 || dbias) return false;
+    if (g.nphase != 1 || g.S != 1 || g.OS != 1 || g.ntaps != 9 || g.wtaps != 9) return false;
+    if (g.C1 != GC || g.C2 != 0 || g.Cout != GC || g.relu1) return false;
+    if ((g.OHg % WTH) || (g.OWg % WTW) || g.H != g.OHg || g.W != g.OWg) return false;
+    return pai_tunable("grouped_wgrad", 1) != 0;
+}
+
+static int grouped3_wgrad_blocks(const GG& g) {
+    const int t = g.N * (g.OHg / WTH) * (g.OWg / WTW);
+    return t < WG_MAX_BLOCKS ? t : WG_MAX_BLOCKS;
+}
+
+int64_t grouped3_wgrad_part_bytes(const GG& g) { return (int64_t)grouped3_wgrad_blocks(g) * WPART * sizeof(float); }
+
+__global__ __launch_bounds__(256, 2) void grouped3_wgrad_k(GG g, WgradArgs a, float* part, int tiles, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) unsigned char xp[WPATCH * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char dyt[WDY * 128];
+    const int c0 = blockIdx.y * (HS * 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bf16_t* x = (const bf16_t*)a.x1;
+    const bf16_t* dy = (const bf16_t*)a.dy;
+    int pofs[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pofs[t] = (1 + g.dy[0][t]) * WPW + 1 + g.dx[0][t];
+    f4_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int tpi = tiles_x * tiles_y;
+    constexpr int NX = (WPATCH * 8 + 255) / 256;     // 7
+    constexpr int NY = WDY * 8 / 256;                // 4
+    uint4 pre[NX + NY];
+    auto fetch = [&](int tile) {
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * WTW;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i >> 3, c = i & 7;
+            const int py = p / WPW, px = p - py * WPW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool inb = i < WPATCH * 8 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const size_t off = inb ? ((size_t)(n * g.H + iy) * g.W + ix) * GC + c0 + c * 8 : 0;
+            pre[j] = *(const uint4*)(x + off);
+            if (!inb) pre[j] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i >> 3, c = i & 7;
+            const int py = p / WTW, px = p - py * WTW;
+            pre[NX + j] = *(const uint4*)(dy + ((size_t)(n * g.H + y0 + py) * g.W + x0 + px) * GC + c0 + c * 8);
+        }
+    };
+    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i >> 3, c = i & 7;
+            if (i < WPATCH * 8) *(uint4*)(xp + p * 128 + ((c ^ gsw(p)) << 4)) = pre[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const int i = tid + 256 * j;
+            const int p = i >> 3, c = i & 7;
+            *(uint4*)(dyt + p * 128 + ((c ^ gsw(p)) << 4)) = pre[NX + j];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+#pragma unroll 1
+        for (int y = 0; y < WTH; ++y) {
+            const bf8_t af = tr_frag16(dyt, y * WTW, 2 * wid, lane);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bf8_t bfr = tr_frag16(xp, y * WPW + pofs[t], 2 * wid, lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // everyone is done with both tiles before the next fill
+    }
+    // D[i = 4 fq + r][j = fr] = dW[co = cs + i][tap][ci = cs + j], cs = c0 + 16 wid
+    const int fr = lane & 15, fq = lane >> 4;
+    float* dst = part + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * HS + wid) * (9 * 256);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[t * 256 + (4 * fq + r) * 16 + fr] = acc[t][r];
+}
+
+struct GroupWt { int wt[9]; };
+
+// dW diagonal blocks = / += sum over the persistent workgroups' partial blocks, in a fixed order: 64 outputs x 4 lanes of
+// the workgroup range per block, eight loads in flight per lane
+__global__ __launch_bounds__(256) void grouped3_wgrad_reduce_k(float* dw, const float* part, int nblk, GroupWt wt, int overwrite) {
+    __shared__ float red[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float sum = 0.f;
+    int b = q;
+    for (; b + 28 < nblk; b += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)(b + 4 * u) * WPART + e];
+        sum += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; b < nblk; b += 4) sum += part[(size_t)b * WPART + e];
+    red[q][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (q == 0) {
+        sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int j = e & 15, i = (e >> 4) & 15, t = (e >> 8) % 9, sl = (e >> 8) / 9;     // sl = half * 4 + slice
+        const int cs = 16 * sl;
+        float* d = dw + ((size_t)(cs + i) * 9 + wt.wt[t]) * GC + cs + j;
+        *d = overwrite ? sum : *d + sum;
+    }
+}
+
+int launch_grouped3_wgrad(const GG& g, const WgradArgs& a, float* part, hipStream_t s) {
+    const int tiles = g.N * (g.OHg / WTH) * (g.OWg / WTW);
+    const int nblk = grouped3_wgrad_blocks(g);
+    hipLaunchKernelGGL(grouped3_wgrad_k, dim3(nblk, GC / (HS * 16)), dim3(256), 0, s, g, a, part, tiles, g.OWg / WTW, g.OHg / WTH);
+    PAI_LAUNCH_CHECK();
+    GroupWt wt;
+    for (int t = 0; t < 9; ++t) wt.wt[t] = g.wt[0][t];
+    hipLaunchKernelGGL(grouped3_wgrad_reduce_k, dim3(WPART / 64), dim3(256), 0, s, a.dw, (const float*)part, nblk, wt, a.overwrite);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

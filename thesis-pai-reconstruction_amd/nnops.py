@@ -90,6 +90,8 @@ class ConvBNAct(torch.autograd.Function):
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
         if Cin <= 2 or Cout <= 2:            # thin layers (in_conv / out): skinny-GEMM scratch of gg_thin.hip
             ops.ensure_scratch(ops.scratch_bytes_for([d]), x.device)
+        # weight-gradient workspace: pixel-split slabs of the patch kernels, partial blocks of the grouped 3 x 3 gradient
+        ops.ensure_wgrad_workspace([d], x.device)
         wm = _dense_fwd_pack(weight, groups)
         if dtype == torch.float32:
             wf = wm
