@@ -10,9 +10,9 @@
 //     k-quarter (pixels 0-3, 12-15 or 4-11) plus 8 of its neighbour, so bit 0 of the slot -- the k-quarter's
 //     channel half -- is kept and the XOR spreads each set of 8 pixels over the 2 x 4 row-parity / slot-pair
 //     positions, for every tap shift);
-//   * its four waves take two pixel rows each and walk the four 16-channel slices: the filter slice (five 16-B
-//     fragments per lane, L1-resident) as the MFMA A operand, the shifted patch pixels as B, no operand is re-read
-//     from memory for the nine taps.  (All eight slices in one workgroup needed 336 registers: one wave per SIMD.)
+//   * wave w takes slice w over the eight pixel rows of the tile: its filter slice (five 16-B fragments per lane, loaded
+//     once per persistent workgroup) is the MFMA A operand, the shifted patch pixels are B, no operand is re-read from
+//     memory for the nine taps.
 //   * bias, BatchNorm partial statistics (one row per persistent workgroup), activation in the store.
 // A first attempt without LDS (per-tap 16-B loads from L1, gg_small.hip in slice mode) ran at the speed of the dense
 // kernel: nine shifted re-reads of every pixel line through the texture path cost as much as the wasted MACs.
@@ -60,7 +60,6 @@ int grouped3_rows(const GG& g) {
 template <bool STATS>
 __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[PATCH_PIXELS * 128];
-    __shared__ float sred[4][2][HS * 16];
     const int c0 = blockIdx.y * (HS * 16);      // first channel of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -84,11 +83,25 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
     }
     // (measured and dropped: partial sums in LDS + a rolled slice loop, 147 VGPRs / three workgroups per CU -- 1361 us
     //  forward, 994 us input gradient at 512 x 512 x 16 against 984 / 916 us for this form at 244 VGPRs / two per CU)
-    float csum[HS][4], csq[HS][4];
+    float csum[4], csq[4];
 #pragma unroll
-    for (int s = 0; s < HS; ++s)
+    for (int r = 0; r < 4; ++r) csum[r] = csq[r] = 0.f;
+    // wave w = slice w of this workgroup's 64 channels, all eight pixel rows of a tile: its filter slice (five 16-B
+    // fragments per lane) and bias are loaded ONCE for the whole (persistent) workgroup.  (Until round 3 every wave walked
+    // the four slices over two pixel rows and re-read 20 filter fragments per tile -- a chain of L1 round trips per slice
+    // that cost more than the patch fetch and the stores together: 1020 -> ~6xx us at 512 x 512 x 16.)
+    const int cs = c0 + 16 * wid;             // first channel of this wave's slice
+    bf8_t af[5];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) csum[s][r] = csq[s][r] = 0.f;
+    for (int ks = 0; ks < 5; ++ks) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (kvalid[ks]) z = *(const uint4*)(w + ((size_t)(cs + fr) * 9 + wtap[ks]) * GC + cs + (fq & 1) * 8);
+        af[ks] = __builtin_bit_cast(bf8_t, z);
+    }
+    float bias4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[cs + 4 * fq + r] : 0.f;
+    const int chunk = 2 * wid + (fq & 1);
 
     const int tpi = tiles_x * tiles_y;
     // The patch of the NEXT tile is fetched into registers while this one is multiplied (a workgroup per tile pays the
@@ -123,85 +136,61 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
         }
         __syncthreads();
         if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
-        // ---- four slices x two pixel rows per wave ----------------------------------------------------
+        // ---- this wave's slice x the eight pixel rows of the tile ---------------------------------------
 #pragma unroll
-        for (int s = 0; s < HS; ++s) {
-            const int cs = c0 + 16 * s;             // first channel of the slice
-            bf8_t af[5];
+        for (int pyo = 0; pyo < TH; ++pyo) {
+            const int pbase = pyo * PW + fr;
+            f4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 5; ++ks) {
-                uint4 z = make_uint4(0, 0, 0, 0);
-                if (kvalid[ks])
-                    z = *(const uint4*)(w + ((size_t)(cs + fr) * 9 + wtap[ks]) * GC + cs + (fq & 1) * 8);
-                af[ks] = __builtin_bit_cast(bf8_t, z);
+                const int p = pbase + pofs[ks];
+                uint4 v = (GROUP_ABL & 2) ? make_uint4(p, chunk, ks, pyo)
+                                          : *(const uint4*)(patch + p * 128 + ((chunk ^ (((p >> 1) & 3) << 1)) << 4));
+                if (!kvalid[ks]) v = make_uint4(0, 0, 0, 0);
+                bf8_t b = __builtin_bit_cast(bf8_t, v);
+                if (g.relu1) b = relu8g(b);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b, acc, 0, 0, 0);
             }
-            float bias4[4];
+            // D[i = 4 fq + r][j = fr]: channel cs + 4 fq + r of pixel (y0 + pyo, x0 + fr)
+            float v4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[cs + 4 * fq + r] : 0.f;
-            const int chunk = 2 * s + (fq & 1);
+            for (int r = 0; r < 4; ++r) v4[r] = acc[r] + bias4[r];
+            if (STATS) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int pyo = 2 * wid + rr;
-                const int pbase = pyo * PW + fr;
-                f4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 5; ++ks) {
-                    const int p = pbase + pofs[ks];
-                    uint4 v = (GROUP_ABL & 2) ? make_uint4(p, chunk, ks, s)
-                                              : *(const uint4*)(patch + p * 128 + ((chunk ^ (((p >> 1) & 3) << 1)) << 4));
-                    if (!kvalid[ks]) v = make_uint4(0, 0, 0, 0);
-                    bf8_t b = __builtin_bit_cast(bf8_t, v);
-                    if (g.relu1) b = relu8g(b);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b, acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    csum[r] += v4[r];
+                    csq[r] = fmaf(v4[r], v4[r], csq[r]);
                 }
-                // D[i = 4 fq + r][j = fr]: channel 16 s + 4 fq + r of pixel (y0 + pyo, x0 + fr)
-                float v4[4];
+            }
+            const size_t o = ((size_t)(n * g.OHg + y0 + pyo) * g.OWg + x0 + fr) * GC + cs + 4 * fq;
+            if ((GROUP_ABL & 1) && v4[0] != 12345.f) continue;
+            if (yraw) *(uint2*)(yraw + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
+            if (yact) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v4[r] = acc[r] + bias4[r];
-                if (STATS) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        csum[s][r] += v4[r];
-                        csq[s][r] = fmaf(v4[r], v4[r], csq[s][r]);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    if (eact == PAI_ACT_LRELU) v4[r] = fmaxf(v4[r], 0.2f * v4[r]);
+                    else if (eact == PAI_ACT_RELU) v4[r] = fmaxf(v4[r], 0.f);
                 }
-                const size_t o = ((size_t)(n * g.OHg + y0 + pyo) * g.OWg + x0 + fr) * GC + cs + 4 * fq;
-                if ((GROUP_ABL & 1) && v4[0] != 12345.f) continue;
-                if (yraw) *(uint2*)(yraw + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
-                if (yact) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (eact == PAI_ACT_LRELU) v4[r] = fmaxf(v4[r], 0.2f * v4[r]);
-                        else if (eact == PAI_ACT_RELU) v4[r] = fmaxf(v4[r], 0.f);
-                    }
-                    *(uint2*)(yact + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
-                }
+                *(uint2*)(yact + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
             }
         }
         __syncthreads();   // everyone is done with the patch before the next fill
     }
     if (!STATS) return;
-    // ---- BatchNorm partial statistics: one row per workgroup --------------------------------------------
+    // ---- BatchNorm partial statistics: one row per workgroup (every wave owns its 16 channels) -----------------
 #pragma unroll
-    for (int s = 0; s < HS; ++s)
+    for (int r = 0; r < 4; ++r) {
+        float s1 = csum[r], s2 = csq[r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s1 = csum[s][r], s2 = csq[s][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s1 += __shfl_xor(s1, o, 64);
-                s2 += __shfl_xor(s2, o, 64);
-            }
-            if (fr == 0) {
-                sred[wid][0][16 * s + 4 * fq + r] = s1;
-                sred[wid][1][16 * s + 4 * fq + r] = s2;
-            }
+        for (int o = 1; o < 16; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
         }
-    __syncthreads();
-    if (tid < HS * 16) {
-        float* dst = a.stats + ((size_t)blockIdx.x * 2) * GC + c0 + tid;
-        dst[0] = sred[0][0][tid] + sred[1][0][tid] + sred[2][0][tid] + sred[3][0][tid];
-        dst[GC] = sred[0][1][tid] + sred[1][1][tid] + sred[2][1][tid] + sred[3][1][tid];
+        if (fr == 0) {
+            float* dst = a.stats + ((size_t)blockIdx.x * 2) * GC + cs + 4 * fq + r;
+            dst[0] = s1;
+            dst[GC] = s2;
+        }
     }
 }
 
