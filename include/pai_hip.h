@@ -316,7 +316,8 @@ int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void* g2, int a
                       void* du, float* partials, float* sums, float* dgamma, float* dbeta,
                       void* stream);
 /* pai_bn_bwd_reduce with the activation's sign taken from pre = z*scale + shift (the coefficients pai_bn_finalize
- * produced) instead of from the stored activated output `a`: one tensor read less. */
+ * produced) instead of from the stored activated output `a`: one tensor read less.  du may be NULL: nothing is stored
+ * and pass 2 is pai_bn_bwd_apply_affine, which rebuilds du (one tensor write and nothing else less). */
 int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, const void* g2, int act2, const void* z,
                              int64_t M, int C, const float* scale, const float* shift, const float* mean,
                              const float* rstd, void* du, float* partials, float* sums, float* dgamma,
@@ -329,6 +330,11 @@ int pai_bn_bwd_finalize(const float* partials, int rows, int C, float* sums, flo
 int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_t M, int C,
                      const float* mean, const float* rstd, const float* gamma,
                      const float* sums, void* dz, void* stream);
+/* Pass 2 behind pai_bn_bwd_reduce_affine(..., du = NULL, ...): du = act1'(z*scale + shift) * g1 is rebuilt (and rounded
+ * to the storage type, as pass 1 did for its sums), then dz as pai_bn_bwd_apply. */
+int pai_bn_bwd_apply_affine(int dtype, const void* g1, int act1, const void* z, int64_t M, int C, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, const float* gamma,
+                            const float* sums, void* dz, void* stream);
 /* du = act1'(a)*g1 + act2'(a)*g2 without BatchNorm (last encoder, discriminator blocks,
  * encoder 0); g2 may be NULL. */
 int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, int act2, const void* a,

@@ -69,6 +69,22 @@ def test_batchnorm_forward_backward(pai, dtype, shape):
     assert rel_err(db.cpu(), br.grad) < max(tol, 2e-4)
     assert rel_err(from_nhwc(dz, N, H, W, C), zr.grad) < max(tol, 2e-4)
 
+    # single-consumer forms of the composable networks: pass 1 stores du (6 tensor passes) or nothing (5: pass 2 rebuilds
+    # du from g1 and z) -- the same dz, dgamma, dbeta bit for bit
+    for act in (ops.ACT_LRELU, ops.ACT_RELU):
+        G1 = nhwc(g1, dtype)
+        du6, dz6, dz5 = torch.empty_like(Z), torch.empty_like(Z), torch.empty_like(Z)
+        dg6, db6, dg5, db5 = (torch.zeros(C, device=dev()) for _ in range(4))
+        ops.bn_bwd_reduce_affine(dtype, G1, act, None, ops.ACT_NONE, Z, M, C, scale, shift, mean, rstd, du6, partials, sums, dg6, db6)
+        ops.bn_bwd_apply(dtype, du6, Z, M, C, mean, rstd, G, sums, dz6)
+        ops.bn_bwd_reduce_affine(dtype, G1, act, None, ops.ACT_NONE, Z, M, C, scale, shift, mean, rstd, None, partials, sums, dg5, db5)
+        ops.bn_bwd_apply_affine(dtype, G1, act, Z, M, C, scale, shift, mean, rstd, G, sums, dz5)
+        torch.cuda.synchronize()
+        assert torch.equal(dz5, dz6) and torch.equal(dg5, dg6) and torch.equal(db5, db6), act
+    with pytest.raises(ops.PaiError):      # a second gradient needs the stored du
+        ops.bn_bwd_reduce_affine(dtype, G1, ops.ACT_RELU, G1, ops.ACT_RELU, Z, M, C, scale, shift, mean, rstd, None, partials,
+                                 sums, dg5, db5)
+
     # eval mode
     ops.bn_eval_coeffs(C, G, B, RM, RV, 1e-5, scale, shift)
     ops.bn_apply(dtype, Z, M, C, scale, shift, ops.ACT_NONE, A)

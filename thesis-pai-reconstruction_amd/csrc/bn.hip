@@ -430,7 +430,8 @@ extern "C" int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, con
                                         const void* z, int64_t M, int C, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, void* du, float* partials,
                                         float* sums, float* dgamma, float* dbeta, void* stream) {
-    PAI_CHECK(g1 && z && du && partials && sums && mean && rstd && scale && shift, "pai_bn_bwd_reduce_affine: null pointer");
+    PAI_CHECK(g1 && z && partials && sums && mean && rstd && scale && shift, "pai_bn_bwd_reduce_affine: null pointer");
+    PAI_CHECK(du || !g2, "pai_bn_bwd_reduce_affine: du may be null only without a second gradient (pass 2 rebuilds du from g1)");
     PAI_CHECK(C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "pai_bn_bwd_reduce_affine: C=%d must be 8 * 2^k", C);
     hipStream_t s = (hipStream_t)stream;
     const int rows = pai_bn_bwd_partial_rows(M);
@@ -450,15 +451,28 @@ extern "C" int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, con
     return 0;
 }
 
+// act1 >= 0 (pai_bn_bwd_apply_affine): `du` is the gradient behind the activation and du proper is rebuilt here as pass 1
+// formed it -- g * act1'(z * scale + shift), rounded to the storage type -- so pass 1 need not store it
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const T* du, const T* z, int64_t nvec, int C,
                                                       float inv_m, const float* mean, const float* rstd,
-                                                      const float* gamma, const float* sums, T* dz) {
+                                                      const float* gamma, const float* sums, T* dz, int act1 = -1,
+                                                      const float* scale = nullptr, const float* shift = nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)((i * 8) % C);
         float d[8], zv[8], mu[8], rs[8], gm[8], sb[8], sg[8];
         V8<T>::ld(du + i * 8, d);
         V8<T>::ld(z + i * 8, zv);
+        if (act1 >= 0) {
+            float sc[8], sh[8];
+            V8<float>::ld(scale + c0, sc);
+            V8<float>::ld(shift + c0, sh);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                d[k] = d[k] * act_grad(fmaf(zv[k], sc[k], sh[k]), act1);
+                if (sizeof(T) == 2) d[k] = bf2f(f2bf(d[k]));
+            }
+        }
         V8<float>::ld(mean + c0, mu);
         V8<float>::ld(rstd + c0, rs);
         V8<float>::ld(sums + c0, sb);
@@ -488,6 +502,27 @@ extern "C" int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_
     else
         hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)du,
                            (const bf16_t*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (bf16_t*)dz);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// Pass 2 for a pass 1 that did not store du (pai_bn_bwd_reduce_affine with du = NULL): g1 is the gradient behind the
+// activation, du = g1 * act1'(z * scale + shift) is rebuilt on the fly -- 5 tensor passes per BatchNorm backward instead of 6.
+extern "C" int pai_bn_bwd_apply_affine(int dtype, const void* g1, int act1, const void* z, int64_t M, int C,
+                                       const float* scale, const float* shift, const float* mean, const float* rstd,
+                                       const float* gamma, const float* sums, void* dz, void* stream) {
+    PAI_CHECK(g1 && z && dz && mean && rstd && sums && scale && shift, "pai_bn_bwd_apply_affine: null pointer");
+    PAI_CHECK(C % 8 == 0, "pai_bn_bwd_apply_affine: C=%d must be a multiple of 8", C);
+    PAI_CHECK(act1 >= 0 && act1 <= PAI_ACT_TANH, "pai_bn_bwd_apply_affine: bad activation %d", act1);
+    const int64_t nvec = M * C / 8;
+    const float inv_m = (float)(1.0 / (double)M);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAI_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1,
+                           (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz, act1, scale, shift);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1,
+                           (const bf16_t*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (bf16_t*)dz, act1, scale, shift);
     PAI_LAUNCH_CHECK();
     return 0;
 }

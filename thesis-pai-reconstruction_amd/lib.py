@@ -100,6 +100,7 @@ SIGNATURES = {
     "pai_bn_bwd_reduce": (_I, [_I, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_bwd_reduce_affine": (_I, [_I, _P, _I, _P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_bwd_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "pai_bn_bwd_apply_affine": (_I, [_I, _P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_act_bwd": (_I, [_I, _P, _I, _P, _I, _P, _L, _P, _P]),
     "pai_maxpool2": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "pai_maxpool2_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -163,17 +163,18 @@ class ConvBNAct(torch.autograd.Function):
             x, out, wd, weight, z, mean, rstd, gamma, scale, shift = ctx.saved_tensors[:10]
             if not ctx.training:
                 raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
-            du = torch.empty_like(z)
             part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * Cout, **f32)
             sums = torch.empty(2 * Cout, **f32)
             dgamma, dbeta = torch.zeros(Cout, **f32), torch.zeros(Cout, **f32)
-            if act != ACT_NONE:     # the activation's sign from z * scale + shift: `out` is not read again
-                ops.bn_bwd_reduce_affine(dtype, g, act, None, ACT_NONE, z, M, Cout, scale, shift, mean, rstd, du, part, sums,
-                                         dgamma, dbeta)
-            else:
-                ops.bn_bwd_reduce(dtype, g, act, None, ACT_NONE, None, z, M, Cout, mean, rstd, du, part, sums, dgamma, dbeta)
             dz = torch.empty_like(z)
-            ops.bn_bwd_apply(dtype, du, z, M, Cout, mean, rstd, gamma.detach(), sums, dz)
+            # five tensor passes: pass 1 reads g and z and stores nothing, pass 2 reads them again and writes dz
+            if act != ACT_NONE:     # the activation's sign from z * scale + shift: `out` is not read again, du never stored
+                ops.bn_bwd_reduce_affine(dtype, g, act, None, ACT_NONE, z, M, Cout, scale, shift, mean, rstd, None, part, sums,
+                                         dgamma, dbeta)
+                ops.bn_bwd_apply_affine(dtype, g, act, z, M, Cout, scale, shift, mean, rstd, gamma.detach(), sums, dz)
+            else:                   # du IS g
+                ops.bn_bwd_reduce(dtype, g, act, None, ACT_NONE, None, z, M, Cout, mean, rstd, None, part, sums, dgamma, dbeta)
+                ops.bn_bwd_apply(dtype, g, z, M, Cout, mean, rstd, gamma.detach(), sums, dz)
         k = weight.shape[2]
         dw = torch.empty(Cout * k * k * Cin, **f32)
         # a conv bias in front of a BatchNorm has an identically zero gradient
@@ -350,18 +351,18 @@ class BNAct(torch.autograd.Function):
         N, H, W, C = z.shape
         M, dtype, act = N * H * W, z.dtype, ctx.act
         f32 = dict(dtype=torch.float32, device=z.device)
-        du = torch.empty_like(z)
+        g = g.contiguous()
         part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * C, **f32)
         sums = torch.empty(2 * C, **f32)
         dgamma, dbeta = torch.zeros(C, **f32), torch.zeros(C, **f32)
-        if act != ACT_NONE:
-            ops.bn_bwd_reduce_affine(dtype, g.contiguous(), act, None, ACT_NONE, z, M, C, scale, shift, mean, rstd, du, part,
-                                     sums, dgamma, dbeta)
-        else:
-            ops.bn_bwd_reduce(dtype, g.contiguous(), act, None, ACT_NONE, None, z, M, C, mean, rstd, du, part, sums, dgamma,
-                              dbeta)
         dz = torch.empty_like(z)
-        ops.bn_bwd_apply(dtype, du, z, M, C, mean, rstd, gamma.detach(), sums, dz)
+        if act != ACT_NONE:         # du is never stored (see ConvBNAct.backward)
+            ops.bn_bwd_reduce_affine(dtype, g, act, None, ACT_NONE, z, M, C, scale, shift, mean, rstd, None, part, sums, dgamma,
+                                     dbeta)
+            ops.bn_bwd_apply_affine(dtype, g, act, z, M, C, scale, shift, mean, rstd, gamma.detach(), sums, dz)
+        else:
+            ops.bn_bwd_reduce(dtype, g, act, None, ACT_NONE, None, z, M, C, mean, rstd, None, part, sums, dgamma, dbeta)
+            ops.bn_bwd_apply(dtype, g, z, M, C, mean, rstd, gamma.detach(), sums, dz)
         return dz, dgamma, dbeta, None, None, None, None
 
 

@@ -426,6 +426,13 @@ def bn_bwd_apply(dtype, du, z, M, C_, mean, rstd, gamma, sums, dz):
                                           _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply")
 
 
+def bn_bwd_apply_affine(dtype, g1, act1, z, M, C_, scale, shift, mean, rstd, gamma, sums, dz):
+    """Pass 2 behind ``bn_bwd_reduce_affine(..., du=None, ...)``: du is rebuilt from g1 and z."""
+    with _TimedBytes("bn_passes", 3 * M * C_ * _es(dtype)):      # read g1 and z, write dz
+        L.check(L.load().pai_bn_bwd_apply_affine(code_of(dtype), _p(g1), act1, _p(z), M, C_, _p(scale), _p(shift), _p(mean),
+                                                 _p(rstd), _p(gamma), _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply_affine")
+
+
 def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
     L.check(L.load().pai_act_bwd(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), numel, _p(du), _stream()),
             "pai_act_bwd")
