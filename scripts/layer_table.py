@@ -1,6 +1,6 @@
 """Per-layer table of the convolution-family launches of one training step of a composable family (HIP events around
 every launch): shape, kernel, op, GFLOP, us, TFLOP/s, and the HBM time of the operands at 6 TB/s.
-    python scripts/layer_table.py pix2pix | resnext_unet | trans_unet        (GPU box)"""
+    python scripts/layer_table.py pix2pix | attention_unet | resnext_unet | trans_unet        (GPU box)"""
 import collections
 import os
 import sys
@@ -22,6 +22,8 @@ def main():
     dev = torch.device("cuda:0")
     if fam == "pix2pix":
         model, n, size = pai.Pix2Pix(1, 1, MULTS, 0.0, "gan"), 64, 256
+    elif fam == "attention_unet":
+        model, n, size = pai.AttentionUnetGAN(1, 1, MULTS, 0.0, "gan"), 64, 256
     elif fam == "resnext_unet":
         model, n, size = pai.ResUnetGAN(1, 1, "next", MULTS, 0.0, "gan"), 16, 512
     else:

@@ -1214,6 +1214,9 @@ const char* fwd_mfma_kernel_name(const GG& g) {
 // streams 16-pixel groups: one 16-B load per lane and 32 input channels, COUT/16 * CIN/32 MFMAs, one or two 16-B
 // stores per lane -- the 16 pixels of a group are contiguous, every load / store instruction covers whole rows.
 // Same epilogue options as the tile kernels: bias, BatchNorm partial statistics, the fused producer backward.
+// (Round 3, measured and dropped: the next group's loads issued before the current group's MFMAs + a forward-only
+//  instantiation without the 80 registers of the fused backward (216 -> 148): the gate's input-gradient launch stayed at
+//  164 us and the Attention U-Net step at 8.68-8.74 ms, three interleaved runs.)
 bool pw_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (dtype != PAI_BF16 || g.ntaps != 1 || g.nphase != 1 || g.C2 != 0 || g.D2 != 0) return false;
     if (!((g.C1 == 64 && g.Cout == 32) || (g.C1 == 32 && g.Cout == 64))) return false;
