@@ -47,7 +47,10 @@ const char* pai_last_error(void);
 /* 100: round 1.  110: per-device handles, pai_set_tunable, pai_adam_dev, pai_scalar_take / pai_metrics_take,
  * pai_pack_weights_multi; pai_bn_bwd_reduce accepts du = NULL.  120: weight-gradient workspace
  * (pai_set_wgrad_workspace), pai_build_flags, PAI_TUNABLE_UNSET; pai_conv_desc.pack_flags bits other than 0-1 and
- * .reserved are CHECKED to be zero (descriptors must be zero-initialised; a 100 caller that did so runs unchanged). */
+ * .reserved are CHECKED to be zero (descriptors must be zero-initialised; a 100 caller that did so runs unchanged),
+ * pai_conv_fwd_bn / pai_conv_dgrad_bn_apply / pai_conv_bn_fused, pai_conv_wgrad_overwrite_w, pai_adam_multi_dev.
+ * 121: pai_adam_pack, pai_bn_bwd_apply_affine (pai_bn_bwd_reduce_affine accepts du = NULL); with groups > 1 the weight
+ * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only. */
 int pai_version(void);
 /* bit 0: the library was built with PAI_EXPERIMENTAL=1 and carries the experiment kernels of round 2 (gg_p2.hip,
  * gg_bd.hip + pai_pack_frag, gg_wg2.hip: bit-exact, slower than the defaults, off unless a tunable selects them).
@@ -92,9 +95,10 @@ typedef struct pai_conv_desc {
                              BLOCK-DIAGONAL dense form of a grouped convolution (nn.Conv2d(groups=32) of
                              ResidualBlockNeXt, models/res_unet.py:151-157) whose groups do not straddle 16-channel
                              slices; forward / input gradient may then skip the zero blocks, and the weight gradient
-                             is only defined on the 64-channel diagonal blocks that contain the groups (the entries
-                             of the structurally zero blocks may be left zero).  Otherwise a hint: every kernel
-                             family computes the same result from the dense packs. */
+                             is only defined on the 16-channel diagonal blocks that contain the groups (with the
+                             weight-gradient workspace registered nothing else of dw is written, not even by the
+                             _overwrite forms; without it the dense kernel leaves cross-group products there).
+                             Otherwise a hint: every kernel family computes the same result from the dense packs. */
     int32_t pack_flags;   /* bit 0: the w_fwd buffer holds the forward pack FOLLOWED BY its fragment-major copy
                              (pai_pack_frag(w_fwd, Cout, taps * (C1 + C2), w_fwd + Cout * taps * (C1 + C2) elements));
                              bit 1: the same for w_dgrad (rows = C1 + C2, K = taps * Cout).  With the copy present the

@@ -14,7 +14,7 @@ void pai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pai_last_error(void) { return g_err; }
-extern "C" int pai_version(void) { return 120; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace
+extern "C" int pai_version(void) { return 121; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine
 
 // bit 0: the experiment kernels (gg_p2.hip, gg_bd.hip, gg_wg2.hip; PAI_EXPERIMENTAL=1 at build time) are present
 extern "C" int pai_build_flags(void) {
