@@ -11,7 +11,7 @@ dev = torch.device("cuda:0"); dt = torch.bfloat16
 junk = torch.empty(256 << 20, dtype=torch.float32, device=dev)
 
 
-def timeit(fn, iters=10, cold=True):
+def timeit(fn, iters=10, cold=False):
     for _ in range(2):
         fn()
     ts = []
