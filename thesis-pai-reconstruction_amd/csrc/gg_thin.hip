@@ -676,8 +676,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
     for (int tt = 0; tt < T; ++tt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tt][j] = (f4_t){0.f, 0.f, 0.f, 0.f};
-    const int bc = tid & 127, bh = tid >> 7;
-    float bsum = 0.f;
+    // bias gradient = column sums of the wide tile: one more MFMA per column tile with a fragment whose row 0 is all ones
+    // (D row 0 = sum over the 32 pixels of the K step).  The 32 two-byte LDS reads per thread and chunk that stood here
+    // were more LDS instructions than the rest of the step.
+    f4_t accb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    const unsigned one2 = fr == 0 ? 0x3f803f80u : 0u;      // bf16 1.0 pairs in MFMA row 0
+    const bf8_t ones = __builtin_bit_cast(bf8_t, make_uint4(one2, one2, one2, one2));
 
     for (int ci = 0; ci < chunks_per_block; ++ci) {
         const int p0 = (blockIdx.x * chunks_per_block + ci) * CH;
@@ -738,13 +744,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
 #pragma unroll
             for (int tt = 0; tt < T; ++tt)
                 acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt], bfr, acc[tt][nt], 0, 0, 0);
-        }
-        if (p.dbias && (pair || bc < WC)) {
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const int row = bh * 32 + r;
-                bsum += bf2f(*(const bf16_t*)(smem + tw_off(row, bc >> 3) + (bc & 7) * 2));
-            }
+            if (p.dbias) accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr, accb[nt], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -771,8 +771,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_bloc
             }
         }
     if (p.dbias) {
+        // D row 0 (fq = 0, r = 0) of column tile nt0 + nt: lane fr holds column 16 (nt0 + nt) + fr of this wave's K-step half
         float* red = (float*)smem;
-        red[tid] = bsum;
+        __syncthreads();
+        if (fq == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (nt < ntn) red[ks * 128 + (nt0 + nt) * 16 + fr] = accb[nt][0];
+        }
         __syncthreads();
         if (tid < (pair ? 128 : WC)) {
             if (part0) {
