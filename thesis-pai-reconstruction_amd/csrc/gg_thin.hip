@@ -257,6 +257,8 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
         }
         return __builtin_bit_cast(us8_t, make_uint4(pa.x, pa.y, pb.x, pb.y));
     };
+    const float act_slope = a.eact == PAI_ACT_LRELU ? 0.2f : 1.f;
+    const float act_floor = a.eact == PAI_ACT_RELU ? 0.f : -__builtin_inff();
     const int pstep = gridDim.x * 64;
     int p0 = (blockIdx.x * 4 + wid) * 16;
     us8_t pv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -296,9 +298,10 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
                 unsigned pk[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float v0 = v[2 * e], v1 = v[2 * e + 1];
-                    if (a.eact == PAI_ACT_LRELU) { v0 = fmaxf(v0, 0.2f * v0); v1 = fmaxf(v1, 0.2f * v1); }
-                    else if (a.eact == PAI_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    // branch-free (the activation is a run-time value: as if / else per element this unrolled loop was
+                    // ~50 scalar branches per 16 pixels): LeakyReLU max(v, 0.2 v), ReLU max(v, 0), none max(v, -inf)
+                    const float v0 = fmaxf(fmaxf(v[2 * e], act_slope * v[2 * e]), act_floor);
+                    const float v1 = fmaxf(fmaxf(v[2 * e + 1], act_slope * v[2 * e + 1]), act_floor);
                     pk[e] = pk2bf(v0, v1);
                 }
                 bf16_t* dst = (bf16_t*)a.yact + pix * g.Cout + co;
