@@ -42,7 +42,7 @@ class _Gate:
 
 
 class AttentionUnetEngine(UnetEngine):
-    overwrites_weight_grads = False    # the gate gradients are added into a cleared arena
+    overwrites_weight_grads = True     # dense U-Net weight gradients are written; the gates' small segments are cleared and added to
 
     def __init__(self, unet: nn.Module):
         super().__init__(unet)
@@ -247,7 +247,10 @@ class AttentionUnetEngine(UnetEngine):
         return pred, S
 
     # ---- backward -------------------------------------------------------------------------------
-    def backward(self, S, gpred: torch.Tensor):
+    def backward(self, S, gpred: torch.Tensor, fresh: bool = False):
+        """``fresh``: see UnetEngine.backward -- the 4 x 4 layers' weight gradients are then WRITTEN
+        (pai_conv_wgrad_overwrite_w); the gates' parameters (registered without a conv module: GradArena._small) and the
+        thin head / first layer keep adding into segments begin_backward cleared."""
         P = S["P"]
         L, N, dtype = self.L, P["N"], P["dtype"]
         eh, ew = P["eh"], P["ew"]
@@ -267,8 +270,11 @@ class AttentionUnetEngine(UnetEngine):
                 hook(A, A.end_of(p))
 
         def wgrad(d, x1, x2, dz, conv, with_bias, last=None):
+            cin, cout = conv.weight.shape[1], conv.weight.shape[0]
+            dense = fresh and conv.weight.shape[2] == 4 and min(cin, cout) > 2       # a 4 x 4 U-Net layer, not a gate's 1 x 1
             with torch.cuda.stream(side.fork(d)):
-                ops.conv_wgrad(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
+                (ops.conv_wgrad_overwrite_w if dense else ops.conv_wgrad)(
+                    d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
                 done(last if last is not None else conv.bias)
 
         def gate_backward(j, relu_out):
