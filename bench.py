@@ -142,8 +142,8 @@ def main():
                          "JSON line then says scaling = strong)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE hipGraph launch (graph.GraphedStep; single process only) instead of issuing "
-                         "every launch from Python.  Measured on MI355X (round 2): host time per step 3.96 -> 0.73 ms, but the "
-                         "step itself 7.42 -> 7.72 ms -- the replay overlaps the three streams of the step less well than "
+                         "every launch from Python.  EXPERIMENTAL.  Measured on MI355X (round 3): host time per step 4.4 -> 0.66 ms, but the "
+                         "step itself 6.64 -> 7.02 ms -- the replay overlaps the three streams of the step less well than "
                          "eager submission does, and the run is GPU-bound -- so eager stays the default")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="wire format of the gradient buckets (dist.GradReducer)")
