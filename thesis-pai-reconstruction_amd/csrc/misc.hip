@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void colsum_k(const T* x, int64_t rows, int C,
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    for (int c0 = 0; c0 < C; c0 += 256) {
+    // blockIdx.y strides over the 256-column chunks (the positional-embedding gradient of the TransUNet is 32 rows x 16384
+    // columns: as a loop inside ONE row block that was 64 chunks in sequence, 400 us)
+    for (int c0 = blockIdx.y * 256; c0 < C; c0 += gridDim.y * 256) {
         const int width = min(C - c0, 256);
         // largest power of two <= 256/width row lanes
         int lanes = 1;
@@ -273,12 +275,14 @@ int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hip
     if (blocks < 1) blocks = 1;
     const int64_t rpb = (rows + blocks - 1) / blocks;
     blocks = (rows + rpb - 1) / rpb;
+    int chunks = cdiv(C, 256);
+    if (chunks > 64) chunks = 64;
+    if (blocks * chunks > 4096) chunks = (int)(4096 / blocks) > 0 ? (int)(4096 / blocks) : 1;
+    const dim3 grid((int)blocks, chunks);
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(colsum_k<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, rows, C, rpb,
-                           out);
+        hipLaunchKernelGGL(colsum_k<float>, grid, dim3(256), 0, s, (const float*)x, rows, C, rpb, out);
     else
-        hipLaunchKernelGGL(colsum_k<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, rows, C,
-                           rpb, out);
+        hipLaunchKernelGGL(colsum_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, C, rpb, out);
     PAI_LAUNCH_CHECK();
     return 0;
 }
