@@ -1,4 +1,5 @@
-"""Adam over a set of ViT-sized weights: pai_adam_multi + one pai_pack_weights per tensor against pai_adam_pack_multi.
+"""Adam over a set of ViT-sized weights: pai_adam_multi alone and followed by one pai_pack_weights per tensor (round 3 measured
+a multi-tensor kernel that writes the packs itself at 3.25 ms against the 3.45 ms of the pair -- not kept).
     python scripts/bench_adam.py      (GPU box)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,14 +34,10 @@ def separate():
         ops.pack_weights(bf, p.reshape(-1), s[0], 1, s[1], wf, wd)
 
 
-def fused():
-    ops.adam_pack_multi(P, G, M, V, [(wf, wd, s[0], s[1]) for s, wf, wd in zip(shapes, WF, WD)], 2e-4, 0.5, 0.999, 1e-7, 3)
-
-
 def plain():
     ops.adam_multi(P, G, M, V, 2e-4, 0.5, 0.999, 1e-7, 3)
 
 
-for name, fn, bytes_per in (("adam_multi", plain, 28), ("adam_multi + packs", separate, 36), ("adam_pack_multi", fused, 32)):
+for name, fn, bytes_per in (("adam_multi", plain, 28), ("adam_multi + packs", separate, 36)):
     ms = timed(fn)
     print(f"{name:22s} {ms:7.3f} ms for {n / 1e6:.0f} M parameters: {bytes_per * n / ms / 1e9:5.2f} TB/s at {bytes_per} B / parameter")
