@@ -38,6 +38,18 @@ def to_nhwc(x: torch.Tensor, dtype) -> torch.Tensor:
     return out
 
 
+_GROUP_IDX = {}
+
+
+def _group_idx(groups: int, device) -> torch.Tensor:
+    """arange(groups) on the device, made once (the grouped layers index their diagonal blocks with it in every forward and
+    backward pass: two 3-us launches each time otherwise)."""
+    key = (groups, str(device))
+    if key not in _GROUP_IDX:
+        _GROUP_IDX[key] = torch.arange(groups, device=device)
+    return _GROUP_IDX[key]
+
+
 def _dense_fwd_pack(weight: torch.Tensor, groups: int) -> torch.Tensor:
     """torch Conv2d weight [Cout, Cin/groups, kh, kw] -> fp32 fwd pack [Cout][kh][kw][Cin] (block-diagonal for
     groups > 1)."""
@@ -48,7 +60,7 @@ def _dense_fwd_pack(weight: torch.Tensor, groups: int) -> torch.Tensor:
     cog = cout // groups
     dense = torch.zeros(cout, kh, kw, cig * groups, dtype=torch.float32, device=weight.device)
     dv = dense.view(groups, cog, kh, kw, groups, cig)
-    idx = torch.arange(groups, device=weight.device)
+    idx = _group_idx(groups, weight.device)
     dv[idx, :, :, :, idx, :] = w.reshape(groups, cog, kh, kw, cig)
     return dense
 
@@ -58,7 +70,7 @@ def _grad_from_fwd_pack(dw: torch.Tensor, weight: torch.Tensor, groups: int) -> 
     d = dw.view(cout, kh, kw, cig * groups)
     if groups > 1:
         cog = cout // groups
-        idx = torch.arange(groups, device=dw.device)
+        idx = _group_idx(groups, dw.device)
         d = d.view(groups, cog, kh, kw, groups, cig)[idx, :, :, :, idx, :].reshape(cout, kh, kw, cig)
     return d.permute(0, 3, 1, 2).contiguous()
 
