@@ -429,3 +429,79 @@ def test_thin_layers_bit_exact_at_config2_shapes(pai, case):
     torch.cuda.synchronize()
     assert torch.equal(unpack_fwd(dw, Cout, Cin, bool(tr)), dw_ref), (name, "wgrad")
     assert torch.equal(db.cpu(), db_ref), (name, "dbias")
+
+
+# stride-1 "same" convolutions of the residual / Trans U-Nets at their configs[3] / configs[4] layer shapes (batch reduced
+# where the tensors would not fit a test): (k, N, H, W, C1, C2, Cout, kernels that may serve forward / input gradient / weight
+# gradient -- the family is asserted, the split choice is the library's)
+TILE = ("gg_fwd_mfma_k<128, 128, false, false, 64>", "gg_fwd_mfma_k<128, 64, false, false, 64>",
+        "gg_fwd_mfma_k<128, 128, true, true, 64>", "gg_fwd_mfma_k<128, 64, true, false, 64>")
+WG = ("gg_wgrad_mfma_k<128>", "gg_wgrad_mfma_k<64>")
+SAME_CASES = [
+    ("res_1x1_64_128", 1, 4, 256, 256, 64, 0, 128, TILE, TILE, WG),           # ResidualBlockNeXt: 1 x 1 up / down projections
+    ("res_1x1_128_64", 1, 4, 256, 256, 128, 0, 64, TILE, TILE, WG),
+    ("res_1x1_cat", 1, 4, 128, 128, 64, 64, 128, TILE, TILE, WG),             # decoder: two sources read as one concatenation
+    ("tr_3x3_cat", 3, 8, 128, 128, 64, 64, 64, TILE, TILE, WG),               # TransUNet decoder block, configs[4] width
+    ("tr_3x3_128", 3, 8, 32, 32, 128, 128, 128, TILE, TILE, WG),
+    ("tr_3x3_16", 3, 4, 256, 256, 16, 0, 16, ("small_mfma_bf16",), ("small_mfma_bf16",), WG),      # 16-channel encoder block
+    ("in_conv_3x3", 3, 4, 256, 256, 1, 0, 64, ("thin_mfma_bf16",), None, ("thin_mfma_bf16",)),   # 1 -> 64 in_conv (no dgrad)
+    ("out_conv_3x3", 3, 4, 256, 256, 64, 0, 1, ("thin_mfma_bf16",), ("thin_mfma_bf16",), ("thin_mfma_bf16",)),
+]
+
+
+@pytest.mark.parametrize("case", SAME_CASES, ids=[c[0] for c in SAME_CASES])
+def test_same_convolutions_of_the_other_families_bit_exact(pai, case):
+    """nn.Conv2d(k = 1 | 3, padding = k // 2) of reference models/res_unet.py:59-62,86-95,265,308 and models/trans_unet.py:66,98,
+    203-227 on the kernels the composable networks run (tile, small-channel and thin families): forward with bias, both
+    input gradients and the weight / bias gradient against PyTorch-CPU on small-integer data, bit for bit."""
+    from thesis_pai_reconstruction_amd import ops
+    name, k, N, H, W, C1, C2, K, kf, kd, kw = case
+    dtype = torch.bfloat16
+    Cin = C1 + C2
+    x1 = _ints((N, C1, H, W), 1).requires_grad_(True)
+    x2 = _ints((N, C2, H, W), 2).requires_grad_(True) if C2 else None
+    w = _ints((K, Cin, k, k), 3).requires_grad_(True)
+    b = _ints((K,), 4, -8, 8).requires_grad_(True)
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    y = F.conv2d(xin, w, b, padding=k // 2)
+    dy = _ints(tuple(y.shape), 5)
+    y.backward(dy)
+    d = ops.make_desc(dtype, 0, N, H, W, C1, C2, K, 1, 0, 0, ops.ACT_NONE, kernel=k)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
+    ops.ensure_wgrad_workspace([d], dev())
+    for op, want in ((0, kf), (1, kd), (2, kw)):
+        if want is not None:
+            _named(ops, d, op, want)
+    wm = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())
+    wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    ops.pack_weights(dtype, wm, K, k * k, Cin, wf, wd)
+    X1, DY = nhwc(x1.detach(), dtype), nhwc(dy, dtype)
+    X2 = nhwc(x2.detach(), dtype) if C2 else None
+    if K > 2:
+        yo = torch.full((N * H * W * K,), 7.0, dtype=dtype, device=dev())
+        ops.conv_fwd(d, X1, X2, wf, b.detach().to(dev()), y_raw=yo)
+        got_y = from_nhwc(yo, N, H, W, K)
+    else:       # 1-channel outputs leave in fp32 (the head of the network)
+        yo = torch.full((N * H * W * K,), 7.0, dtype=torch.float32, device=dev())
+        ops.conv_fwd(d, X1, X2, wf, b.detach().to(dev()), y_f32=yo)
+        got_y = from_nhwc(yo, N, H, W, K)
+    torch.cuda.synchronize()
+    want_y = y.detach().to(dtype).float() if K > 2 else y.detach()
+    assert torch.equal(got_y, want_y), name
+    if kd is not None:
+        dx1 = torch.full((N * H * W * C1,), 7.0, dtype=dtype, device=dev())
+        dx2 = torch.full((N * H * W * C2,), 7.0, dtype=dtype, device=dev()) if C2 else None
+        ops.conv_dgrad(d, DY, wd, dx1, dx2)
+        torch.cuda.synchronize()
+        assert torch.equal(from_nhwc(dx1, N, H, W, C1), x1.grad.to(dtype).float()), name
+        if C2:
+            assert torch.equal(from_nhwc(dx2, N, H, W, C2), x2.grad.to(dtype).float()), name
+    dw = torch.full((wm.numel(),), float("nan"), dtype=torch.float32, device=dev())
+    db = torch.full((K,), float("nan"), dtype=torch.float32, device=dev())
+    ops.conv_wgrad_overwrite(d, X1, X2, DY, dw, db)
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu().view(K, k, k, Cin).permute(0, 3, 1, 2), w.grad), name
+    assert torch.equal(db.cpu(), b.grad), name
+
