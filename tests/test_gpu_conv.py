@@ -368,7 +368,8 @@ def test_grouped_conv3x3(pai, dtype, C, groups, N, H, W):
 
 @pytest.mark.parametrize("N,H,W", [(2, 8, 32), (3, 12, 64), (9, 128, 64)])
 def test_grouped_conv3x3_weight_gradient_exact(pai, N, H, W):
-    """The weight gradient of the grouped 3 x 3 convolution on grouped3_wgrad_k (diagonal 16-channel blocks only, partial
+    """Forward (with bias and BatchNorm partial statistics) and input gradient on grouped3_k, and the weight gradient of the
+    grouped 3 x 3 convolution on grouped3_wgrad_k (diagonal 16-channel blocks only, partial
     blocks of the persistent workgroups summed in a fixed order): on small-integer data every sum is exact in fp32, so the
     group blocks must equal PyTorch-CPU's F.conv2d(groups=32) weight gradient BIT FOR BIT -- accumulating into a non-zero
     dW and overwriting a dirty one; (9, 128, 64): 576 tiles on 512 workgroups, some take two.  Without the weight-gradient
@@ -386,6 +387,26 @@ def test_grouped_conv3x3_weight_gradient_exact(pai, N, H, W):
     assert ops.conv_wgrad_workspace_bytes(d) > 0
     assert ops.conv_kernel_id(d, 2) == 6 and ops.conv_kernel_name(d, 2) == "grouped3_wgrad_k"
     X, DY = nhwc(x.detach(), dtype), nhwc(dy, dtype)
+    # forward and input gradient on grouped3_k (wave = slice, filter fragments resident), bit for bit as well
+    if H % 8 == 0 and W % 16 == 0:
+        assert ops.conv_kernel_id(d, 0) == 6 and ops.conv_kernel_id(d, 1) == 6
+    wm = nnops._dense_fwd_pack(w.detach().to(dev()), groups)
+    wf = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    wd = torch.empty(wm.numel(), dtype=dtype, device=dev())
+    ops.pack_weights(dtype, wm, C, 9, C, wf, wd)
+    bias = torch.randint(-8, 9, (C,), generator=g).float()
+    yo = torch.full((N * H * W * C,), 7.0, dtype=dtype, device=dev())
+    stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * C, dtype=torch.float32, device=dev())
+    ops.conv_fwd(d, X, None, wf, bias.to(dev()), y_raw=yo, stats=stats)
+    dxo = torch.full((N * H * W * C,), 7.0, dtype=dtype, device=dev())
+    ops.conv_dgrad(d, DY, wd, dxo, None)
+    torch.cuda.synchronize()
+    y_ref = F.conv2d(x.detach(), w.detach(), bias, padding=1, groups=groups)
+    assert torch.equal(from_nhwc(yo, N, H, W, C), y_ref.to(dtype).float())
+    rows = ops.conv_fwd_stats_rows(d)
+    st = stats[:rows * 2 * C].view(rows, 2, C).double().sum(0).cpu()
+    assert torch.equal(st[0], y_ref.double().sum((0, 2, 3))) and torch.equal(st[1], (y_ref.double() ** 2).sum((0, 2, 3)))
+    assert torch.equal(from_nhwc(dxo, N, H, W, C), x.grad.to(dtype).float())
     base = torch.randint(-3, 4, (C * 9 * C,), generator=g).float().to(dev())
     dw = base.clone()
     ops.conv_wgrad(d, X, None, DY, dw, None)                    # dW += ...
