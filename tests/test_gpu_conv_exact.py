@@ -444,6 +444,8 @@ SAME_CASES = [
     ("tr_3x3_cat", 3, 8, 128, 128, 64, 64, 64, TILE, TILE, WG),               # TransUNet decoder block, configs[4] width
     ("tr_3x3_128", 3, 8, 32, 32, 128, 128, 128, TILE, TILE, WG),
     ("tr_3x3_16", 3, 4, 256, 256, 16, 0, 16, ("small_mfma_bf16",), ("small_mfma_bf16",), WG),      # 16-channel encoder block
+    ("gate_1x1_64_32", 1, 8, 128, 128, 64, 0, 32, ("thin_mfma_bf16",), ("thin_mfma_bf16",), WG),   # AttentionBlock W_x / W_g (pw_k)
+    ("gate_1x1_128_64", 1, 8, 64, 64, 128, 0, 64, TILE, TILE, WG),
     ("in_conv_3x3", 3, 4, 256, 256, 1, 0, 64, ("thin_mfma_bf16",), None, ("thin_mfma_bf16",)),   # 1 -> 64 in_conv (no dgrad)
     ("out_conv_3x3", 3, 4, 256, 256, 64, 0, 1, ("thin_mfma_bf16",), ("thin_mfma_bf16",), ("thin_mfma_bf16",)),
 ]
