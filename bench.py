@@ -32,7 +32,6 @@ TRANS_MULTS = (1, 2, 2, 4, 4)       # TransUnetGAN's class default; the CLI defa
 SIZE = 256
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0          # HBM3E, same guide
-PEAK_HBM_GBS = 8000.0
 # conv MACs per image: generator G, discriminator D, first layers G1, D1
 G_MAC, D_MAC, G1_MAC, D1_MAC = 5_947_523_072, 1_646_010_368, 16_777_216, 33_554_432
 
@@ -72,11 +71,21 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(attention=False, b4_steps=20, b64_steps=3):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(attention=False, b4=(3, 20), b64=(3, 5)):
     """The oracle's CPU restatement of the same GAN step (fp32, the ATen kernels the reference dispatches to) on this
-    box's host cores, at BOTH batch sizes BASELINE.md section 4 asks for: batch 4 (BASELINE configs[0], the headline
-    `value`: 1 warm-up + 20 timed steps) and batch 64 (the GPU workload's batch: 1 warm-up + 3 timed steps of ~7 s each,
-    bounded so that the default run still ends within minutes)."""
+    box's host cores, at BOTH batch sizes BASELINE.md section 4 asks for, each with >= 3 warm-up and >= 5 timed steps:
+    batch 4 (BASELINE configs[0], the headline `value`: 3 + 20 steps, ~10 s) and batch 64 (the GPU workload's batch:
+    3 + 5 steps of ~8 s each), bounded so that the default run still ends within minutes."""
     import oracle
     torch.set_num_threads(host_cores())
     make = oracle.make_attention_unet_state if attention else oracle.make_unet_state
@@ -95,11 +104,12 @@ def cpu_baseline(attention=False, b4_steps=20, b64_steps=3):
             oracle.gan_training_step(g, d, og, od, x, t)
         return batch * steps / (time.perf_counter() - t0)
 
-    v4 = run(4, 1, b4_steps)
-    v64 = run(64, 1, b64_steps) if b64_steps > 0 else None
+    v4 = run(4, *b4)
+    v64 = run(64, *b64) if b64 and b64[1] > 0 else None
     return {"value": round(v4, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{b4_steps} fp32 GAN steps at batch 4 (BASELINE configs[0]), 1 warm-up, oracle/step_ref.py on "
-                      f"torch-CPU; value_b64: {b64_steps} timed steps at batch 64 after 1 warm-up step, same cores",
+            "cpu_model": cpu_model(), "physical_cores_visible": os.cpu_count(),
+            "sample": f"{b4[1]} fp32 GAN steps at batch 4 (BASELINE configs[0]) after {b4[0]} warm-up steps, oracle/step_ref.py "
+                      f"on torch-CPU; value_b64: {b64[1]} timed steps at batch 64 after {b64[0]} warm-up steps, same cores",
             "value_b64": None if v64 is None else round(v64, 3)}
 
 
@@ -140,6 +150,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling: total images per step, split evenly over the ranks (overrides --batch; the "
                          "JSON line then says scaling = strong)")
+    ap.add_argument("--launch", default="plan", choices=["plan", "eager"],
+                    help="plan (default): the step is recorded once into a C-side launch plan (plan.PlannedStep -> "
+                         "pai_plan_run) and replayed with ONE C call per step -- same kernels, arguments, streams and "
+                         "order as the eager step; eager: every launch issued from Python (PAI_PLAN=0 does the same)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE hipGraph launch (graph.GraphedStep; single process only) instead of issuing "
                          "every launch from Python.  EXPERIMENTAL.  Measured on MI355X (round 3): host time per step 4.4 -> 0.66 ms, but the "
@@ -225,11 +239,17 @@ def main():
     # --graph: one hipGraph launch per step (the same kernels on the same three streams, captured after three eager
     # steps); with more than one rank the bucketed RCCL exchange is not captured and the step is issued from Python.
     from thesis_pai_reconstruction_amd.graph import GraphedStep
+    from thesis_pai_reconstruction_amd import plan as pplan
     graphed = GraphedStep(model, warmup=3) if (world == 1 and args.graph) else None
+    planned = None
+    if graphed is None and args.launch == "plan" and pplan.enabled_by_default():
+        planned = pplan.PlannedStep(model, warmup=3)
 
     def run_step(b, i):
         if graphed is not None:
             graphed(b, i)
+        elif planned is not None:
+            planned(b, i)
         else:
             model.training_step(b, i)
 
@@ -397,10 +417,14 @@ def main():
                    "channel_mults": list(mults), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}",
                    "grad_bucket_dtype": args.grad_dtype,
-                   **({"backend": torch.distributed.get_backend(), "gpus_visible": torch.cuda.device_count()} if world > 1 else {})},
+                   **({"backend": torch.distributed.get_backend(), "gpus_visible": torch.cuda.device_count(),
+                       "rccl_ranks": reducer.rccl_ranks() if reducer is not None else 0} if world > 1 else {})},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "launch_mode": ("hipGraph replay (one launch per step)" if graphed is not None and graphed.graph is not None else
-                        "eager" + (f" ({graphed.disabled})" if graphed is not None and graphed.disabled else "")),
+                        "launch plan (pai_plan_run: one C call per step)" if planned is not None and planned.replays > 0 else
+                        "eager" + (f" ({graphed.disabled})" if graphed is not None and graphed.disabled else "")
+                        + (f" (plan refused: {planned.disabled})" if planned is not None and planned.disabled else "")),
+        "launch_plan": planned.describe() if planned is not None else None,
         "clock_ramp_steps": prewarm_steps,
         "step_conv_gflop_per_image": None if gflop != gflop else round(gflop, 2),
         "step_conv_gflop_source": gflop_src,

@@ -50,7 +50,8 @@ const char* pai_last_error(void);
  * .reserved are CHECKED to be zero (descriptors must be zero-initialised; a 100 caller that did so runs unchanged),
  * pai_conv_fwd_bn / pai_conv_dgrad_bn_apply / pai_conv_bn_fused, pai_conv_wgrad_overwrite_w, pai_adam_multi_dev.
  * 121: pai_adam_pack, pai_bn_bwd_apply_affine (pai_bn_bwd_reduce_affine accepts du = NULL); with groups > 1 the weight
- * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only. */
+ * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only.  130: launch plans (pai_plan_*,
+ * pai_stream_wait), pai_zero_multi. */
 int pai_version(void);
 /* bit 0: the library was built with PAI_EXPERIMENTAL=1 and carries the experiment kernels of round 2 (gg_p2.hip,
  * gg_bd.hip + pai_pack_frag, gg_wg2.hip: bit-exact, slower than the defaults, off unless a tunable selects them).
@@ -548,6 +549,46 @@ int pai_comm_unique_id(void* id_out_host);
 int pai_comm_init(const void* id_host, int rank, int world, void** comm_out);
 int pai_allreduce(void* comm, void* ptr, int64_t count, int dtype, void* stream);
 int pai_comm_destroy(void* comm);
+
+/* ---------------------------------------------------------------------------
+ * Launch plans: the training step as ONE host call.
+ * The reference's step is a single Python call (models/wrapper.py:117-162: UnetWrapper.training_step); issued launch
+ * by launch through this ABI it is ~205 calls and 5.5 ms of host time per 6.4 ms step.  A plan records the launches the
+ * library makes between pai_plan_begin and pai_plan_end -- kernel, grid, LDS size, stream and the argument block BY
+ * VALUE -- while they execute normally, from every host thread of the process (autograd runs the backward pass on a
+ * thread of its own); pai_plan_run re-issues the sequence on the same streams in the same order.
+ *   - the caller owns validity: every device pointer a recorded call was given must still be alive and mean the same
+ *     thing at replay (activations, packs, arenas, the handle's workspaces).  Re-record after any buffer changes.
+ *   - cross-stream ordering must go through pai_stream_wait to be part of the plan (an event recorded on
+ *     `signalling_stream`, waited for by `waiting_stream`; outside a recording it is the same edge, eagerly).
+ *   - pai_adam / pai_adam_pack / pai_adam_multi take the optimizer step count t by value: a recorded launch keeps t0 and
+ *     replays with t0 + step_delta (the number of optimizer steps taken since the recording), bit-identical to the
+ *     eager launch of that step.  Everything else step-dependent already lives on the device.
+ *   - pai_allreduce calls are recorded too (the data-parallel step as one plan per rank).
+ *   - one plan may be recorded at a time per process; replay is not re-entrant per plan.
+ * pai_plan_info: launches = kernel + memset + collective nodes, waits = stream-wait edges, streams = distinct streams.
+ * ------------------------------------------------------------------------- */
+typedef struct pai_plan_s* pai_plan_t;
+int pai_plan_create(pai_plan_t* out);
+int pai_plan_destroy(pai_plan_t plan);
+int pai_plan_begin(pai_plan_t plan);
+int pai_plan_end(pai_plan_t plan);
+int pai_plan_run(pai_plan_t plan, int64_t step_delta);
+int pai_plan_info(pai_plan_t plan, int* launches, int* waits, int* streams, int64_t* runs);
+int pai_stream_wait(void* waiting_stream, void* signalling_stream);
+/* The same edge in two halves, for a wait that is issued later than the point it refers to (the thin weight gradients
+ * of one backward pass share scratch: the second waits for the mark behind the first, not for what the first one's
+ * stream was given since).  Caller-owned events (no timing); a recorded plan keeps the handle, so the event must outlive
+ * every plan that was recorded while it was in use. */
+typedef struct pai_event_s* pai_event_t;
+int pai_event_create(pai_event_t* out);
+int pai_event_destroy(pai_event_t ev);
+int pai_event_record(pai_event_t ev, void* stream);
+int pai_stream_wait_event(void* waiting_stream, pai_event_t ev);
+/* p[i][0 .. numel[i]) = 0 for `count` fp32 buffers in one launch per 96 buffers (host pointer tables): the accumulated
+ * segments of a gradient arena in front of a backward pass (replaces torch._foreach_zero_, so that the clear is a node
+ * of the plan like everything else). */
+int pai_zero_multi(int count, void* const* ptrs, const int64_t* numels, void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,9 @@ class AttentionUnetEngine(UnetEngine):
         self.gates = [_Gate(b, self.weights_generation) for b in unet.attention_blocks]
         assert len(self.gates) == self.L - 1
 
+    def all_packs(self):
+        return self.enc_packs + self.dec_packs + [pk for g in self.gates for pk in (g.pack_i, g.pack_s)]
+
     # gate of decoder j (j >= 1) and the encoder level whose output it gates
     def _gate(self, j):
         return self.gates[j - 1]

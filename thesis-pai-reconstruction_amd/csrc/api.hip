@@ -14,7 +14,7 @@ void pai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pai_last_error(void) { return g_err; }
-extern "C" int pai_version(void) { return 121; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine
+extern "C" int pai_version(void) { return 130; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine; 130: launch plans
 
 // bit 0: the experiment kernels (gg_p2.hip, gg_bd.hip, gg_wg2.hip; PAI_EXPERIMENTAL=1 at build time) are present
 extern "C" int pai_build_flags(void) {
@@ -737,10 +737,10 @@ static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x
             a.overwrite = 1;       // every element has exactly one writer: plain stores, nothing to clear
             a.overwrite_bias = overwrite == 1;
         } else {                   // the accumulating kernels: clear first
-            hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * g.wtaps * g.Cin * sizeof(float), s);
+            hipError_t e = pai::memset_async(dw, 0, (size_t)g.Cout * g.wtaps * g.Cin * sizeof(float), s);
             PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_overwrite: hipMemsetAsync: %s", hipGetErrorString(e));
             if (dbias && overwrite == 1) {
-                e = hipMemsetAsync(dbias, 0, (size_t)g.Cout * sizeof(float), s);
+                e = pai::memset_async(dbias, 0, (size_t)g.Cout * sizeof(float), s);
                 PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_overwrite: hipMemsetAsync: %s", hipGetErrorString(e));
             }
         }

@@ -135,7 +135,7 @@ extern "C" int pai_bn_finalize(const float* stats, int rows, int C, int64_t coun
     hipStream_t s = (hipStream_t)stream;
     const double* stage = nullptr;
     if (rows > 16) {
-        hipLaunchKernelGGL(bn_finalize_wide_k, dim3(cdiv(C, 8)), dim3(1024), 0, s, stats, rows, C, (double)count, gamma,
+        PAI_LAUNCH(bn_finalize_wide_k, dim3(cdiv(C, 8)), dim3(1024), 0, s, stats, rows, C, (double)count, gamma,
                            beta, eps, momentum, n_updates, running_mean, running_var, num_batches_tracked, mean, rstd,
                            scale, shift);
         PAI_LAUNCH_CHECK();
@@ -145,12 +145,12 @@ extern "C" int pai_bn_finalize(const float* stats, int rows, int C, int64_t coun
         // scratch = the 2*STAGE_ROWS float rows that follow the partials (pai_bn_stats_buffer_rows)
         double* scratch = (double*)(stats + (size_t)rows * 2 * C);
         const int per = cdiv(rows, STAGE_ROWS);
-        hipLaunchKernelGGL(bn_stats_stage1_k, dim3(STAGE_ROWS, cdiv(2 * C, 256)), dim3(256), 0, s, stats,
+        PAI_LAUNCH(bn_stats_stage1_k, dim3(STAGE_ROWS, cdiv(2 * C, 256)), dim3(256), 0, s, stats,
                            rows, 2 * C, per, scratch);
         PAI_LAUNCH_CHECK();
         stage = scratch;
     }
-    hipLaunchKernelGGL(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, s, stats, stage, rows, C,
+    PAI_LAUNCH(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, s, stats, stage, rows, C,
                        (double)count, gamma, beta, eps, momentum, n_updates, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift);
     PAI_LAUNCH_CHECK();
@@ -171,7 +171,7 @@ extern "C" int pai_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
                                   const float* running_var, float eps, float* scale, float* shift,
                                   void* stream) {
     PAI_CHECK(running_mean && running_var && scale && shift, "pai_bn_eval_coeffs: null pointer");
-    hipLaunchKernelGGL(bn_eval_coeffs_k, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma,
+    PAI_LAUNCH(bn_eval_coeffs_k, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma,
                        beta, running_mean, running_var, eps, scale, shift);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -209,10 +209,10 @@ extern "C" int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const fl
     const int64_t nvec = M * C / 8;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)z, nvec, C,
+        PAI_LAUNCH(bn_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)z, nvec, C,
                            scale, shift, act, (float*)out);
     else
-        hipLaunchKernelGGL(bn_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)z, nvec,
+        PAI_LAUNCH(bn_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)z, nvec,
                            C, scale, shift, act, (bf16_t*)out);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -379,11 +379,11 @@ int bn_bwd_reduce_affine(int dtype, void* g1_du, int act1, const void* g2, int a
     // without an affine map the stored tensor itself carries the sign
     const void* a = scale ? nullptr : z;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1_du, act1,
+        PAI_LAUNCH(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1_du, act1,
                            (const float*)g2, act2, (const float*)a, (const float*)z, M, C, rpb, mean, rstd,
                            (float*)g1_du, partials, scale, shift);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1_du, act1,
+        PAI_LAUNCH(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1_du, act1,
                            (const bf16_t*)g2, act2, (const bf16_t*)a, (const bf16_t*)z, M, C, rpb, mean, rstd,
                            (bf16_t*)g1_du, partials, scale, shift);
     PAI_LAUNCH_CHECK();
@@ -393,7 +393,7 @@ int bn_bwd_reduce_affine(int dtype, void* g1_du, int act1, const void* g2, int a
 extern "C" int pai_bn_bwd_finalize(const float* partials, int rows, int C, float* sums, float* dgamma,
                                    float* dbeta, void* stream) {
     PAI_CHECK(partials && sums && rows > 0 && C > 0, "pai_bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, (hipStream_t)stream, partials, rows, C,
+    PAI_LAUNCH(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, (hipStream_t)stream, partials, rows, C,
                        sums, dgamma, dbeta);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -411,15 +411,15 @@ extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void
     const int rows = pai_bn_bwd_partial_rows(M);
     const int64_t rpb = (M + rows - 1) / rows;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
+        PAI_LAUNCH(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
                            (const float*)g2, act2, (const float*)a, (const float*)z, M, C, rpb, mean, rstd,
-                           (float*)du, partials);
+                           (float*)du, partials, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1, act1,
+        PAI_LAUNCH(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1, act1,
                            (const bf16_t*)g2, act2, (const bf16_t*)a, (const bf16_t*)z, M, C, rpb, mean, rstd,
-                           (bf16_t*)du, partials);
+                           (bf16_t*)du, partials, nullptr, nullptr);
     PAI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, s, partials, rows, C, sums, dgamma,
+    PAI_LAUNCH(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, s, partials, rows, C, sums, dgamma,
                        dbeta);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -439,15 +439,15 @@ extern "C" int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, con
     const int rows = pai_bn_bwd_partial_rows(M);
     const int64_t rpb = (M + rows - 1) / rows;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
+        PAI_LAUNCH(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
                            (const float*)g2, act2, (const float*)nullptr, (const float*)z, M, C, rpb, mean, rstd,
                            (float*)du, partials, scale, shift);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1, act1,
+        PAI_LAUNCH(bn_bwd_reduce_k<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)g1, act1,
                            (const bf16_t*)g2, act2, (const bf16_t*)nullptr, (const bf16_t*)z, M, C, rpb, mean, rstd,
                            (bf16_t*)du, partials, scale, shift);
     PAI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, s, partials, rows, C, sums, dgamma,
+    PAI_LAUNCH(bn_bwd_finalize_k, dim3(cdiv(C, 8)), dim3(8 * FIN_LANES), 0, s, partials, rows, C, sums, dgamma,
                        dbeta);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -499,11 +499,11 @@ extern "C" int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_
     const float inv_m = (float)(1.0 / (double)M);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)du,
-                           (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz);
+        PAI_LAUNCH(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)du,
+                           (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz, -1, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)du,
-                           (const bf16_t*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (bf16_t*)dz);
+        PAI_LAUNCH(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)du,
+                           (const bf16_t*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (bf16_t*)dz, -1, nullptr, nullptr);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -520,10 +520,10 @@ extern "C" int pai_bn_bwd_apply_affine(int dtype, const void* g1, int act1, cons
     const float inv_m = (float)(1.0 / (double)M);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1,
+        PAI_LAUNCH(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1,
                            (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz, act1, scale, shift);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1,
+        PAI_LAUNCH(bn_bwd_apply_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1,
                            (const bf16_t*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (bf16_t*)dz, act1, scale, shift);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -556,10 +556,10 @@ extern "C" int pai_act_bwd(int dtype, const void* g1, int act1, const void* g2, 
     const int64_t nvec = numel / 8;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(act_bwd_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1, act1,
+        PAI_LAUNCH(act_bwd_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1, act1,
                            (const float*)g2, act2, (const float*)a, nvec, (float*)du);
     else
-        hipLaunchKernelGGL(act_bwd_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1, act1,
+        PAI_LAUNCH(act_bwd_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)g1, act1,
                            (const bf16_t*)g2, act2, (const bf16_t*)a, nvec, (bf16_t*)du);
     PAI_LAUNCH_CHECK();
     return 0;

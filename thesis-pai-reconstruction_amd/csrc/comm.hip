@@ -46,6 +46,17 @@ int rccl_load() {
 }
 
 const char* rccl_err(int rc) { return g_rccl.errstr ? g_rccl.errstr(rc) : "?"; }
+
+// a recorded pai_allreduce (launch plans, plan.h): the same in-place collective on the same stream at every replay
+struct AllReduceOp final : pai::PlanOp {
+    void* comm; void* ptr; size_t count; int nccl_dtype; hipStream_t st;
+    AllReduceOp(void* c, void* p, size_t n, int dt, hipStream_t s) : comm(c), ptr(p), count(n), nccl_dtype(dt), st(s) {}
+    hipError_t run(int64_t) override {
+        return g_rccl.allreduce(ptr, ptr, count, nccl_dtype, 0, comm, st) == 0 ? hipSuccess : hipErrorUnknown;
+    }
+    int kind() const override { return 4; }
+    hipStream_t stream() const override { return st; }
+};
 }  // namespace
 
 extern "C" int pai_comm_unique_id(void* id_out) {
@@ -74,6 +85,7 @@ extern "C" int pai_allreduce(void* comm, void* ptr, int64_t count, int dtype, vo
     PAI_CHECK(g_rccl.handle != nullptr, "pai_allreduce: no communicator was created in this process");
     if (count == 0) return 0;
     // ncclFloat32 = 7, ncclBfloat16 = 9, ncclSum = 0 (rccl.h); in place
+    if (pai::recording()) pai::plan_push(new AllReduceOp(comm, ptr, (size_t)count, dtype == PAI_F32 ? 7 : 9, (hipStream_t)stream));
     const int rc = g_rccl.allreduce(ptr, ptr, (size_t)count, dtype == PAI_F32 ? 7 : 9, 0, comm, (hipStream_t)stream);
     PAI_CHECK(rc == 0, "ncclAllReduce: %s", rccl_err(rc));
     return 0;

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/pai_hip.h"
+#include "plan.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 

@@ -237,10 +237,10 @@ extern "C" int pai_gate_hidden(int dtype, const void* ig, const void* sg, int64_
     const int64_t rpb = (M + blocks - 1) / blocks;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gate_hidden_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)ig, (const float*)sg, M, K,
+        PAI_LAUNCH(gate_hidden_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)ig, (const float*)sg, M, K,
                            scale_i, shift_i, scale_s, shift_s, w_a, b_a, (float*)h, logit, partials, rpb);
     else
-        hipLaunchKernelGGL(gate_hidden_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)ig, (const bf16_t*)sg, M,
+        PAI_LAUNCH(gate_hidden_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)ig, (const bf16_t*)sg, M,
                            K, scale_i, shift_i, scale_s, shift_s, w_a, b_a, (bf16_t*)h, logit, partials, rpb);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -254,10 +254,10 @@ extern "C" int pai_gate_apply(int dtype, const void* x, const float* logit, int6
     if (b > 8192) b = 8192;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gate_apply_k<float>, dim3((int)b), dim3(256), 0, s, (const float*)x, logit, M, C, scale_a,
+        PAI_LAUNCH(gate_apply_k<float>, dim3((int)b), dim3(256), 0, s, (const float*)x, logit, M, C, scale_a,
                            shift_a, (float*)out, att);
     else
-        hipLaunchKernelGGL(gate_apply_k<bf16_t>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)x, logit, M, C, scale_a,
+        PAI_LAUNCH(gate_apply_k<bf16_t>, dim3((int)b), dim3(256), 0, s, (const bf16_t*)x, logit, M, C, scale_a,
                            shift_a, (bf16_t*)out, att);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -272,10 +272,10 @@ extern "C" int pai_gate_apply_bwd(int dtype, const void* dout, const void* x, co
     const int64_t rpb = (M + blocks - 1) / blocks;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gate_apply_bwd_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)dout, (const float*)x,
+        PAI_LAUNCH(gate_apply_bwd_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)dout, (const float*)x,
                            att, logit, M, C, mean_a, rstd_a, (float*)dx_skip, dl, partials, rpb, relu_out);
     else
-        hipLaunchKernelGGL(gate_apply_bwd_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dout,
+        PAI_LAUNCH(gate_apply_bwd_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dout,
                            (const bf16_t*)x, att, logit, M, C, mean_a, rstd_a, (bf16_t*)dx_skip, dl, partials, rpb, relu_out);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -294,11 +294,11 @@ extern "C" int pai_gate_hidden_bwd(int dtype, const float* dl, const float* logi
     const int64_t rpb = (M + blocks - 1) / blocks;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gate_hidden_bwd_k<float>, dim3(blocks), dim3(256), 0, s, dl, logit, (const float*)h,
+        PAI_LAUNCH(gate_hidden_bwd_k<float>, dim3(blocks), dim3(256), 0, s, dl, logit, (const float*)h,
                            (const float*)ig, (const float*)sg, M, K, mean_a, rstd_a, gamma_a, sums_a, w_a, mean_i, rstd_i,
                            mean_s, rstd_s, (float*)dsum, partials_i, partials_s, dw_a, db_a, rpb);
     else
-        hipLaunchKernelGGL(gate_hidden_bwd_k<bf16_t>, dim3(blocks), dim3(256), 0, s, dl, logit, (const bf16_t*)h,
+        PAI_LAUNCH(gate_hidden_bwd_k<bf16_t>, dim3(blocks), dim3(256), 0, s, dl, logit, (const bf16_t*)h,
                            (const bf16_t*)ig, (const bf16_t*)sg, M, K, mean_a, rstd_a, gamma_a, sums_a, w_a, mean_i,
                            rstd_i, mean_s, rstd_s, (bf16_t*)dsum, partials_i, partials_s, dw_a, db_a, rpb);
     PAI_LAUNCH_CHECK();

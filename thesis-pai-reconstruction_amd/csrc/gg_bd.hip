@@ -513,7 +513,7 @@ extern "C" int pai_pack_frag(const void* w_rowmajor, int rows, int K, void* w_fr
     PAI_CHECK(rows % 64 == 0 && K % 32 == 0, "pai_pack_frag: rows=%d must be a multiple of 64, K=%d of 32", rows, K);
     const int64_t n = (int64_t)rows * K / 8;
     const int64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(pack_frag_k, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+    PAI_LAUNCH(pack_frag_k, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)w_rowmajor, rows, K, (uint4*)w_frag);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -553,11 +553,11 @@ int launch_fwd_bd(const GG& g, const FwdArgs& a, hipStream_t s) {
     const dim3 grid(mtiles * ntiles * g.nphase), block(BD_NTHR);
     const bool relu = g.relu1 || g.relu2;
     if (pai_tunable("fwd_bd", 1) == 2) {
-        if (relu) hipLaunchKernelGGL((gg_fwd_bd_k<true, true>), grid, block, BD_LDS, s, pr, a);
-        else hipLaunchKernelGGL((gg_fwd_bd_k<true, false>), grid, block, BD_LDS, s, pr, a);
+        if (relu) PAI_LAUNCH((gg_fwd_bd_k<true, true>), grid, block, BD_LDS, s, pr, a);
+        else PAI_LAUNCH((gg_fwd_bd_k<true, false>), grid, block, BD_LDS, s, pr, a);
     } else {
-        if (relu) hipLaunchKernelGGL((gg_fwd_bd_k<false, true>), grid, block, BD_LDS, s, pr, a);
-        else hipLaunchKernelGGL((gg_fwd_bd_k<false, false>), grid, block, BD_LDS, s, pr, a);
+        if (relu) PAI_LAUNCH((gg_fwd_bd_k<false, true>), grid, block, BD_LDS, s, pr, a);
+        else PAI_LAUNCH((gg_fwd_bd_k<false, false>), grid, block, BD_LDS, s, pr, a);
     }
     PAI_LAUNCH_CHECK();
     return 0;

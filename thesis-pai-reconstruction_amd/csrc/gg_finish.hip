@@ -290,13 +290,13 @@ static int fb_row_lanes(const GG& g) {      // row lanes of a workgroup: the row
 }
 
 int launch_finish_bn(const GG& g, const FinishBnArgs& f, hipStream_t s) {
-    hipLaunchKernelGGL(splitk_finish_bn_k, dim3(g.Cout / 8), dim3(256), 0, s, g, f, fb_row_lanes(g));
+    PAI_LAUNCH(splitk_finish_bn_k, dim3(g.Cout / 8), dim3(256), 0, s, g, f, fb_row_lanes(g));
     PAI_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_finish_bnbwd(const GG& g, const FwdArgs& a, const FinishBwdArgs& f, hipStream_t s) {
-    hipLaunchKernelGGL(splitk_finish_bnbwd_k, dim3(g.Cout / 8), dim3(256), 0, s, g, a, f, fb_row_lanes(g));
+    PAI_LAUNCH(splitk_finish_bnbwd_k, dim3(g.Cout / 8), dim3(256), 0, s, g, a, f, fb_row_lanes(g));
     PAI_LAUNCH_CHECK();
     return 0;
 }

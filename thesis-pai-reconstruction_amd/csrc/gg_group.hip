@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
 int launch_grouped3(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int tiles = grouped3_tiles(g);
     const dim3 grid(grouped3_rows(g), GC / (HS * 16));
-    if (a.stats) hipLaunchKernelGGL(grouped3_k<true>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
-    else hipLaunchKernelGGL(grouped3_k<false>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    if (a.stats) PAI_LAUNCH(grouped3_k<true>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    else PAI_LAUNCH(grouped3_k<false>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -372,11 +372,11 @@ __global__ __launch_bounds__(256) void grouped3_wgrad_reduce_k(float* dw, const 
 int launch_grouped3_wgrad(const GG& g, const WgradArgs& a, float* part, hipStream_t s) {
     const int tiles = g.N * (g.OHg / WTH) * (g.OWg / WTW);
     const int nblk = grouped3_wgrad_blocks(g);
-    hipLaunchKernelGGL(grouped3_wgrad_k, dim3(nblk, GC / (HS * 16)), dim3(256), 0, s, g, a, part, tiles, g.OWg / WTW, g.OHg / WTH);
+    PAI_LAUNCH(grouped3_wgrad_k, dim3(nblk, GC / (HS * 16)), dim3(256), 0, s, g, a, part, tiles, g.OWg / WTW, g.OHg / WTH);
     PAI_LAUNCH_CHECK();
     GroupWt wt;
     for (int t = 0; t < 9; ++t) wt.wt[t] = g.wt[0][t];
-    hipLaunchKernelGGL(grouped3_wgrad_reduce_k, dim3(WPART / 64), dim3(256), 0, s, a.dw, (const float*)part, nblk, wt, a.overwrite);
+    PAI_LAUNCH(grouped3_wgrad_reduce_k, dim3(WPART / 64), dim3(256), 0, s, a.dw, (const float*)part, nblk, wt, a.overwrite);
     PAI_LAUNCH_CHECK();
     return 0;
 }

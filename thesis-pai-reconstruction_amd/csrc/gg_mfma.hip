@@ -1086,7 +1086,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int ntiles = g.Cout / c.bn;
     const dim3 grid(mtiles * ntiles * g.nphase * c.ksplit);
 #define FWD_LAUNCH(BM, BN, SK, DB)                                                                  \
-    hipLaunchKernelGGL((gg_fwd_mfma_k<BM, BN, SK, DB>), grid, dim3(BM * 2), (fwd_lds_bytes<BM, BN, DB>()), s, g, \
+    PAI_LAUNCH((gg_fwd_mfma_k<BM, BN, SK, DB>), grid, dim3(BM * 2), (fwd_lds_bytes<BM, BN, DB>()), s, g, \
                        a, mtiles, ntiles, c.ksplit, pai_ctx()->workspace)
     if (c.bm == 256) {
         static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
@@ -1101,7 +1101,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     } else if (c.bm == -128) {
         FWD_LAUNCH(128, 128, false, true);
     } else if (c.bm == 128 && c.bn == 128 && c.ksplit == 1 && getenv("PAI_FWD_MODE") && atoi(getenv("PAI_FWD_MODE")) == 3) {
-        hipLaunchKernelGGL((gg_fwd_mfma_k<128, 128, false, false, 32>), grid, dim3(512),
+        PAI_LAUNCH((gg_fwd_mfma_k<128, 128, false, false, 32>), grid, dim3(512),
                            (fwd_lds_bytes<128, 128, false, 32>()), s, g, a, mtiles, ntiles, c.ksplit, pai_ctx()->workspace);
     } else if (c.ksplit > 1) {
         if (c.bn == 128) {
@@ -1113,7 +1113,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
         PAI_LAUNCH_CHECK();
         if (a.skip_finish) return 0;      // the caller finishes the slabs itself (gg_finish.hip)
         const int ftiles = cdiv(g.M, FIN_ROWS);
-        hipLaunchKernelGGL(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
+        PAI_LAUNCH(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
                            pai_ctx()->workspace, ftiles, c.ksplit);
     } else {
         PatchGeo pg;
@@ -1129,8 +1129,8 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             const size_t need = lds > epi ? lds : epi;
             const int mt256 = g.M / 256;
             const dim3 grid256(mt256 * ntiles * g.nphase);
-            if (db) hipLaunchKernelGGL((gg_fwd_patch1_k<256, 64, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
-            else hipLaunchKernelGGL((gg_fwd_patch1_k<256, 64, false>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
+            if (db) PAI_LAUNCH((gg_fwd_patch1_k<256, 64, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
+            else PAI_LAUNCH((gg_fwd_patch1_k<256, 64, false>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
         } else if (prow == 256 && patch_geo(g, 16, &pg)) {
             typedef PatchDims<256> PD;
             const bool db = (dbb & 1) != 0;
@@ -1157,9 +1157,9 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
                     PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
                     attrw = true;
                 }
-                hipLaunchKernelGGL((gg_fwd_patchw_k<256, 128, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
-            } else if (db) hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
-            else hipLaunchKernelGGL((gg_fwd_patch_k<256, 128, false>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+                PAI_LAUNCH((gg_fwd_patchw_k<256, 128, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
+            } else if (db) PAI_LAUNCH((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+            else PAI_LAUNCH((gg_fwd_patch_k<256, 128, false>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
         } else if (prow == 128 && patch_geo(g, 8, &pg)) {
             typedef PatchDims<128> PD;
             const bool db = (dbb & (c.bn == 128 ? 2 : 4)) != 0;
@@ -1167,11 +1167,11 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 4 * 2 * c.bn * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
             if (c.bn == 128) {
-                if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
-                else hipLaunchKernelGGL((gg_fwd_patch_k<128, 128, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                if (db) PAI_LAUNCH((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                else PAI_LAUNCH((gg_fwd_patch_k<128, 128, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
             } else {
-                if (db) hipLaunchKernelGGL((gg_fwd_patch_k<128, 64, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
-                else hipLaunchKernelGGL((gg_fwd_patch_k<128, 64, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                if (db) PAI_LAUNCH((gg_fwd_patch_k<128, 64, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
+                else PAI_LAUNCH((gg_fwd_patch_k<128, 64, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
             }
         } else if (c.bn == 128) FWD_LAUNCH(128, 128, false, false); else FWD_LAUNCH(128, 64, false, false);
     }
@@ -1346,8 +1346,8 @@ int launch_pw(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int blocks = pw_rows(g);
     const int64_t ngroups = ((int64_t)g.M + 15) / 16;
     const int gpw = (int)((ngroups + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4));
-    if (g.C1 == 64) hipLaunchKernelGGL((pw_k<64, 32>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
-    else hipLaunchKernelGGL((pw_k<32, 64>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    if (g.C1 == 64) PAI_LAUNCH((pw_k<64, 32>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    else PAI_LAUNCH((pw_k<32, 64>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -1910,22 +1910,22 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
         const size_t plds = 64 * 256 + 128 * 64;
         dim3 pgrid(tiles * psplits);
         if (big)
-            hipLaunchKernelGGL(gg_wgrad_patch_k<128>, pgrid, dim3(256), plds, s, g, a, pg, cotiles, jtiles, psplits, per);
+            PAI_LAUNCH(gg_wgrad_patch_k<128>, pgrid, dim3(256), plds, s, g, a, pg, cotiles, jtiles, psplits, per);
         else
-            hipLaunchKernelGGL(gg_wgrad_patch_k<64>, pgrid, dim3(256), plds, s, g, a, pg, cotiles, jtiles, psplits, per);
+            PAI_LAUNCH(gg_wgrad_patch_k<64>, pgrid, dim3(256), plds, s, g, a, pg, cotiles, jtiles, psplits, per);
         PAI_LAUNCH_CHECK();
         return 0;
     }
     const size_t lds = 2 * 64 * 256;
     dim3 grid(tiles * splits);
     if (a.overwrite_bias && a.dbias && g.nphase > 1) {
-        hipError_t e = hipMemsetAsync(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
+        hipError_t e = pai::memset_async(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
         PAI_CHECK(e == hipSuccess, "launch_wgrad_mfma: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     if (big)
-        hipLaunchKernelGGL(gg_wgrad_mfma_k<128>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
+        PAI_LAUNCH(gg_wgrad_mfma_k<128>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
     else
-        hipLaunchKernelGGL(gg_wgrad_mfma_k<64>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
+        PAI_LAUNCH(gg_wgrad_mfma_k<64>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
     PAI_LAUNCH_CHECK();
     return 0;
 }

@@ -496,8 +496,8 @@ static int p2_launch(const GG& g, const FwdArgs& a, const PatchGeo& pg, hipStrea
     P2Prob pr;
     p2_prob(g, pg, mtiles, ntiles, &pr);
     const dim3 grid(mtiles * ntiles * g.nphase), block(PD::NTHR);
-    if (g.relu1 || g.relu2) hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, MT, NRING, true>), grid, block, lds, s, pr, a);
-    else hipLaunchKernelGGL((gg_fwd_p2_k<TH, NW, MT, NRING, false>), grid, block, lds, s, pr, a);
+    if (g.relu1 || g.relu2) PAI_LAUNCH((gg_fwd_p2_k<TH, NW, MT, NRING, true>), grid, block, lds, s, pr, a);
+    else PAI_LAUNCH((gg_fwd_p2_k<TH, NW, MT, NRING, false>), grid, block, lds, s, pr, a);
     PAI_LAUNCH_CHECK();
     return 0;
 }

@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void gg_fwd_simt_k(GG g, FwdArgs a) {
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     dim3 grid(cdiv(g.M, SBM), cdiv(g.Cout, SBN), g.nphase);
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gg_fwd_simt_k<float>, grid, dim3(256), 0, s, g, a);
+        PAI_LAUNCH(gg_fwd_simt_k<float>, grid, dim3(256), 0, s, g, a);
     else
-        hipLaunchKernelGGL(gg_fwd_simt_k<bf16_t>, grid, dim3(256), 0, s, g, a);
+        PAI_LAUNCH(gg_fwd_simt_k<bf16_t>, grid, dim3(256), 0, s, g, a);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void gg_fwd_rowdot_k(GG g, FwdArgs a) {
 
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     dim3 grid(cdiv(g.M, 16 * RD_ROWS_PER_GROUP), g.nphase);
-#define RD_LAUNCH(T, NCO) hipLaunchKernelGGL((gg_fwd_rowdot_k<T, NCO>), grid, dim3(256), 0, s, g, a)
+#define RD_LAUNCH(T, NCO) PAI_LAUNCH((gg_fwd_rowdot_k<T, NCO>), grid, dim3(256), 0, s, g, a)
     if (dtype == PAI_F32) {
         if (g.Cout == 1) RD_LAUNCH(float, 1); else RD_LAUNCH(float, 2);
     } else {
@@ -378,9 +378,9 @@ int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s)
     splits = cdiv(g.M, rows);
     dim3 grid(cdiv(g.Cout, SBM), cdiv(g.ntaps * g.Cin, SBN), g.nphase * splits);
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gg_wgrad_simt_k<float>, grid, dim3(256), 0, s, g, a, splits, rows);
+        PAI_LAUNCH(gg_wgrad_simt_k<float>, grid, dim3(256), 0, s, g, a, splits, rows);
     else
-        hipLaunchKernelGGL(gg_wgrad_simt_k<bf16_t>, grid, dim3(256), 0, s, g, a, splits, rows);
+        PAI_LAUNCH(gg_wgrad_simt_k<bf16_t>, grid, dim3(256), 0, s, g, a, splits, rows);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -468,7 +468,7 @@ int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t 
     dim3 grid(blocks, g.nphase);
     size_t lds = ((size_t)g.Cout * g.ntaps * g.Cin + g.Cout) * sizeof(float);
     PAI_CHECK(lds <= 64 * 1024, "wgrad_rowdot: LDS %zu too large", lds);
-#define WR_LAUNCH(T, NT) hipLaunchKernelGGL((gg_wgrad_rowdot_k<T, NT>), grid, dim3(256), lds, s, g, a, rows)
+#define WR_LAUNCH(T, NT) PAI_LAUNCH((gg_wgrad_rowdot_k<T, NT>), grid, dim3(256), lds, s, g, a, rows)
     if (dtype == PAI_F32) {
         if (g.ntaps == 4) WR_LAUNCH(float, 4); else if (g.ntaps == 9) WR_LAUNCH(float, 9); else WR_LAUNCH(float, 16);
     } else {

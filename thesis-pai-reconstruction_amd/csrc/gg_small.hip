@@ -185,7 +185,7 @@ int launch_small(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int bx = small_blocks(g);
     const int gpw = cdiv(cdiv(g.M, 16), bx * 4);
     const dim3 grid(bx, g.Cout / (16 * ntb));
-#define SMALL_LAUNCH(KS_, NT_) hipLaunchKernelGGL((small_fwd_k<KS_, NT_>), grid, dim3(256), 0, s, g, a, gpw)
+#define SMALL_LAUNCH(KS_, NT_) PAI_LAUNCH((small_fwd_k<KS_, NT_>), grid, dim3(256), 0, s, g, a, gpw)
 #define SMALL_NT(KS_, MAXNT)                                         \
     do {                                                             \
         if (ntb == 1) SMALL_LAUNCH(KS_, 1);                          \

@@ -323,8 +323,8 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
     // (scripts/micro/convbench, thin_sect = 0 / 1: encoders[0] forward 43.7 -> 42.8 us, D block 0 forward 76.9 -> 75.2,
     // input gradient of decoders[7] 56.6 -> 54.0; bit-identical outputs)
     if (pai_tunable("thin_sect", 1) && (g.D2 == 0 || (g.D1 % 64) == 0)) fast_ok |= 2;
-    if (g.C2 == 0) hipLaunchKernelGGL(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
-    else hipLaunchKernelGGL(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
+    if (g.C2 == 0) PAI_LAUNCH(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
+    else PAI_LAUNCH(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -562,17 +562,17 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     if (thin_up_ok(g)) {
         const int tx = g.W / 16, ty = g.H / 16;
         const dim3 grid(g.N * tx * ty);
-        if (T == 1 && g.Cin == 128) hipLaunchKernelGGL((thin_up_k<1, 4>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
-        else if (T == 1) hipLaunchKernelGGL((thin_up_k<1, 2>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
-        else if (g.Cin == 128) hipLaunchKernelGGL((thin_up_k<2, 4>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
-        else hipLaunchKernelGGL((thin_up_k<2, 2>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        if (T == 1 && g.Cin == 128) PAI_LAUNCH((thin_up_k<1, 4>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        else if (T == 1) PAI_LAUNCH((thin_up_k<1, 2>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        else if (g.Cin == 128) PAI_LAUNCH((thin_up_k<2, 4>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
+        else PAI_LAUNCH((thin_up_k<2, 2>), grid, dim3(256), 0, s, g, a, t0, tx, ty);
         PAI_LAUNCH_CHECK();
         return 0;
     }
     // every wave keeps the whole filter in registers: give it >= 4 pixel groups to amortise that
     int blocks = cdiv((int64_t)g.N * g.H * g.W, 256);
     if (blocks > 4096) blocks = 4096;
-#define TDG(TT, KK) hipLaunchKernelGGL((thin_dgrad_gemm_k<TT, KK>), dim3(blocks), dim3(256), 0, s, g, a, pai_ctx()->scratch, t0)
+#define TDG(TT, KK) PAI_LAUNCH((thin_dgrad_gemm_k<TT, KK>), dim3(blocks), dim3(256), 0, s, g, a, pai_ctx()->scratch, t0)
 #define TDG_K(TT)                                     \
     switch (g.Cin / 32) {                             \
         case 1: TDG(TT, 1); break;                    \
@@ -589,7 +589,7 @@ int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
     PAI_CHECK((int64_t)g.N * g.OH * g.OW < (1ll << 31), "thin dgrad: more than 2^31 output pixels");
     int64_t b2 = ((int64_t)g.N * g.OH * g.OW + 255) / 256;
     if (b2 > 8192) b2 = 8192;
-    hipLaunchKernelGGL(thin_col2im_k, dim3((int)b2), dim3(256), 0, s, g, a, (const float*)pai_ctx()->scratch, T, t0);
+    PAI_LAUNCH(thin_col2im_k, dim3((int)b2), dim3(256), 0, s, g, a, (const float*)pai_ctx()->scratch, T, t0);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -908,12 +908,12 @@ static int launch_tw(ThinW& p, int T, hipStream_t s) {
     int blocks = tw_blocks(p.M, groups, two_stage);
     const int cpb = cdiv(chunks, blocks);
     p.partial = two_stage ? (float*)((char*)ctx->scratch + (ctx->scratch_bytes - need)) : nullptr;
-    if (T == 1) hipLaunchKernelGGL(thin_wgrad_k<1>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
-    else hipLaunchKernelGGL(thin_wgrad_k<2>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
+    if (T == 1) PAI_LAUNCH(thin_wgrad_k<1>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
+    else PAI_LAUNCH(thin_wgrad_k<2>, dim3(blocks, groups), dim3(256), 64 * 256, s, p, cpb);
     PAI_LAUNCH_CHECK();
     if (two_stage) {
         const int elems = groups * (16 * T + 1) * 128;
-        hipLaunchKernelGGL(thin_wgrad_reduce_k, dim3(cdiv(elems, 64), 16), dim3(256), 0, s, p, T, blocks * 2, groups);
+        PAI_LAUNCH(thin_wgrad_reduce_k, dim3(cdiv(elems, 64), 16), dim3(256), 0, s, p, T, blocks * 2, groups);
         PAI_LAUNCH_CHECK();
     }
     return 0;
@@ -946,7 +946,7 @@ int launch_thin_wgrad_convt(const GG& g, const WgradArgs& a, hipStream_t s) {
     if (launch_tw(p, 1, s)) return 1;
     if (a.dbias) {
         const int64_t n = (int64_t)g.N * g.OH * g.OW;
-        hipLaunchKernelGGL(sum1_k, dim3(256), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
+        PAI_LAUNCH(sum1_k, dim3(256), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
         PAI_LAUNCH_CHECK();
     }
     return 0;
@@ -972,7 +972,7 @@ int launch_thin_wgrad_conv1(const GG& g, const WgradArgs& a, hipStream_t s) {
     if (launch_tw(p, 1, s)) return 1;
     if (a.dbias) {
         const int64_t n = (int64_t)g.N * g.OH * g.OW;
-        hipLaunchKernelGGL(sum1_k, dim3(64), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
+        PAI_LAUNCH(sum1_k, dim3(64), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
         PAI_LAUNCH_CHECK();
     }
     return 0;
@@ -1017,7 +1017,7 @@ int launch_thin_wgrad_conv3t(const GG& g, const WgradArgs& a, hipStream_t s) {
     if (launch_tw(p, 1, s)) return 1;
     if (a.dbias) {
         const int64_t n = (int64_t)g.N * g.OH * g.OW;
-        hipLaunchKernelGGL(sum1_k, dim3(64), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
+        PAI_LAUNCH(sum1_k, dim3(64), dim3(256), 0, s, (const bf16_t*)a.dy, n, a.dbias);
         PAI_LAUNCH_CHECK();
     }
     return 0;

@@ -274,7 +274,7 @@ int launch_wgrad2(const GG& g, const WgradArgs& a, hipStream_t s) {
     const int per = cdiv(kblocks, splits);
     const int psplits = cdiv(kblocks, per);
     const size_t lds = 2 * (64 * 256 + 128 * 128);      // two stages of dY tile + X patch
-    hipLaunchKernelGGL(gg_wgrad_patch2_k<128>, dim3(tiles * psplits), dim3(512), lds, s, g, a, pg, cotiles, jtiles, psplits, per);
+    PAI_LAUNCH(gg_wgrad_patch2_k<128>, dim3(tiles * psplits), dim3(512), lds, s, g, a, pg, cotiles, jtiles, psplits, per);
     PAI_LAUNCH_CHECK();
     return 0;
 }

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_sum_k(float* __restrict__ dw, 
 int launch_wgrad_slab_sum(float* dw, const float* slab, int nsplits, int64_t n, int overwrite, hipStream_t s) {
     PAI_CHECK((n % 4) == 0, "wgrad slab sum: %lld elements are not a multiple of 4", (long long)n);
     const long n4 = (long)(n / 4);
-    hipLaunchKernelGGL(wgrad_slab_sum_k, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, dw, slab, nsplits, n4, n4, overwrite);
+    PAI_LAUNCH(wgrad_slab_sum_k, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s, dw, slab, nsplits, n4, n4, overwrite);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -460,7 +460,7 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     if (c.psplits > 1 && pai_tunable("wgrad_slab", 1)) slab = wgrad_slab_acquire(need);
     a.slab = slab;
     if (a.overwrite_bias && a.dbias) {   // the bias sums of the workgroups meet by atomics
-        hipError_t e = hipMemsetAsync(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
+        hipError_t e = pai::memset_async(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
         PAI_CHECK(e == hipSuccess, "launch_wgrad3: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     static bool attr = false;
@@ -479,13 +479,13 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     const dim3 grid(c.tiles * c.psplits);
     if (variant == 1) {
         const size_t lds = 2 * (64 * 256 + 96 * 128);
-        hipLaunchKernelGGL((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
     } else if (variant == 2) {
         const size_t lds = 2 * (64 * 128 + 96 * 256);
-        hipLaunchKernelGGL((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
     } else {
         const size_t lds = 2 * (64 * 256 + 128 * 128);
-        hipLaunchKernelGGL((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
     }
     PAI_LAUNCH_CHECK();
     if (slab) return launch_wgrad_slab_sum(a.dw, slab, c.psplits, dwn, a.overwrite, s);

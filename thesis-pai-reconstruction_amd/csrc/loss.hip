@@ -50,7 +50,7 @@ static int launch_loss(const float* x, const float* t, float tconst, int64_t num
     int64_t blocks = (numel + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(loss_k<KIND>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, t, tconst,
+    PAI_LAUNCH(loss_k<KIND>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, t, tconst,
                        numel, (double)loss_scale / (double)numel, loss,
                        (float)((double)grad_scale / (double)numel), grad);
     PAI_LAUNCH_CHECK();
@@ -81,7 +81,7 @@ __global__ void scalar_take_k(double* acc, float* out) {
 }
 extern "C" int pai_scalar_take(double* acc, float* out, void* stream) {
     PAI_CHECK(acc && out, "pai_scalar_take: null pointer");
-    hipLaunchKernelGGL(scalar_take_k, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, out);
+    PAI_LAUNCH(scalar_take_k, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, out);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -94,7 +94,7 @@ __global__ void metrics_take_k(double* sums, double inv_images, double inv_numel
 }
 extern "C" int pai_metrics_take(double* sums, int64_t n_images, int64_t numel, float* out3, void* stream) {
     PAI_CHECK(sums && out3 && n_images > 0 && numel > 0, "pai_metrics_take: bad arguments");
-    hipLaunchKernelGGL(metrics_take_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, 1.0 / (double)n_images,
+    PAI_LAUNCH(metrics_take_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, 1.0 / (double)n_images,
                        1.0 / (double)numel, out3);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -116,10 +116,10 @@ extern "C" int pai_tanh_bwd(int dtype, const float* pred, const float* g_a, cons
     int64_t blocks = (numel + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(tanh_bwd_k<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, pred, g_a,
+        PAI_LAUNCH(tanh_bwd_k<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, pred, g_a,
                            g_b, numel, (float*)dh);
     else
-        hipLaunchKernelGGL(tanh_bwd_k<bf16_t>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, pred,
+        PAI_LAUNCH(tanh_bwd_k<bf16_t>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, pred,
                            g_a, g_b, numel, (bf16_t*)dh);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -140,7 +140,7 @@ extern "C" int pai_denormalize(const float* x, const float* grad_out_or_null, in
     int64_t blocks = (numel + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(denorm_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, grad_out_or_null,
+    PAI_LAUNCH(denorm_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, grad_out_or_null,
                        numel, out);
     PAI_LAUNCH_CHECK();
     return 0;

@@ -16,13 +16,13 @@ extern "C" int pai_cast(int src_dtype, const void* src, int dst_dtype, void* dst
     hipStream_t s = (hipStream_t)stream;
     dim3 g((int)blocks), b(256);
     if (src_dtype == PAI_F32 && dst_dtype == PAI_BF16)
-        hipLaunchKernelGGL((cast_k<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, numel);
+        PAI_LAUNCH((cast_k<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, numel);
     else if (src_dtype == PAI_BF16 && dst_dtype == PAI_F32)
-        hipLaunchKernelGGL((cast_k<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, numel);
+        PAI_LAUNCH((cast_k<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, numel);
     else if (src_dtype == PAI_F32 && dst_dtype == PAI_F32)
-        hipLaunchKernelGGL((cast_k<float, float>), g, b, 0, s, (const float*)src, (float*)dst, numel);
+        PAI_LAUNCH((cast_k<float, float>), g, b, 0, s, (const float*)src, (float*)dst, numel);
     else if (src_dtype == PAI_BF16 && dst_dtype == PAI_BF16)
-        hipLaunchKernelGGL((cast_k<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, numel);
+        PAI_LAUNCH((cast_k<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, numel);
     else
         PAI_CHECK(false, "pai_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
     PAI_LAUNCH_CHECK();
@@ -54,10 +54,10 @@ extern "C" int pai_dropout2d(int dtype, const void* x, const float* mask, int N,
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(dropout2d_k<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, mask, nvec, vpi, C,
+        PAI_LAUNCH(dropout2d_k<float>, dim3((int)blocks), dim3(256), 0, s, (const float*)x, mask, nvec, vpi, C,
                            (float*)out);
     else
-        hipLaunchKernelGGL(dropout2d_k<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, mask, nvec, vpi,
+        PAI_LAUNCH(dropout2d_k<bf16_t>, dim3((int)blocks), dim3(256), 0, s, (const bf16_t*)x, mask, nvec, vpi,
                            C, (bf16_t*)out);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -197,7 +197,7 @@ extern "C" int pai_pack_weights_multi(int n, const float* const* w_master, const
             blocks += (int64_t)(cin[k] / 64) * (cout[k] / 64) * taps[k];
             PAI_CHECK(blocks < (1ll << 31), "pai_pack_weights_multi: too many tiles");
         }
-        hipLaunchKernelGGL(pack64_multi_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pm);
+        PAI_LAUNCH(pack64_multi_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pm);
         PAI_LAUNCH_CHECK();
     }
     return 0;
@@ -207,17 +207,17 @@ extern "C" int pai_pack_weights(int dtype, const float* w_master, int Cout, int 
                                 void* w_fwd, void* w_dgrad, void* stream) {
     PAI_CHECK(w_master && (w_fwd || w_dgrad), "pai_pack_weights: null pointer");
     if (dtype == PAI_BF16 && (Cin % 64) == 0 && (Cout % 64) == 0 && Cout / 64 <= 65535 && taps <= 65535) {
-        hipLaunchKernelGGL(pack64_k, dim3(Cin / 64, Cout / 64, taps), dim3(256), 0, (hipStream_t)stream, w_master, Cout,
+        PAI_LAUNCH(pack64_k, dim3(Cin / 64, Cout / 64, taps), dim3(256), 0, (hipStream_t)stream, w_master, Cout,
                            taps, Cin, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
         PAI_LAUNCH_CHECK();
         return 0;
     }
     dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), taps);
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(pack_k<float>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
+        PAI_LAUNCH(pack_k<float>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
                            (float*)w_fwd, (float*)w_dgrad);
     else
-        hipLaunchKernelGGL(pack_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
+        PAI_LAUNCH(pack_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, taps, Cin,
                            (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -234,7 +234,7 @@ __global__ void reduce_rows_k(const float* partial, int rows, int C, float* out,
 extern "C" int pai_reduce_rows(const float* partial, int rows, int C, float* out, int accumulate,
                                void* stream) {
     PAI_CHECK(partial && out, "pai_reduce_rows: null pointer");
-    hipLaunchKernelGGL(reduce_rows_k, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
+    PAI_LAUNCH(reduce_rows_k, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, partial, rows, C,
                        out, accumulate);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -280,9 +280,9 @@ int launch_colsum(int dtype, const void* x, int64_t rows, int C, float* out, hip
     if (blocks * chunks > 4096) chunks = (int)(4096 / blocks) > 0 ? (int)(4096 / blocks) : 1;
     const dim3 grid((int)blocks, chunks);
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(colsum_k<float>, grid, dim3(256), 0, s, (const float*)x, rows, C, rpb, out);
+        PAI_LAUNCH(colsum_k<float>, grid, dim3(256), 0, s, (const float*)x, rows, C, rpb, out);
     else
-        hipLaunchKernelGGL(colsum_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, C, rpb, out);
+        PAI_LAUNCH(colsum_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, C, rpb, out);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -317,14 +317,15 @@ __global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m
 extern "C" int pai_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                         float lr, float beta1, float beta2, float eps, int step_count, void* stream) {
     PAI_CHECK(param && grad && exp_avg && exp_avg_sq && step_count >= 1, "pai_adam: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, step_count);
-    const double bc2 = 1.0 - pow((double)beta2, step_count);
+    float lr_over_bc1, inv_sqrt_bc2;
+    pai::adam_coeffs(lr, beta1, beta2, step_count, &lr_over_bc1, &inv_sqrt_bc2);
     int64_t blocks = (numel + 1023) / 1024;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, numel, (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1),
-                       (float)(1.0 - (double)beta2), eps, (float)(1.0 / sqrt(bc2)));
+    pai::plan_mark_adam(5, 11, lr, beta1, beta2, step_count);     // a recorded launch re-derives arguments 5 and 11 per replay
+    PAI_LAUNCH(adam_k, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, numel, lr_over_bc1, beta1, beta2, (float)(1.0 - (double)beta1),
+                       (float)(1.0 - (double)beta2), eps, inv_sqrt_bc2);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -406,12 +407,13 @@ extern "C" int pai_adam_pack(float* param, const float* grad, float* exp_avg, fl
     int64_t extra = (rest + 1023) / 1024;
     if (extra > 256) extra = 256;
     PAI_CHECK(ntiles + extra < (1ll << 31), "pai_adam_pack: too many tiles");
-    const double bc1 = 1.0 - pow((double)beta1, step_count);
-    const double bc2 = 1.0 - pow((double)beta2, step_count);
-    hipLaunchKernelGGL(adam_pack64_k, dim3((unsigned)(ntiles + extra)), dim3(256), 0, (hipStream_t)stream, param, grad,
+    float lr_over_bc1, inv_sqrt_bc2;
+    pai::adam_coeffs(lr, beta1, beta2, step_count, &lr_over_bc1, &inv_sqrt_bc2);
+    pai::plan_mark_adam(12, 18, lr, beta1, beta2, step_count);
+    PAI_LAUNCH(adam_pack64_k, dim3((unsigned)(ntiles + extra)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, numel, w_off, Cout, taps, Cin, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, (int)ntiles,
-                       (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps,
-                       (float)(1.0 / sqrt(bc2)));
+                       lr_over_bc1, beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps,
+                       inv_sqrt_bc2);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -443,12 +445,12 @@ extern "C" int pai_adam_dev(float* param, const float* grad, float* exp_avg, flo
                             void* stream) {
     PAI_CHECK(param && grad && exp_avg && exp_avg_sq && step_dev && coeff2_dev, "pai_adam_dev: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_coeff_k, dim3(1), dim3(1), 0, s, (long long*)step_dev, coeff2_dev, lr, beta1, beta2);
+    PAI_LAUNCH(adam_coeff_k, dim3(1), dim3(1), 0, s, (long long*)step_dev, coeff2_dev, lr, beta1, beta2);
     PAI_LAUNCH_CHECK();
     int64_t blocks = (numel + 1023) / 1024;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_dev_k, dim3((int)blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, numel,
+    PAI_LAUNCH(adam_dev_k, dim3((int)blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, numel,
                        (const float*)coeff2_dev, beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -501,7 +503,7 @@ extern "C" int pai_adam_multi_dev(int count, void* const* params, const void* co
     PAI_CHECK(count >= 0 && (count == 0 || (params && grads && exp_avgs && exp_avg_sqs && numels)) && step_dev && coeff2_dev,
               "pai_adam_multi_dev: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_coeff_k, dim3(1), dim3(1), 0, s, (long long*)step_dev, coeff2_dev, lr, beta1, beta2);
+    PAI_LAUNCH(adam_coeff_k, dim3(1), dim3(1), 0, s, (long long*)step_dev, coeff2_dev, lr, beta1, beta2);
     PAI_LAUNCH_CHECK();
     for (int i0 = 0; i0 < count; i0 += ADAM_CHUNK) {
         const int nt = count - i0 < ADAM_CHUNK ? count - i0 : ADAM_CHUNK;
@@ -520,7 +522,7 @@ extern "C" int pai_adam_multi_dev(int count, void* const* params, const void* co
         }
         int64_t bx = (big + 1023) / 1024;
         if (bx > 2048) bx = 2048;
-        hipLaunchKernelGGL(adam_multi_dev_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, s, c, (const float*)coeff2_dev,
+        PAI_LAUNCH(adam_multi_dev_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, s, c, (const float*)coeff2_dev,
                            beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps);
         PAI_LAUNCH_CHECK();
     }
@@ -532,8 +534,8 @@ extern "C" int pai_adam_multi(int count, void* const* params, const void* const*
                               float eps, int step_count, void* stream) {
     PAI_CHECK(count >= 0 && (count == 0 || (params && grads && exp_avgs && exp_avg_sqs && numels)) && step_count >= 1,
               "pai_adam_multi: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, step_count);
-    const double bc2 = 1.0 - pow((double)beta2, step_count);
+    float lr_over_bc1, inv_sqrt_bc2;
+    pai::adam_coeffs(lr, beta1, beta2, step_count, &lr_over_bc1, &inv_sqrt_bc2);
     for (int i0 = 0; i0 < count; i0 += ADAM_CHUNK) {
         const int nt = count - i0 < ADAM_CHUNK ? count - i0 : ADAM_CHUNK;
         AdamChunk c;
@@ -551,9 +553,44 @@ extern "C" int pai_adam_multi(int count, void* const* params, const void* const*
         }
         int64_t bx = (big + 1023) / 1024;
         if (bx > 2048) bx = 2048;
-        hipLaunchKernelGGL(adam_multi_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, c,
-                           (float)(lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps,
-                           (float)(1.0 / sqrt(bc2)));
+        pai::plan_mark_adam(1, 7, lr, beta1, beta2, step_count);
+        PAI_LAUNCH(adam_multi_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, c,
+                           lr_over_bc1, beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps,
+                           inv_sqrt_bc2);
+        PAI_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ---- multi-tensor zero fill (gradient-arena segments that are accumulated into) -----------------------------------
+#define ZERO_CHUNK 96
+struct ZeroChunk {
+    float* p[ZERO_CHUNK];
+    int64_t n[ZERO_CHUNK];
+};
+
+__global__ __launch_bounds__(256) void zero_multi_k(ZeroChunk c) {
+    float* p = c.p[blockIdx.y];
+    const int64_t n = c.n[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+
+extern "C" int pai_zero_multi(int count, void* const* ptrs, const int64_t* numels, void* stream) {
+    PAI_CHECK(count >= 0 && (count == 0 || (ptrs && numels)), "pai_zero_multi: bad arguments");
+    for (int i0 = 0; i0 < count; i0 += ZERO_CHUNK) {
+        const int nt = count - i0 < ZERO_CHUNK ? count - i0 : ZERO_CHUNK;
+        ZeroChunk c;
+        memset(&c, 0, sizeof(c));
+        int64_t big = 1;
+        for (int i = 0; i < nt; ++i) {
+            PAI_CHECK(ptrs[i0 + i] && numels[i0 + i] >= 0, "pai_zero_multi: null tensor %d", i0 + i);
+            c.p[i] = (float*)ptrs[i0 + i];
+            c.n[i] = numels[i0 + i];
+            if (c.n[i] > big) big = c.n[i];
+        }
+        int64_t bx = (big + 1023) / 1024;
+        if (bx > 256) bx = 256;
+        PAI_LAUNCH(zero_multi_k, dim3((unsigned)bx, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, c);
         PAI_LAUNCH_CHECK();
     }
     return 0;

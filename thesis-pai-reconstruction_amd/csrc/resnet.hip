@@ -136,9 +136,9 @@ extern "C" int pai_maxpool2(int dtype, const void* x, int N, int H, int W, int C
     PAI_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "pai_maxpool2: C=%d must be a multiple of 8, H=%d W=%d even", C, H, W);
     const dim3 grid(ew_blocks((int64_t)N * (H / 2) * (W / 2) * (C / 8)));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(maxpool2_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)out, idx);
+        PAI_LAUNCH(maxpool2_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)out, idx);
     else
-        hipLaunchKernelGGL(maxpool2_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, N, H, W, C, (bf16_t*)out, idx);
+        PAI_LAUNCH(maxpool2_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, N, H, W, C, (bf16_t*)out, idx);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -149,9 +149,9 @@ extern "C" int pai_maxpool2_bwd(int dtype, const void* dout, const unsigned char
     PAI_CHECK(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "pai_maxpool2_bwd: bad shape");
     const dim3 grid(ew_blocks((int64_t)N * (H / 2) * (W / 2) * (C / 8)));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(maxpool2_bwd_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, idx, N, H, W, C, (float*)dx);
+        PAI_LAUNCH(maxpool2_bwd_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, idx, N, H, W, C, (float*)dx);
     else
-        hipLaunchKernelGGL(maxpool2_bwd_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, idx, N, H, W, C, (bf16_t*)dx);
+        PAI_LAUNCH(maxpool2_bwd_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, idx, N, H, W, C, (bf16_t*)dx);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -160,9 +160,9 @@ extern "C" int pai_upsample2(int dtype, const void* x, int N, int H, int W, int 
     PAI_CHECK(x && out && C % 8 == 0, "pai_upsample2: bad arguments");
     const dim3 grid(ew_blocks((int64_t)N * H * W * (C / 8)));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(upsample2_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)out);
+        PAI_LAUNCH(upsample2_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H, W, C, (float*)out);
     else
-        hipLaunchKernelGGL(upsample2_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, N, H, W, C, (bf16_t*)out);
+        PAI_LAUNCH(upsample2_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, N, H, W, C, (bf16_t*)out);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -171,9 +171,9 @@ extern "C" int pai_upsample2_bwd(int dtype, const void* dout, int N, int H, int 
     PAI_CHECK(dout && dx && C % 8 == 0, "pai_upsample2_bwd: bad arguments");
     const dim3 grid(ew_blocks((int64_t)N * H * W * (C / 8)));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(upsample2_bwd_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, N, H, W, C, (float*)dx);
+        PAI_LAUNCH(upsample2_bwd_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, N, H, W, C, (float*)dx);
     else
-        hipLaunchKernelGGL(upsample2_bwd_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx);
+        PAI_LAUNCH(upsample2_bwd_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -183,9 +183,9 @@ extern "C" int pai_add_act(int dtype, const void* a, const void* b, int64_t nume
     PAI_CHECK(act == PAI_ACT_NONE || act == PAI_ACT_RELU || act == PAI_ACT_LRELU, "pai_add_act: act=%d", act);
     const dim3 grid(ew_blocks(numel / 8));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(add_act_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, numel / 8, act, (float*)out);
+        PAI_LAUNCH(add_act_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, numel / 8, act, (float*)out);
     else
-        hipLaunchKernelGGL(add_act_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, numel / 8, act, (bf16_t*)out);
+        PAI_LAUNCH(add_act_k<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, numel / 8, act, (bf16_t*)out);
     PAI_LAUNCH_CHECK();
     return 0;
 }

@@ -201,7 +201,7 @@ extern "C" int pai_ssim_sse(const float* pred, const float* target, int NC, int 
     if (xtiles < 1 || (int64_t)cdiv(H, TS) * NC < 512) xtiles = 1;
     if (xtiles > xt_all) xtiles = xt_all;
     dim3 grid(cdiv(xt_all, xtiles), cdiv(H, TS), NC);
-    hipLaunchKernelGGL(ssim_k<0>, grid, dim3(256), 0, (hipStream_t)stream, pred, target, H, W, denorm, gk,
+    PAI_LAUNCH(ssim_k<0>, grid, dim3(256), 0, (hipStream_t)stream, pred, target, H, W, denorm, gk,
                        inv_crop, out2, per_image, full_map, (float*)nullptr, NC, 0.f, xtiles);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -282,10 +282,10 @@ extern "C" int pai_ssim_psnr_bwd(const float* pred, const float* target, int NC,
     const float wscale = (float)((double)w_ssim / (crop * (double)NC));
     dim3 grid(cdiv(W, TS), cdiv(H, TS), NC);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssim_k<1>, grid, dim3(256), 0, s, pred, target, H, W, denorm, gk, 0.0,
+    PAI_LAUNCH(ssim_k<1>, grid, dim3(256), 0, s, pred, target, H, W, denorm, gk, 0.0,
                        (double*)nullptr, (double*)nullptr, (float*)nullptr, workspace, NC, wscale, 1);
     PAI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ssim_bwd2_k, grid, dim3(256), 0, s, pred, target, H, W, denorm, gk, workspace, NC,
+    PAI_LAUNCH(ssim_bwd2_k, grid, dim3(256), 0, s, pred, target, H, W, denorm, gk, workspace, NC,
                        w_psnr, sse, grad);
     PAI_LAUNCH_CHECK();
     return 0;

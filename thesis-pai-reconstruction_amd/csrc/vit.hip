@@ -128,10 +128,10 @@ extern "C" int pai_layernorm_fwd(int dtype, const void* x, const void* res, int6
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)(D + 8) * sizeof(float);
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(layernorm_fwd_k<float>, dim3((unsigned)M), dim3(256), lds, s, (const float*)x,
+        PAI_LAUNCH(layernorm_fwd_k<float>, dim3((unsigned)M), dim3(256), lds, s, (const float*)x,
                            (const float*)res, D, gamma, beta, eps, post, P, (float*)sum_out, (float*)y, mean, rstd);
     else
-        hipLaunchKernelGGL(layernorm_fwd_k<bf16_t>, dim3((unsigned)M), dim3(256), lds, s, (const bf16_t*)x,
+        PAI_LAUNCH(layernorm_fwd_k<bf16_t>, dim3((unsigned)M), dim3(256), lds, s, (const bf16_t*)x,
                            (const bf16_t*)res, D, gamma, beta, eps, post, P, (bf16_t*)sum_out, (bf16_t*)y, mean, rstd);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -150,16 +150,16 @@ extern "C" int pai_layernorm_bwd(int dtype, const void* dy, const void* xs, int6
     const int slabs = pai_layernorm_partial_rows(M);
     const int64_t rps = (M + slabs - 1) / slabs;
     if (dtype == PAI_F32) {
-        hipLaunchKernelGGL(layernorm_bwd_dx_k<float>, dim3((unsigned)M), dim3(256), lds, s, (const float*)dy,
+        PAI_LAUNCH(layernorm_bwd_dx_k<float>, dim3((unsigned)M), dim3(256), lds, s, (const float*)dy,
                            (const float*)xs, D, gamma, mean, rstd, (float*)dx);
         if (dgamma_dbeta)
-            hipLaunchKernelGGL(layernorm_bwd_param_k<float>, dim3(cdiv(D, 256), slabs), dim3(256), 0, s,
+            PAI_LAUNCH(layernorm_bwd_param_k<float>, dim3(cdiv(D, 256), slabs), dim3(256), 0, s,
                                (const float*)dy, (const float*)xs, M, D, mean, rstd, rps, partials);
     } else {
-        hipLaunchKernelGGL(layernorm_bwd_dx_k<bf16_t>, dim3((unsigned)M), dim3(256), lds, s, (const bf16_t*)dy,
+        PAI_LAUNCH(layernorm_bwd_dx_k<bf16_t>, dim3((unsigned)M), dim3(256), lds, s, (const bf16_t*)dy,
                            (const bf16_t*)xs, D, gamma, mean, rstd, (bf16_t*)dx);
         if (dgamma_dbeta)
-            hipLaunchKernelGGL(layernorm_bwd_param_k<bf16_t>, dim3(cdiv(D, 256), slabs), dim3(256), 0, s,
+            PAI_LAUNCH(layernorm_bwd_param_k<bf16_t>, dim3(cdiv(D, 256), slabs), dim3(256), 0, s,
                                (const bf16_t*)dy, (const bf16_t*)xs, M, D, mean, rstd, rps, partials);
     }
     PAI_LAUNCH_CHECK();
@@ -201,9 +201,9 @@ extern "C" int pai_gelu(int dtype, const void* z, int64_t numel, void* out, void
     PAI_CHECK(z && out && numel > 0, "pai_gelu: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gelu_k<float>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const float*)z, numel, (float*)out);
+        PAI_LAUNCH(gelu_k<float>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const float*)z, numel, (float*)out);
     else
-        hipLaunchKernelGGL(gelu_k<bf16_t>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const bf16_t*)z, numel, (bf16_t*)out);
+        PAI_LAUNCH(gelu_k<bf16_t>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const bf16_t*)z, numel, (bf16_t*)out);
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -213,10 +213,10 @@ extern "C" int pai_gelu_bwd(int dtype, const void* dy, const void* z, int64_t nu
     PAI_CHECK(dy && z && dz && numel > 0, "pai_gelu_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(gelu_bwd_k<float>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const float*)dy,
+        PAI_LAUNCH(gelu_bwd_k<float>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const float*)dy,
                            (const float*)z, numel, (float*)dz);
     else
-        hipLaunchKernelGGL(gelu_bwd_k<bf16_t>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const bf16_t*)dy,
+        PAI_LAUNCH(gelu_bwd_k<bf16_t>, dim3(ew_blocks(numel)), dim3(256), 0, s, (const bf16_t*)dy,
                            (const bf16_t*)z, numel, (bf16_t*)dz);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -378,10 +378,10 @@ extern "C" int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, 
     const size_t lds = (size_t)(hd + S + 16) * sizeof(float);
     const dim3 grid((unsigned)(S * B * heads));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(mha_fwd_k<float>, grid, dim3(256), lds, s, (const float*)qkv, S, B, heads, hd, scale,
+        PAI_LAUNCH(mha_fwd_k<float>, grid, dim3(256), lds, s, (const float*)qkv, S, B, heads, hd, scale,
                            (float*)out, probs, mask);
     else
-        hipLaunchKernelGGL(mha_fwd_k<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)qkv, S, B, heads, hd, scale,
+        PAI_LAUNCH(mha_fwd_k<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)qkv, S, B, heads, hd, scale,
                            (bf16_t*)out, probs, mask);
     PAI_LAUNCH_CHECK();
     return 0;
@@ -396,14 +396,14 @@ extern "C" int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const f
     const size_t lds_q = (size_t)(hd + S + 16) * sizeof(float), lds_kv = (size_t)(2 * S) * sizeof(float);
     const dim3 grid((unsigned)(S * B * heads));
     if (dtype == PAI_F32) {
-        hipLaunchKernelGGL(mha_bwd_q_k<float>, grid, dim3(256), lds_q, s, (const float*)dout, (const float*)qkv, probs,
+        PAI_LAUNCH(mha_bwd_q_k<float>, grid, dim3(256), lds_q, s, (const float*)dout, (const float*)qkv, probs,
                            S, B, heads, hd, scale, (float*)dqkv, ds_workspace, mask);
-        hipLaunchKernelGGL(mha_bwd_kv_k<float>, grid, dim3(256), lds_kv, s, (const float*)dout, (const float*)qkv,
+        PAI_LAUNCH(mha_bwd_kv_k<float>, grid, dim3(256), lds_kv, s, (const float*)dout, (const float*)qkv,
                            probs, ds_workspace, S, B, heads, hd, scale, (float*)dqkv, mask);
     } else {
-        hipLaunchKernelGGL(mha_bwd_q_k<bf16_t>, grid, dim3(256), lds_q, s, (const bf16_t*)dout, (const bf16_t*)qkv,
+        PAI_LAUNCH(mha_bwd_q_k<bf16_t>, grid, dim3(256), lds_q, s, (const bf16_t*)dout, (const bf16_t*)qkv,
                            probs, S, B, heads, hd, scale, (bf16_t*)dqkv, ds_workspace, mask);
-        hipLaunchKernelGGL(mha_bwd_kv_k<bf16_t>, grid, dim3(256), lds_kv, s, (const bf16_t*)dout, (const bf16_t*)qkv,
+        PAI_LAUNCH(mha_bwd_kv_k<bf16_t>, grid, dim3(256), lds_kv, s, (const bf16_t*)dout, (const bf16_t*)qkv,
                            probs, ds_workspace, S, B, heads, hd, scale, (bf16_t*)dqkv, mask);
     }
     PAI_LAUNCH_CHECK();
@@ -447,11 +447,11 @@ static int subsample_launch(const char* who, bool bwd, int dtype, const void* sr
     const int64_t total = bwd ? (int64_t)N * H * W * C : (int64_t)N * (H / 2) * (W / 2) * C;
     const dim3 grid(ew_blocks(total));
     if (dtype == PAI_F32) {
-        if (bwd) hipLaunchKernelGGL((subsample2_k<float, true>), grid, dim3(256), 0, s, (const float*)src, N, H, W, C, (float*)dst);
-        else hipLaunchKernelGGL((subsample2_k<float, false>), grid, dim3(256), 0, s, (const float*)src, N, H, W, C, (float*)dst);
+        if (bwd) PAI_LAUNCH((subsample2_k<float, true>), grid, dim3(256), 0, s, (const float*)src, N, H, W, C, (float*)dst);
+        else PAI_LAUNCH((subsample2_k<float, false>), grid, dim3(256), 0, s, (const float*)src, N, H, W, C, (float*)dst);
     } else {
-        if (bwd) hipLaunchKernelGGL((subsample2_k<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)src, N, H, W, C, (bf16_t*)dst);
-        else hipLaunchKernelGGL((subsample2_k<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)src, N, H, W, C, (bf16_t*)dst);
+        if (bwd) PAI_LAUNCH((subsample2_k<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)src, N, H, W, C, (bf16_t*)dst);
+        else PAI_LAUNCH((subsample2_k<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)src, N, H, W, C, (bf16_t*)dst);
     }
     PAI_LAUNCH_CHECK();
     return 0;
@@ -520,9 +520,9 @@ extern "C" int pai_bn_stats(int dtype, const void* z, int64_t M, int C, float* s
     const int64_t rps = bn_stats_rps(M);
     const dim3 grid((unsigned)((M + rps - 1) / rps));
     if (dtype == PAI_F32)
-        hipLaunchKernelGGL(bn_stats_k<float>, grid, dim3(256), 0, s, (const float*)z, M, C, rps, stats);
+        PAI_LAUNCH(bn_stats_k<float>, grid, dim3(256), 0, s, (const float*)z, M, C, rps, stats);
     else
-        hipLaunchKernelGGL(bn_stats_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)z, M, C, rps, stats);
+        PAI_LAUNCH(bn_stats_k<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)z, M, C, rps, stats);
     PAI_LAUNCH_CHECK();
     return 0;
 }

@@ -71,6 +71,18 @@ class GradReducer:
         self._foreign_params: List[torch.nn.Parameter] = []
         self.stats = {"buckets": 0, "bytes": 0}
 
+    plannable = False      # plan.PlannedStep: the exchange contains torch-launched kernels (averaging, staging copies)
+
+    def rccl_ranks(self) -> int:
+        """Ranks of the RCCL communicator the buckets actually travel over: the C-ABI communicator's own count, or the
+        size of the torch.distributed group when its backend is "nccl" (= RCCL on ROCm); 0 when the exchange is not RCCL
+        (gloo, one rank)."""
+        if self.comm is not None:
+            return int(self.comm.world)
+        if dist.is_initialized() and dist.get_backend(self.pg) == "nccl":
+            return int(dist.get_world_size(self.pg))
+        return 0
+
     # ---- wiring ---------------------------------------------------------------------------
     def attach(self, model: torch.nn.Module):
         """Hook every HIP engine found under ``model``; remember the parameters that are not

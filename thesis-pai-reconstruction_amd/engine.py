@@ -84,6 +84,7 @@ class GradArena:
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.views = {}
         self.params = []
+        self._zero_small = self._zero_all = None
         self._small = []      # segments that are ACCUMULATED into (BatchNorm gamma / beta) or never written (conv biases in
         #                       front of a BatchNorm): cleared per backward pass; the conv weights are overwritten instead
         for p, mod in entries:
@@ -120,7 +121,16 @@ class GradArena:
         grads = [p.grad for p in params if p.requires_grad]
         if all(g is None for g in grads):
             if overwrite_weights and self._small:
-                torch._foreach_zero_(self._small)
+                if self.flat.is_cuda:
+                    if self._zero_small is None:
+                        self._zero_small = ops.ZeroList(self._small)
+                    self._zero_small()       # one pai_zero_multi launch: a node of the launch plan like everything else
+                else:
+                    torch._foreach_zero_(self._small)
+            elif self.flat.is_cuda:
+                if self._zero_all is None:
+                    self._zero_all = ops.ZeroList([self.flat])
+                self._zero_all()
             else:
                 self.flat.zero_()
             return True
@@ -231,6 +241,10 @@ class _Packs:
         (self.wf, self.wd), self._spare = self._spare, (self.wf, self.wd)
         self._mark(self.dtype)
 
+    def commit_replayed(self):
+        """``commit`` for a step replayed from a launch plan: the recorded Adam launch has filled the spare set."""
+        self.commit()
+
     def get(self, dtype):
         if self._stale(dtype):
             w, cout, taps, cin, wf_out, wd_out = self._prepare(dtype)
@@ -320,6 +334,7 @@ class _SideStream:
         self.stream = None
         self.stream2 = None
         self.scratch_ev = None
+        self._scratch_marked = False
         self.on = _SideStream.enabled and os.environ.get("PAI_NO_OVERLAP", "0") in ("", "0")
         # optional cap (GFLOP per launch) on what goes to the side stream.  Measured at batch 64: the
         # gain comes from co-scheduling the BIG layers (11.68 -> 11.15 ms/step); small layers alone
@@ -334,7 +349,7 @@ class _SideStream:
             return torch.cuda.current_stream()
         if self.stream is None:
             self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
+        ops.stream_wait(self.stream, torch.cuda.current_stream())      # C-ABI edge: recorded into launch plans
         return self.stream
 
     def fork_tail(self):
@@ -345,24 +360,25 @@ class _SideStream:
             return torch.cuda.current_stream()
         if self.stream2 is None:
             self.stream2 = torch.cuda.Stream()
-        self.stream2.wait_stream(torch.cuda.current_stream())
-        if self.scratch_ev is not None:
+        ops.stream_wait(self.stream2, torch.cuda.current_stream())
+        if self._scratch_marked:
             # the thin weight-gradient kernels share the tail of the registered scratch buffer
-            self.stream2.wait_event(self.scratch_ev)
+            self.scratch_ev.wait(self.stream2)
         return self.stream2
 
     def mark_scratch(self):
         """Call inside the side-stream context right after a thin-layer weight gradient has been issued."""
         if self.on and self.stream is not None:
             if self.scratch_ev is None:
-                self.scratch_ev = torch.cuda.Event()
+                self.scratch_ev = ops.Event()
             self.scratch_ev.record(self.stream)
+            self._scratch_marked = True
 
     def join(self):
         if self.on and self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            ops.stream_wait(torch.cuda.current_stream(), self.stream)
         if self.on and self.stream2 is not None:
-            torch.cuda.current_stream().wait_stream(self.stream2)
+            ops.stream_wait(torch.cuda.current_stream(), self.stream2)
 
 
 # --------------------------------------------------------------------------------------
@@ -441,7 +457,13 @@ class UnetEngine:
         return self._arena
 
     def pack_targets(self):
-        return pack_targets(self.arena(), self.enc_packs + self.dec_packs)
+        arena = self.arena()
+        if getattr(self, "_pt_cache", (None, None))[0] is not arena:
+            self._pt_cache = (arena, pack_targets(arena, self.enc_packs + self.dec_packs))
+        return self._pt_cache[1]
+
+    def all_packs(self):
+        return self.enc_packs + self.dec_packs
 
     # ---- plan / buffers ------------------------------------------------------------------
     def _plan(self, N, H, W, dtype, device):
@@ -812,7 +834,13 @@ class DiscEngine:
         return self._arena
 
     def pack_targets(self):
-        return pack_targets(self.arena(), self.packs)
+        arena = self.arena()
+        if getattr(self, "_pt_cache", (None, None))[0] is not arena:
+            self._pt_cache = (arena, pack_targets(arena, self.packs))
+        return self._pt_cache[1]
+
+    def all_packs(self):
+        return self.packs
 
     def _plan(self, N, H, W, dtype, device):
         key = (N, H, W, dtype, str(device))

@@ -128,6 +128,60 @@ class DiscPairsFunction(torch.autograd.Function):
         return (None,) * (5 + len(params))
 
 
+class DiscGenLossFunction(torch.autograd.Function):
+    """The generator's GAN loss in one node: ``BCE(D(x, pred), 1) + l1_weight * L1(pred, target)`` (reference
+    models/wrapper.py:44-50).  ``pred`` feeds both terms; as two autograd nodes their gradients meet in an aten ``add``
+    that torch launches itself -- the one kernel of the GAN step outside the C ABI, which a launch plan (plan.py) cannot
+    contain.  Here the backward pass runs the discriminator's input gradient and adds the L1 term with ``pai_add_act``.
+    Gradients flow to ``pred`` and, when they require them, to the discriminator's parameters."""
+
+    @staticmethod
+    def forward(ctx, x, pred, target, engine, dtype, l1_weight, *params):
+        _check_f32_cuda(x, pred, target)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise ops.PaiError("gradient w.r.t. the conditioning image / the target is not supported")
+        logits, slot = engine.forward(x, pred, dtype)
+        pc, tc = pred.contiguous().float(), target.contiguous().float()
+        need_pred, need_params = ctx.needs_input_grad[1], any(ctx.needs_input_grad[6:])
+        need = need_pred or need_params
+        gl = torch.empty_like(logits) if need else None
+        gp = torch.empty_like(pc) if need_pred else None
+        ent = _ACC.get(pc.device, "gan_g")
+        ops.bce_logits(logits, 1.0, 1.0, ent[0], 1.0, gl)
+        ops.l1(pc, tc, float(l1_weight), ent[0], float(l1_weight), gp)
+        out = torch.empty((), dtype=torch.float32, device=pc.device)
+        ops.scalar_take(ent[0], out)
+        _ACC.taken(ent)
+        if need:
+            ctx.engine, ctx.ref, ctx.params = engine, _SlotRef(engine, slot), params
+            ctx.need_pred, ctx.need_params = need_pred, need_params
+            ctx.save_for_backward(*[g for g in (gl, gp) if g is not None])
+        else:
+            engine.release(slot)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        engine, slot, params = ctx.engine, ctx.ref.take(), ctx.params
+        saved = list(ctx.saved_tensors)
+        gl = _scaled(saved.pop(0), gout)
+        fresh = False
+        if ctx.need_params:
+            arena = engine.arena()
+            fresh = arena.begin_backward(params, overwrite_weights=True)
+        gy = engine.backward(slot, gl, ctx.need_params, ctx.need_pred, fresh)
+        if ctx.need_params:
+            arena.attach(params)
+        engine.release(slot)
+        if ctx.need_pred:
+            gp = _scaled(saved.pop(0), gout)
+            if gy.is_contiguous() and gy.numel() % 8 == 0:
+                ops.add_act(torch.float32, gy, gp, ops.ACT_NONE, gy)
+            else:
+                gy = gy + gp
+        return (None, gy, None, None, None, None) + (None,) * len(params)
+
+
 # --------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ class GraphedStep:
             eng = getattr(mod, "engine", None) if hasattr(type(mod), "engine") else None
             side = getattr(eng, "_side", None)
             if side is not None:
-                side.scratch_ev = None
+                side._scratch_marked = False
         self.static = tuple(torch.empty_like(b) for b in batch)
         for s, b in zip(self.static, batch):
             s.copy_(b)

@@ -146,6 +146,18 @@ SIGNATURES = {
     "pai_comm_destroy": (_I, [_P]),
     "pai_adam_multi": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "pai_adam_multi_dev": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _P]),
+    "pai_plan_create": (_I, [C.POINTER(_P)]),
+    "pai_plan_destroy": (_I, [_P]),
+    "pai_plan_begin": (_I, [_P]),
+    "pai_plan_end": (_I, [_P]),
+    "pai_plan_run": (_I, [_P, _L]),
+    "pai_plan_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_L)]),
+    "pai_stream_wait": (_I, [_P, _P]),
+    "pai_event_create": (_I, [C.POINTER(_P)]),
+    "pai_event_destroy": (_I, [_P]),
+    "pai_event_record": (_I, [_P, _P]),
+    "pai_stream_wait_event": (_I, [_P, _P]),
+    "pai_zero_multi": (_I, [_I, _P, _P, _P]),
 }
 
 _lib = None

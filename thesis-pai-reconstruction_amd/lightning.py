@@ -482,6 +482,15 @@ class Trainer:
             cb.on_fit_start(self, model)
         if ckpt_path is not None:
             self.restore(model, ckpt_path)
+        # The training step as one C call (plan.PlannedStep): recorded after a few eager steps, replayed from then on;
+        # anything it cannot own (torch-launched kernels inside the step, dropout masks, CPU tensors) makes it step aside
+        # and the call below IS model.training_step.  PAI_PLAN=0 turns it off.
+        step_fn = model.training_step
+        self.planned_step = None
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            from . import plan as _plan
+            if _plan.enabled_by_default():
+                self.planned_step = step_fn = _plan.PlannedStep(model)
         t0 = time.time()
         done = False
         epoch = self.current_epoch
@@ -491,7 +500,7 @@ class Trainer:
                 train_loader.set_epoch(epoch)
             for bi, batch in enumerate(DevicePrefetcher(train_loader, self.device)):
                 self._step_logs = {}
-                model.training_step(batch, bi)
+                step_fn(batch, bi)
                 self.batches_seen += 1
                 self.global_step = model._pai_opt_steps
                 for cb in self.callbacks:

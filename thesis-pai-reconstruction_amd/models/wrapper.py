@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as PF
+from .. import ops
 from ..engine import DiscEngine
 from ..lightning import LightningModule
 from .utils import denormalize, init_weights, psnr, rmse, ssim  # noqa: F401
@@ -49,6 +50,10 @@ class UnetWrapper(LightningModule):
     def loss(self, x, pred, target):
         """Reference models/wrapper.py:42-66."""
         if self.loss_type == "gan":
+            if pred.is_cuda and getattr(self.discriminator, "supports_fused_generator_loss", False):
+                # D(x, pred) -> BCE + L1_WEIGHT * L1 as ONE autograd node: the two gradients w.r.t. pred are summed by a
+                # C-ABI launch instead of autograd's own aten add (the step then contains no kernel of torch's)
+                return self.discriminator.generator_loss(x, pred, target, L1_WEIGHT)
             pred_label = self.discriminator(x, pred)
             if pred.is_cuda:
                 # bce(pred_label, ones) + L1_WEIGHT * l1(pred, target) in three launches, no tensor-op glue
@@ -95,13 +100,13 @@ class UnetWrapper(LightningModule):
         if side is None:
             side = torch.cuda.Stream(device=pred.device)
             object.__setattr__(self, "_metrics_stream", side)
-        side.wait_stream(torch.cuda.current_stream())
+        ops.stream_wait(side, torch.cuda.current_stream())      # C-ABI edges: part of a recorded launch plan
         with torch.cuda.stream(side):
             return PF.metrics_of_normalized(pred, target)
 
     def _metrics_join(self, vals):
         cur = torch.cuda.current_stream()
-        cur.wait_stream(self._metrics_stream)
+        ops.stream_wait(cur, self._metrics_stream)
         for v in vals:
             v.record_stream(cur)   # allocated on the side stream's pool, consumed on this one
         return vals
@@ -224,6 +229,7 @@ class Discriminator(nn.Module):
         self.in_channels = in_channels
         self.compute_dtype = torch.float32
         self.supports_batched_pairs = True
+        self.supports_fused_generator_loss = True
         self.discriminator = nn.Sequential(
             DiscriminatorBlock(in_channels * 2, 64, norm=False),
             DiscriminatorBlock(64, 128),
@@ -243,6 +249,13 @@ class Discriminator(nn.Module):
         eng = self.engine
         params = [p for p, _ in eng.ordered_params()]
         return PF.DiscFunction.apply(x, y, eng, self.compute_dtype, *params)
+
+    def generator_loss(self, x, y, target, l1_weight):
+        """``bce(forward(x, y), ones) + l1_weight * l1(y, target)`` (the "gan" branch of reference
+        models/wrapper.py:44-50) as one autograd node (``PF.DiscGenLossFunction``)."""
+        eng = self.engine
+        params = [p for p, _ in eng.ordered_params()]
+        return PF.DiscGenLossFunction.apply(x, y, target, eng, self.compute_dtype, float(l1_weight), *params)
 
     def forward_pairs(self, x, y_real, y_fake):
         """``forward(cat([x, x]), cat([y_real, y_fake]))`` without the concatenations; inputs carry no gradient."""

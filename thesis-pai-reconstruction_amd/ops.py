@@ -679,6 +679,120 @@ def adam_multi_dev(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, 
             "pai_adam_multi_dev")
 
 
+# ---- streams, events, launch plans (include/pai_hip.h: "Launch plans") --------------------------------------------
+def _raw(stream) -> int:
+    return stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+
+
+def stream_wait(waiting, signalling) -> None:
+    """``waiting.wait_stream(signalling)`` through the C ABI (pai_stream_wait), so that the edge is part of a plan being
+    recorded.  Takes torch streams or raw handles."""
+    L.check(L.load().pai_stream_wait(_raw(waiting), _raw(signalling)), "pai_stream_wait")
+
+
+class Event:
+    """A caller-owned event of the C ABI (pai_event_*): ``record(stream)`` now, ``wait(stream)`` later."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        L.check(L.load().pai_event_create(C.byref(self._h)), "pai_event_create")
+
+    def record(self, stream=None):
+        L.check(L.load().pai_event_record(self._h, _raw(stream) if stream is not None else _stream()), "pai_event_record")
+
+    def wait(self, stream=None):
+        L.check(L.load().pai_stream_wait_event(_raw(stream) if stream is not None else _stream(), self._h),
+                "pai_stream_wait_event")
+
+    # never destroyed: a recorded plan may hold the handle (see the header); one event per side stream per process
+
+
+def zero_multi(tensors) -> None:
+    """t.zero_() for a list of contiguous fp32 HIP tensors in one launch per 96 (pai_zero_multi)."""
+    n = len(tensors)
+    if n == 0:
+        return
+    for t in tensors:
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise PaiError("zero_multi needs contiguous fp32 HIP tensors")
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    numels = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    L.check(L.load().pai_zero_multi(n, ptrs, numels, _stream()), "pai_zero_multi")
+
+
+class ZeroList:
+    """``zero_multi`` of a FIXED tensor list with the pointer tables built once (a gradient arena clears the same ~45
+    segments in front of every backward pass)."""
+
+    def __init__(self, tensors):
+        for t in tensors:
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise PaiError("ZeroList needs contiguous fp32 HIP tensors")
+        self.keep = list(tensors)
+        self.n = len(self.keep)
+        self.ptrs = (C.c_void_p * max(self.n, 1))(*[t.data_ptr() for t in self.keep])
+        self.numels = (C.c_int64 * max(self.n, 1))(*[t.numel() for t in self.keep])
+
+    def __call__(self):
+        if self.n:
+            L.check(L.load().pai_zero_multi(self.n, self.ptrs, self.numels, _stream()), "pai_zero_multi")
+
+
+class Plan:
+    """A recorded launch sequence of libpai_hip.so (pai_plan_*).  ``with plan.recording(): ...`` executes the body
+    normally while every launch the library makes (from any thread) is appended; ``run(step_delta)`` re-issues them."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        L.check(L.load().pai_plan_create(C.byref(self._h)), "pai_plan_create")
+        self.recorded = False
+
+    def begin(self):
+        L.check(L.load().pai_plan_begin(self._h), "pai_plan_begin")
+
+    def end(self):
+        L.check(L.load().pai_plan_end(self._h), "pai_plan_end")
+        self.recorded = True
+
+    def recording(self):
+        plan = self
+
+        class _Ctx:
+            def __enter__(self_):
+                plan.begin()
+                return plan
+
+            def __exit__(self_, *exc):
+                plan.end()
+                return False
+        return _Ctx()
+
+    def run(self, step_delta: int = 0):
+        rc = self._run(self._h, step_delta)
+        if rc:
+            L.check(rc, "pai_plan_run")
+
+    @property
+    def _run(self):
+        return L.load().pai_plan_run
+
+    def info(self) -> dict:
+        a, b, c, r = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        L.check(L.load().pai_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(r)), "pai_plan_info")
+        return {"launches": a.value, "waits": b.value, "streams": c.value, "runs": r.value}
+
+    def destroy(self):
+        if self._h:
+            L.check(L.load().pai_plan_destroy(self._h), "pai_plan_destroy")
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:       # interpreter shutdown / still recording
+            pass
+
+
 class Comm:
     """RCCL communicator behind the C ABI (pai_comm_* / pai_allreduce): in-place SUM all-reduce of device tensors on the
     current stream.  ``unique_id()`` on rank 0, ship the 128 bytes to the other ranks, then ``Comm(id, rank, world)``

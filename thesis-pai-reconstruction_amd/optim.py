@@ -38,6 +38,7 @@ class ArenaAdam(torch.optim.Adam):
         self._fuse_packs = os.environ.get("PAI_ADAM_PACK", "1") not in ("", "0")
         self._pack_targets = None      # armed step without a reducer: the engine's pack_targets()
         self._packs_written = []       # _Packs whose spare buffers the armed step has filled; committed by step()
+        self._last_commits = []        # ... of the most recent step() (plan_commits)
 
     # ---- hipGraph support -----------------------------------------------------------------------------
     def enable_device_step(self):
@@ -51,6 +52,41 @@ class ArenaAdam(torch.optim.Adam):
 
     def note_replays(self, n: int = 1):
         self._arena_steps += n
+
+    # ---- launch-plan support (plan.PlannedStep) -----------------------------------------------------------------
+    def plan_state(self):
+        """Hashable signature of everything a recorded training step froze about this optimizer and its engine: the
+        update rule's constants, the arenas and WHICH of the double-buffered filter packs is current (the streamed update
+        writes the spare set and ``step()`` swaps, so the roles alternate from step to step).  None while the optimizer
+        is not in its steady state (parameters not adopted by the arena yet, packs stale, a device-side step count)."""
+        eng = self._engine
+        arena = eng.arena()
+        if self._dev_step is not None or self._streamed is not None or not arena.params_adopted():
+            return None
+        if len(self.param_groups) != 1:
+            return None
+        g = self.param_groups[0]
+        ptrs = []
+        for pk in eng.all_packs():
+            if pk.wf is None or pk.dtype is None:
+                return None
+            ptrs.append(pk.wf.data_ptr())
+        for t in (eng.pack_targets() if self._fuse_packs else ()):
+            if t[5].dtype == torch.bfloat16 and t[5]._stale(t[5].dtype):      # fp32: the parameter IS the pack
+                return None
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), arena.flat.data_ptr(),
+                arena.pflat.data_ptr(), tuple(ptrs))
+
+    def plan_commits(self):
+        """The layers whose spare packs the LAST ``step()`` committed (what a replay of that step has to commit too)."""
+        return list(self._last_commits)
+
+    def plan_replayed(self, commits):
+        """Host-side bookkeeping of one replayed step: what ``step()`` does besides launching."""
+        self._arena_steps += 1
+        self._engine.weights_generation[0] += 1
+        for pk in commits:
+            pk.commit_replayed()
 
     # ---- streaming step -------------------------------------------------------------------------------
     def arm_streaming(self) -> bool:
@@ -206,6 +242,7 @@ class ArenaAdam(torch.optim.Adam):
         if self._adam_pending:
             torch.cuda.current_stream().wait_stream(self._adam_stream)     # everything behind step() sees the updated ranges
             self._adam_pending = False
+        self._last_commits = []
         arena = self._arena_ready()
         if arena is None:
             if streamed:
@@ -221,6 +258,7 @@ class ArenaAdam(torch.optim.Adam):
             self._engine.weights_generation[0] += 1
             for pk in self._packs_written:      # their spare buffers hold the packs of the weights as they are now
                 pk.commit()
+            self._last_commits = self._packs_written
             self._packs_written = []
             return None
         if self._dev_step is not None:
