@@ -77,7 +77,11 @@ template <class... P, class... A>
 inline void launch(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, A&&... a) {
     static_assert(sizeof...(P) == sizeof...(A), "pai::launch: argument count does not match the kernel's parameters");
     std::tuple<P...> t(static_cast<P>(a)...);
-    if (recording()) plan_push(new KernelOp<P...>(k, g, b, (unsigned)sh, st, t, plan_take_adam()));
+    if (recording()) {
+        AdamPatch patch = plan_take_adam();
+        if (patch.active && (patch.arg_lr_over_bc1 >= (int)sizeof...(P) || patch.arg_inv_sqrt_bc2 >= (int)sizeof...(P))) patch.active = 0;
+        plan_push(new KernelOp<P...>(k, g, b, (unsigned)sh, st, t, patch));
+    }
     (void)launch_now(k, g, b, (unsigned)sh, st, t, std::index_sequence_for<P...>{});   // errors surface in PAI_LAUNCH_CHECK
 }
 

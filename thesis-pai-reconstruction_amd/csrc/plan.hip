@@ -44,7 +44,10 @@ void plan_push(PlanOp* op) {
 }
 
 void plan_mark_adam(int a_lr, int a_bc2, double lr, double beta1, double beta2, int64_t step) {
-    t_adam = {1, a_lr, a_bc2, lr, beta1, beta2, step};
+    // only while a plan is being recorded: the mark is consumed by the launch that follows on this thread, and a mark
+    // left behind by an un-recorded call would be applied to whatever kernel this thread records next
+    if (recording()) t_adam = {1, a_lr, a_bc2, lr, beta1, beta2, step};
+    else t_adam.active = 0;
 }
 
 AdamPatch plan_take_adam() {
@@ -95,7 +98,7 @@ struct WaitOp final : PlanOp {
 // still pending.
 static const int RING = 256, MAX_DEV = 16;
 static hipEvent_t g_ring[MAX_DEV][RING];
-static bool g_ring_made[MAX_DEV];
+static std::atomic<bool> g_ring_made[MAX_DEV];
 static std::atomic<unsigned> g_ring_next{0};
 static std::mutex g_ring_mu;
 
@@ -104,14 +107,14 @@ static hipError_t ring_event(hipEvent_t* out) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
-    if (!g_ring_made[dev]) {
+    if (!g_ring_made[dev].load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lk(g_ring_mu);
-        if (!g_ring_made[dev]) {
+        if (!g_ring_made[dev].load(std::memory_order_relaxed)) {
             for (int i = 0; i < RING; ++i) {
                 e = hipEventCreateWithFlags(&g_ring[dev][i], hipEventDisableTiming);
                 if (e != hipSuccess) return e;
             }
-            g_ring_made[dev] = true;
+            g_ring_made[dev].store(true, std::memory_order_release);
         }
     }
     *out = g_ring[dev][g_ring_next.fetch_add(1) % RING];

@@ -907,10 +907,7 @@ class DiscEngine:
             for src, dst in ((x, S["x"][:half]), (x, S["x"][half:]), (y, S["y"][:half]), (y2, S["y"][half:])):
                 t = src.detach().to(torch.float32)
                 t = t.contiguous() if C == 1 else t.permute(0, 2, 3, 1).contiguous()
-                if dtype == torch.float32:
-                    dst.copy_(t.reshape(-1))
-                else:
-                    ops.cast(t, dst)
+                ops.cast(t, dst)       # fp32 too: a C-ABI copy (a node of the launch plan), not torch's copy_
             S["xin"], S["yin"] = S["x"], S["y"]
         refresh_packs(self.packs, dtype)
         wf, _ = self.packs[0].get(dtype)
@@ -978,10 +975,7 @@ class DiscEngine:
         if not need_dy:
             return None
         gy = torch.empty(N * H * W * self.in_ch, dtype=torch.float32, device=dev)
-        if dtype == torch.float32:
-            gy.copy_(G["dy"])
-        else:
-            ops.cast(G["dy"], gy)
+        ops.cast(G["dy"], gy)
         if self.in_ch == 1:
             return gy.view(N, 1, H, W)
         return gy.view(N, H, W, self.in_ch).permute(0, 3, 1, 2)

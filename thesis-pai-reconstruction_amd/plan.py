@@ -207,7 +207,7 @@ class PlannedStep:
 
     def describe(self) -> dict:
         return {"plans": len(self.plans), "records": self.records, "replays": self.replays, "disabled": self.disabled,
-                "nodes": [r.info for r in self.plans.values()]}
+                "nodes": [r.plan.info() for r in self.plans.values()]}
 
 
 def enabled_by_default() -> bool:
