@@ -589,6 +589,9 @@ int pai_stream_wait_event(void* waiting_stream, pai_event_t ev);
  * segments of a gradient arena in front of a backward pass (replaces torch._foreach_zero_, so that the clear is a node
  * of the plan like everything else). */
 int pai_zero_multi(int count, void* const* ptrs, const int64_t* numels, void* stream);
+/* ptr[0 .. numel) *= factor (fp32, 16-byte aligned): the x 1/world_size average behind the SUM all-reduce of a gradient
+ * bucket (DDP averages, reference main.py:123-136 through pl.Trainer), as a node of the plan. */
+int pai_scale(float* ptr, int64_t numel, float factor, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,3 +43,34 @@ def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
 
 def max_err(got, want) -> float:
     return float((got.double() - want.double()).abs().max() / max(float(want.double().abs().max()), 1e-30))
+
+
+# ---- training-state copies between two models (launch-plan / graph tests) -------------------------------------
+def sync_training_state(src, dst):
+    """dst <- src, in place (a recorded plan holds the addresses): parameters, BatchNorm buffers, Adam moments."""
+    with torch.no_grad():
+        sd = dst.state_dict()
+        for k, v in src.state_dict().items():
+            sd[k].copy_(v)
+        for os_, od in zip(src._all_optimizers(), dst._all_optimizers()):
+            a_s, a_d = os_._engine.arena(), od._engine.arena()
+            if getattr(a_s, "mflat", None) is not None and getattr(a_d, "mflat", None) is not None:
+                a_d.mflat.copy_(a_s.mflat)
+                a_d.vflat.copy_(a_s.vflat)
+        # the bf16 filter packs follow the master weights: the copy above went behind the engines' backs
+        for mod in dst.modules():
+            eng = getattr(mod, "engine", None) if hasattr(type(mod), "engine") else None
+            if eng is not None:
+                repack(eng)
+
+
+def repack(eng):
+    """Rewrite the CURRENT packs of every layer from the (just overwritten) master weights, in place."""
+    from thesis_pai_reconstruction_amd import ops
+    for pk in eng.all_packs():
+        if pk.dtype is None or pk.wf is None:
+            continue
+        w, cout, taps, cin, wf_out, wd_out = pk._prepare(pk.dtype)
+        if wf_out is not None or wd_out is not None:
+            ops.pack_weights(pk.dtype, w, cout, taps, cin, wf_out, wd_out)
+        pk._mark(pk.dtype)

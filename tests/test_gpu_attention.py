@@ -355,3 +355,38 @@ def test_baseline_config_properties(pai):
         first = first or vals
     assert vals["train_rmse"] < first["train_rmse"]
     assert int(m.unet.attention_blocks[0].attention[1].num_batches_tracked) == 1 + 2 * 4
+
+
+def test_rgb_encoder0_gradient_is_not_accumulated_across_steps(pai):
+    """in_channels = 3 (the class default of AttentionUnet, reference models/attention_unet.py:27-34): encoder 0 is then
+    NOT a thin layer, its weight-gradient segment is not among the cleared small ones and has to be overwritten on the
+    first backward pass of every step.  Two "mse" steps against the oracle: the second step's gradient of every
+    parameter must be that step's gradient, not the running sum of both."""
+    mults = (1, 2, 2)
+    rng = np.random.default_rng(77)
+    m = pai.AttentionUnetGAN(in_channels=3, out_channels=3, channel_mults=mults, dropout=0.0, loss_type="mse")
+    g = oracle.init_state_portable(oracle.make_attention_unet_state(3, 3, mults), 5, perturb_bn=True)
+    m.unet.load_state_dict(g, strict=True)
+    m.to(DEV)
+    m.set_precision("32")
+    m.train()
+    og = oracle.AdamState()
+    for step in range(2):
+        x = torch.from_numpy(rng.random((2, 3, 32, 32), dtype=np.float32) * 2 - 1)
+        t = torch.from_numpy(rng.random((2, 3, 32, 32), dtype=np.float32) * 2 - 1)
+        want_logs, want = oracle.gan_training_step(g, None, og, None, x, t, loss_type="mse", return_grads=True)
+        m.logged = {}
+        m.training_step((x.to(DEV), t.to(DEV)), step)
+        assert abs(float(m.logged["loss"]) - float(want_logs["loss"])) <= 1e-4 * max(1.0, abs(float(want_logs["loss"]))), step
+        bad = []
+        for k, p in m.unet.named_parameters():
+            if _zero_grad_bias(k, set(g.keys())):
+                continue
+            w = want["g"][k]
+            e = float((p.grad.cpu() - w).norm() / max(float(w.norm()), 1e-30))
+            # step 1 starts from parameters one Adam step (+-lr per element, sign-like) away from the oracle's: its bound
+            # only separates "this step's gradient" from "the sum of both steps'" (relative error ~1)
+            tol = (2e-3 if p.numel() > 1 else 2e-2) if step == 0 else 0.3
+            if e >= tol:
+                bad.append((step, k, e))
+        assert not bad, bad

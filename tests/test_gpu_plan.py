@@ -9,6 +9,7 @@ import torch
 
 import oracle
 from oracle.gen_golden import synth_batch
+from _gpu_util import sync_training_state as _sync_training_state
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -27,36 +28,6 @@ def _build(pai, family, mults, seed, dtype):
     m.set_precision("32" if dtype == torch.float32 else "bf16-mixed")
     m.train()
     return m
-
-
-def _sync_training_state(src, dst):
-    """dst <- src, in place (a recorded plan holds the addresses): parameters, BatchNorm buffers, Adam moments."""
-    with torch.no_grad():
-        sd = dst.state_dict()
-        for k, v in src.state_dict().items():
-            sd[k].copy_(v)
-        for os_, od in zip(src._all_optimizers(), dst._all_optimizers()):
-            a_s, a_d = os_._engine.arena(), od._engine.arena()
-            if getattr(a_s, "mflat", None) is not None and getattr(a_d, "mflat", None) is not None:
-                a_d.mflat.copy_(a_s.mflat)
-                a_d.vflat.copy_(a_s.vflat)
-        # the bf16 filter packs follow the master weights: the copy above went behind the engines' backs
-        for mod in dst.modules():
-            eng = getattr(mod, "engine", None) if hasattr(type(mod), "engine") else None
-            if eng is not None:
-                _repack(eng)
-
-
-def _repack(eng):
-    """Rewrite the CURRENT packs of every layer from the (just overwritten) master weights, in place."""
-    from thesis_pai_reconstruction_amd import ops
-    for pk in eng.all_packs():
-        if pk.dtype is None or pk.wf is None:
-            continue
-        w, cout, taps, cin, wf_out, wd_out = pk._prepare(pk.dtype)
-        if wf_out is not None or wd_out is not None:
-            ops.pack_weights(pk.dtype, w, cout, taps, cin, wf_out, wd_out)
-        pk._mark(pk.dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

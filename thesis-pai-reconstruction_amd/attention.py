@@ -381,6 +381,10 @@ class AttentionUnetEngine(UnetEngine):
             fused_rows = enc_dgrad(i, dz, wd)
         conv0 = self.enc_conv[0]
         with torch.cuda.stream(side.fork_tail()):
-            ops.conv_wgrad(P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
+            # same selection as the local wgrad(): with in_channels >= 3 encoder 0 is not a thin layer, its segment is NOT
+            # among the cleared small ones (GradArena._small) and must be overwritten on the first pass, not added to
+            c0_in, c0_out = conv0.weight.shape[1], conv0.weight.shape[0]
+            (ops.conv_wgrad_overwrite_w if (fresh and min(c0_in, c0_out) > 2) else ops.conv_wgrad)(
+                P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
         side.join()
         done(conv0.bias)

@@ -595,3 +595,24 @@ extern "C" int pai_zero_multi(int count, void* const* ptrs, const int64_t* numel
     }
     return 0;
 }
+
+// ---- x *= factor over an fp32 buffer (the 1 / world_size average behind a SUM all-reduce) ------------------------------
+__global__ __launch_bounds__(256) void scale_k(float* p, int64_t n4, int64_t n, float f) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = ((float4*)p)[i];
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        ((float4*)p)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] *= f;
+}
+
+extern "C" int pai_scale(float* ptr, int64_t numel, float factor, void* stream) {
+    PAI_CHECK(ptr && numel >= 0 && (((uintptr_t)ptr) & 15) == 0, "pai_scale: bad arguments (16-byte aligned fp32 buffer expected)");
+    if (numel == 0) return 0;
+    int64_t blocks = (numel / 4 + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    PAI_LAUNCH(scale_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ptr, numel / 4, numel, factor);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

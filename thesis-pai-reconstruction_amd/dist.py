@@ -19,13 +19,54 @@ import torch.distributed as dist
 
 
 class _CommWork:
-    """Completion handle of a pai_allreduce issued on the communication stream (mirrors torch's Work.wait())."""
+    """Completion handle of a pai_allreduce issued on the communication stream (mirrors torch's Work.wait()); the event
+    is an ``ops.Event`` of the reducer's pool, so record and wait are C-ABI calls (nodes of a launch plan)."""
 
     def __init__(self, event):
         self.event = event
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self.event)
+        self.event.wait(torch.cuda.current_stream())
+
+
+class _TorchWork:
+    """A torch.distributed collective as a pair of HOST nodes of the launch plan (plan.host_op): ``issue`` launches it
+    (torch's process-group stream waits for the stream that is current at that point), ``wait`` orders the current
+    stream behind it.  Replayed from Python with the same buffers, in the same order, between the C-side segments."""
+
+    def __init__(self, buf, pg):
+        from . import plan as _plan
+        self._plan = _plan
+        self.work = None
+
+        def issue():
+            self.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+        self._plan.host_op(issue)
+
+    def wait(self):
+        self._plan.host_op(lambda: self.work.wait())
+
+
+def _cast(src, dst):
+    """dst <- src across fp32 / bf16: a C-ABI launch on the HIP device (a node of the launch plan), torch's copy_ on CPU."""
+    if src.is_cuda:
+        from . import ops
+        ops.cast(src, dst)
+    else:
+        dst.copy_(src)
+
+
+def _scale(t, f):
+    if t.is_cuda:
+        from . import ops
+        ops.scale_(t, f)
+    else:
+        t.mul_(f)
+
+
+def _stream_wait(waiting, signalling):
+    from . import ops
+    ops.stream_wait(waiting, signalling)
 
 
 def make_rccl_comm(process_group=None):
@@ -61,6 +102,7 @@ class GradReducer:
                 dist.get_world_size(process_group) > 1 and torch.cuda.is_available():
             self.comm = make_rccl_comm(process_group)
         self._comm_stream = None
+        self._events, self._ev_next = [], 0
         self.bucket_elems = max(int(bucket_bytes) // 4, 1)
         self.overlap = overlap
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -71,7 +113,11 @@ class GradReducer:
         self._foreign_params: List[torch.nn.Parameter] = []
         self.stats = {"buckets": 0, "bytes": 0}
 
-    plannable = False      # plan.PlannedStep: the exchange contains torch-launched kernels (averaging, staging copies)
+    def plannable(self) -> bool:
+        """plan.PlannedStep: the arena buckets are exchanged with C-ABI launches (cast, scale, pai_allreduce) plus, on the
+        torch.distributed path, host nodes for the collectives; gradients OUTSIDE the arenas (the composable networks)
+        go through torch-launched staging kernels and cannot be replayed."""
+        return not self._foreign_params
 
     def rccl_ranks(self) -> int:
         """Ranks of the RCCL communicator the buckets actually travel over: the C-ABI communicator's own count, or the
@@ -135,7 +181,7 @@ class GradReducer:
                 if st["stage"] is None:
                     st["stage"] = torch.empty(arena.flat.numel(), dtype=self.grad_dtype, device=buf.device)
                 stage = st["stage"][lo:hi]
-                stage.copy_(buf)                                   # fp32 -> bf16, ordered before the collective
+                _cast(buf, stage)                                  # fp32 -> bf16, ordered before the collective
                 work = self._all_reduce_async(stage)
             fn = self._subs.get(id(arena))
             if fn is None:
@@ -146,8 +192,8 @@ class GradReducer:
                 with torch.cuda.stream(self._post_stream):
                     work.wait()                                    # this stream (only) runs behind the collective
                     if stage is not None:
-                        buf.copy_(stage)
-                    buf.mul_(1.0 / self.world)
+                        _cast(stage, buf)
+                    _scale(buf, 1.0 / self.world)
                     fn(arena, lo, hi)
                 st["post"] = True
                 self.stats["post_buckets"] = self.stats.get("post_buckets", 0) + 1
@@ -158,14 +204,19 @@ class GradReducer:
         """In-place SUM all-reduce of ``buf``, ordered after the work already issued on the current stream; returns a
         handle whose wait() orders the current stream behind the collective."""
         if self.comm is None:
-            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            return _TorchWork(buf, self.pg) if buf.is_cuda else \
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        from . import ops
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
-        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        ops.stream_wait(self._comm_stream, torch.cuda.current_stream())
         with torch.cuda.stream(self._comm_stream):
             self.comm.all_reduce(buf)
-            ev = torch.cuda.Event()
-            ev.record()
+            if self._ev_next == len(self._events):
+                self._events.append(ops.Event())
+            ev = self._events[self._ev_next]      # pooled: the same events in the same order every step (finish() rewinds)
+            self._ev_next += 1
+            ev.record(self._comm_stream)
         buf.record_stream(self._comm_stream)
         return _CommWork(ev)
 
@@ -193,14 +244,15 @@ class GradReducer:
             for w, stage, lo, hi in st["works"]:
                 w.wait()
                 if stage is not None:
-                    st["arena"].flat[lo:hi].copy_(stage)           # reduced bf16 sum back into the fp32 master gradient
+                    _cast(stage, st["arena"].flat[lo:hi])          # reduced bf16 sum back into the fp32 master gradient
             if st["post"]:
                 # every bucket of this arena was averaged (and handed to the subscriber) on the post stream
-                torch.cuda.current_stream(st["arena"].flat.device).wait_stream(self._post_stream)
+                _stream_wait(torch.cuda.current_stream(st["arena"].flat.device), self._post_stream)
             elif self.world > 1:
-                st["arena"].flat.mul_(1.0 / self.world)
+                _scale(st["arena"].flat, 1.0 / self.world)
             self._subs.pop(id(st["arena"]), None)
             st["sent"], st["works"], st["active"], st["post"] = 0, [], False, False
+        self._ev_next = 0
         grads = [p.grad for p in self._foreign_params if p.requires_grad and p.grad is not None]
         if grads and self.world > 1:
             self._reduce_foreign(grads)

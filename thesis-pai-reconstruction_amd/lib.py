@@ -158,6 +158,7 @@ SIGNATURES = {
     "pai_event_record": (_I, [_P, _P]),
     "pai_stream_wait_event": (_I, [_P, _P]),
     "pai_zero_multi": (_I, [_I, _P, _P, _P]),
+    "pai_scale": (_I, [_P, _L, _F, _P]),
 }
 
 _lib = None

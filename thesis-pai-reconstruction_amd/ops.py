@@ -720,6 +720,13 @@ def zero_multi(tensors) -> None:
     L.check(L.load().pai_zero_multi(n, ptrs, numels, _stream()), "pai_zero_multi")
 
 
+def scale_(t, factor: float) -> None:
+    """t *= factor for a contiguous fp32 HIP tensor (pai_scale)."""
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise PaiError("scale_ needs a contiguous fp32 HIP tensor")
+    L.check(L.load().pai_scale(t.data_ptr(), t.numel(), float(factor), _stream()), "pai_scale")
+
+
 class ZeroList:
     """``zero_multi`` of a FIXED tensor list with the pointer tables built once (a gradient arena clears the same ~45
     segments in front of every backward pass)."""

@@ -17,7 +17,11 @@ What a plan freezes, and how each piece stays valid:
   * the Adam step count: recorded Adam launches re-derive their two step-dependent arguments from
     ``step0 + step_delta`` (``pai_plan_run(plan, step_delta)``), the host keeps counting;
   * host-side bookkeeping of a step (optimizer step counts, weight generations, pack commits, logged scalars) is
-    replayed in Python after the C call -- a few dozen attribute updates.
+    replayed in Python after the C call -- a few dozen attribute updates;
+  * data parallel: the bucketed all-reduce of ``dist.GradReducer`` through torch.distributed is not a launch of this
+    library.  Each collective (and the wait on it) is a HOST node (``host_op``): the recording is split into C-side
+    segments around it and the replay alternates ``pai_plan_run`` with those ~2 x buckets Python calls.  With the
+    C-ABI communicator (PAI_COMM=rccl, ``pai_allreduce``) the collectives are plan nodes themselves.
 Anything the recorder cannot own makes it refuse (``disabled`` says why) and the step runs eagerly: kernels launched by
 torch itself inside the step (the op-level residual / Trans U-Nets of nnops.py, loss types other than "gan"), dropout
 masks drawn on the host side, per-launch profiling.
@@ -43,18 +47,63 @@ _NO_KERNEL = {
 }
 
 
+_ACTIVE = None      # the _Recorder of the step being recorded (process-wide: engine hooks run on autograd's thread)
+
+
+def host_op(fn):
+    """Run ``fn()`` now; while a step is being recorded, also make it a HOST node of the plan: the C-side segment
+    recorded so far is closed, ``fn`` is replayed from Python between it and the next segment, under the stream that is
+    current now.  For the few things a step does that are not launches of libpai_hip.so and cannot be: collectives of
+    torch.distributed (dist.GradReducer) and the waits on them.  ``fn`` must only touch buffers that outlive the plan."""
+    rec = _ACTIVE
+    if rec is None:
+        return fn()
+    return rec.host_op(fn)
+
+
 class _Recorder(TorchDispatchMode):
-    """Holds every tensor created while a plan is recorded and lists the aten kernels torch launched itself."""
+    """Holds every tensor created while a plan is recorded, lists the aten kernels torch launched itself, and splits
+    the recording into C-side segments around host nodes (``host_op``)."""
 
     def __init__(self):
         super().__init__()
         self.keep = []
         self.foreign = []
+        self.items = []         # ("plan", ops.Plan) | ("host", fn, stream)
+        self.cur = None
+        self.exempt = 0
+
+    # ---- segments ----------------------------------------------------------------------------------------
+    def begin(self):
+        self.cur = ops.Plan()
+        self.cur.begin()
+
+    def _close(self):
+        if self.cur is not None:
+            self.cur.end()
+            if self.cur.info()["launches"] + self.cur.info()["waits"] > 0:
+                self.items.append(("plan", self.cur))
+            self.cur = None
+
+    def end(self):
+        self._close()
+
+    def host_op(self, fn):
+        stream = torch.cuda.current_stream()
+        self._close()
+        self.exempt += 1
+        try:
+            out = fn()
+        finally:
+            self.exempt -= 1
+            self.items.append(("host", fn, stream))
+            self.begin()
+        return out
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
-        launches = name not in _NO_KERNEL
+        launches = name not in _NO_KERNEL and not self.exempt
         if launches and name in ("_to_copy", "to", "clone", "contiguous"):
             # a dtype / layout "conversion" that returned its argument launched nothing
             launches = not (torch.is_tensor(out) and args and torch.is_tensor(args[0]) and out.data_ptr() == args[0].data_ptr())
@@ -68,7 +117,21 @@ class _Recorder(TorchDispatchMode):
 
 
 class _Recorded:
-    __slots__ = ("plan", "keep", "logs", "step0", "commits", "opt_steps", "static", "info")
+    __slots__ = ("items", "keep", "logs", "step0", "commits", "opt_steps", "static")
+
+    def info(self):
+        out = {"launches": 0, "waits": 0, "streams": 0, "runs": 0, "segments": 0, "host_nodes": 0}
+        for it in self.items:
+            if it[0] == "plan":
+                i = it[1].info()
+                out["launches"] += i["launches"]
+                out["waits"] += i["waits"]
+                out["streams"] = max(out["streams"], i["streams"])
+                out["runs"] = i["runs"]
+                out["segments"] += 1
+            else:
+                out["host_nodes"] += 1
+        return out
 
 
 class PlannedStep:
@@ -99,8 +162,8 @@ class PlannedStep:
             return "per-launch event profiling is on"
         tr = getattr(m, "trainer", None)
         red = getattr(tr, "reducer", None) if tr is not None else None
-        if red is not None and not getattr(red, "plannable", False):
-            return "the gradient exchange goes through torch.distributed (set PAI_COMM=rccl for a plannable exchange)"
+        if red is not None and not red.plannable():
+            return "the gradient exchange covers parameters outside the engines' arenas (torch-launched staging kernels)"
         for opt in m._all_optimizers():
             if not hasattr(opt, "plan_state"):
                 return f"{type(opt).__name__} is not a plan-aware optimizer"
@@ -159,18 +222,24 @@ class PlannedStep:
             logs.append((name, value.detach() if torch.is_tensor(value) else value, a, k))
             return orig_log(name, value, *a, **k)
         m.log = record_log
-        rec.plan = ops.Plan()
+        global _ACTIVE
         recorder = _Recorder()
         try:
-            with recorder, rec.plan.recording():
-                out = m.training_step(rec.static, batch_idx)
+            with recorder:
+                recorder.begin()
+                _ACTIVE = recorder
+                try:
+                    out = m.training_step(rec.static, batch_idx)
+                finally:
+                    _ACTIVE = None
+                    recorder.end()
         finally:
             del m.log
+        rec.items = recorder.items
         rec.keep = recorder.keep
         rec.logs = logs
         rec.opt_steps = m._pai_opt_steps - before
         rec.commits = [opt.plan_commits() for opt in m._all_optimizers()]
-        rec.info = rec.plan.info()
         self.records += 1
         if recorder.foreign:
             kinds = sorted(set(recorder.foreign))
@@ -195,7 +264,14 @@ class PlannedStep:
         delta = now[0] - rec.step0[0]
         if any(n - s0 != delta for n, s0 in zip(now, rec.step0)) or delta < 0:
             raise ops.PaiError("PlannedStep: the optimizers' step counts moved apart since the plan was recorded")
-        rec.plan.run(delta)
+        for it in rec.items:
+            if it[0] == "plan":
+                it[1].run(delta)
+            elif it[2].cuda_stream == torch.cuda.current_stream().cuda_stream:
+                it[1]()
+            else:
+                with torch.cuda.stream(it[2]):
+                    it[1]()
         # the host-side bookkeeping of the step, as the eager call leaves it
         for opt, commits in zip(m._all_optimizers(), rec.commits):
             opt.plan_replayed(commits)
@@ -207,7 +283,7 @@ class PlannedStep:
 
     def describe(self) -> dict:
         return {"plans": len(self.plans), "records": self.records, "replays": self.replays, "disabled": self.disabled,
-                "nodes": [r.plan.info() for r in self.plans.values()]}
+                "nodes": [r.info() for r in self.plans.values()]}
 
 
 def enabled_by_default() -> bool:
