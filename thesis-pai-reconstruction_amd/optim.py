@@ -71,10 +71,15 @@ class ArenaAdam(torch.optim.Adam):
             if pk.wf is None or pk.dtype is None:
                 return None
             ptrs.append(pk.wf.data_ptr())
-        for t in (eng.pack_targets() if self._fuse_packs else ()):
-            if t[5].dtype == torch.bfloat16 and t[5]._stale(t[5].dtype):      # fp32: the parameter IS the pack
-                return None
-        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), arena.flat.data_ptr(),
+        mode, _ = self._stream_mode()
+        if mode == "hook" and self._fuse_packs:
+            # the streamed update writes the packs itself: in the steady state none is stale when a step starts (a stale
+            # one means the previous step went another way -- the next forward re-packs, and THAT step must not be the
+            # recorded one).  Without the streamed update every step starts stale and re-packs: that IS its steady state.
+            for t in eng.pack_targets():
+                if t[5].dtype == torch.bfloat16 and t[5]._stale(t[5].dtype):      # fp32: the parameter IS the pack
+                    return None
+        return (mode, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), arena.flat.data_ptr(),
                 arena.pflat.data_ptr(), tuple(ptrs))
 
     def plan_commits(self):
@@ -99,31 +104,12 @@ class ArenaAdam(torch.optim.Adam):
         bookkeeping and disarms.  Returns False (and changes nothing) when something else owns the hook (a gradient
         reducer: the all-reduce has to come first), when the step count lives on the device (graph capture) or the
         arena preconditions do not hold."""
-        if os.environ.get("PAI_NO_STREAM_ADAM", "0") not in ("", "0"):      # A/B switch
-            return False
-        hook = getattr(self._engine, "grad_ready_hook", None)
-        reducer = getattr(hook, "__self__", None) if hook is not None else None
-        if self._dev_step is not None or (hook is not None and not hasattr(reducer, "subscribe")):
-            return False
-        group = self.param_groups[0]
-        if len(self.param_groups) != 1 or group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
-            return False
-        params = group["params"]
-        if not params or not params[0].is_cuda:
+        mode, reducer = self._stream_mode()
+        if mode is None:
             return False
         arena = self._engine.arena()
-        # only once the parameters already LIVE in the arena (the first fused step() moves them there): moving them
-        # between a forward pass and its backward pass would invalidate the filter packs that forward made
-        if len(params) != len(arena.params) or not arena.params_adopted():
-            return False
         self._pack_targets = None
         if reducer is not None:
-            # data parallel: the reducer owns the hook; the update of a bucket follows its all-reduce + average.
-            # OPT-IN (PAI_DDP_STREAM_ADAM=1): this path updates parameters on a third stream while the backward pass
-            # is still running and has only been exercised with two ranks on ONE GPU over gloo (tests/test_gpu_ddp.py),
-            # never over RCCL on several GPUs; until it has, the default under a reducer is the update in step().
-            if os.environ.get("PAI_DDP_STREAM_ADAM", "0") in ("", "0"):
-                return False
             if not reducer.subscribe(arena, self._on_reduced):
                 return False
             self._reducer = reducer
@@ -135,6 +121,39 @@ class ArenaAdam(torch.optim.Adam):
         self._streamed = 0
         self._stream_step = self.total_steps + 1
         return True
+
+    def _stream_mode(self):
+        """(mode, reducer): whether ``arm_streaming`` would arm now -- "hook" (this optimizer takes the engine's
+        gradient-ready hook), "reducer" (it subscribes to the GradReducer that owns the hook) or None."""
+        if os.environ.get("PAI_NO_STREAM_ADAM", "0") not in ("", "0"):      # A/B switch
+            return None, None
+        hook = getattr(self._engine, "grad_ready_hook", None)
+        if hook is not None and getattr(hook, "__func__", None) is getattr(self._on_ready, "__func__", object()) \
+                and getattr(hook, "__self__", None) is self:
+            hook = None            # our own hook, left armed: same as free
+        reducer = getattr(hook, "__self__", None) if hook is not None else None
+        if self._dev_step is not None or (hook is not None and not hasattr(reducer, "subscribe")):
+            return None, None
+        group = self.param_groups[0]
+        if len(self.param_groups) != 1 or group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+            return None, None
+        params = group["params"]
+        if not params or not params[0].is_cuda:
+            return None, None
+        arena = self._engine.arena()
+        # only once the parameters already LIVE in the arena (the first fused step() moves them there): moving them
+        # between a forward pass and its backward pass would invalidate the filter packs that forward made
+        if len(params) != len(arena.params) or not arena.params_adopted():
+            return None, None
+        if reducer is not None:
+            # data parallel: the reducer owns the hook; the update of a bucket follows its all-reduce + average.
+            # OPT-IN (PAI_DDP_STREAM_ADAM=1): this path updates parameters on a third stream while the backward pass
+            # is still running and has only been exercised with two ranks on ONE GPU over gloo (tests/test_gpu_ddp.py),
+            # never over RCCL on several GPUs; until it has, the default under a reducer is the update in step().
+            if os.environ.get("PAI_DDP_STREAM_ADAM", "0") in ("", "0") or reducer.world < 2:
+                return None, None
+            return "reducer", reducer
+        return "hook", None
 
     def _adam_range(self, arena, a, b, step):
         group = self.param_groups[0]
