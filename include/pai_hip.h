@@ -51,11 +51,11 @@ const char* pai_last_error(void);
  * pai_conv_fwd_bn / pai_conv_dgrad_bn_apply / pai_conv_bn_fused, pai_conv_wgrad_overwrite_w, pai_adam_multi_dev.
  * 121: pai_adam_pack, pai_bn_bwd_apply_affine (pai_bn_bwd_reduce_affine accepts du = NULL); with groups > 1 the weight
  * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only.  130: launch plans (pai_plan_*,
- * pai_stream_wait), pai_zero_multi. */
+ * pai_stream_wait, pai_event_*), pai_zero_multi, pai_scale; pai_pack_frag and the pack_flags bits are gone (removed
+ * experiment kernels: pack_flags MUST be zero). */
 int pai_version(void);
-/* bit 0: the library was built with PAI_EXPERIMENTAL=1 and carries the experiment kernels of round 2 (gg_p2.hip,
- * gg_bd.hip + pai_pack_frag, gg_wg2.hip: bit-exact, slower than the defaults, off unless a tunable selects them).
- * The default build returns 0 and pai_pack_frag fails. */
+/* Build-option bits.  0 since ABI 130: bit 0 used to announce the round-2 experiment kernels (and pai_pack_frag), which
+ * were removed from the library. */
 int pai_build_flags(void);
 /* Device properties of the current HIP device (host out-params). */
 int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
@@ -100,22 +100,13 @@ typedef struct pai_conv_desc {
                              weight-gradient workspace registered nothing else of dw is written, not even by the
                              _overwrite forms; without it the dense kernel leaves cross-group products there).
                              Otherwise a hint: every kernel family computes the same result from the dense packs. */
-    int32_t pack_flags;   /* bit 0: the w_fwd buffer holds the forward pack FOLLOWED BY its fragment-major copy
-                             (pai_pack_frag(w_fwd, Cout, taps * (C1 + C2), w_fwd + Cout * taps * (C1 + C2) elements));
-                             bit 1: the same for w_dgrad (rows = C1 + C2, K = taps * Cout).  With the copy present the
-                             forward / input-gradient call may run the kernel that feeds its weights to the matrix
-                             cores straight from memory (pai_conv_kernel_name says whether it does; PAI_EXPERIMENTAL
-                             builds only, pai_build_flags); 0: row-major packs only.  Bits 2-31 MUST be zero. */
+    int32_t pack_flags;   /* MUST be zero (checked).  ABI 110-121 announced fragment-major pack copies here for an
+                             experiment kernel that was removed in ABI 130. */
     int32_t reserved;     /* MUST be zero (checked) */
 } pai_conv_desc;
 
 /* Output spatial size of the layer. */
 int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW);
-/* Fragment-major copy of a row-major bf16 filter pack [rows][K] (rows % 64 == 0, K % 32 == 0), same size: for every
- * 64-row tile t and 32-deep K slice s the 4 KB block (t * K/32 + s) holds, for nt = 0..3 and lane = 0..63, the 8
- * elements  w[64 t + 16 ((lane % 16) / 4) + 4 nt + lane % 4][32 s + 8 (lane / 16) .. + 8]  -- the matrix-core operand
- * fragments of one wave in lane order.  See pai_conv_desc.pack_flags. */
-int pai_pack_frag(const void* w_rowmajor, int rows, int K, void* w_frag, void* stream);
 /* Number of partial-statistics rows pai_conv_fwd writes when stats != NULL, and the
  * number of rows the caller must allocate for that buffer (the tail is scratch for
  * pai_bn_finalize's two-stage fp64 reduction). */

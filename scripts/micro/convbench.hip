@@ -7,7 +7,7 @@
 //
 // build: hipcc -O2 --offload-arch=gfx950 scripts/micro/convbench.hip -Iinclude -Lthesis-pai-reconstruction_amd
 //              -lpai_hip -Wl,-rpath,'$ORIGIN/../../thesis-pai-reconstruction_amd' -o scripts/micro/convbench
-// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--frag] [--bias] [--bnbwd] [--zeros PCT] [--cold] [--set name=v,name=v ;...]
+// usage: convbench [--filter name] [--ops fdw] [--iters N] [--rounds R] [--batch B] [--bias] [--bnbwd] [--zeros PCT] [--cold] [--set name=v,name=v ;...]
 //        every --set adds one setting (comma-separated tunables); default: the library defaults only.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -97,7 +97,7 @@ static std::vector<float> read3(float* d) {
 int main(int argc, char** argv) {
     const char* filter = "";
     const char* ops = "fdw";
-    int iters = 10, rounds = 3, batch = 64, frag = 0, bias = 0, bnbwd = 0, zero_pct = 0, cold = 0;
+    int iters = 10, rounds = 3, batch = 64, bias = 0, bnbwd = 0, zero_pct = 0, cold = 0;
     std::vector<Setting> settings;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--filter") && i + 1 < argc) filter = argv[++i];
@@ -110,7 +110,6 @@ int main(int argc, char** argv) {
                                                          // (affine pre-activation, second gradient, partial sums) fused into the store
         else if (!strcmp(argv[i], "--zeros") && i + 1 < argc) zero_pct = atoi(argv[++i]);   // percent of exact zeros in x1 / x2 / dy
         else if (!strcmp(argv[i], "--bias")) bias = 1;   // weight gradients also produce (and compare) the bias gradient
-        else if (!strcmp(argv[i], "--frag")) frag = 1;   // packs followed by their fragment-major copy (pack_flags = 3)
         else if (!strcmp(argv[i], "--set") && i + 1 < argc) {
             Setting s;
             s.label = argv[++i];
@@ -173,8 +172,6 @@ int main(int argc, char** argv) {
         HCHECK(hipMalloc(&x1, nx1 * 2));
         if (nx2) HCHECK(hipMalloc(&x2, nx2 * 2));
         HCHECK(hipMalloc(&wf, nw * 4)); HCHECK(hipMalloc(&wd, nw * 4)); HCHECK(hipMalloc(&dy, ny * 2));
-        const bool fragok = frag && (L.Cout % 64) == 0 && (Cin % 64) == 0;
-        d.pack_flags = fragok ? 3 : 0;
         for (int k = 0; k < 2; ++k) {
             HCHECK(hipMalloc(&y[k], ny * 2)); HCHECK(hipMalloc(&dx1[k], nx1 * 2));
             if (nx2) HCHECK(hipMalloc(&dx2[k], nx2 * 2));
@@ -202,10 +199,6 @@ int main(int argc, char** argv) {
             fill_bf16<<<1024, 256, 0, st>>>(wf, nw, 13u, 0.05f, mode, 2);
             fill_bf16<<<1024, 256, 0, st>>>(wd, nw, 14u, 0.05f, mode, 2);
             fill_bf16<<<1024, 256, 0, st>>>(dy, ny, 15u, 1.0f, mode, 2, zero_pct);
-            if (fragok) {
-                PCHECK(pai_pack_frag(wf, L.Cout, 16 * Cin, wf + nw, st));
-                PCHECK(pai_pack_frag(wd, Cin, 16 * L.Cout, wd + nw, st));
-            }
             HCHECK(hipStreamSynchronize(st));
         };
         auto run = [&](char op, int k) {

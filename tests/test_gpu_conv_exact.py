@@ -66,9 +66,8 @@ def _reference(tr, x1, x2, w, dy, relu, bias=None):
     return y.detach(), x.grad, wr.grad
 
 
-def _run_case(pai, case, tunables=(), workspace=True, frag=False):
-    """frag=True: both filter packs carry their fragment-major copy (pai_pack_frag, pai_conv_desc.pack_flags = 3).
-    workspace=False: a handle WITHOUT split-K workspace, the setting the kernel names of CASES were recorded in
+def _run_case(pai, case, tunables=(), workspace=True):
+    """workspace=False: a handle WITHOUT split-K workspace, the setting the kernel names of CASES were recorded in
     (pai_conv_kernel_name on the host); True: the default handle with the workspace registered, where the library may
     pick the split-K kernels for the smaller cases -- same bits either way."""
     from thesis_pai_reconstruction_amd import ops
@@ -84,7 +83,6 @@ def _run_case(pai, case, tunables=(), workspace=True, frag=False):
     assert float(y_ref.abs().max()) < 2 ** 24 and float(dw_ref.abs().max()) < 2 ** 24     # exact in fp32
 
     d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, relu, relu if C2 else 0, ops.ACT_NONE)
-    d.pack_flags = 3 if frag else 0
     default = ops.handle_for(dev())
     bare = None
     if workspace:
@@ -98,12 +96,9 @@ def _run_case(pai, case, tunables=(), workspace=True, frag=False):
         ops.set_tunable(k, v)
     try:
         wm = fwd_pack(w, bool(tr))
-        wf = torch.empty(wm.numel() * (2 if frag else 1), dtype=dt, device=dev())
-        wd = torch.empty(wm.numel() * (2 if frag else 1), dtype=dt, device=dev())
+        wf = torch.empty(wm.numel(), dtype=dt, device=dev())
+        wd = torch.empty(wm.numel(), dtype=dt, device=dev())
         ops.pack_weights(dt, wm, Cout, 16, Cin, wf, wd)
-        if frag:
-            ops.pack_frag(wf, Cout, 16 * Cin, wf[wm.numel():])
-            ops.pack_frag(wd, Cin, 16 * Cout, wd[wm.numel():])
         X1, X2, DY = nhwc(x1, dt), (nhwc(x2, dt) if C2 else None), nhwc(dy, dt)
         used = []
         # forward
@@ -164,36 +159,6 @@ def test_wide_wave_tile_form_of_the_256_row_tile_bit_exact(pai, case):
     gg_fwd_patch_k<256, 128> (eight waves of 64 x 64), which the named run above pins."""
     used = _run_case(pai, case, tunables=(("fwd_wide", 1),))
     assert any(u == "gg_fwd_patchw_k<256, 128, true>" for u in used[:2]), used
-
-
-@pytest.mark.parametrize("mode", [1, 2], ids=["8wave", "4wave"])
-@pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
-def test_pipelined_p2_kernels_bit_exact(pai, case, mode):
-    """gg_p2.hip (PAI_EXPERIMENTAL builds, tunable fwd_p2): the one-workgroup-per-CU pipelined variants give the same bits."""
-    if not pai.ops.experimental_built():
-        pytest.skip("library built without PAI_EXPERIMENTAL=1")
-    used = _run_case(pai, case, tunables=(("fwd_p2", mode),))
-    assert any(u.startswith("gg_fwd_p2_k<") for u in used[:2]), used
-
-
-# layers whose forward or input gradient gives gg_fwd_bd_k >= 512 workgroups; cfg2_D1 / cfg2_D2: grids of several rounds,
-# where the two workgroups of a CU run out of phase (the setting that exposed a wait counting an LDS-DMA together with
-# register loads, see gg_bd.hip)
-BD_CASES = [c for c in CASES if c[0] in ("cfg2_enc2", "cfg2_dec4", "cfg2_dec5", "cfg2_D1", "cfg2_D2", "cfg2_D3")]
-
-
-@pytest.mark.parametrize("mode", [1, 2], ids=["2x2", "wide"])
-@pytest.mark.parametrize("case", BD_CASES, ids=[c[0] for c in BD_CASES])
-def test_register_direct_weight_kernel_bit_exact(pai, case, mode):
-    """gg_bd.hip: the patch-resident kernel that feeds the matrix cores their weights straight from a fragment-major
-    copy of the filter pack (pai_pack_frag) -- other operand path, other tile split, accumulators in the accumulation
-    registers -- gives the same bits; without the copy (pack_flags = 0) the default kernels run."""
-    if not pai.ops.experimental_built():
-        pytest.skip("library built without PAI_EXPERIMENTAL=1")
-    used = _run_case(pai, case, tunables=(("fwd_bd", mode),), frag=True)
-    want = "gg_fwd_bd_k<true, " if mode == 2 else "gg_fwd_bd_k<false, "
-    assert any(u.startswith(want) for u in used[:2]), used
-    assert not any(u.startswith("gg_fwd_bd_k") for u in _run_case(pai, case, tunables=(("fwd_bd", mode),))[:2])
 
 
 OLD_WGRAD = {"enc_patch": "gg_wgrad_patch_k<128>", "dec_patch": "gg_wgrad_patch_k<128>", "dec_patch256x64": "gg_wgrad_patch_k<64>",

@@ -386,28 +386,3 @@ def test_fused_gan_losses_equal_the_composed_ones(pai):
         dp, dt = PF.denormalize(pred.detach()), PF.denormalize(tgt)
         assert abs(float(s) - float(PF.ssim(dp, dt))) <= 1e-6
         assert abs(float(p) - float(PF.psnr(dp, dt))) <= 1e-5 and abs(float(r) - float(PF.rmse(dp, dt))) <= 1e-7
-
-
-def test_pack_frag_is_the_documented_fragment_major_layout(pai):
-    """pai_pack_frag (include/pai_hip.h): block (64-row tile t, 32-deep K slice s) = 4 KB at (t * K/32 + s); inside it,
-    for nt = 0..3 and lane = 0..63, the 8 elements w[64 t + 16 ((lane % 16) / 4) + 4 nt + lane % 4][32 s + 8 (lane / 16) ..]."""
-    if not pai.ops.experimental_built():
-        pytest.skip("pai_pack_frag belongs to gg_bd.hip: library built without PAI_EXPERIMENTAL=1")
-    from thesis_pai_reconstruction_amd import ops
-    rows, K = 128, 96
-    w = torch.arange(rows * K, dtype=torch.float32).remainder(251.0).bfloat16().to(dev())    # distinct enough, exact in bf16
-    out = torch.empty_like(w)
-    ops.pack_frag(w, rows, K, out)
-    torch.cuda.synchronize()
-    W = w.float().cpu().view(rows, K)
-    got = out.float().cpu().view(rows // 64, K // 32, 4, 64, 8)
-    t = torch.arange(rows // 64).view(-1, 1, 1, 1, 1)
-    s = torch.arange(K // 32).view(1, -1, 1, 1, 1)
-    nt = torch.arange(4).view(1, 1, -1, 1, 1)
-    lane = torch.arange(64).view(1, 1, 1, -1, 1)
-    e = torch.arange(8).view(1, 1, 1, 1, -1)
-    r = 64 * t + 16 * ((lane % 16) // 4) + 4 * nt + lane % 4
-    k = 32 * s + 8 * (lane // 16) + e
-    assert torch.equal(got, W[r.expand_as(got), k.expand_as(got)])
-    with pytest.raises(ops.PaiError, match="multiple"):
-        ops.pack_frag(w, 96, 128, out)

@@ -14,17 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpai_hip.so")
 STAMPS = os.path.join(CSRC, ".build_stamps.json")     # object / library -> content hash of what it was built from
-# PAI_EXPERIMENTAL=1: also build the experiment kernels of round 2 (bit-exact, measured slower than the defaults; their
-# tests skip without them).  The default library carries stubs instead (gg_stubs.hip).
-EXPERIMENTAL = os.environ.get("PAI_EXPERIMENTAL", "0") not in ("", "0")
-SOURCES = ["api.hip", "gg_simt.hip", "gg_mfma.hip", "gg_wg3.hip", "gg_finish.hip", "gg_thin.hip", "gg_small.hip", "gg_group.hip", "bn.hip", "gate.hip", "resnet.hip", "vit.hip", "loss.hip", "ssim.hip", "misc.hip", "comm.hip", "plan.hip"] + \
-    (["gg_p2.hip", "gg_bd.hip", "gg_wg2.hip"] if EXPERIMENTAL else ["gg_stubs.hip"])
+SOURCES = ["api.hip", "gg_simt.hip", "gg_mfma.hip", "gg_wg3.hip", "gg_finish.hip", "gg_thin.hip", "gg_small.hip", "gg_group.hip", "bn.hip", "gate.hip", "resnet.hip", "vit.hip", "loss.hip", "ssim.hip", "misc.hip", "comm.hip", "plan.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "plan.h"), os.path.join(CSRC, "gg_tile.h"), os.path.join(HERE, "..", "include", "pai_hip.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in the (unified) VGPR file.  Without it hipcc 7.2
 # put the wgrad accumulators in AGPRs with a different source/destination register per MFMA and
 # copied all 64 of them through VGPRs every K-step (192 -> 138 registers, +1 wave per SIMD).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + (["-DPAI_EXPERIMENTAL=1"] if EXPERIMENTAL else [])
+         "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():

@@ -16,14 +16,8 @@ void pai_set_error(const char* fmt, ...) {
 extern "C" const char* pai_last_error(void) { return g_err; }
 extern "C" int pai_version(void) { return 130; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine; 130: launch plans
 
-// bit 0: the experiment kernels (gg_p2.hip, gg_bd.hip, gg_wg2.hip; PAI_EXPERIMENTAL=1 at build time) are present
-extern "C" int pai_build_flags(void) {
-#ifdef PAI_EXPERIMENTAL
-    return 1;
-#else
-    return 0;
-#endif
-}
+// build-option bits; none since ABI 130 (bit 0 announced the round-2 experiment kernels, which were removed)
+extern "C" int pai_build_flags(void) { return 0; }
 
 extern "C" int pai_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -96,7 +90,7 @@ static int check_desc(const pai_conv_desc* d) {
             PAI_CHECK(d->H >= 2 && d->W >= 2, "k4 s1 p1 Conv2d needs H, W >= 2");
     }
     PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
-    PAI_CHECK((d->pack_flags & ~3) == 0 && d->reserved == 0, "pai_conv_desc: pack_flags bits other than 0-1 / reserved must be zero (got %d, %d)",
+    PAI_CHECK(d->pack_flags == 0 && d->reserved == 0, "pai_conv_desc: pack_flags / reserved must be zero (got %d, %d)",
               d->pack_flags, d->reserved);
     if (d->groups > 1) {
         PAI_CHECK(d->kernel == 3 && d->C2 == 0 && d->C1 == d->Cout && (d->C1 % d->groups) == 0 && (d->C1 % 16) == 0 &&
@@ -197,7 +191,6 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
     g->D1 = d->Cout; g->D2 = 0;
     g->wtaps = 16;
     g->gslice = d->groups > 1 ? 16 : 0;
-    g->wfrag = (d->pack_flags >> 0) & 1;
     g->relu1 = d->relu1; g->relu2 = d->relu2;
     int OH, OW;
     pai_conv_out_hw(d, &OH, &OW);
@@ -232,7 +225,6 @@ int gg_build_dgrad(const pai_conv_desc* d, GG* g) {
     g->D1 = d->C1; g->D2 = d->C2;
     g->wtaps = 16;
     g->gslice = d->groups > 1 ? 16 : 0;
-    g->wfrag = (d->pack_flags >> 1) & 1;
     g->OH = d->H; g->OW = d->W;
     if (d->kernel == 1) {
         g->OHg = d->H; g->OWg = d->W;

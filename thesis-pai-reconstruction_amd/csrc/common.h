@@ -132,7 +132,6 @@ struct GG {
     signed char dy[4][16], dx[4][16], wt[4][16];
     signed char poy[4], pox[4];
     int gslice;  // > 0: block-diagonal filter (pai_conv_desc.groups): 16-channel slices are independent
-    int wfrag;   // 1: the filter pack is followed by its fragment-major copy (pai_pack_frag; pai_conv_desc.pack_flags)
 };
 
 // forward gather of a pai_conv_desc (Conv2d or ConvTranspose2d)
@@ -191,14 +190,6 @@ int fwd_mfma_ksplit_effective(const GG& g);     // the K split launch_fwd_mfma u
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s);
-// pipelined one-workgroup-per-CU forward / input-gradient kernel (gg_p2.hip); rows = 0: not eligible
-int fwd_p2_rows(const GG& g);
-int launch_fwd_p2(const GG& g, const FwdArgs& a, hipStream_t s);
-const char* fwd_p2_kernel_name(const GG& g);
-// patch-resident kernel with register-direct weights (gg_bd.hip); needs GG.wfrag
-int fwd_bd_rows(const GG& g);
-int launch_fwd_bd(const GG& g, const FwdArgs& a, hipStream_t s);
-const char* fwd_bd_kernel_name(const GG& g);
 // run-time tunables (pai_set_tunable): kernel-selection switches for A/B timing and for tests that pin a kernel
 int pai_tunable(const char* name, int def);
 int fwd_mfma_ksplit(const GG& g);
@@ -271,9 +262,6 @@ int launch_wgrad_simt(int dtype, const GG& g, const WgradArgs& a, hipStream_t s)
 int launch_wgrad_rowdot(int dtype, const GG& g, const WgradArgs& a, hipStream_t s);
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s);
 bool wgrad_mfma_ok(int dtype, const GG& g);
-// 128 x 256-tile patch-resident weight gradient (gg_wg2.hip)
-bool wgrad2_ok(const GG& g);
-int launch_wgrad2(const GG& g, const WgradArgs& a, hipStream_t s);
 bool thin_wgrad_conv_ok(int dtype, const GG& g);
 bool thin_wgrad_convt_ok(int dtype, const GG& g);
 int launch_thin_wgrad_conv(const GG& g, const WgradArgs& a, hipStream_t s);

@@ -50,10 +50,6 @@ struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
     FwdCfg c;
-    if (fwd_bd_rows(g) || fwd_p2_rows(g)) {   // gg_bd.hip / gg_p2.hip: never split
-        c.bm = 128; c.bn = 128; c.ksplit = 1;
-        return c;
-    }
     c.bn = ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 128 : 64;
     c.bm = 128;
     c.ksplit = 1;
@@ -126,8 +122,6 @@ int fwd_mfma_ksplit_effective(const GG& g) { return fwd_effective_ksplit(g); }
 static int patch_rows(const GG& g, const FwdCfg& c);
 
 int fwd_mfma_mtiles(const GG& g) {
-    if (const int rows = fwd_bd_rows(g)) return g.M / rows;
-    if (const int rows = fwd_p2_rows(g)) return g.M / rows;
     if (fwd_effective_ksplit(g) > 1) return cdiv(g.M, FIN_ROWS);
     const FwdCfg c = fwd_cfg(g);
     return patch_rows(g, c) == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
@@ -1078,8 +1072,6 @@ static size_t fwd_lds_bytes() {
 }
 
 int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
-    if (fwd_bd_rows(g)) return launch_fwd_bd(g, a, s);
-    if (fwd_p2_rows(g)) return launch_fwd_p2(g, a, s);
     FwdCfg c = fwd_cfg(g);
     c.ksplit = fwd_effective_ksplit(g);
     const int mtiles = cdiv(g.M, abs(c.bm));
@@ -1182,8 +1174,6 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
 
 // rocprofv3-visible symbol of the main kernel launch_fwd_mfma picks for this problem (same decisions, no launch)
 const char* fwd_mfma_kernel_name(const GG& g) {
-    if (fwd_bd_rows(g)) return fwd_bd_kernel_name(g);
-    if (fwd_p2_rows(g)) return fwd_p2_kernel_name(g);
     FwdCfg c = fwd_cfg(g);
     c.ksplit = fwd_effective_ksplit(g);
     const int mode = getenv("PAI_FWD_MODE") ? atoi(getenv("PAI_FWD_MODE")) : 0;
@@ -1851,7 +1841,6 @@ static bool wgrad_mfma_uses_patch(const GG& g) {
 }
 bool wgrad_mfma_can_overwrite(const GG& g) {
     int rows;
-    if (wgrad2_ok(g)) return false;
     if (wgrad3_ok(g)) return wgrad3_overwrites(g);
     // un-split gg_wgrad_mfma_k: one writer per dW element (the taps of different phases are disjoint); the bias sums of
     // several phases meet by atomics, launch_wgrad_mfma clears dbias for them
@@ -1893,7 +1882,6 @@ static int wgrad_mfma_splits(const GG& g, int* rows_out) {
 }
 
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
-    if (wgrad2_ok(g)) return launch_wgrad2(g, a, s);
     if (wgrad3_ok(g)) return launch_wgrad3(g, a, s);
     const bool big = (g.Cout % 128) == 0;
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
@@ -1931,7 +1919,6 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
 }
 
 const char* wgrad_mfma_kernel_name(const GG& g) {
-    if (wgrad2_ok(g)) return "gg_wgrad_patch2_k<128>";
     if (wgrad3_ok(g)) return wgrad3_kernel_name(g);
     const bool big = (g.Cout % 128) == 0;
     const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;

@@ -90,7 +90,6 @@ SIGNATURES = {
     "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_conv_wgrad_overwrite_w": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
-    "pai_pack_frag": (_I, [_P, _I, _I, _P, _P]),
     "pai_build_flags": (_I, []),
     "pai_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -356,16 +356,6 @@ def set_tunable(name: str, value: int = TUNABLE_UNSET) -> None:
     L.check(L.load().pai_set_tunable(name.encode(), int(value)), "pai_set_tunable")
 
 
-def experimental_built() -> bool:
-    """True when libpai_hip.so carries the experiment kernels of round 2 (built with PAI_EXPERIMENTAL=1)."""
-    return bool(L.load().pai_build_flags() & 1)
-
-
-def pack_frag(w_rowmajor, rows, K, w_frag):
-    """Fragment-major copy of a row-major bf16 filter pack [rows][K] (pai_pack_frag; see pai_conv_desc.pack_flags)."""
-    L.check(L.load().pai_pack_frag(_p(w_rowmajor, torch.bfloat16), rows, K, _p(w_frag, torch.bfloat16), _stream()), "pai_pack_frag")
-
-
 def pack_weights_multi(items):
     """items: [(w_master fp32, Cout, taps, Cin, w_fwd | None, w_dgrad | None)], bf16 packs, Cin and Cout multiples of
     64: every layer in one launch."""
