@@ -47,12 +47,12 @@ const char* pai_last_error(void);
 /* 100: round 1.  110: per-device handles, pai_set_tunable, pai_adam_dev, pai_scalar_take / pai_metrics_take,
  * pai_pack_weights_multi; pai_bn_bwd_reduce accepts du = NULL.  120: weight-gradient workspace
  * (pai_set_wgrad_workspace), pai_build_flags, PAI_TUNABLE_UNSET; pai_conv_desc.pack_flags bits other than 0-1 and
- * .reserved are CHECKED to be zero (descriptors must be zero-initialised; a 100 caller that did so runs unchanged),
+ * .reserved (ABI 130: .hints) are CHECKED to be zero (descriptors must be zero-initialised; a 100 caller that did so runs unchanged),
  * pai_conv_fwd_bn / pai_conv_dgrad_bn_apply / pai_conv_bn_fused, pai_conv_wgrad_overwrite_w, pai_adam_multi_dev.
  * 121: pai_adam_pack, pai_bn_bwd_apply_affine (pai_bn_bwd_reduce_affine accepts du = NULL); with groups > 1 the weight
  * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only.  130: launch plans (pai_plan_*,
  * pai_stream_wait, pai_event_*), pai_zero_multi, pai_scale; pai_pack_frag and the pack_flags bits are gone (removed
- * experiment kernels: pack_flags MUST be zero). */
+ * experiment kernels: pack_flags MUST be zero); pai_conv_desc.reserved became .hints (PAI_HINT_SOLO). */
 int pai_version(void);
 /* Build-option bits.  0 since ABI 130: bit 0 used to announce the round-2 experiment kernels (and pai_pack_frag), which
  * were removed from the library. */
@@ -102,8 +102,13 @@ typedef struct pai_conv_desc {
                              Otherwise a hint: every kernel family computes the same result from the dense packs. */
     int32_t pack_flags;   /* MUST be zero (checked).  ABI 110-121 announced fragment-major pack copies here for an
                              experiment kernel that was removed in ABI 130. */
-    int32_t reserved;     /* MUST be zero (checked) */
+    int32_t hints;        /* PAI_HINT_* bits; the others MUST be zero (checked).  Hints change launch geometry only, never
+                             results beyond summation order (and not even that where the library sums in a fixed order). */
 } pai_conv_desc;
+/* The launch will run ALONE on the device (no other stream has work beside it): the weight gradient of the last layers
+ * of a backward pass, when the input-gradient chain has already ended.  The library then sizes the grid for the whole
+ * chip (two workgroups per CU) instead of for co-scheduling with the input-gradient stream (one per CU). */
+#define PAI_HINT_SOLO 1
 
 /* Output spatial size of the layer. */
 int pai_conv_out_hw(const pai_conv_desc* d, int* OH, int* OW);

@@ -90,8 +90,8 @@ static int check_desc(const pai_conv_desc* d) {
             PAI_CHECK(d->H >= 2 && d->W >= 2, "k4 s1 p1 Conv2d needs H, W >= 2");
     }
     PAI_CHECK((int64_t)d->N * d->H * d->W * 4 < (int64_t)1 << 31, "problem too large for int32 rows");
-    PAI_CHECK(d->pack_flags == 0 && d->reserved == 0, "pai_conv_desc: pack_flags / reserved must be zero (got %d, %d)",
-              d->pack_flags, d->reserved);
+    PAI_CHECK(d->pack_flags == 0 && (d->hints & ~PAI_HINT_SOLO) == 0, "pai_conv_desc: pack_flags / unknown hint bits must be zero (got %d, %d)",
+              d->pack_flags, d->hints);
     if (d->groups > 1) {
         PAI_CHECK(d->kernel == 3 && d->C2 == 0 && d->C1 == d->Cout && (d->C1 % d->groups) == 0 && (d->C1 % 16) == 0 &&
                       (16 % (d->C1 / d->groups)) == 0,
@@ -191,6 +191,7 @@ int gg_build_fwd(const pai_conv_desc* d, GG* g) {
     g->D1 = d->Cout; g->D2 = 0;
     g->wtaps = 16;
     g->gslice = d->groups > 1 ? 16 : 0;
+    g->solo = (d->hints & PAI_HINT_SOLO) ? 1 : 0;
     g->relu1 = d->relu1; g->relu2 = d->relu2;
     int OH, OW;
     pai_conv_out_hw(d, &OH, &OW);

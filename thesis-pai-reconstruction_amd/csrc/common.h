@@ -132,6 +132,7 @@ struct GG {
     signed char dy[4][16], dx[4][16], wt[4][16];
     signed char poy[4], pox[4];
     int gslice;  // > 0: block-diagonal filter (pai_conv_desc.groups): 16-channel slices are independent
+    int solo;    // pai_conv_desc.hints & PAI_HINT_SOLO: nothing else runs beside this launch (launch geometry only)
 };
 
 // forward gather of a pai_conv_desc (Conv2d or ConvTranspose2d)

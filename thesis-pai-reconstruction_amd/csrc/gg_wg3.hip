@@ -403,7 +403,7 @@ bool wgrad3_ok(const GG& g) { return wg3_variant(g) != 0; }
 
 struct Wg3Cfg { int bmc, ci, cotiles, jtiles, tiles, psplits, per; };
 
-static Wg3Cfg wg3_cfg(const GG& g) {
+static Wg3Cfg wg3_cfg(const GG& g, int solo = -1) {      // solo: -1 = as the problem says, 0 / 1 = forced (workspace sizing)
     PatchGeo pg;
     const int v = wg3_variant(g);
     if (v == 3) patch_geo(g, 8, &pg, 8); else patch_geo(g, 4, &pg);
@@ -419,7 +419,10 @@ static Wg3Cfg wg3_cfg(const GG& g) {
     // workgroups they flush half the slab bytes (32 instead of 64 MB per layer, and wgrad_slab_sum_k reads half) and leave
     // the other half of every CU to the main stream -- same-box step, two interleaved runs each: 6.36 ms at 256, 6.42-6.44
     // at 192, 6.49 at 384, 6.55 at 512, 6.67 at 768, 7.05 at 128.  A split never gets fewer than 512 pixels.
-    int splits = cdiv(pai_tunable("wgrad3_target", 256), c.tiles);
+    // PAI_HINT_SOLO (the last weight gradients of a backward pass: the input-gradient chain has ended, the main stream only
+    // waits for them): two workgroups per CU, the grid that is fastest alone (D block 1: 292 -> ~180 us in the step's tail).
+    if (solo < 0) solo = g.solo;
+    int splits = cdiv(solo ? pai_tunable("wgrad3_target_solo", 512) : pai_tunable("wgrad3_target", 256), c.tiles);
     const int max_splits = cdiv(g.M, pai_tunable("wgrad3_minrows", 512));
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -430,8 +433,9 @@ static Wg3Cfg wg3_cfg(const GG& g) {
 
 int64_t wgrad3_slab_bytes(const GG& g) {
     if (!wgrad3_ok(g)) return 0;
-    const Wg3Cfg c = wg3_cfg(g);
-    return c.psplits > 1 ? (int64_t)c.psplits * g.Cout * g.wtaps * g.Cin * 4 : 0;
+    const Wg3Cfg c0 = wg3_cfg(g, 0), c1 = wg3_cfg(g, 1);     // the workspace serves the layer with and without PAI_HINT_SOLO
+    const int ps = c0.psplits > c1.psplits ? c0.psplits : c1.psplits;
+    return ps > 1 ? (int64_t)ps * g.Cout * g.wtaps * g.Cin * 4 : 0;
 }
 
 // pai_conv_wgrad_overwrite needs no zero fill: every dW element has one writer (un-split: the taps of different phases

@@ -290,6 +290,28 @@ def pack_targets(arena, packs):
     return out
 
 
+def solo_desc(d):
+    """A copy of a convolution descriptor with PAI_HINT_SOLO set: the launch geometry for a call that runs ALONE on the
+    device -- the weight gradient of the last dense layer of a backward pass, issued when the input-gradient chain is
+    about to end (the main stream then only waits for it)."""
+    c = type(d).from_buffer_copy(d)
+    c.hints |= ops.L.HINT_SOLO
+    return c
+
+
+def _defer_wgrad() -> int:
+    """How many of the first decoders' weight gradients UnetEngine.backward holds back until the main stream reaches the
+    bottleneck chain (PAI_DEFER_WGRAD, default 3: decoders[6], [5], [4] of the 8-level U-Net)."""
+    import os
+    return int(os.environ.get("PAI_DEFER_WGRAD", "3"))
+
+
+def _solo_tail() -> int:
+    """How many trailing dense weight gradients of a backward pass get PAI_HINT_SOLO (PAI_SOLO_TAIL, default 1; 0: none)."""
+    import os
+    return int(os.environ.get("PAI_SOLO_TAIL", "1"))
+
+
 class _BNState:
     """Per-slot BatchNorm side tensors."""
 
@@ -485,6 +507,9 @@ class UnetEngine:
             act = ACT_LRELU if i == 0 else ACT_NONE
             P["enc_desc"].append(ops.make_desc(dtype, 0, N, hin, win, cin, 0, self.enc_c[i], 2, 0, 0, act))
             cin = self.enc_c[i]
+        # weight-gradient calls of the last dense layers of the backward pass (encoders[1], [2], ...): the input-gradient
+        # chain ends while they run
+        P["enc_wdesc"] = [solo_desc(d) if 1 <= i <= _solo_tail() else d for i, d in enumerate(P["enc_desc"])]
         P["dec_desc"] = []
         for j in range(L):
             hin, win = eh[L - 1 - j], ew[L - 1 - j]
@@ -693,12 +718,31 @@ class UnetEngine:
         # segments GradArena.begin_backward cleared in one launch
         conv_wgrad = ops.conv_wgrad_overwrite_w if fresh else ops.conv_wgrad
 
-        def wgrad(d, x1, x2, dz, conv, with_bias):
+        # The weight gradients of the first (largest) decoders are NOT issued beside their own input gradients: two
+        # matrix-bound launches sharing every CU each run ~1.6x longer (decoders[6]: 312 us input gradient beside a 266 us
+        # weight gradient; alone ~190 and ~150) and the main stream is the critical path.  They are held back until the
+        # main stream enters the bottleneck chain (decoders[3] .. encoders[4]: ~0.75 ms of latency-bound split-K launches
+        # that leave most of the chip idle) and run beside THAT.  Same launches, same order on the side stream, so the
+        # gradient arena still becomes final front to back (PAI_DEFER_WGRAD = number of decoders held back; 0: none).
+        deferred = []
+        n_defer = min(_defer_wgrad(), max(L - 2, 0)) if side.on else 0
+
+        def wgrad(d, x1, x2, dz, conv, with_bias, defer=False):
             """Weight (and bias) gradient of one layer on the side stream."""
-            with torch.cuda.stream(side.fork(d)):
-                fn = ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad
-                fn(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
-                done(conv.bias)
+            def issue():
+                with torch.cuda.stream(side.fork(d)):
+                    fn = ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad
+                    fn(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
+                    done(conv.bias)
+            if defer:
+                deferred.append(issue)
+            else:
+                flush_deferred()
+                issue()
+
+        def flush_deferred():
+            while deferred:
+                deferred.pop(0)()
 
         # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
         j = L - 1
@@ -746,7 +790,7 @@ class UnetEngine:
                 x1, x2 = S["r"][j - 1], (S["a"][skip] if skip > 0 else S["z"][0])
             # a conv bias in front of a BatchNorm has an identically zero gradient (BN subtracts the
             # batch mean); the arena already holds zeros for it, no reduction pass is spent on it
-            wgrad(d, x1, x2, dz, conv, False)
+            wgrad(d, x1, x2, dz, conv, False, defer=(j >= L - 1 - n_defer))
             _, wd = self.dec_packs[j].get(dtype)
             if j == 0:
                 # producer: the norm-free last encoder, consumed through ReLU -> dz_last = relu'(z_last) * g
@@ -763,6 +807,7 @@ class UnetEngine:
                                         ACT_NONE, pst.scale, pst.shift, pst.mean, pst.rstd, part, pbn.weight, pst.sums,
                                         A.seg(pbn.weight), A.seg(pbn.bias), G["dz_dec"][j - 1])
                 fused_rows = -1
+        flush_deferred()
         # last encoder (no norm)
         i = L - 1
         conv = self.enc_conv[i]
@@ -791,7 +836,7 @@ class UnetEngine:
             C = self.enc_c[i]
             dz = G["dz_enc"][i]       # written by encoder i+1's input-gradient call (pai_conv_dgrad_bn_apply)
             d = P["enc_desc"][i]
-            wgrad(d, S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
+            wgrad(P["enc_wdesc"][i], S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)
             fused_rows = enc_dgrad(i, dz, wd)
         # encoder 0 (its dz came out of encoder 1's input gradient): on the tail stream, beside encoder 1's
@@ -855,6 +900,7 @@ class DiscEngine:
             P["desc"].append(ops.make_desc(dtype, 0, N, H >> k, W >> k, self.chans[k - 1], 0, self.chans[k], 2, 0, 0,
                                            ACT_LRELU))
         P["desc"].append(ops.make_desc(dtype, 0, N, H >> 4, W >> 4, self.chans[3], 0, 1, 1, 0, 0, ACT_NONE))
+        P["wdesc"] = [solo_desc(d) if 1 <= k <= _solo_tail() else d for k, d in enumerate(P["desc"])]
         P["oh"], P["ow"] = (H >> 4) - 1, (W >> 4) - 1
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["desc"] for op in (0, 1)), device)
         ops.ensure_scratch(ops.scratch_bytes_for(P["desc"]), device)
@@ -960,7 +1006,7 @@ class DiscEngine:
                         d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
             elif need_params:
                 with torch.cuda.stream(side.fork(d)):
-                    conv_wgrad(d, S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                    conv_wgrad(P["wdesc"][k], S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
                     if hook is not None:
                         hook(A, A.end_of(conv.bias))
             if k > 0:

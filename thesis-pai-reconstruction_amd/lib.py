@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PAI_HIP_LIB") or os.path.join(HERE, "libpai_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+HINT_SOLO = 1
 
 
 class PaiError(RuntimeError):
@@ -28,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("C1", C.c_int32), ("C2", C.c_int32), ("Cout", C.c_int32),
                 ("kernel", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("relu1", C.c_int32), ("relu2", C.c_int32), ("epilogue_act", C.c_int32),
-                ("groups", C.c_int32), ("pack_flags", C.c_int32), ("reserved", C.c_int32)]
+                ("groups", C.c_int32), ("pack_flags", C.c_int32), ("hints", C.c_int32)]
 
 
 class BwdEpilogue(C.Structure):
