@@ -9,6 +9,7 @@
 // of the weight-gradient stream with the input-gradient chain -- which a replayed hipGraph serialised (round 2/3:
 // 4-6 % slower than eager) -- is unchanged.
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -31,6 +32,15 @@ struct Plan {
 };
 
 std::atomic<Plan*> g_recording{nullptr};
+
+// Events that order one stream of the device behind another need no SYSTEM-scope fence (nothing on the host inspects
+// them): with hipEventDisableSystemFence the marker packet releases at agent scope only (PAI_EVENT_FLAGS overrides the
+// flag word for A/B timing).
+static unsigned event_flags() {
+    static const unsigned f = getenv("PAI_EVENT_FLAGS") ? (unsigned)strtoul(getenv("PAI_EVENT_FLAGS"), nullptr, 0)
+                                                         : (hipEventDisableTiming | hipEventDisableSystemFence);
+    return f;
+}
 static thread_local AdamPatch t_adam = {0, 0, 0, 0.0, 0.0, 0.0, 0};
 
 void plan_push(PlanOp* op) {
@@ -111,7 +121,7 @@ static hipError_t ring_event(hipEvent_t* out) {
         std::lock_guard<std::mutex> lk(g_ring_mu);
         if (!g_ring_made[dev].load(std::memory_order_relaxed)) {
             for (int i = 0; i < RING; ++i) {
-                e = hipEventCreateWithFlags(&g_ring[dev][i], hipEventDisableTiming);
+                e = hipEventCreateWithFlags(&g_ring[dev][i], event_flags());
                 if (e != hipSuccess) return e;
             }
             g_ring_made[dev].store(true, std::memory_order_release);
@@ -132,7 +142,7 @@ extern "C" int pai_stream_wait(void* waiting_stream, void* signalling_stream) {
     hipEvent_t ev = nullptr;
     hipError_t e;
     if (p) {
-        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        e = hipEventCreateWithFlags(&ev, pai::event_flags());
         PAI_CHECK(e == hipSuccess, "pai_stream_wait: hipEventCreate: %s", hipGetErrorString(e));
         std::lock_guard<std::mutex> lk(p->mu);
         p->events.push_back(ev);
@@ -152,7 +162,7 @@ extern "C" int pai_stream_wait(void* waiting_stream, void* signalling_stream) {
 extern "C" int pai_event_create(pai_event_t* out) {
     PAI_CHECK(out != nullptr, "pai_event_create: null pointer");
     hipEvent_t ev = nullptr;
-    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    const hipError_t e = hipEventCreateWithFlags(&ev, pai::event_flags());
     PAI_CHECK(e == hipSuccess, "pai_event_create: %s", hipGetErrorString(e));
     *out = (pai_event_t)ev;
     return 0;

@@ -301,15 +301,18 @@ def solo_desc(d):
 
 def _defer_wgrad() -> int:
     """How many of the first decoders' weight gradients UnetEngine.backward holds back until the main stream reaches the
-    bottleneck chain (PAI_DEFER_WGRAD, default 3: decoders[6], [5], [4] of the 8-level U-Net)."""
+    bottleneck chain (PAI_DEFER_WGRAD; 3 = decoders[6], [5], [4] of the 8-level U-Net).  Default 0: measured round 4, same
+    box, three interleaved rounds: 6.25-6.27 ms/step as issued today, 6.40-6.42 with 3 held back, 6.34-6.36 with 2,
+    6.46-6.48 with 4 -- the chain's split-K launches want the whole chip too, and the side stream then ends later."""
     import os
-    return int(os.environ.get("PAI_DEFER_WGRAD", "3"))
+    return int(os.environ.get("PAI_DEFER_WGRAD", "0"))
 
 
 def _solo_tail() -> int:
-    """How many trailing dense weight gradients of a backward pass get PAI_HINT_SOLO (PAI_SOLO_TAIL, default 1; 0: none)."""
+    """How many trailing dense weight gradients of a backward pass get PAI_HINT_SOLO (PAI_SOLO_TAIL; default 0: measured
+    round 4, same box, 6.24-6.27 ms/step with 1 against 6.25-6.27 without -- within the noise)."""
     import os
-    return int(os.environ.get("PAI_SOLO_TAIL", "1"))
+    return int(os.environ.get("PAI_SOLO_TAIL", "0"))
 
 
 class _BNState:
@@ -718,12 +721,10 @@ class UnetEngine:
         # segments GradArena.begin_backward cleared in one launch
         conv_wgrad = ops.conv_wgrad_overwrite_w if fresh else ops.conv_wgrad
 
-        # The weight gradients of the first (largest) decoders are NOT issued beside their own input gradients: two
-        # matrix-bound launches sharing every CU each run ~1.6x longer (decoders[6]: 312 us input gradient beside a 266 us
-        # weight gradient; alone ~190 and ~150) and the main stream is the critical path.  They are held back until the
-        # main stream enters the bottleneck chain (decoders[3] .. encoders[4]: ~0.75 ms of latency-bound split-K launches
-        # that leave most of the chip idle) and run beside THAT.  Same launches, same order on the side stream, so the
-        # gradient arena still becomes final front to back (PAI_DEFER_WGRAD = number of decoders held back; 0: none).
+        # Experiment switch (PAI_DEFER_WGRAD, default 0 = off): hold the weight gradients of the first (largest) decoders
+        # back until the main stream enters the bottleneck chain (decoders[3] .. encoders[4]: ~0.75 ms of split-K
+        # launches) instead of issuing them beside their own input gradients, where two matrix-bound launches sharing
+        # every CU each run ~1.6x longer.  Measured SLOWER (see _defer_wgrad); same launches, same order on the side stream.
         deferred = []
         n_defer = min(_defer_wgrad(), max(L - 2, 0)) if side.on else 0
 
