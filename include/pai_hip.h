@@ -572,6 +572,10 @@ int pai_plan_end(pai_plan_t plan);
 int pai_plan_run(pai_plan_t plan, int64_t step_delta);
 int pai_plan_info(pai_plan_t plan, int* launches, int* waits, int* streams, int64_t* runs);
 int pai_stream_wait(void* waiting_stream, void* signalling_stream);
+/* The same edge when its source is the LAST launch this library made on `signalling_stream` and the caller enqueued
+ * nothing else there since.  Executed eagerly it is pai_stream_wait; in a plan the source launch itself carries the
+ * event, so the replayed signalling stream has no marker packet between that launch and the next one. */
+int pai_stream_wait_last(void* waiting_stream, void* signalling_stream);
 /* The same edge in two halves, for a wait that is issued later than the point it refers to (the thin weight gradients
  * of one backward pass share scratch: the second waits for the mark behind the first, not for what the first one's
  * stream was given since).  Caller-owned events (no timing); a recorded plan keeps the handle, so the event must outlive

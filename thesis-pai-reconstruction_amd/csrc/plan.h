@@ -6,6 +6,7 @@
 // (Reference: the step is one Python call, models/wrapper.py:117-162; here it is one C call per recorded step.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -19,6 +20,10 @@ struct PlanOp {
     virtual hipError_t run(int64_t step_delta) = 0;
     virtual int kind() const = 0;      // 0 kernel, 1 memset, 2 event record, 3 stream wait, 4 host call (collective)
     virtual hipStream_t stream() const = 0;
+    // kernels only: the launch signals `ev` when it completes (hipExtLaunchKernel's stop event) -- the edge to another
+    // stream then needs no marker packet behind it on this stream (pai_stream_wait_last)
+    virtual bool set_stop_event(hipEvent_t) { return false; }
+    virtual hipEvent_t stop_event() const { return nullptr; }
 };
 
 // Adam launches carry two kernel arguments derived from the optimizer step count on the host (lr / (1 - beta1^t),
@@ -48,6 +53,7 @@ struct KernelOp final : PlanOp {
     std::tuple<P...> args;
     void* ptrs[sizeof...(P) + 1];
     AdamPatch patch;
+    hipEvent_t stop = nullptr;
 
     template <size_t... I> void bind(std::index_sequence<I...>) { ((ptrs[I] = (void*)&std::get<I>(args)), ...); }
     KernelOp(void (*k_)(P...), dim3 g_, dim3 b_, unsigned sh_, hipStream_t st_, const std::tuple<P...>& a, const AdamPatch& p)
@@ -59,10 +65,13 @@ struct KernelOp final : PlanOp {
             adam_coeffs(patch.lr, patch.beta1, patch.beta2, patch.step0 + step_delta, (float*)ptrs[patch.arg_lr_over_bc1],
                         (float*)ptrs[patch.arg_inv_sqrt_bc2]);
         }
+        if (stop) return hipExtLaunchKernel((const void*)k, g, b, ptrs, sh, st, nullptr, stop, 0);
         return hipLaunchKernel((const void*)k, g, b, ptrs, sh, st);
     }
     int kind() const override { return 0; }
     hipStream_t stream() const override { return st; }
+    bool set_stop_event(hipEvent_t ev) override { stop = ev; return true; }
+    hipEvent_t stop_event() const override { return stop; }
 };
 
 template <class... P, size_t... I>

@@ -159,6 +159,46 @@ extern "C" int pai_stream_wait(void* waiting_stream, void* signalling_stream) {
     return 0;
 }
 
+// pai_stream_wait for an edge whose source is the LAST launch this library made on `signalling_stream` (the caller
+// promises that nothing else was enqueued on that stream since).  Executed now it is the same record + wait.  In a plan it
+// is recorded differently: the source launch itself carries the event (hipExtLaunchKernel's stop event) and only the wait
+// is a node -- no marker packet sits between the source launch and its successor on the signalling stream, which in the
+// replayed step cost the main stream a ~5 us bubble in front of every input-gradient launch (one fork per layer).
+extern "C" int pai_stream_wait_last(void* waiting_stream, void* signalling_stream) {
+    hipStream_t w = (hipStream_t)waiting_stream, s = (hipStream_t)signalling_stream;
+    if (w == s) return 0;
+    Plan* p = pai::g_recording.load(std::memory_order_acquire);
+    static const bool off = getenv("PAI_NO_STOP_EVENTS") && atoi(getenv("PAI_NO_STOP_EVENTS")) != 0;
+    if (!p || off) return pai_stream_wait(waiting_stream, signalling_stream);
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        pai::PlanOp* src = nullptr;
+        for (size_t i = p->ops.size(); i-- > 0;) {
+            if (p->ops[i]->stream() != s) continue;
+            if (p->ops[i]->kind() == 0) src = p->ops[i];     // the last node of that stream is a kernel launch
+            break;
+        }
+        if (src) {
+            ev = src->stop_event();
+            if (!ev) {
+                const hipError_t e = hipEventCreateWithFlags(&ev, pai::event_flags());
+                PAI_CHECK(e == hipSuccess, "pai_stream_wait_last: hipEventCreate: %s", hipGetErrorString(e));
+                p->events.push_back(ev);
+                src->set_stop_event(ev);
+            }
+            p->ops.push_back(new pai::WaitOp(ev, w));
+        }
+    }
+    if (!ev) return pai_stream_wait(waiting_stream, signalling_stream);     // no launch of that stream in this plan yet
+    // the step being recorded runs now: an ordinary marker on this event
+    hipError_t e = hipEventRecord(ev, s);
+    PAI_CHECK(e == hipSuccess, "pai_stream_wait_last: hipEventRecord: %s", hipGetErrorString(e));
+    e = hipStreamWaitEvent(w, ev, 0);
+    PAI_CHECK(e == hipSuccess, "pai_stream_wait_last: hipStreamWaitEvent: %s", hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" int pai_event_create(pai_event_t* out) {
     PAI_CHECK(out != nullptr, "pai_event_create: null pointer");
     hipEvent_t ev = nullptr;

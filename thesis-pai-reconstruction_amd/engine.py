@@ -374,7 +374,7 @@ class _SideStream:
             return torch.cuda.current_stream()
         if self.stream is None:
             self.stream = torch.cuda.Stream()
-        ops.stream_wait(self.stream, torch.cuda.current_stream())      # C-ABI edge: recorded into launch plans
+        ops.stream_wait_last(self.stream, torch.cuda.current_stream())      # C-ABI edge: recorded into launch plans
         return self.stream
 
     def fork_tail(self):
@@ -385,7 +385,7 @@ class _SideStream:
             return torch.cuda.current_stream()
         if self.stream2 is None:
             self.stream2 = torch.cuda.Stream()
-        ops.stream_wait(self.stream2, torch.cuda.current_stream())
+        ops.stream_wait_last(self.stream2, torch.cuda.current_stream())
         if self._scratch_marked:
             # the thin weight-gradient kernels share the tail of the registered scratch buffer
             self.scratch_ev.wait(self.stream2)
@@ -401,9 +401,9 @@ class _SideStream:
 
     def join(self):
         if self.on and self.stream is not None:
-            ops.stream_wait(torch.cuda.current_stream(), self.stream)
+            ops.stream_wait_last(torch.cuda.current_stream(), self.stream)
         if self.on and self.stream2 is not None:
-            ops.stream_wait(torch.cuda.current_stream(), self.stream2)
+            ops.stream_wait_last(torch.cuda.current_stream(), self.stream2)
 
 
 # --------------------------------------------------------------------------------------

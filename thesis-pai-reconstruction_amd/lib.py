@@ -153,6 +153,7 @@ SIGNATURES = {
     "pai_plan_run": (_I, [_P, _L]),
     "pai_plan_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_L)]),
     "pai_stream_wait": (_I, [_P, _P]),
+    "pai_stream_wait_last": (_I, [_P, _P]),
     "pai_event_create": (_I, [C.POINTER(_P)]),
     "pai_event_destroy": (_I, [_P]),
     "pai_event_record": (_I, [_P, _P]),

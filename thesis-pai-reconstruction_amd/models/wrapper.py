@@ -100,13 +100,13 @@ class UnetWrapper(LightningModule):
         if side is None:
             side = torch.cuda.Stream(device=pred.device)
             object.__setattr__(self, "_metrics_stream", side)
-        ops.stream_wait(side, torch.cuda.current_stream())      # C-ABI edges: part of a recorded launch plan
+        ops.stream_wait_last(side, torch.cuda.current_stream())      # C-ABI edges: part of a recorded launch plan
         with torch.cuda.stream(side):
             return PF.metrics_of_normalized(pred, target)
 
     def _metrics_join(self, vals):
         cur = torch.cuda.current_stream()
-        ops.stream_wait(cur, self._metrics_stream)
+        ops.stream_wait_last(cur, self._metrics_stream)
         for v in vals:
             v.record_stream(cur)   # allocated on the side stream's pool, consumed on this one
         return vals

@@ -680,6 +680,12 @@ def stream_wait(waiting, signalling) -> None:
     L.check(L.load().pai_stream_wait(_raw(waiting), _raw(signalling)), "pai_stream_wait")
 
 
+def stream_wait_last(waiting, signalling) -> None:
+    """``stream_wait`` for an edge whose source is the LAST pai launch on ``signalling`` (nothing else was enqueued there
+    since): in a recorded plan the source launch carries the event itself (pai_stream_wait_last)."""
+    L.check(L.load().pai_stream_wait_last(_raw(waiting), _raw(signalling)), "pai_stream_wait_last")
+
+
 class Event:
     """A caller-owned event of the C ABI (pai_event_*): ``record(stream)`` now, ``wait(stream)`` later."""
 
