@@ -589,6 +589,11 @@ int pai_stream_wait_event(void* waiting_stream, pai_event_t ev);
  * segments of a gradient arena in front of a backward pass (replaces torch._foreach_zero_, so that the clear is a node
  * of the plan like everything else). */
 int pai_zero_multi(int count, void* const* ptrs, const int64_t* numels, void* stream);
+/* Up to 8 pai_cast calls of one dtype pair in ONE launch (host pointer tables; every numel a multiple of 8, every pointer
+ * 16-byte aligned): the four NHWC input copies in front of the batched PatchGAN pass (models/wrapper.py:236-238, torch.cat
+ * of the conditioning image and the real / generated one) were four 7-12 us launches. */
+int pai_cast_multi(int count, int src_dtype, const void* const* srcs, int dst_dtype, void* const* dsts,
+                   const int64_t* numels, void* stream);
 /* ptr[0 .. numel) *= factor (fp32, 16-byte aligned): the x 1/world_size average behind the SUM all-reduce of a gradient
  * bucket (DDP averages, reference main.py:123-136 through pl.Trainer), as a node of the plan. */
 int pai_scale(float* ptr, int64_t numel, float factor, void* stream);

@@ -313,6 +313,151 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
     }
 }
 
+// Round 4: the same computation with the run-time switches of the store path compiled away and the per-value vector work
+// cut from ~5 to ~2.5 instructions (the loop was as long as the store stream and the two did not overlap, DESIGN.md
+// section 10): the bias rides in as the MFMA's C operand, the activation is a template parameter (LeakyReLU = mul + max,
+// ReLU = max, none = nothing; no floor / slope registers), stores go through buffer descriptors with 32-bit offsets that
+// advance by a constant per iteration (rows beyond M fall outside the descriptor and are dropped: no predication), and
+// the two 8-channel pieces of a lane always form whole 64-B sectors.  4 x 4 kernels with even row length only
+// (thin_gather4); everything else stays on thin_fwd_k.
+//   RAW: write the un-activated output (y1 | y2);  ACTM: 0 no activated output, 1 LeakyReLU(0.2), 2 ReLU, 3 identity
+template <int T, bool RAW, int ACTM, int NG>      // NG: 64-channel groups (Cout / 64)
+__global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* w = (const bf16_t*)a.w;
+    constexpr int mtiles = 4 * NG;
+    constexpr int KT = 16 * T;
+    bf8_t af[4 * NG];
+#pragma unroll
+    for (int mt = 0; mt < 4 * NG; ++mt) {
+        us8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int co = 64 * (mt >> 2) + 32 * ((mt & 3) >> 1) + 8 * (fr >> 2) + 4 * (mt & 1) + (fr & 3);
+        if (mt < mtiles && 8 * fq < KT) z = *(const us8_t*)(w + (size_t)co * KT + 8 * fq);
+        af[mt] = __builtin_bit_cast(bf8_t, z);
+    }
+    // bias as the accumulator the MFMA starts from: acc[r] of tile q is channel 64 gq + 32 (q >> 1) + 8 fq + 4 (q & 1) + r
+    f4_t bias4[NG][4];
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bias4[gq][q][r] = a.bias ? a.bias[64 * gq + 32 * (q >> 1) + 8 * fq + 4 * (q & 1) + r] : 0.f;
+    const int pdx0 = g.dx[0][(8 * fq < KT) ? (8 * fq) / T : 0];
+    const int pdyA = g.dy[0][(8 * fq < KT) ? (8 * fq) / T : 0];
+    const int pdyB = g.dy[0][(8 * fq + 4 < KT) ? (8 * fq + 4) / T : 0];
+    const unsigned thin_bytes = (unsigned)(g.N * g.H * g.W) * 2u;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x1), 0, thin_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(T == 2 ? a.x2 : a.x1), 0, thin_bytes, 0x00020000);
+    const bool lane_k = 8 * fq < KT;
+    auto gather_fast = [&](int p0) {
+        const int m = p0 + fr;
+        int n, gy, gx;
+        decode_row2(g, m < g.M ? m : 0, n, gy, gx);
+        const int ix0 = gx * g.S + pdx0;
+        const int iyA = gy * g.S + pdyA, iyB = gy * g.S + pdyB;
+        const bool okA = lane_k && m < g.M && (unsigned)iyA < (unsigned)g.H;
+        uint2 pa, pb;
+        if (T == 1) {
+            const bool okB = lane_k && m < g.M && (unsigned)iyB < (unsigned)g.H;
+            pa = thin_gather4(rs1, (n * g.H + iyA) * g.W, ix0, g.W, okA);
+            pb = thin_gather4(rs1, (n * g.H + iyB) * g.W, ix0, g.W, okB);
+            if (g.relu1) { pa.x = relu2u(pa.x); pa.y = relu2u(pa.y); pb.x = relu2u(pb.x); pb.y = relu2u(pb.y); }
+        } else {
+            uint2 qa = thin_gather4(rs1, (n * g.H + iyA) * g.W, ix0, g.W, okA);
+            uint2 qb = thin_gather4(rs2, (n * g.H + iyA) * g.W, ix0, g.W, okA);
+            if (g.relu1) { qa.x = relu2u(qa.x); qa.y = relu2u(qa.y); }
+            if (g.relu2) { qb.x = relu2u(qb.x); qb.y = relu2u(qb.y); }
+            pa = make_uint2(__builtin_amdgcn_perm(qb.x, qa.x, 0x05040100u), __builtin_amdgcn_perm(qb.x, qa.x, 0x07060302u));
+            pb = make_uint2(__builtin_amdgcn_perm(qb.y, qa.y, 0x05040100u), __builtin_amdgcn_perm(qb.y, qa.y, 0x07060302u));
+        }
+        return __builtin_bit_cast(us8_t, make_uint4(pa.x, pa.y, pb.x, pb.y));
+    };
+    // output descriptors: 32-bit byte offsets, rows >= M are out of range (dropped by the hardware)
+    const unsigned raw1_bytes = (unsigned)g.M * (unsigned)g.D1 * 2u, raw2_bytes = (unsigned)g.M * (unsigned)g.D2 * 2u;
+    const __amdgpu_buffer_rsrc_t y1rs = __builtin_amdgcn_make_buffer_rsrc(a.y1, 0, RAW ? raw1_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.y2 ? a.y2 : a.y1, 0, (RAW && a.y2) ? raw2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yars = __builtin_amdgcn_make_buffer_rsrc(a.yact, 0, ACTM ? (unsigned)g.M * (unsigned)g.Cout * 2u : 0u, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    const int pstep = gridDim.x * 64;
+    int p0 = (blockIdx.x * 4 + wid) * 16;
+    // this lane's byte offsets of its first 8-channel piece (group 0) in each output
+    unsigned o_act = (unsigned)(p0 + fr) * (unsigned)g.Cout * 2u + 16u * fq;
+    unsigned o_r1 = (unsigned)(p0 + fr) * (unsigned)g.D1 * 2u + 16u * fq;
+    unsigned o_r2 = (unsigned)(p0 + fr) * (unsigned)g.D2 * 2u + 16u * fq;
+    const unsigned s_act = (unsigned)pstep * (unsigned)g.Cout * 2u, s_r1 = (unsigned)pstep * (unsigned)g.D1 * 2u,
+                   s_r2 = (unsigned)pstep * (unsigned)g.D2 * 2u;
+    const bool second_raw = RAW && g.D2 > 0;      // group 1 of a 128-channel layer goes to y2 (D1 = D2 = 64), else to y1 + 128 B
+    // The patch gathers run THREE iterations ahead (4 registers each): an iteration is one round trip to L2 / HBM
+    // (~2-3 us under load), each CU holds 6-7 waves per SIMD and every wave has only ~18 iterations -- one iteration of
+    // lookahead left the loop latency-bound (D block 0 at batch 128: 81 us warm against 40 us of stores).
+    constexpr int AHEAD = 3;
+    us8_t pq[AHEAD];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) {
+        pq[i] = (us8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        if ((int64_t)p0 + (int64_t)i * pstep < g.M) pq[i] = gather_fast(p0 + i * pstep);
+    }
+    for (; p0 < g.M; p0 += pstep) {
+        us8_t pnext = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((int64_t)p0 + (int64_t)AHEAD * pstep < g.M) pnext = gather_fast(p0 + AHEAD * pstep);
+        const bf8_t bfrag = __builtin_bit_cast(bf8_t, pq[0]);
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            f4_t acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[gq * 4 + q], bfrag, bias4[gq][q], 0, 0, 0);
+            if (RAW) {
+                const u4_t lo = {pk2bf(acc[0][0], acc[0][1]), pk2bf(acc[0][2], acc[0][3]), pk2bf(acc[1][0], acc[1][1]), pk2bf(acc[1][2], acc[1][3])};
+                const u4_t hi = {pk2bf(acc[2][0], acc[2][1]), pk2bf(acc[2][2], acc[2][3]), pk2bf(acc[3][0], acc[3][1]), pk2bf(acc[3][2], acc[3][3])};
+                if (gq == 1 && second_raw) {
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, y2rs, (int)o_r2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, y2rs, (int)o_r2 + 64, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, y1rs, (int)o_r1 + 128 * gq, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, y1rs, (int)o_r1 + 128 * gq + 64, 0, 0);
+                }
+            }
+            if (ACTM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ACTM == 1) acc[q][r] = fmaxf(acc[q][r], 0.2f * acc[q][r]);
+                        else if (ACTM == 2) acc[q][r] = fmaxf(acc[q][r], 0.f);
+                    }
+                const u4_t lo = {pk2bf(acc[0][0], acc[0][1]), pk2bf(acc[0][2], acc[0][3]), pk2bf(acc[1][0], acc[1][1]), pk2bf(acc[1][2], acc[1][3])};
+                const u4_t hi = {pk2bf(acc[2][0], acc[2][1]), pk2bf(acc[2][2], acc[2][3]), pk2bf(acc[3][0], acc[3][1]), pk2bf(acc[3][2], acc[3][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(lo, yars, (int)o_act + 128 * gq, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(hi, yars, (int)o_act + 128 * gq + 64, 0, 0);
+            }
+        }
+        o_act += s_act; o_r1 += s_r1; o_r2 += s_r2;
+#pragma unroll
+        for (int i = 0; i + 1 < AHEAD; ++i) pq[i] = pq[i + 1];
+        pq[AHEAD - 1] = pnext;
+    }
+}
+
+template <int T>
+static void launch_thin_fwd2(const GG& g, const FwdArgs& a, int blocks, hipStream_t s) {
+    const bool raw = a.y1 || a.y2;
+    const int actm = !a.yact ? 0 : (a.eact == PAI_ACT_LRELU ? 1 : (a.eact == PAI_ACT_RELU ? 2 : 3));
+#define TF2(RAWV, ACTV)                                                                                   \
+    do {                                                                                                  \
+        if (g.Cout == 64) PAI_LAUNCH((thin_fwd2_k<T, RAWV, ACTV, 1>), dim3(blocks), dim3(256), 0, s, g, a); \
+        else PAI_LAUNCH((thin_fwd2_k<T, RAWV, ACTV, 2>), dim3(blocks), dim3(256), 0, s, g, a);             \
+    } while (0)
+    if (raw) {
+        if (actm == 0) TF2(true, 0); else if (actm == 1) TF2(true, 1); else if (actm == 2) TF2(true, 2); else TF2(true, 3);
+    } else {
+        if (actm == 1) TF2(false, 1); else if (actm == 2) TF2(false, 2); else TF2(false, 3);
+    }
+#undef TF2
+}
+
 int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
     int blocks = cdiv(g.M, 64);
     static const int cap = getenv("PAI_TF_BLOCKS") ? atoi(getenv("PAI_TF_BLOCKS")) : 4096;
@@ -323,6 +468,15 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
     // (scripts/micro/convbench, thin_sect = 0 / 1: encoders[0] forward 43.7 -> 42.8 us, D block 0 forward 76.9 -> 75.2,
     // input gradient of decoders[7] 56.6 -> 54.0; bit-identical outputs)
     if (pai_tunable("thin_sect", 1) && (g.D2 == 0 || (g.D1 % 64) == 0)) fast_ok |= 2;
+    // thin_fwd2_k: 4 x 4 kernels, whole-sector stores, every output below 4 GB, tanh not needed here, an output to write
+    const bool out_ok = (a.y1 || a.y2 || a.yact) && (!a.yact || a.eact != PAI_ACT_TANH) && (!a.y2 || a.y1) &&
+                        (int64_t)g.M * g.Cout * 2 < (1ll << 32) && (g.D2 == 0 || (g.D1 == 64 && g.D2 == 64));
+    if (pai_tunable("thin_fwd2", 1) && fast_ok == 3 && g.ntaps == 16 && out_ok && (g.Cout == 64 || g.Cout == 128) && !(a.yact && (a.y1 || a.y2) && g.D2 > 0)) {
+        if (g.C2 == 0) launch_thin_fwd2<1>(g, a, blocks, s);
+        else launch_thin_fwd2<2>(g, a, blocks, s);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     if (g.C2 == 0) PAI_LAUNCH(thin_fwd_k<1>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
     else PAI_LAUNCH(thin_fwd_k<2>, dim3(blocks), dim3(256), 0, s, g, a, fast_ok);
     PAI_LAUNCH_CHECK();

@@ -616,3 +616,53 @@ extern "C" int pai_scale(float* ptr, int64_t numel, float factor, void* stream) 
     PAI_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- several dtype casts in one launch (the four NHWC copies in front of a batched discriminator pass) --------------
+#define CAST_CHUNK 8
+struct CastChunk {
+    const void* src[CAST_CHUNK];
+    void* dst[CAST_CHUNK];
+    int64_t nvec[CAST_CHUNK];      // 8-element vectors per tensor
+};
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_multi_k(CastChunk c) {
+    const S* src = (const S*)c.src[blockIdx.y];
+    D* dst = (D*)c.dst[blockIdx.y];
+    const int64_t n = c.nvec[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        V8<S>::ld(src + 8 * i, v);
+        V8<D>::st(dst + 8 * i, v);
+    }
+}
+
+extern "C" int pai_cast_multi(int count, int src_dtype, const void* const* srcs, int dst_dtype, void* const* dsts,
+                              const int64_t* numels, void* stream) {
+    PAI_CHECK(count >= 0 && count <= CAST_CHUNK && (count == 0 || (srcs && dsts && numels)), "pai_cast_multi: 0..%d tensors", CAST_CHUNK);
+    PAI_CHECK((src_dtype == PAI_F32 || src_dtype == PAI_BF16) && (dst_dtype == PAI_F32 || dst_dtype == PAI_BF16),
+              "pai_cast_multi: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    if (count == 0) return 0;
+    CastChunk c;
+    memset(&c, 0, sizeof(c));
+    int64_t big = 1;
+    for (int i = 0; i < count; ++i) {
+        PAI_CHECK(srcs[i] && dsts[i] && numels[i] >= 0 && (numels[i] % 8) == 0 &&
+                      ((((uintptr_t)srcs[i]) | ((uintptr_t)dsts[i])) & 15) == 0,
+                  "pai_cast_multi: tensor %d: null, not a multiple of 8 elements, or not 16-byte aligned", i);
+        c.src[i] = srcs[i];
+        c.dst[i] = dsts[i];
+        c.nvec[i] = numels[i] / 8;
+        if (c.nvec[i] > big) big = c.nvec[i];
+    }
+    int64_t bx = (big + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const dim3 grid((unsigned)bx, (unsigned)count);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == PAI_F32 && dst_dtype == PAI_BF16) PAI_LAUNCH((cast_multi_k<float, bf16_t>), grid, dim3(256), 0, s, c);
+    else if (src_dtype == PAI_BF16 && dst_dtype == PAI_F32) PAI_LAUNCH((cast_multi_k<bf16_t, float>), grid, dim3(256), 0, s, c);
+    else if (src_dtype == PAI_F32) PAI_LAUNCH((cast_multi_k<float, float>), grid, dim3(256), 0, s, c);
+    else PAI_LAUNCH((cast_multi_k<bf16_t, bf16_t>), grid, dim3(256), 0, s, c);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

@@ -946,15 +946,21 @@ class DiscEngine:
         reps = 1 if y2 is None else 2
         S = self.acquire(N * reps, H, W, dtype, x.device)
         P = S["P"]
-        if y2 is None:
+        if y2 is None and dtype != torch.float32 and C == 1:
+            ops.cast_multi([(x.detach().to(torch.float32).contiguous().reshape(-1), S["x"]),
+                            (y.detach().to(torch.float32).contiguous().reshape(-1), S["y"])])
+            S["xin"], S["yin"] = S["x"], S["y"]
+        elif y2 is None:
             S["xin"] = self._to_nhwc(x, S["x"], dtype)
             S["yin"] = self._to_nhwc(y, S["y"], dtype)
         else:
             half = N * H * W * C
+            pairs = []
             for src, dst in ((x, S["x"][:half]), (x, S["x"][half:]), (y, S["y"][:half]), (y2, S["y"][half:])):
                 t = src.detach().to(torch.float32)
                 t = t.contiguous() if C == 1 else t.permute(0, 2, 3, 1).contiguous()
-                ops.cast(t, dst)       # fp32 too: a C-ABI copy (a node of the launch plan), not torch's copy_
+                pairs.append((t.reshape(-1), dst))
+            ops.cast_multi(pairs)      # one launch; fp32 too: C-ABI copies (nodes of the launch plan), not torch's copy_
             S["xin"], S["yin"] = S["x"], S["y"]
         refresh_packs(self.packs, dtype)
         wf, _ = self.packs[0].get(dtype)

@@ -611,6 +611,25 @@ def cast(src, dst):
             "pai_cast")
 
 
+def cast_multi(pairs) -> None:
+    """``cast(src, dst)`` for up to 8 (src, dst) pairs of ONE dtype pair in one launch (pai_cast_multi); pairs that do not
+    fit its contract (a multiple of 8 elements, 16-byte aligned) go through ``cast`` one by one."""
+    pairs = list(pairs)
+    ok = len(pairs) > 1 and len(pairs) <= 8 and len({(s.dtype, d.dtype) for s, d in pairs}) == 1 and all(
+        s.numel() == d.numel() and s.numel() % 8 == 0 and s.data_ptr() % 16 == 0 and d.data_ptr() % 16 == 0 and s.is_cuda
+        and d.is_cuda and s.is_contiguous() and d.is_contiguous() for s, d in pairs)
+    if not ok:
+        for s, d in pairs:
+            cast(s, d)
+        return
+    n = len(pairs)
+    srcs = (C.c_void_p * n)(*[s.data_ptr() for s, _ in pairs])
+    dsts = (C.c_void_p * n)(*[d.data_ptr() for _, d in pairs])
+    numels = (C.c_int64 * n)(*[s.numel() for s, _ in pairs])
+    L.check(L.load().pai_cast_multi(n, code_of(pairs[0][0].dtype), srcs, code_of(pairs[0][1].dtype), dsts, numels, _stream()),
+            "pai_cast_multi")
+
+
 def reduce_rows(partial, rows, C_, out, accumulate=False):
     L.check(L.load().pai_reduce_rows(_p(partial, torch.float32), rows, C_, _p(out, torch.float32),
                                      int(accumulate), _stream()), "pai_reduce_rows")
