@@ -131,7 +131,8 @@ def test_plan_replay_is_one_c_call_of_host_time(pai):
     eager = (time.perf_counter() - t0) / 20
     torch.cuda.synchronize()
     print(f"host issue per step: plan {host * 1e3:.3f} ms, eager {eager * 1e3:.3f} ms, {ps.describe()['nodes']}")
-    assert host < 1.2e-3 and host < 0.5 * eager
+    # ~0.75-0.95 ms on an idle box (160 launches + 25 edges at ~5 us); the bound leaves room for a loaded host
+    assert host < 2.5e-3 and host < 0.5 * eager
     assert np.isfinite(float(m.logged["loss"]))
 
 

@@ -642,26 +642,37 @@ __global__ __launch_bounds__(256) void thin_up_k(GG g, FwdArgs a, int t0, int ti
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             af[tt][s] = *(const bf8_t*)(w + (size_t)((t0 + tt) * g.wtaps + fr) * g.Cin + 32 * s + 8 * fq);
-    for (int gi = wid; gi < TU_GROUPS; gi += 4) {
+    // A wave's pixel groups (5 or 6 of the 21) are loaded TWO AT A TIME ahead of the MFMAs that consume them: with one
+    // group per round trip the wave waited out an L2 / HBM latency five times over (round 4).
+    auto load_group = [&](int gi, bf8_t (&bfr)[KS]) {
         const int p = gi * 16 + fr;
         const int hy = p / TU_HW, hx = p - hy * TU_HW;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        const bool inb = p < TU_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        const bool inb = gi < TU_GROUPS && p < TU_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
         const size_t m = inb ? (size_t)(n * g.H + iy) * g.W + ix : 0;
-        bf8_t bfr[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c = 32 * s + 8 * fq;
             bfr[s] = __builtin_bit_cast(bf8_t, make_uint4(0, 0, 0, 0));
             if (inb) {
-                if (c < g.C1) {
-                    bfr[s] = *(const bf8_t*)(x1 + m * g.C1 + c);
-                    if (g.relu1) bfr[s] = relu8(bfr[s]);
-                } else {
-                    bfr[s] = *(const bf8_t*)(x2 + m * g.C2 + (c - g.C1));
-                    if (g.relu2) bfr[s] = relu8(bfr[s]);
-                }
+                if (c < g.C1) bfr[s] = *(const bf8_t*)(x1 + m * g.C1 + c);
+                else bfr[s] = *(const bf8_t*)(x2 + m * g.C2 + (c - g.C1));
             }
+        }
+    };
+    bf8_t cur[KS], nxt[KS], nx2[KS];
+    load_group(wid, cur);
+    load_group(wid + 4, nxt);
+    for (int gi = wid; gi < TU_GROUPS; gi += 4) {
+        const int p = gi * 16 + fr;
+        load_group(gi + 8, nx2);
+        bf8_t bfr[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bfr[s] = cur[s];
+            if ((32 * s + 8 * fq < g.C1) ? g.relu1 : g.relu2) bfr[s] = relu8(bfr[s]);
+            cur[s] = nxt[s];
+            nxt[s] = nx2[s];
         }
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
