@@ -583,6 +583,14 @@ extern "C" int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const v
         if (partial_rows) *partial_rows = !e->partials ? 0 : (pw_ok(d->dtype, g, a) ? pw_rows(g) : fwd_mfma_mtiles(g) * g.nphase);
         return run_fwd(d->dtype, g, a, s);
     }
+    if (e->partials) {
+        // thin -> wide input gradient (the head of the U-Net): the pass rides on thin_fwd2_k's store
+        if (const int rows = thin_fwd_bwd_rows(d->dtype, g, a, e->act1, e->add, e->scale)) {
+            a.bz = e->z; a.bmean = e->mean; a.brstd = e->rstd; a.bpart = e->partials; a.bact1 = e->act1;
+            *partial_rows = rows;
+            return run_fwd(d->dtype, g, a, s);
+        }
+    }
     // other kernel families: plain input gradient, then the same arithmetic as a second pass in place
     int rc = run_fwd(d->dtype, g, a, s);
     if (rc) return rc;

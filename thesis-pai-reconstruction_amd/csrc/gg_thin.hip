@@ -321,7 +321,11 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
 // the two 8-channel pieces of a lane always form whole 64-B sectors.  4 x 4 kernels with even row length only
 // (thin_gather4); everything else stays on thin_fwd_k.
 //   RAW: write the un-activated output (y1 | y2);  ACTM: 0 no activated output, 1 LeakyReLU(0.2), 2 ReLU, 3 identity
-template <int T, bool RAW, int ACTM, int NG>      // NG: 64-channel groups (Cout / 64)
+//   BWD (RAW, D1 = 64): the first pass of the BatchNorm backward of the layer that PRODUCED the y1 tensor rides on the
+//   store (pai_conv_dgrad_bn with act1 = none, no second gradient: du IS the value stored): z of the same elements is
+//   read beside the store and one partial row [2][64] = (sum du, sum du * xhat) is written per workgroup -- decoders[6]
+//   behind the head's input gradient: bn_bwd_reduce_k (88 us in the step: 268 MB read) becomes 134 MB read here.
+template <int T, bool RAW, int ACTM, int NG, bool BWD = false>      // NG: 64-channel groups (Cout / 64)
 __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -381,6 +385,10 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
     const __amdgpu_buffer_rsrc_t y2rs = __builtin_amdgcn_make_buffer_rsrc(a.y2 ? a.y2 : a.y1, 0, (RAW && a.y2) ? raw2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t yars = __builtin_amdgcn_make_buffer_rsrc(a.yact, 0, ACTM ? (unsigned)g.M * (unsigned)g.Cout * 2u : 0u, 0x00020000);
     typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.bz ? a.bz : a.x1), 0, (BWD && RAW) ? raw1_bytes : 0u, 0x00020000);
+    float bs1[BWD ? 16 : 1], bs2[BWD ? 16 : 1];      // this lane's 16 channels of group 0: sum du, sum du * z
+#pragma unroll
+    for (int c = 0; c < (BWD ? 16 : 1); ++c) bs1[c] = bs2[c] = 0.f;
     const int pstep = gridDim.x * 64;
     int p0 = (blockIdx.x * 4 + wid) * 16;
     // this lane's byte offsets of its first 8-channel piece (group 0) in each output
@@ -404,6 +412,11 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
         us8_t pnext = {0, 0, 0, 0, 0, 0, 0, 0};
         if ((int64_t)p0 + (int64_t)AHEAD * pstep < g.M) pnext = gather_fast(p0 + AHEAD * pstep);
         const bf8_t bfrag = __builtin_bit_cast(bf8_t, pq[0]);
+        u4_t zlo = {0u, 0u, 0u, 0u}, zhi = {0u, 0u, 0u, 0u};
+        if (BWD) {      // rows >= M: out of range, read as zero (and the value stored for them is dropped)
+            zlo = __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)o_r1, 0, 0);
+            zhi = __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)o_r1 + 64, 0, 0);
+        }
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
             f4_t acc[4];
@@ -412,6 +425,19 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
             if (RAW) {
                 const u4_t lo = {pk2bf(acc[0][0], acc[0][1]), pk2bf(acc[0][2], acc[0][3]), pk2bf(acc[1][0], acc[1][1]), pk2bf(acc[1][2], acc[1][3])};
                 const u4_t hi = {pk2bf(acc[2][0], acc[2][1]), pk2bf(acc[2][2], acc[2][3]), pk2bf(acc[3][0], acc[3][1]), pk2bf(acc[3][2], acc[3][3])};
+                if (BWD && gq == 0 && p0 + fr < g.M) {
+                    // the bf16 values as stored (what a second pass would read back), against z of the same elements
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g0 = __uint_as_float(lo[e] << 16), g1 = __uint_as_float(lo[e] & 0xffff0000u);
+                        const float h0 = __uint_as_float(hi[e] << 16), h1 = __uint_as_float(hi[e] & 0xffff0000u);
+                        bs1[2 * e] += g0; bs1[2 * e + 1] += g1; bs1[8 + 2 * e] += h0; bs1[8 + 2 * e + 1] += h1;
+                        bs2[2 * e] = fmaf(g0, __uint_as_float(zlo[e] << 16), bs2[2 * e]);
+                        bs2[2 * e + 1] = fmaf(g1, __uint_as_float(zlo[e] & 0xffff0000u), bs2[2 * e + 1]);
+                        bs2[8 + 2 * e] = fmaf(h0, __uint_as_float(zhi[e] << 16), bs2[8 + 2 * e]);
+                        bs2[8 + 2 * e + 1] = fmaf(h1, __uint_as_float(zhi[e] & 0xffff0000u), bs2[8 + 2 * e + 1]);
+                    }
+                }
                 if (gq == 1 && second_raw) {
                     __builtin_amdgcn_raw_buffer_store_b128(lo, y2rs, (int)o_r2, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(hi, y2rs, (int)o_r2 + 64, 0, 0);
@@ -439,6 +465,36 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
         for (int i = 0; i + 1 < AHEAD; ++i) pq[i] = pq[i + 1];
         pq[AHEAD - 1] = pnext;
     }
+    if (BWD) {
+        // sum over the wave's 16 pixel lanes (fr: one DPP row), then over the four waves through LDS; channel of
+        // accumulator c of row fq: 8 fq + c (c < 8), 32 + 8 fq + (c - 8) otherwise
+        __shared__ float red[4][2][64];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float s1 = bs1[c], s2 = bs2[c];
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xF, 0xF, false));
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, false));
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x4E, 0xF, 0xF, false));
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x141, 0xF, 0xF, false));
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x141, 0xF, 0xF, false));
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x140, 0xF, 0xF, false));
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x140, 0xF, 0xF, false));
+            if (fr == 0) {
+                const int ch = (c < 8) ? 8 * fq + c : 32 + 8 * fq + (c - 8);
+                red[wid][0][ch] = s1;
+                red[wid][1][ch] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const float s1 = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+            const float s2 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+            float* row = a.bpart + (size_t)blockIdx.x * 2 * g.D1;
+            row[tid] = s1;
+            row[g.D1 + tid] = a.brstd[tid] * (s2 - a.bmean[tid] * s1);      // sum du * xhat
+        }
+    }
 }
 
 template <int T>
@@ -450,7 +506,9 @@ static void launch_thin_fwd2(const GG& g, const FwdArgs& a, int blocks, hipStrea
         if (g.Cout == 64) PAI_LAUNCH((thin_fwd2_k<T, RAWV, ACTV, 1>), dim3(blocks), dim3(256), 0, s, g, a); \
         else PAI_LAUNCH((thin_fwd2_k<T, RAWV, ACTV, 2>), dim3(blocks), dim3(256), 0, s, g, a);             \
     } while (0)
-    if (raw) {
+    if (raw && a.bz) {      // thin_fwd_bwd_rows: T = 1, D1 = D2 = 64, no activated output
+        PAI_LAUNCH((thin_fwd2_k<1, true, 0, 2, true>), dim3(blocks), dim3(256), 0, s, g, a);
+    } else if (raw) {
         if (actm == 0) TF2(true, 0); else if (actm == 1) TF2(true, 1); else if (actm == 2) TF2(true, 2); else TF2(true, 3);
     } else {
         if (actm == 1) TF2(false, 1); else if (actm == 2) TF2(false, 2); else TF2(false, 3);
@@ -458,10 +516,31 @@ static void launch_thin_fwd2(const GG& g, const FwdArgs& a, int blocks, hipStrea
 #undef TF2
 }
 
-int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
+static int thin_fwd_blocks(const GG& g) {
     int blocks = cdiv(g.M, 64);
     static const int cap = getenv("PAI_TF_BLOCKS") ? atoi(getenv("PAI_TF_BLOCKS")) : 4096;
-    if (blocks > cap) blocks = cap;
+    return blocks > cap ? cap : blocks;
+}
+
+static bool thin_fwd2_ok(const GG& g, const FwdArgs& a) {
+    const bool fast = pai_tunable("thin_fast", 1) && (g.W % 2) == 0 && (int64_t)g.N * g.H * g.W * 2 < (1ll << 31) &&
+                      pai_tunable("thin_sect", 1) && (g.D2 == 0 || (g.D1 % 64) == 0);
+    const bool out_ok = (a.y1 || a.y2 || a.yact) && (!a.yact || a.eact != PAI_ACT_TANH) && (!a.y2 || a.y1) &&
+                        (int64_t)g.M * g.Cout * 2 < (1ll << 32) && (g.D2 == 0 || (g.D1 == 64 && g.D2 == 64));
+    return pai_tunable("thin_fwd2", 1) && fast && g.ntaps == 16 && out_ok && (g.Cout == 64 || g.Cout == 128) &&
+           !(a.yact && (a.y1 || a.y2) && g.D2 > 0);
+}
+
+// pai_conv_dgrad_bn on a thin -> wide input gradient: the producer's first BatchNorm-backward pass in the store
+// (thin_fwd2_k<..., BWD>); returns the partial rows the launch writes (one per workgroup), 0 = not this kernel
+int thin_fwd_bwd_rows(int dtype, const GG& g, const FwdArgs& a, int act1, const void* add, const float* scale) {
+    if (!thin_fwd_ok(dtype, g, a) || !thin_fwd2_ok(g, a) || !pai_tunable("thin_bwd", 1)) return 0;
+    if (g.C2 != 0 || g.D1 != 64 || g.D2 != 64 || !a.y1 || !a.y2 || a.yact || act1 != PAI_ACT_NONE || add || scale) return 0;
+    return thin_fwd_blocks(g);
+}
+
+int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
+    int blocks = thin_fwd_blocks(g);
     // thin_gather4: even row length, 32-bit byte offsets
     int fast_ok = pai_tunable("thin_fast", 1) && (g.W % 2) == 0 && (int64_t)g.N * g.H * g.W * 2 < (1ll << 31);
     // whole-sector stores need both 8-channel pieces of a lane in the same output tensor: 64-channel groups
@@ -469,9 +548,7 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
     // input gradient of decoders[7] 56.6 -> 54.0; bit-identical outputs)
     if (pai_tunable("thin_sect", 1) && (g.D2 == 0 || (g.D1 % 64) == 0)) fast_ok |= 2;
     // thin_fwd2_k: 4 x 4 kernels, whole-sector stores, every output below 4 GB, tanh not needed here, an output to write
-    const bool out_ok = (a.y1 || a.y2 || a.yact) && (!a.yact || a.eact != PAI_ACT_TANH) && (!a.y2 || a.y1) &&
-                        (int64_t)g.M * g.Cout * 2 < (1ll << 32) && (g.D2 == 0 || (g.D1 == 64 && g.D2 == 64));
-    if (pai_tunable("thin_fwd2", 1) && fast_ok == 3 && g.ntaps == 16 && out_ok && (g.Cout == 64 || g.Cout == 128) && !(a.yact && (a.y1 || a.y2) && g.D2 > 0)) {
+    if (thin_fwd2_ok(g, a)) {
         if (g.C2 == 0) launch_thin_fwd2<1>(g, a, blocks, s);
         else launch_thin_fwd2<2>(g, a, blocks, s);
         PAI_LAUNCH_CHECK();

@@ -545,7 +545,7 @@ class UnetEngine:
         for i in range(2, L):      # fused first pass of encoder i-1's BatchNorm backward in encoder i's dgrad
             if self.enc_bn[i - 1] is not None:
                 mx = max(mx, ops.conv_dgrad_bn_rows_max(P["enc_desc"][i]) * 2 * self.enc_c[i - 1])
-        for j in range(1, L - 1):  # ... of decoder j-1's in decoder j's dgrad
+        for j in range(1, L):      # ... of decoder j-1's in decoder j's dgrad (j = L-1: the head's thin kernel)
             if self.dec_bn[j - 1] is not None:
                 mx = max(mx, ops.conv_dgrad_bn_rows_max(P["dec_desc"][j]) * 2 * self.dec_c[j - 1])
         P["bwd_partials"] = torch.empty(mx, dtype=torch.float32, device=device)
@@ -755,16 +755,23 @@ class UnetEngine:
         wgrad(d, x1, x2, dh, self.dec_conv[j], True)
         side.mark_scratch()
         _, wd = self.dec_packs[j].get(dtype)
-        ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
-        if (j - 1) in S["drop"]:
-            ops.dropout2d(dtype, G["gr"][j - 1], S["drop"][j - 1], N, S["dh"][j - 1] * S["dw"][j - 1], self.dec_c[j - 1],
-                          G["gr"][j - 1])
-        # From here on every input-gradient launch also runs the first half of the backward of the layer
-        # that PRODUCED its input (activation derivative, the encoder/skip sum, BatchNorm-backward partial
-        # sums) in its store (pai_conv_dgrad_bn): the gradient tensor it writes is already `du`, and
-        # `fused_rows` partial rows wait in P["bwd_partials"] for pai_bn_bwd_finalize.
-        fused_rows = None   # None: the head's thin kernel wrote a plain gradient for decoder L-2
         part = P["bwd_partials"]
+        # Every input-gradient launch also runs the first half of the backward of the layer that PRODUCED its input
+        # (activation derivative, the encoder/skip sum, BatchNorm-backward partial sums) in its store
+        # (pai_conv_dgrad_bn): the gradient tensor it writes is already `du`.  The head's thin kernel does so too
+        # (decoders[L-2] is read without an activation: du IS the gradient it stores), unless Dropout2d sits in between.
+        fused_rows = None   # None: a plain gradient for decoder L-2 waits in G["gr"][L-2]
+        if (j - 1) in S["drop"] or self.dec_bn[j - 1] is None:
+            ops.conv_dgrad(d, dh, wd, G["gr"][j - 1], G["gskip"][0])
+            if (j - 1) in S["drop"]:
+                ops.dropout2d(dtype, G["gr"][j - 1], S["drop"][j - 1], N, S["dh"][j - 1] * S["dw"][j - 1], self.dec_c[j - 1],
+                              G["gr"][j - 1])
+        else:
+            pst, pbn = S["dbn"][j - 1], self.dec_bn[j - 1]
+            ops.conv_dgrad_bn_apply(d, dh, wd, G["gr"][j - 1], G["gskip"][0], S["w"][j - 1], ACT_NONE, None, ACT_NONE,
+                                    None, None, pst.mean, pst.rstd, part, pbn.weight, pst.sums, A.seg(pbn.weight),
+                                    A.seg(pbn.bias), G["dz_dec"][j - 1])
+            fused_rows = -1
         # BN decoders
         for j in range(L - 2, -1, -1):
             bn, st, conv = self.dec_bn[j], S["dbn"][j], self.dec_conv[j]
