@@ -331,6 +331,51 @@ def test_fused_producer_backward_bit_exact(pai, cfg):
         assert float((P[1] - s2).abs().max()) <= 1e-5 * float((du_bf.abs() * 8).double().sum((0, 2, 3)).max())
 
 
+@pytest.mark.parametrize("shape", [(64, 128), (3, 16)], ids=["cfg2_dec7", "small"])
+def test_fused_producer_backward_of_the_thin_head_bit_exact(pai, shape):
+    """pai_conv_dgrad_bn on the head (ConvTranspose2d(64|64 -> 1), reference models/pix2pix.py:185-193): the input
+    gradient runs on thin_fwd2_k and the first BatchNorm-backward pass of decoders[6] (read without an activation: du is
+    the gradient itself) rides on its store.  Integer data: both halves of the gradient and the partial sums
+    (sum du, sum du * xhat per channel, one row per workgroup) equal the PyTorch-CPU restatement bit for bit; with the
+    fusion switched off (tunable thin_bwd = 0) the entry point's two-pass form gives the same du and the same sums."""
+    from thesis_pai_reconstruction_amd import ops
+    N, H = shape
+    C1 = C2 = 64
+    dt = torch.bfloat16
+    w = _ints((C1 + C2, 1, 4, 4), 3)
+    dy = _ints((N, 1, 2 * H, 2 * H), 5)
+    x = torch.zeros(N, C1 + C2, H, H, requires_grad=True)
+    F.conv_transpose2d(x, w, None, stride=2, padding=1).backward(dy)
+    g = x.grad.bfloat16().float()
+    z = _ints((N, C1, H, H), 11, -3, 3)
+    mean = torch.tensor([1.0, -1.0, 0.0, 2.0]).repeat(C1 // 4)
+    rstd = torch.tensor([0.5, 1.0, 2.0, 0.25]).repeat(C1 // 4)
+    s1 = g[:, :C1].double().sum((0, 2, 3))
+    s2 = (g[:, :C1].double() * ((z.double() - mean.view(1, -1, 1, 1).double()) * rstd.view(1, -1, 1, 1).double())).sum((0, 2, 3))
+    d = ops.make_desc(dt, 1, N, H, H, C1, C2, 1, 2, 0, 0, ops.ACT_NONE)
+    ops.ensure_scratch(ops.scratch_bytes_for([d]), dev())
+    wd = torch.empty(w.numel(), dtype=dt, device=dev())
+    ops.pack_weights(dt, fwd_pack(w, True), 1, 16, C1 + C2, None, wd)
+    f = lambda t: t.to(dev())
+    for fused in (1, 0):
+        ops.set_tunable("thin_bwd", fused)
+        try:
+            dx1 = torch.empty(N * H * H * C1, dtype=dt, device=dev())
+            dx2 = torch.empty(N * H * H * C2, dtype=dt, device=dev())
+            part = torch.full((ops.conv_dgrad_bn_rows_max(d) * 2 * C1,), float("nan"), device=dev())
+            rows = ops.conv_dgrad_bn(d, nhwc(dy, dt), wd, dx1, dx2, nhwc(z, dt), ops.ACT_NONE, None, ops.ACT_NONE, None, None,
+                                     f(mean), f(rstd), part)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_tunable("thin_bwd")
+        assert ops.conv_kernel_id(d, 1) == 4 and rows > 0, (fused, rows)
+        if fused:
+            assert rows == min((N * H * H + 63) // 64, 4096), rows          # one partial row per workgroup of thin_fwd2_k
+        assert torch.equal(from_nhwc(dx1, N, H, H, C1), g[:, :C1]) and torch.equal(from_nhwc(dx2, N, H, H, C2), g[:, C1:]), fused
+        P = part[: rows * 2 * C1].view(rows, 2, C1).double().sum(0).cpu()
+        assert torch.equal(P[0], s1) and torch.equal(P[1], s2), fused
+
+
 # ---- the thin layers at the benchmark's own shapes (BASELINE configs[1]) --------------------------------------------
 # (name, transposed, N, H, C1, C2, Cout): encoders[0], discriminator block 0 at the 2 x 64 batch of its own phase, and
 # decoders[7] (reference models/pix2pix.py:141-147,185-193, models/wrapper.py:229)
