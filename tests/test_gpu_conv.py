@@ -57,7 +57,7 @@ CASES = [
 BF16_FAMILY = {
     "enc0_cin1": (4, 1, 4), "disc0_cin1x2": (4, 1, 4), "enc_mid": (2, 3, 2), "enc_wide": (2, 2, 2),
     "enc_bottleneck": (2, 2, 2), "dec0": (2, 2, 2), "dec_skip": (3, 3, 3), "dec_skip_wide": (2, 2, 2),
-    "head_cout1": (1, 4, 4), "patch_final": (1, 4, 1), "patch_final_wide": (1, 0, 4), "head_relu_skip": (1, 4, 4),
+    "head_cout1": (1, 4, 4), "patch_final": (1, 4, 1), "patch_final_wide": (1, 4, 4), "head_relu_skip": (1, 4, 4),
     "odd_batch_rgb": (0, 0, 0), "enc_patch": (2, 3, 2), "dec_patch": (2, 3, 2), "enc_patch256": (2, 3, 2),
     "dec_patch256": (2, 2, 2), "enc0_wide": (4, 1, 4), "disc0_wide": (4, 1, 4), "head_wide": (1, 4, 4),
     "dec_patch256x64": (3, 2, 3), "enc_dgrad256": (2, 2, 2), "enc_splitk": (2, 2, 2), "dec_splitk": (2, 2, 2),

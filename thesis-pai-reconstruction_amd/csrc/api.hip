@@ -447,6 +447,11 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
     }
     if (op != 2 && grouped3_ok(d->dtype, g, a)) return 6;
     if (thin_fwd_ok(d->dtype, g, a) || thin_dgrad_ok(d->dtype, g, a) || pw_ok(d->dtype, g, a)) return 4;
+    if (op == 1 && g.D2 == 0) {          // single-destination input gradients: the PatchGAN head's own kernel
+        FwdArgs a1 = a;
+        a1.y2 = nullptr;
+        if (head_dgrad_ok(d->dtype, g, a1)) return 4;
+    }
     if (fwd_rowdot_ok(g, a)) return 1;
     if (fwd_mfma_ok(d->dtype, g, a))
         return ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 2 : 3;
@@ -481,6 +486,7 @@ static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     if (grouped3_ok(dtype, g, a)) return launch_grouped3(g, a, s);   // grouped 3x3: 16-channel slices, patch in LDS
     if (pw_ok(dtype, g, a)) return launch_pw(g, a, s);
     if (thin_fwd_ok(dtype, g, a)) return launch_thin_fwd(g, a, s);
+    if (head_dgrad_ok(dtype, g, a)) return launch_head_dgrad(g, a, s);
     if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);
     if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
     if (use_mfma(dtype, g, a)) return launch_fwd_mfma(g, a, s);
@@ -538,7 +544,8 @@ extern "C" int pai_conv_dgrad_act(const pai_conv_desc* d, const void* dy, const 
     a.x1 = dy; a.w = w_dgrad;
     a.y1 = dx1; a.y2 = dx2;
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = dgrad_store_fusable(d, g, a);
+    // (the PatchGAN head's own kernel applies the activation derivative in its store too: nothing else is asked of it here)
+    const bool fused = dgrad_store_fusable(d, g, a) || (!thin_fwd_ok(d->dtype, g, a) && head_dgrad_ok(d->dtype, g, a));
     if (fused) { a.bz = a1; a.bact1 = act1; }
     int rc = run_fwd(d->dtype, g, a, s);
     if (rc || fused || act1 == PAI_ACT_NONE) return rc;

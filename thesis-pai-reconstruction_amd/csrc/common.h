@@ -234,6 +234,9 @@ bool thin_dgrad_ok(int dtype, const GG& g, const FwdArgs& a);
 bool thin_dgrad_shape_ok(int dtype, const GG& g);
 int64_t thin_dgrad_scratch_bytes(const GG& g, const FwdArgs& a);
 int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s);
+// input gradient of a many-channel -> 1 convolution (the PatchGAN head), activation derivative in the store (gg_thin.hip)
+bool head_dgrad_ok(int dtype, const GG& g, const FwdArgs& a);
+int launch_head_dgrad(const GG& g, const FwdArgs& a, hipStream_t s);
 int thin_fwd_bwd_rows(int dtype, const GG& g, const FwdArgs& a, int act1, const void* add, const float* scale);
 int launch_thin_dgrad(const GG& g, const FwdArgs& a, hipStream_t s);
 

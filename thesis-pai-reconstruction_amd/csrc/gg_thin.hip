@@ -561,6 +561,74 @@ int launch_thin_fwd(const GG& g, const FwdArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// TH: thin -> wide with MANY output channels and a tiny 1-channel source: the input gradient of the PatchGAN head
+// (Conv2d(512, 1, k4, s1, p1), reference models/wrapper.py:233): dx[n][y][x][c] = sum over the 16 taps of
+// dl[n][y + dy_t][x + dx_t] * w[c][wt_t], times the activation derivative of the layer that produced the head's input
+// (pai_conv_dgrad_act).  0.24 GFLOP against 33 MB written and 33 MB read at batch 128: a store stream.  It used to run
+// on the generic vector-ALU kernel (51 us + a separate 15 us activation pass in the step); here a workgroup owns one
+// image row (16 pixels x 512 channels), the source image and the transposed filter sit in LDS, and the derivative is
+// applied in the store (round 4).
+// ------------------------------------------------------------------------------------------------
+bool head_dgrad_ok(int dtype, const GG& g, const FwdArgs& a) {
+    return dtype == PAI_BF16 && pai_tunable("head_dgrad", 1) && g.nphase == 1 && g.ntaps == 16 && g.S == 1 && g.OS == 1 &&
+           g.C1 == 1 && g.C2 == 0 && g.D2 == 0 && g.Cout == g.D1 && (g.Cout % 8) == 0 && g.Cout <= 1024 && g.OW <= 64 &&
+           g.H * g.W <= 4096 && a.y1 && !a.y2 && !a.yact && !a.yf32 && !a.stats && !a.bias && !g.relu1 && !a.badd &&
+           !a.bscale && !a.bpart && !a.skip_d1;
+}
+
+__global__ __launch_bounds__(256) void head_dgrad_k(GG g, FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    bf16_t* wt = (bf16_t*)hsm;                                   // [16 taps][Cout]
+    float* src = (float*)(hsm + (size_t)16 * g.Cout * 2);        // the source image of this block's sample, H x W
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / g.OH, oy = blockIdx.x - n * g.OH;
+    const bf16_t* w = (const bf16_t*)a.w;                        // [Cout][16] (one source channel)
+    for (int i = tid; i < g.Cout * 16; i += 256) {
+        const int c = i >> 4, t = i & 15;
+        wt[t * g.Cout + c] = w[i];
+    }
+    const bf16_t* x = (const bf16_t*)a.x1 + (size_t)n * g.H * g.W;
+    for (int i = tid; i < g.H * g.W; i += 256) src[i] = bf2f(x[i]);
+    __syncthreads();
+    const int groups = g.Cout / 8;                               // 8-channel pieces per pixel
+    const bf16_t* az = (const bf16_t*)a.bz;
+    for (int item = tid; item < g.OW * groups; item += 256) {
+        const int ox = item / groups, cg = item - ox * groups;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int sy = oy + g.dy[0][t], sx = ox + g.dx[0][t];
+            if ((unsigned)sy >= (unsigned)g.H || (unsigned)sx >= (unsigned)g.W) continue;
+            const float v = src[sy * g.W + sx];
+            float wv[8];
+            V8<bf16_t>::ld(wt + g.wt[0][t] * g.Cout + cg * 8, wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wv[j], acc[j]);
+        }
+        const size_t o = ((size_t)(n * g.OH + oy) * g.OW + ox) * g.Cout + cg * 8;
+        if (az) {          // pai_conv_dgrad_act: the bf16-rounded gradient times act'(stored activation)
+            float zv[8];
+            V8<bf16_t>::ld(az + o, zv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gq = bf2f(f2bf(acc[j]));
+                acc[j] = a.bact1 == PAI_ACT_NONE ? gq : gq * act_grad(zv[j], a.bact1);
+            }
+        }
+        V8<bf16_t>::st((bf16_t*)a.y1 + o, acc);
+    }
+}
+
+int launch_head_dgrad(const GG& g, const FwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)16 * g.Cout * 2 + (size_t)g.H * g.W * 4;
+    PAI_LAUNCH(head_dgrad_k, dim3(g.N * g.OH), dim3(256), lds, s, g, a);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // TD: wide -> thin (4-phase transposed form, Cout <= 2): skinny GEMM into fp32 scratch, then col2im.
 // ------------------------------------------------------------------------------------------------
 static int thin_dgrad_T(const GG& g, const FwdArgs& a) { return (g.Cout == 2 && !a.skip_d1) ? 2 : 1; }
