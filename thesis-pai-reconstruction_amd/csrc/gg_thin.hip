@@ -300,8 +300,11 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
                 for (int e = 0; e < 8; ++e) {
                     // branch-free (the activation is a run-time value: as if / else per element this unrolled loop was
                     // ~50 scalar branches per 16 pixels): LeakyReLU max(v, 0.2 v), ReLU max(v, 0), none max(v, -inf)
-                    const float v0 = fmaxf(fmaxf(v[2 * e], act_slope * v[2 * e]), act_floor);
-                    const float v1 = fmaxf(fmaxf(v[2 * e + 1], act_slope * v[2 * e + 1]), act_floor);
+                    // (a NaN pre-activation stays a NaN, as in aten: fmaxf(NaN, x) = x would have laundered it into
+                    //  -inf / 0 and hidden a diverged run from isfinite checks -- the clamp is a compare + select)
+                    float v0 = fmaxf(v[2 * e], act_slope * v[2 * e]), v1 = fmaxf(v[2 * e + 1], act_slope * v[2 * e + 1]);
+                    v0 = v0 < act_floor ? act_floor : v0;
+                    v1 = v1 < act_floor ? act_floor : v1;
                     pk[e] = pk2bf(v0, v1);
                 }
                 bf16_t* dst = (bf16_t*)a.yact + pix * g.Cout + co;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (ACTM == 1) acc[q][r] = fmaxf(acc[q][r], 0.2f * acc[q][r]);
-                        else if (ACTM == 2) acc[q][r] = fmaxf(acc[q][r], 0.f);
+                        else if (ACTM == 2) acc[q][r] = acc[q][r] < 0.f ? 0.f : acc[q][r];      // NaN stays NaN (aten's relu)
                     }
                 const u4_t lo = {pk2bf(acc[0][0], acc[0][1]), pk2bf(acc[0][2], acc[0][3]), pk2bf(acc[1][0], acc[1][1]), pk2bf(acc[1][2], acc[1][3])};
                 const u4_t hi = {pk2bf(acc[2][0], acc[2][1]), pk2bf(acc[2][2], acc[2][3]), pk2bf(acc[3][0], acc[3][1]), pk2bf(acc[3][2], acc[3][3])};

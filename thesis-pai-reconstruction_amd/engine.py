@@ -361,16 +361,15 @@ class _SideStream:
         self.scratch_ev = None
         self._scratch_marked = False
         self.on = _SideStream.enabled and os.environ.get("PAI_NO_OVERLAP", "0") in ("", "0")
-        # optional cap (GFLOP per launch) on what goes to the side stream.  Measured at batch 64: the
-        # gain comes from co-scheduling the BIG layers (11.68 -> 11.15 ms/step); small layers alone
-        # gain nothing.  Each co-scheduled kernel runs longer (per-kernel TFLOP/s drop ~30 %) while
-        # the step gets shorter -- the kernels are latency-bound, not throughput-bound.
-        self.max_gflop = float(os.environ.get("PAI_OVERLAP_GFLOP", "1e9"))
+        # (round 3 measured a cap on what goes to the side stream, PAI_OVERLAP_GFLOP: 6.33-6.35 ms/step with every weight
+        #  gradient there, 6.67-6.89 with only the launches below 100 / 50 / 20 GFLOP -- the large layers carry the gain.
+        #  The switch is gone: weight gradients of one pass all run on ONE stream, which is also what keeps the handle's
+        #  single weight-gradient slab buffer free of cross-stream races.)
         # (stream priorities measured at batch 64: side stream at high priority 14.2 ms/step, at low priority
         #  7.49, main stream at high priority 7.39 against 7.47 with both at the default -- left at the default)
 
     def fork(self, d=None):
-        if not self.on or (d is not None and ops.conv_flops(d) > self.max_gflop * 1e9):
+        if not self.on:
             return torch.cuda.current_stream()
         if self.stream is None:
             self.stream = torch.cuda.Stream()

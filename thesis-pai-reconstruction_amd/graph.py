@@ -33,6 +33,7 @@ class GraphedStep:
         # and nodes created on the default stream make the backward pass of the capture synchronise with it -- an
         # illegal operation during capture (the process aborts).  torch's own recipe: warm up on the capture stream.
         self.stream = None
+        self.handle_epoch = -1
         self.disabled = None          # reason string when capture is not possible
 
     # ---- eligibility ------------------------------------------------------------------------------------
@@ -75,6 +76,11 @@ class GraphedStep:
             eager = self._capture(batch)
             if self.graph is None:       # capture refused (self.disabled says why): that call ran the step eagerly
                 return eager
+        if ops.handle_for(batch[0].device).epoch != self.handle_epoch:
+            # a workspace / scratch / weight-gradient slab of the handle was re-registered (a validation pass at a larger
+            # batch, another layer's plan): the captured kernel arguments point at freed memory
+            raise ops.PaiError("GraphedStep: the device handle's buffers were replaced after the capture; the graph is stale "
+                               "(size the buffers before capturing, or build a new GraphedStep)")
         for s, b in zip(self.static, batch):
             s.copy_(b, non_blocking=True)
         self.graph.replay()
@@ -121,6 +127,7 @@ class GraphedStep:
             del m.log                 # back to the class's method
             assert m.log.__func__ is orig_log.__func__
         self.logs = logs
+        self.handle_epoch = ops.handle_for(batch[0].device).epoch
         # the capture itself executed nothing: undo the host-side bookkeeping of the captured step() calls
         self.opt_steps_per_replay = m._pai_opt_steps - before
         m._pai_opt_steps = before

@@ -161,6 +161,9 @@ class Handle:
         self.workspace = None
         self.scratch = None
         self.wgrad_workspace = None
+        # bumped whenever a registered buffer is replaced: a captured hipGraph (graph.GraphedStep) or a recorded launch
+        # plan holds the OLD addresses in its kernel arguments and must not be replayed past such a change
+        self.epoch = 0
 
     def bind(self):
         L.check(L.load().pai_bind(self._h), "pai_bind")
@@ -172,6 +175,7 @@ class Handle:
             return
         if self.workspace is None or self.workspace.numel() * 4 < nbytes:
             self.workspace = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self.epoch += 1
             L.check(L.load().pai_handle_set_workspace(self._h, self.workspace.data_ptr(), self.workspace.numel() * 4),
                     "pai_handle_set_workspace")
 
@@ -181,6 +185,7 @@ class Handle:
             return
         if self.scratch is None or self.scratch.numel() * 4 < nbytes:
             self.scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self.epoch += 1
             L.check(L.load().pai_handle_set_scratch(self._h, self.scratch.data_ptr(), self.scratch.numel() * 4),
                     "pai_handle_set_scratch")
 
@@ -192,6 +197,7 @@ class Handle:
             if self.wgrad_workspace is not None:
                 torch.cuda.synchronize(self.device)     # side-stream launches may still be writing the old buffer
             self.wgrad_workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self.epoch += 1
             L.check(L.load().pai_handle_set_wgrad_workspace(self._h, self.wgrad_workspace.data_ptr(),
                                                            self.wgrad_workspace.numel() * 4),
                     "pai_handle_set_wgrad_workspace")

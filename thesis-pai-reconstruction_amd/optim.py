@@ -372,17 +372,25 @@ class MultiAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        def stock(*a):
+            # a captured step (device-side count, graph.GraphedStep) must never reach the stock implementation: it would
+            # bake the HOST step count of the capture into the graph and every replay would reuse one bias correction
+            if self._dev_step is not None:
+                raise ops.PaiError("MultiAdam: the fused update's preconditions do not hold (closure / several param groups / "
+                                   "weight decay / non-contiguous or non-fp32 gradients / mixed step counts) while the step "
+                                   "count lives on the device (captured step): run this model eagerly")
+            return torch.optim.Adam.step(self, *a)
         if closure is not None or len(self.param_groups) != 1:
-            return super().step(closure)
+            return stock(closure)
         group = self.param_groups[0]
         if group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
-            return super().step()
+            return stock()
         ps = [p for p in group["params"] if p.grad is not None]
         if not ps:
             return None
         if any((not p.is_cuda) or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse
                or not p.is_contiguous() or not p.grad.is_contiguous() for p in ps):
-            return super().step()
+            return stock()
         steps = set()
         for p in ps:
             st = self.state[p]
@@ -391,10 +399,10 @@ class MultiAdam(torch.optim.Adam):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             if st["step"].is_cuda:
-                return super().step()
+                return stock()
             steps.add(int(st["step"]))
         if len(steps) != 1:          # parameters with different histories (e.g. unused in some steps): stock path
-            return super().step()
+            return stock()
         if self._dev_step is not None:
             # captured step: the count lives on the device and advances with every replay (note_replays keeps the host
             # bookkeeping in step with it)
