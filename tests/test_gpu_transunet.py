@@ -93,6 +93,44 @@ def test_mha_core_matches_torch_mha(pai, dtype, S, B, heads, hd):
     assert rel_err(qd.grad.float().cpu(), qr.grad) < _tol(dtype, 4e-6, 1.2e-2)
 
 
+@pytest.mark.parametrize("S,B,heads,hd,drop", [(32, 4, 8, 512, False), (32, 16, 8, 128, True), (7, 3, 2, 64, True), (1, 2, 4, 32, False)])
+def test_mha_matrix_core_path_against_the_vector_path(pai, S, B, heads, hd, drop):
+    """bf16 storage, S <= 32, head dim % 32 == 0: pai_mha_fwd / pai_mha_bwd run mha_fwd_mfma_k / mha_bwd_mfma_k
+    (v_mfma_f32_32x32x16_bf16 for K Q^T, P V, dO V^T, dS K, dS^T Q, P^T dO; BASELINE configs[4] "attention-MFMA",
+    reference models/trans_unet.py:151-161 through nn.MultiheadAttention).  With the tunable mha_mfma = 0 the same calls take
+    the vector-ALU kernels: outputs, kept probabilities and all three gradients of the two paths agree to bf16 rounding,
+    with and without an attention-dropout mask, full and ragged sequence lengths."""
+    from thesis_pai_reconstruction_amd import ops
+    E = heads * hd
+    dt = torch.bfloat16
+    qkv = _d(q(rnd((S * B, 3 * E), 21) * 0.7, dt), dt)
+    gy = _d(q(rnd((S * B, E), 22), dt), dt)
+    mask = None
+    if drop:
+        torch.manual_seed(5)
+        mask = (torch.bernoulli(torch.full((B * heads, S, S), 0.7)) / 0.7).to(DEV).contiguous()
+    res = []
+    for mfma in (1, 0):
+        ops.set_tunable("mha_mfma", mfma)
+        try:
+            out = torch.empty(S * B, E, dtype=dt, device=DEV)
+            probs = torch.full((B * heads * S * S,), float("nan"), dtype=torch.float32, device=DEV)
+            ops.mha_fwd(dt, qkv, S, B, heads, hd, out, probs, mask)
+            dqkv = torch.full_like(qkv, float("nan"))
+            ds = torch.empty_like(probs)
+            ops.mha_bwd(dt, gy, qkv, probs, S, B, heads, hd, dqkv, ds, mask)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_tunable("mha_mfma")
+        assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(probs).all()) and bool(torch.isfinite(dqkv.float()).all())
+        res.append((out.float().cpu(), probs.cpu(), dqkv.float().cpu()))
+    (o1, p1, g1), (o0, p0, g0) = res
+    assert rel_err(p1, p0) < 2e-3 and float((p1.view(-1, S).sum(1) - 1).abs().max()) < 1e-5      # fp32 softmax of bf16 products
+    assert rel_err(o1, o0) < 8e-3
+    for part, name in ((slice(0, E), "dQ"), (slice(E, 2 * E), "dK"), (slice(2 * E, 3 * E), "dV")):
+        assert rel_err(g1[:, part], g0[:, part]) < 1.5e-2, name
+
+
 @DTYPES
 @pytest.mark.parametrize("M,K,O", [(16, 96, 40), (64, 512, 1536), (128, 1024, 2048), (12, 256, 256)])
 def test_linear(pai, dtype, M, K, O):

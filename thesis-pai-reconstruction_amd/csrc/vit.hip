@@ -361,6 +361,229 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_k(const T* dout, const T* qkv,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same attention core on the matrix cores (bf16 storage, S <= 32 tokens per sequence -- the sequence axis is the image
+// batch, 32 at BASELINE configs[4] -- head dim a multiple of 32): one workgroup of four waves per (b, h).
+//   forward   S^T = K Q^T          v_mfma_f32_32x32x16_bf16, A = K rows, B = Q rows (both contiguous 16-B fragments straight
+//                                  from memory), the head dim split over the waves, partial tiles summed through LDS;
+//             softmax              one thread per (query, 4 keys), row max / sum over 8 lanes; fp32 probabilities kept for
+//                                  the backward pass as before;
+//             O = P V              A = P (bf16, LDS rows), B = V fetched from a row-major LDS image with
+//                                  ds_read_b64_tr_b16 (the hardware transpose: V is k-strided for this product).
+//   backward  dP = dO V^T          A = dO rows (LDS), B = V rows (memory): no transpose;
+//             dS = P (dP - <P, dP>) as above;
+//             dQ = dS K, dK = dS^T Q, dV = P^T dO    A from small bf16 LDS tiles (dS, dS^T, P^T), B = K, Q, dO through
+//                                  transposed reads of their row-major LDS images.
+// Rows beyond S are zero fragments (never loaded), keys beyond S get a score of -inf.  Everything else (fp32 storage,
+// longer sequences, odd head dims) stays on the vector-ALU kernels above.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 mbf8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 mbf4_t;
+typedef __attribute__((ext_vector_type(16))) float mf16_t;
+
+__device__ __forceinline__ mbf8_t mha_tr_frag(const bf16_t* img, int ld, int R0, int C0, int lane) {
+    // B operand fragment: element e of lane (r = lane & 31, hh = lane >> 5) = img[R0 + e][C0' + (lane & 15)], C0' = the
+    // caller's C0 + 16 for the odd 16-lane groups; two transposed reads of 4 rows x 16 columns each (guide T10)
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const bf16_t* a0 = img + (size_t)(R0 + q) * ld + C0 + 16 * ((lane >> 4) & 1) + 4 * p;
+    typedef mbf4_t __attribute__((address_space(3))) * lds4_t;
+    const mbf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(const void*)a0);
+    const mbf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(const void*)(a0 + 4 * ld));
+    return (mbf8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ void mha_stage_rows(bf16_t* dst, const bf16_t* src, int64_t rs, int S, int hd, int tid) {
+    // 32 rows x hd bf16, row-major; rows >= S are zero
+    const int cpr = hd / 8;
+    for (int c = tid; c < 32 * cpr; c += 256) {
+        const int row = c / cpr, col = (c - row * cpr) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < S) v = *(const uint4*)(src + row * rs + col);
+        *(uint4*)(dst + (size_t)row * hd + col) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mha_fwd_mfma_k(const bf16_t* qkv, int S, int B, int heads, int hd, float scale,
+                                                      bf16_t* out, float* probs, const float* mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
+    bf16_t* Vs = (bf16_t*)msm;                                   // [32][hd]
+    float* part = (float*)(msm + (size_t)32 * hd * 2);           // [4][32 j][33]
+    bf16_t* Ps = (bf16_t*)(part + 4 * 32 * 33);                  // [32 i][32 j]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads;
+    const int E = heads * hd;
+    const int64_t rs = (int64_t)B * 3 * E;
+    const bf16_t* base = qkv + (int64_t)b * 3 * E + h * hd;
+    mha_stage_rows(Vs, base + 2 * E, rs, S, hd, tid);
+    mf16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const mbf8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ks = w; ks < hd / 16; ks += 4) {
+        mbf8_t kf = zero8, qf = zero8;
+        if (r < S) {
+            kf = *(const mbf8_t*)(base + r * rs + E + 16 * ks + 8 * hh);
+            qf = *(const mbf8_t*)(base + r * rs + 16 * ks + 8 * hh);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, acc, 0, 0, 0);     // D[row j][col i]
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[(w * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)) * 33 + r] = acc[i];
+    __syncthreads();
+    {
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        float sc[4], mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            float v = part[(0 * 32 + j) * 33 + i] + part[(1 * 32 + j) * 33 + i] + part[(2 * 32 + j) * 33 + i] + part[(3 * 32 + j) * 33 + i];
+            sc[e] = j < S ? v * scale : -INFINITY;
+            mx = fmaxf(mx, sc[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = (j0 + e) < S ? expf(sc[e] - mx) : 0.f; sum += sc[e]; }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            float pv = sc[e] * inv;
+            if (i < S && j < S) {
+                const int64_t idx = ((int64_t)bh * S + i) * S + j;
+                probs[idx] = pv;                       // the softmax itself is what the backward pass needs
+                if (mask) pv *= mask[idx];             // attention dropout: 0 or 1 / (1 - p)
+            } else {
+                pv = 0.f;
+            }
+            Ps[i * 32 + j] = f2bf(pv);
+        }
+    }
+    __syncthreads();
+    for (int t = w; t < hd / 32; t += 4) {
+        const int d0 = 32 * t;
+        mf16_t o;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const mbf8_t pf = *(const mbf8_t*)(Ps + r * 32 + 16 * s2 + 8 * hh);
+            const mbf8_t vf = mha_tr_frag(Vs, hd, 16 * s2 + 8 * hh, d0, lane);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o, 0, 0, 0);      // D[row i][col d]
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qi = 8 * (i >> 2) + 4 * hh + (i & 3);
+            if (qi < S) out[((int64_t)qi * B + b) * E + h * hd + d0 + r] = f2bf(o[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mha_bwd_mfma_k(const bf16_t* dout, const bf16_t* qkv, const float* probs, int S, int B,
+                                                      int heads, int hd, float scale, bf16_t* dqkv, const float* mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
+    bf16_t* Qs = (bf16_t*)msm;                                   // [32][hd] each, row-major
+    bf16_t* Ks = Qs + (size_t)32 * hd;
+    bf16_t* Os = Ks + (size_t)32 * hd;                           // dO
+    float* part = (float*)(Os + (size_t)32 * hd);                // [4][32 i][33]
+    bf16_t* dSs = (bf16_t*)(part + 4 * 32 * 33);                 // [32 i][32 j]
+    bf16_t* dSt = dSs + 32 * 32;                                 // [32 j][32 i]
+    bf16_t* Pt = dSt + 32 * 32;                                  // [32 j][32 i]  (softmax x dropout mask)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads;
+    const int E = heads * hd;
+    const int64_t rs = (int64_t)B * 3 * E, ors = (int64_t)B * E;
+    const bf16_t* base = qkv + (int64_t)b * 3 * E + h * hd;
+    mha_stage_rows(Qs, base, rs, S, hd, tid);
+    mha_stage_rows(Ks, base + E, rs, S, hd, tid);
+    mha_stage_rows(Os, dout + (int64_t)b * E + h * hd, ors, S, hd, tid);
+    __syncthreads();
+    mf16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const mbf8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ks = w; ks < hd / 16; ks += 4) {
+        const mbf8_t of = *(const mbf8_t*)(Os + (size_t)r * hd + 16 * ks + 8 * hh);
+        mbf8_t vf = zero8;
+        if (r < S) vf = *(const mbf8_t*)(base + r * rs + 2 * E + 16 * ks + 8 * hh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf, acc, 0, 0, 0);     // dP: D[row i][col j]
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[(w * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)) * 33 + r] = acc[i];
+    __syncthreads();
+    {
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        float dp[4], pr[4], pm[4], dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            dp[e] = part[(0 * 32 + i) * 33 + j] + part[(1 * 32 + i) * 33 + j] + part[(2 * 32 + i) * 33 + j] + part[(3 * 32 + i) * 33 + j];
+            pr[e] = 0.f;
+            pm[e] = 0.f;
+            if (i < S && j < S) {
+                const int64_t idx = ((int64_t)bh * S + i) * S + j;
+                pr[e] = probs[idx];
+                const float mk = mask ? mask[idx] : 1.f;
+                pm[e] = pr[e] * mk;
+                dp[e] *= mk;
+            } else {
+                dp[e] = 0.f;
+            }
+            dl = fmaf(pr[e], dp[e], dl);
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        dl += __shfl_xor(dl, 2, 64);
+        dl += __shfl_xor(dl, 4, 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            const bf16_t dsv = f2bf(pr[e] * (dp[e] - dl));
+            dSs[i * 32 + j] = dsv;
+            dSt[j * 32 + i] = dsv;
+            Pt[j * 32 + i] = f2bf(pm[e]);
+        }
+    }
+    __syncthreads();
+    bf16_t* drow = dqkv + (int64_t)b * 3 * E + h * hd;
+    for (int t = w; t < hd / 32; t += 4) {
+        const int d0 = 32 * t;
+        mf16_t aq, ak, av;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aq[i] = ak[i] = av[i] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int k0 = 16 * s2 + 8 * hh;
+            const mbf8_t dsf = *(const mbf8_t*)(dSs + r * 32 + k0);      // A[row i][k = j]
+            const mbf8_t dtf = *(const mbf8_t*)(dSt + r * 32 + k0);      // A[row j][k = i]
+            const mbf8_t ptf = *(const mbf8_t*)(Pt + r * 32 + k0);       // A[row j][k = i]
+            aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, mha_tr_frag(Ks, hd, k0, d0, lane), aq, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dtf, mha_tr_frag(Qs, hd, k0, d0, lane), ak, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ptf, mha_tr_frag(Os, hd, k0, d0, lane), av, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 8 * (i >> 2) + 4 * hh + (i & 3);
+            if (row < S) {
+                bf16_t* o = drow + (int64_t)row * rs + d0 + r;
+                o[0] = f2bf(aq[i] * scale);
+                o[E] = f2bf(ak[i] * scale);
+                o[2 * E] = f2bf(av[i]);
+            }
+        }
+    }
+}
+
+static bool mha_mfma_ok(int dtype, int S, int hd) {
+    return dtype == PAI_BF16 && S <= 32 && (hd % 32) == 0 && hd <= 512 && pai_tunable("mha_mfma", 1);
+}
+
 static int mha_check(const char* who, int dtype, int S, int B, int heads, int hd) {
     PAI_CHECK(dtype == PAI_F32 || dtype == PAI_BF16, "%s: bad dtype %d", who, dtype);
     PAI_CHECK(S > 0 && B > 0 && heads > 0 && hd > 0, "%s: bad shape S=%d B=%d heads=%d hd=%d", who, S, B, heads, hd);
@@ -377,6 +600,21 @@ extern "C" int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, 
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds = (size_t)(hd + S + 16) * sizeof(float);
     const dim3 grid((unsigned)(S * B * heads));
+    if (mha_mfma_ok(dtype, S, hd)) {
+        const size_t ml = (size_t)32 * hd * 2 + 4 * 32 * 33 * sizeof(float) + 32 * 32 * 2;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_fwd_mfma_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_mfma_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+            attr = true;
+        }
+        PAI_LAUNCH(mha_fwd_mfma_k, dim3((unsigned)(B * heads)), dim3(256), ml, s, (const bf16_t*)qkv, S, B, heads, hd, scale,
+                   (bf16_t*)out, probs, mask);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == PAI_F32)
         PAI_LAUNCH(mha_fwd_k<float>, grid, dim3(256), lds, s, (const float*)qkv, S, B, heads, hd, scale,
                            (float*)out, probs, mask);
@@ -395,6 +633,19 @@ extern "C" int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const f
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds_q = (size_t)(hd + S + 16) * sizeof(float), lds_kv = (size_t)(2 * S) * sizeof(float);
     const dim3 grid((unsigned)(S * B * heads));
+    if (mha_mfma_ok(dtype, S, hd)) {
+        const size_t ml = (size_t)3 * 32 * hd * 2 + 4 * 32 * 33 * sizeof(float) + 3 * 32 * 32 * 2;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_mfma_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+            attr = true;
+        }
+        PAI_LAUNCH(mha_bwd_mfma_k, dim3((unsigned)(B * heads)), dim3(256), ml, s, (const bf16_t*)dout, (const bf16_t*)qkv, probs,
+                   S, B, heads, hd, scale, (bf16_t*)dqkv, mask);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == PAI_F32) {
         PAI_LAUNCH(mha_bwd_q_k<float>, grid, dim3(256), lds_q, s, (const float*)dout, (const float*)qkv, probs,
                            S, B, heads, hd, scale, (float*)dqkv, ds_workspace, mask);
