@@ -312,7 +312,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax)
 
-    # ---- per-kernel roofline from the HIP-event brackets --------------------------------------
+    # ---- per-kernel roofline from the launches' own HIP events --------------------------------------
     def roofline_of(prof, nsteps, dom=None):
         fam = {}
         for kid, op, flops, e0, e1 in prof:
@@ -382,8 +382,9 @@ def main():
             e._side.on = on
         _, roofline_isolated = roofline_of(prof2, 3, dom)
         if roofline is not None:
-            roofline["note"] = ("HIP-event launch durations over a repeat of the K timed steps (events kept out of the "
-                                "timed region, they cost 2-5 ms/step); weight-gradient kernels co-scheduled on a second stream")
+            roofline["note"] = ("each launch's own HIP start/stop events (hipExtLaunchKernel through pai_profile_arm: the duration "
+                                "rocprofv3 reports, no marker packets) over an eager repeat of the K timed steps, outside the timed "
+                                "region; weight-gradient kernels co-scheduled on a second stream")
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3

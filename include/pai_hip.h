@@ -584,6 +584,12 @@ typedef struct pai_event_s* pai_event_t;
 int pai_event_create(pai_event_t* out);
 int pai_event_destroy(pai_event_t ev);
 int pai_event_record(pai_event_t ev, void* stream);
+/* Measurement: events WITH timing, and "the next launch this thread makes through the library carries (start, stop) as its
+ * own start / stop events" -- the launch's duration as the command processor stamps it (what rocprofv3 --kernel-trace
+ * reports), without marker packets around it.  pai_profile_arm(NULL, NULL) disarms.  bench.py's roofline uses it. */
+int pai_event_create_timing(pai_event_t* out);
+int pai_event_elapsed_ms(pai_event_t start, pai_event_t stop, float* ms_host);
+int pai_profile_arm(pai_event_t start, pai_event_t stop);
 int pai_stream_wait_event(void* waiting_stream, pai_event_t ev);
 /* p[i][0 .. numel[i]) = 0 for `count` fp32 buffers in one launch per 96 buffers (host pointer tables): the accumulated
  * segments of a gradient arena in front of a backward pass (replaces torch._foreach_zero_, so that the clear is a node

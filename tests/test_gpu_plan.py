@@ -210,3 +210,27 @@ def test_plan_abi_streams_events_and_adam(pai):
         assert torch.equal(p, pe) and torch.equal(m, me) and torch.equal(v, ve), delta
     with pytest.raises(ops.PaiError):
         plan2.run(-1)
+
+
+def test_launch_timer_rides_on_one_launch(pai):
+    """pai_profile_arm: the armed events time exactly the next launch (its own start / stop events), are consumed by it, and
+    an unused arming can be withdrawn."""
+    from thesis_pai_reconstruction_amd import ops
+
+    t = torch.ones(1 << 24, device=DEV)
+    ops.scale_(t, 1.0)
+    torch.cuda.synchronize()
+    timer = ops.LaunchTimer()
+    timer.arm()
+    ops.scale_(t, 2.0)          # timed
+    ops.scale_(t, 2.0)          # not timed: the arming was consumed
+    torch.cuda.synchronize()
+    ms = timer.elapsed_time()
+    # 128 MB of traffic: 16-40 us on this part; two launches, or a bracket with gaps, would read far longer
+    assert 0.005 < ms < 0.2, ms
+    assert float(t[0]) == 4.0
+    timer.arm()
+    ops.LaunchTimer.disarm()
+    ops.scale_(t, 0.5)
+    torch.cuda.synchronize()
+    assert abs(timer.elapsed_time() - ms) < 1e-9      # the withdrawn arming did not touch the events

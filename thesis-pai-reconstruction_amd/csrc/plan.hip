@@ -53,6 +53,25 @@ void plan_push(PlanOp* op) {
     p->ops.push_back(op);
 }
 
+static thread_local hipEvent_t t_prof[2] = {nullptr, nullptr};
+static std::atomic<int> g_prof_armed{0};      // fast path: no thread has armed anything
+
+bool profile_take(hipEvent_t* start, hipEvent_t* stop) {
+    if (g_prof_armed.load(std::memory_order_relaxed) == 0 || !t_prof[1]) return false;
+    *start = t_prof[0];
+    *stop = t_prof[1];
+    t_prof[0] = t_prof[1] = nullptr;
+    g_prof_armed.fetch_sub(1, std::memory_order_relaxed);
+    return true;
+}
+
+static void profile_arm(hipEvent_t start, hipEvent_t stop) {
+    if (t_prof[1]) g_prof_armed.fetch_sub(1, std::memory_order_relaxed);      // an unused arming is replaced
+    t_prof[0] = start;
+    t_prof[1] = stop;
+    if (stop) g_prof_armed.fetch_add(1, std::memory_order_relaxed);
+}
+
 void plan_mark_adam(int a_lr, int a_bc2, double lr, double beta1, double beta2, int64_t step) {
     // only while a plan is being recorded: the mark is consumed by the launch that follows on this thread, and a mark
     // left behind by an un-recorded call would be applied to whatever kernel this thread records next
@@ -205,6 +224,28 @@ extern "C" int pai_event_create(pai_event_t* out) {
     const hipError_t e = hipEventCreateWithFlags(&ev, pai::event_flags());
     PAI_CHECK(e == hipSuccess, "pai_event_create: %s", hipGetErrorString(e));
     *out = (pai_event_t)ev;
+    return 0;
+}
+
+extern "C" int pai_event_create_timing(pai_event_t* out) {
+    PAI_CHECK(out != nullptr, "pai_event_create_timing: null pointer");
+    hipEvent_t ev = nullptr;
+    const hipError_t e = hipEventCreate(&ev);
+    PAI_CHECK(e == hipSuccess, "pai_event_create_timing: %s", hipGetErrorString(e));
+    *out = (pai_event_t)ev;
+    return 0;
+}
+
+extern "C" int pai_event_elapsed_ms(pai_event_t start, pai_event_t stop, float* ms) {
+    PAI_CHECK(start && stop && ms, "pai_event_elapsed_ms: null pointer");
+    const hipError_t e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    PAI_CHECK(e == hipSuccess, "pai_event_elapsed_ms: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pai_profile_arm(pai_event_t start, pai_event_t stop) {
+    PAI_CHECK((start == nullptr) == (stop == nullptr), "pai_profile_arm: both events or neither");
+    pai::profile_arm((hipEvent_t)start, (hipEvent_t)stop);
     return 0;
 }
 

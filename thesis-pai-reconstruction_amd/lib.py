@@ -157,6 +157,9 @@ SIGNATURES = {
     "pai_event_create": (_I, [C.POINTER(_P)]),
     "pai_event_destroy": (_I, [_P]),
     "pai_event_record": (_I, [_P, _P]),
+    "pai_event_create_timing": (_I, [C.POINTER(_P)]),
+    "pai_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
+    "pai_profile_arm": (_I, [_P, _P]),
     "pai_stream_wait_event": (_I, [_P, _P]),
     "pai_zero_multi": (_I, [_I, _P, _P, _P]),
     "pai_scale": (_I, [_P, _L, _F, _P]),

@@ -99,23 +99,55 @@ def conv_flops(d: ConvDesc) -> int:
     return 2 * d.N * oh * ow * d.kernel * d.kernel * (d.C1 + d.C2) * d.Cout // groups
 
 
+class LaunchTimer:
+    """start / stop timing events that ride on ONE launch (pai_profile_arm -> hipExtLaunchKernel): ``elapsed_time`` is the
+    kernel's own duration, as rocprofv3 reports it.  Events recorded around a launch put marker packets on the stream and
+    read 10-15 % long (round 3: 153.8 us under brackets against 134.6 us in the kernel trace)."""
+
+    def __init__(self):
+        self.h0, self.h1 = C.c_void_p(), C.c_void_p()
+        L.check(L.load().pai_event_create_timing(C.byref(self.h0)), "pai_event_create_timing")
+        L.check(L.load().pai_event_create_timing(C.byref(self.h1)), "pai_event_create_timing")
+
+    def arm(self):
+        L.check(L.load().pai_profile_arm(self.h0, self.h1), "pai_profile_arm")
+
+    @staticmethod
+    def disarm():
+        L.check(L.load().pai_profile_arm(None, None), "pai_profile_arm")
+
+    def elapsed_time(self, _other=None) -> float:
+        ms = C.c_float()
+        L.check(L.load().pai_event_elapsed_ms(self.h0, self.h1, C.byref(ms)), "pai_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            L.load().pai_event_destroy(self.h0)
+            L.load().pai_event_destroy(self.h1)
+        except Exception:
+            pass
+
+
 class _Timed:
+    """The FIRST launch of the bracketed call (the convolution-family kernel itself; finish / BatchNorm launches behind it
+    are not part of the figure) is timed by events of its own."""
+
     def __init__(self, d, op):
         self.on = PROFILE is not None
         if self.on:
             self.d, self.op = d, op
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.t = LaunchTimer()
 
     def __enter__(self):
         if self.on:
-            self.e0.record()
+            self.t.arm()
 
     def __exit__(self, *exc):
         if self.on:
-            self.e1.record()
+            LaunchTimer.disarm()
             # forward and input-gradient share kernels; keyed by the symbol rocprofv3 reports
-            PROFILE.append((conv_kernel_name(self.d, self.op), self.op, conv_flops(self.d), self.e0, self.e1))
+            PROFILE.append((conv_kernel_name(self.d, self.op), self.op, conv_flops(self.d), self.t, self.t))
         return False
 
 
