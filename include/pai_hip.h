@@ -600,6 +600,13 @@ int pai_zero_multi(int count, void* const* ptrs, const int64_t* numels, void* st
  * of the conditioning image and the real / generated one) were four 7-12 us launches. */
 int pai_cast_multi(int count, int src_dtype, const void* const* srcs, int dst_dtype, void* const* dsts,
                    const int64_t* numels, void* stream);
+
+/* nn.Conv2d filters ([Cout][Cin / groups][kh][kw] fp32; reference models/res_unet.py:147-151 uses groups = 32) to and from
+ * the dense tap-major fp32 layout [Cout][kh * kw][Cin] of pai_pack_weights / pai_conv_wgrad (groups as diagonal blocks,
+ * zeros elsewhere): one launch each on the caller's stream. */
+int pai_filter_to_dense(const float* w_oihw, int Cout, int Cin_per_group, int taps, int groups, float* dense, void* stream);
+int pai_filter_grad_from_dense(const float* dense_dw, int Cout, int Cin_per_group, int taps, int groups, float* dw_oihw,
+                               void* stream);
 /* ptr[0 .. numel) *= factor (fp32, 16-byte aligned): the x 1/world_size average behind the SUM all-reduce of a gradient
  * bucket (DDP averages, reference main.py:123-136 through pl.Trainer), as a node of the plan. */
 int pai_scale(float* ptr, int64_t numel, float factor, void* stream);

@@ -386,3 +386,30 @@ def test_fused_gan_losses_equal_the_composed_ones(pai):
         dp, dt = PF.denormalize(pred.detach()), PF.denormalize(tgt)
         assert abs(float(s) - float(PF.ssim(dp, dt))) <= 1e-6
         assert abs(float(p) - float(PF.psnr(dp, dt))) <= 1e-5 and abs(float(r) - float(PF.rmse(dp, dt))) <= 1e-7
+
+
+@pytest.mark.parametrize("shape,groups", [((64, 32, 1, 1), 1), ((128, 4, 3, 3), 32), ((24, 7, 3, 3), 1), ((32, 8, 1, 1), 4),
+                                          ((6, 5, 4, 4), 2)])
+def test_filter_layout_kernels(pai, shape, groups):
+    """pai_filter_to_dense / pai_filter_grad_from_dense against the permute / block-diagonal formulation."""
+    from thesis_pai_reconstruction_amd import ops
+
+    cout, cig, kh, kw = shape
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(*shape, generator=g).to(dev())
+    dense = torch.full((cout, kh, kw, cig * groups), 7.0, device=dev())
+    ops.filter_to_dense(w, cout, cig, kh * kw, groups, dense)
+    want = torch.zeros(cout, kh, kw, cig * groups, device=dev())
+    cog = cout // groups
+    for gi in range(groups):
+        want[gi * cog:(gi + 1) * cog, :, :, gi * cig:(gi + 1) * cig] = w[gi * cog:(gi + 1) * cog].permute(0, 2, 3, 1)
+    assert torch.equal(dense, want)
+    dw_dense = torch.randn(cout, kh, kw, cig * groups, generator=g).to(dev())
+    dw = torch.full(shape, 7.0, device=dev())
+    ops.filter_grad_from_dense(dw_dense, cout, cig, kh * kw, groups, dw)
+    want = torch.empty(shape, device=dev())
+    for gi in range(groups):
+        want[gi * cog:(gi + 1) * cog] = dw_dense[gi * cog:(gi + 1) * cog, :, :, gi * cig:(gi + 1) * cig].permute(0, 3, 1, 2)
+    assert torch.equal(dw, want)
+    with pytest.raises(ops.PaiError):
+        ops.filter_to_dense(w, cout, cig, kh * kw, 5 if cout % 5 else 7, dense)

@@ -666,3 +666,65 @@ extern "C" int pai_cast_multi(int count, int src_dtype, const void* const* srcs,
     PAI_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- torch Conv2d filter <-> the library's dense tap-major layout ---------------------------------------------------------
+// nn.Conv2d keeps its filter as [Cout][Cin / groups][kh][kw] (reference models/res_unet.py:147-151: groups = 32); the
+// convolution entry points take [Cout][kh * kw][Cin] with the groups as diagonal blocks.  One launch each way, on the
+// caller's stream, instead of permute / zeros / index_put chains of the tensor library.
+__global__ __launch_bounds__(256) void filter_to_dense_k(const float* __restrict__ w, int Cout, int cig, int taps, int groups,
+                                                         float* __restrict__ dense) {
+    const int Cin = cig * groups, cog = Cout / groups;
+    const int64_t total = (int64_t)Cout * taps * Cin;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(o % Cin);
+        const int t = (int)((o / Cin) % taps);
+        const int co = (int)(o / ((int64_t)Cin * taps));
+        const int gi = ci / cig;
+        dense[o] = gi == co / cog ? w[((int64_t)co * cig + (ci - gi * cig)) * taps + t] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void filter_grad_from_dense_k(const float* __restrict__ dense, int Cout, int cig, int taps,
+                                                                int groups, float* __restrict__ dw) {
+    const int Cin = cig * groups, cog = Cout / groups;
+    const int64_t total = (int64_t)Cout * cig * taps;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int t = (int)(o % taps);
+        const int cg = (int)((o / taps) % cig);
+        const int co = (int)(o / ((int64_t)taps * cig));
+        dw[o] = dense[((int64_t)co * taps + t) * Cin + (co / cog) * cig + cg];
+    }
+}
+
+static int filter_args_ok(const void* a, const void* b, int Cout, int cig, int taps, int groups) {
+    return a && b && Cout > 0 && cig > 0 && taps > 0 && groups > 0 && Cout % groups == 0 &&
+           (int64_t)Cout * taps * cig * groups < ((int64_t)1 << 31);
+}
+
+extern "C" int pai_filter_to_dense(const float* w_oihw, int Cout, int Cin_per_group, int taps, int groups, float* dense,
+                                   void* stream) {
+    PAI_CHECK(filter_args_ok(w_oihw, dense, Cout, Cin_per_group, taps, groups),
+              "pai_filter_to_dense: bad arguments (Cout %d, Cin/groups %d, taps %d, groups %d)", Cout, Cin_per_group, taps, groups);
+    const int64_t total = (int64_t)Cout * taps * Cin_per_group * groups;
+    int64_t bx = (total + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    PAI_LAUNCH(filter_to_dense_k, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin_per_group, taps, groups,
+               dense);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pai_filter_grad_from_dense(const float* dense_dw, int Cout, int Cin_per_group, int taps, int groups,
+                                          float* dw_oihw, void* stream) {
+    PAI_CHECK(filter_args_ok(dense_dw, dw_oihw, Cout, Cin_per_group, taps, groups),
+              "pai_filter_grad_from_dense: bad arguments (Cout %d, Cin/groups %d, taps %d, groups %d)", Cout, Cin_per_group, taps,
+              groups);
+    const int64_t total = (int64_t)Cout * taps * Cin_per_group;
+    int64_t bx = (total + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    PAI_LAUNCH(filter_grad_from_dense_k, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, dense_dw, Cout, Cin_per_group,
+               taps, groups, dw_oihw);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

@@ -164,6 +164,8 @@ SIGNATURES = {
     "pai_zero_multi": (_I, [_I, _P, _P, _P]),
     "pai_scale": (_I, [_P, _L, _F, _P]),
     "pai_cast_multi": (_I, [_I, _I, _P, _I, _P, _P, _P]),
+    "pai_filter_to_dense": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "pai_filter_grad_from_dense": (_I, [_P, _I, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

@@ -154,6 +154,8 @@ class LightningModule(nn.Module):
             loss.backward(gradient=PF.unit_seed(loss.device))
         else:
             loss.backward(*args, **kwargs)
+        from . import nnops
+        nnops.join_wgrads()      # composable networks: weight gradients run on a second stream (nnops._WgradStream)
         if self.trainer is not None and self.trainer.reducer is not None:
             self.trainer.reducer.finish()
 

@@ -38,41 +38,91 @@ def to_nhwc(x: torch.Tensor, dtype) -> torch.Tensor:
     return out
 
 
-_GROUP_IDX = {}
-
-
-def _group_idx(groups: int, device) -> torch.Tensor:
-    """arange(groups) on the device, made once (the grouped layers index their diagonal blocks with it in every forward and
-    backward pass: two 3-us launches each time otherwise)."""
-    key = (groups, str(device))
-    if key not in _GROUP_IDX:
-        _GROUP_IDX[key] = torch.arange(groups, device=device)
-    return _GROUP_IDX[key]
-
-
 def _dense_fwd_pack(weight: torch.Tensor, groups: int) -> torch.Tensor:
     """torch Conv2d weight [Cout, Cin/groups, kh, kw] -> fp32 fwd pack [Cout][kh][kw][Cin] (block-diagonal for
-    groups > 1)."""
+    groups > 1): one library launch (pai_filter_to_dense); a 1x1 filter without groups already IS that layout."""
     cout, cig, kh, kw = weight.shape
-    w = weight.detach().to(torch.float32).permute(0, 2, 3, 1)           # [Cout, kh, kw, Cin/g]
-    if groups == 1:
-        return w.contiguous()
-    cog = cout // groups
-    dense = torch.zeros(cout, kh, kw, cig * groups, dtype=torch.float32, device=weight.device)
-    dv = dense.view(groups, cog, kh, kw, groups, cig)
-    idx = _group_idx(groups, weight.device)
-    dv[idx, :, :, :, idx, :] = w.reshape(groups, cog, kh, kw, cig)
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.to(torch.float32).contiguous()
+    if groups == 1 and kh * kw == 1:
+        return w.view(cout, 1, 1, cig)
+    dense = torch.empty(cout, kh, kw, cig * groups, dtype=torch.float32, device=weight.device)
+    ops.filter_to_dense(w, cout, cig, kh * kw, groups, dense)
     return dense
 
 
 def _grad_from_fwd_pack(dw: torch.Tensor, weight: torch.Tensor, groups: int) -> torch.Tensor:
     cout, cig, kh, kw = weight.shape
-    d = dw.view(cout, kh, kw, cig * groups)
-    if groups > 1:
-        cog = cout // groups
-        idx = _group_idx(groups, dw.device)
-        d = d.view(groups, cog, kh, kw, groups, cig)[idx, :, :, :, idx, :].reshape(cout, kh, kw, cig)
-    return d.permute(0, 3, 1, 2).contiguous()
+    if groups == 1 and kh * kw == 1:
+        return dw.view(cout, cig, 1, 1)
+    out = torch.empty(cout, cig, kh, kw, dtype=torch.float32, device=dw.device)
+    ops.filter_grad_from_dense(dw, cout, cig, kh * kw, groups, out)
+    return out
+
+
+class _WgradStream:
+    """The weight gradients of the composable networks leave the critical path of the backward pass the way the Pix2Pix
+    engine's do (engine._SideStream): each is issued on ONE second stream per device, ordered after the launch that produced
+    its dz, and runs beside the next layers' BatchNorm-backward passes (HBM-bound) and input gradients.  ``join`` -- queued as
+    the end-of-backward callback of the autograd engine, and called again by ``manual_backward`` and the optimizers -- makes
+    the stream the backward pass was started from wait for them.  One
+    stream: the library's weight-gradient slab buffer is used by one launch at a time.  PAI_NO_OVERLAP=1 turns it off."""
+
+    KEEP_BYTES = 48 << 30
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get("PAI_NO_OVERLAP", "0") in ("", "0")
+        self.streams = {}
+        self.pending = set()
+        self.keep, self.kept_bytes = [], 0
+
+    def run(self, device, reads, fn, params=()):
+        """fn() -> (results, temporaries) with the library's launches on the side stream.  `reads`: the tensors those
+        launches read; they and the temporaries were allocated on the main stream and must outlive the side stream's use.
+        A parameter that already HAS a gradient makes autograd add the new one to it on the main stream, during the backward
+        pass: such a layer's weight gradient stays on the main stream."""
+        if not self.on or any(p is not None and p.grad is not None for p in params):
+            return fn()[0]
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        s = self.streams.get(idx)
+        if s is None:
+            s = self.streams[idx] = torch.cuda.Stream(device=idx)
+        ops.stream_wait_last(s, torch.cuda.current_stream(idx))
+        with ops.on_stream(s):          # library launches only: fn allocates on the main stream, see `reads`
+            out, temps = fn()
+        reads = tuple(reads) + tuple(temps)
+        # main-stream tensors the side stream reads stay referenced until the join (the main stream then waits for the side
+        # stream before anything can reuse their memory) -- record_stream costs an allocator event per tensor, ~8 ms of host
+        # time per residual U-Net step; past KEEP_BYTES it is used after all
+        nbytes = sum(t.numel() * t.element_size() for t in reads if t is not None)
+        if self.kept_bytes + nbytes <= self.KEEP_BYTES:
+            self.keep.append(reads)
+            self.kept_bytes += nbytes
+        else:
+            for t in reads:
+                if t is not None:
+                    t.record_stream(s)
+        if not self.pending:
+            # the backward pass ends with the join: callers of a bare loss.backward() read complete gradients as well
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        self.pending.add(idx)
+        return out
+
+    def join(self):
+        for idx in tuple(self.pending):
+            ops.stream_wait_last(torch.cuda.current_stream(idx), self.streams[idx])
+        self.pending.clear()
+        self.keep, self.kept_bytes = [], 0
+
+
+WGRAD = _WgradStream()
+
+
+def join_wgrads() -> None:
+    """The current stream waits for every weight gradient issued on the side stream (no-op when none is pending)."""
+    WGRAD.join()
 
 
 class ConvBNAct(torch.autograd.Function):
@@ -117,6 +167,7 @@ class ConvBNAct(torch.autograd.Function):
         b32 = None if bias is None else bias.detach().float()
         ctx.d, ctx.act, ctx.groups, ctx.dtype, ctx.has_bn, ctx.out_f32 = d, act, groups, dtype, bn is not None, out_f32
         ctx.has_x2 = x2 is not None
+        ctx.bias_ref = bias
         extra = [x2] if x2 is not None else []
         if bn is None:
             if out_f32:                       # final conv + tanh (reference :307-315): fp32 NCHW-compatible output
@@ -190,17 +241,22 @@ class ConvBNAct(torch.autograd.Function):
                 ops.bn_bwd_reduce(dtype, g, act, None, ACT_NONE, None, z, M, Cout, mean, rstd, None, part, sums, None, None)
                 ops.bn_bwd_apply(dtype, g, z, M, Cout, mean, rstd, gamma.detach(), sums, dz)
         k = weight.shape[2]
-        dw = torch.empty(Cout * k * k * Cin, **f32)
         # a conv bias in front of a BatchNorm has an identically zero gradient
         with_bias = ctx.needs_input_grad[3] and not ctx.has_bn       # inputs: x, x2, weight, bias, gamma, beta, ...
-        dbias = (torch.empty(Cout, **f32) if with_bias else torch.zeros(Cout, **f32)) if ctx.needs_input_grad[3] else None
-        ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
+        groups = ctx.groups
+
+        def wgrad():
+            dw = torch.empty(Cout * k * k * Cin, **f32)
+            dbias = (torch.empty(Cout, **f32) if with_bias else torch.zeros(Cout, **f32)) if ctx.needs_input_grad[3] else None
+            ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
+            return (_grad_from_fwd_pack(dw, weight, groups), dbias), (dw,)
+
+        gw, dbias = WGRAD.run(dev, (x, x2, dz), wgrad, (weight, ctx.bias_ref))
         dx = dx2 = None
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
             dx = torch.empty(N, H, W, C1, dtype=dtype, device=dev)
             dx2 = torch.empty(N, H, W, C2, dtype=dtype, device=dev) if ctx.has_x2 else None
             ops.conv_dgrad(d, dz, wd, dx, dx2)
-        gw = _grad_from_fwd_pack(dw, weight, ctx.groups)
         return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -413,6 +469,7 @@ class Linear(torch.autograd.Function):
         ops.conv_fwd(d, x, None, wf, None if bias is None else bias.detach(), y_raw=y)
         ctx.d = d
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, wd)
         return y
 
@@ -423,9 +480,15 @@ class Linear(torch.autograd.Function):
         g = g.contiguous()
         M, K, out_f = d.W, d.C1, d.Cout
         f32 = dict(dtype=torch.float32, device=g.device)
-        dw = torch.empty(out_f, K, **f32)
-        db = torch.empty(out_f, **f32) if ctx.has_bias else None
-        ops.conv_wgrad_overwrite(d, x, None, g, dw, db)
+        has_bias = ctx.has_bias
+
+        def wgrad():
+            dw = torch.empty(out_f, K, **f32)
+            db = torch.empty(out_f, **f32) if has_bias else None
+            ops.conv_wgrad_overwrite(d, x, None, g, dw, db)
+            return (dw, db), ()
+
+        dw, db = WGRAD.run(g.device, (x, g), wgrad, ctx.params)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=g.dtype, device=g.device)

@@ -372,6 +372,9 @@ class MultiAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        from . import nnops
+        nnops.join_wgrads()      # weight gradients of the composable networks run on a second stream; no-op after manual_backward
+
         def stock(*a):
             # a captured step (device-side count, graph.GraphedStep) must never reach the stock implementation: it would
             # bake the HOST step count of the capture into the graph and every replay would reuse one bias correction
