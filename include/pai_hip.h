@@ -607,6 +607,11 @@ int pai_cast_multi(int count, int src_dtype, const void* const* srcs, int dst_dt
 int pai_filter_to_dense(const float* w_oihw, int Cout, int Cin_per_group, int taps, int groups, float* dense, void* stream);
 int pai_filter_grad_from_dense(const float* dense_dw, int Cout, int Cin_per_group, int taps, int groups, float* dw_oihw,
                                void* stream);
+
+/* dst[a][c][b][:] = src[a][b][c][:] for a contiguous [A][B][C][D] tensor of 2- or 4-byte elements (D * elem_bytes a
+ * multiple of 16): the "n c (h p1) (w p2) <-> n (h w) (p1 p2 c)" rearrangement around the ViT bottleneck (reference
+ * models/trans_unet.py:139-141,175-179) on NHWC storage, with A = n * grid, (B, C) = (p1, grid) or (grid, p1), D = p2 * c. */
+int pai_swap_mid(int elem_bytes, const void* src, int64_t A, int B, int C, int64_t D, void* dst, void* stream);
 /* ptr[0 .. numel) *= factor (fp32, 16-byte aligned): the x 1/world_size average behind the SUM all-reduce of a gradient
  * bucket (DDP averages, reference main.py:123-136 through pl.Trainer), as a node of the plan. */
 int pai_scale(float* ptr, int64_t numel, float factor, void* stream);

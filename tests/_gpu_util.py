@@ -53,6 +53,12 @@ def sync_training_state(src, dst):
         for k, v in src.state_dict().items():
             sd[k].copy_(v)
         for os_, od in zip(src._all_optimizers(), dst._all_optimizers()):
+            if not hasattr(os_, "_engine"):        # MultiAdam: stock per-parameter state, same parameter order
+                for ps, pd in zip(os_.param_groups[0]["params"], od.param_groups[0]["params"]):
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        if key in os_.state.get(ps, ()) and key in od.state.get(pd, ()):
+                            od.state[pd][key].copy_(os_.state[ps][key])
+                continue
             a_s, a_d = os_._engine.arena(), od._engine.arena()
             if getattr(a_s, "mflat", None) is not None and getattr(a_d, "mflat", None) is not None:
                 a_d.mflat.copy_(a_s.mflat)

@@ -136,21 +136,91 @@ def test_plan_replay_is_one_c_call_of_host_time(pai):
     assert np.isfinite(float(m.logged["loss"]))
 
 
-@pytest.mark.parametrize("family", ["resnext_unet", "trans_unet"])
-def test_composable_families_step_aside(pai, family):
-    """The op-level networks (nnops.py) launch torch kernels of their own inside the step (layout copies, autograd's
-    gradient sums): the recorder sees them, refuses, and every call runs the eager step -- never a partial replay."""
-    from thesis_pai_reconstruction_amd.plan import PlannedStep
+def _build_composable(pai, family, dtype):
     torch.manual_seed(0)
-    m = (pai.ResUnetGAN(1, 1, "next", (1, 2), 0.0, "gan") if family == "resnext_unet"
-         else pai.TransUnetGAN(1, 1, (1, 2), 2, 0.0, "gan"))
+    m = {"resnext_unet": lambda: pai.ResUnetGAN(1, 1, "next", (1, 2), 0.0, "gan"),
+         "res18_unet": lambda: pai.ResUnetGAN(1, 1, "18", (1, 2), 0.0, "gan"),
+         "trans_unet": lambda: pai.TransUnetGAN(1, 1, (1, 2), 2, 0.0, "gan")}[family]()
     m.to(DEV)
-    m.set_precision("bf16-mixed")
+    m.set_precision("32" if dtype == torch.float32 else "bf16-mixed")
+    m.train()
+    return m
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("family", ["resnext_unet", "res18_unet", "trans_unet"])
+def test_composable_families_replay_from_a_plan(pai, family, dtype):
+    """The op-level networks (nnops.py): every launch of their step is a library launch too (gradient fan-in through
+    nnops.Fork, filter layout / patch rearrangement kernels, MultiAdam), so the step records and replays like the Pix2Pix
+    one.  Same protocol as test_planned_step_matches_eager: both models start every step from the same state."""
+    from thesis_pai_reconstruction_amd.plan import PlannedStep
+    steps = 8
+    size = 256 if family == "trans_unet" else 64
+    eager, planned = _build_composable(pai, family, dtype), _build_composable(pai, family, dtype)
+    planned.load_state_dict(eager.state_dict())
+    ps = PlannedStep(planned, warmup=3)
+    for s in range(steps):
+        b = tuple(t.to(DEV) for t in synth_batch(300 + s, 2, size))
+        eager.logged, planned.logged = {}, {}
+        eager.training_step(b, s)
+        ps(b, s)
+        torch.cuda.synchronize()
+        assert ps.disabled is None, ps.disabled
+        assert set(eager.logged) == set(planned.logged) == {"d_loss", "loss", "train_ssim", "train_psnr", "train_rmse"}
+        for k, v in eager.logged.items():
+            a, g = float(v), float(planned.logged[k])
+            tol = 1e-4 if k == "loss" else 0.0
+            assert abs(a - g) <= tol * max(1.0, abs(a)), (s, k, a, g)
+        for (k, p), (_, q) in zip(eager.state_dict().items(), planned.state_dict().items()):
+            if k.endswith("num_batches_tracked"):
+                assert int(p) == int(q), k
+            else:
+                d = (p.float() - q.float()).abs()
+                # (a conv bias in front of a BatchNorm-led block has a gradient that is fp32 rounding noise: Adam turns its
+                #  sign into +-lr steps -- small tensors of that kind are held to the max bound only)
+                assert float(d.max()) <= 4.1e-4 and (d.numel() < 1024 or float(d.mean()) <= 1e-5), \
+                    (s, k, float(d.max()), float(d.mean()))
+        # gradients of the replayed step are where the host expects them
+        gp = [p.grad for p in planned.unet.parameters() if p.grad is not None]
+        ge = [p.grad for p in eager.unet.parameters() if p.grad is not None]
+        assert len(gp) == len(ge) > 10
+        scale = max(float(g.norm()) for g in ge)
+        # (behind the discriminator's update, whose atomics-ordered bias gradients differ in the last bits: bf16 storage
+        #  rounds those differences up to ~1 % at the far end of the generator's backward pass)
+        rtol = 1e-3 if dtype == torch.float32 else 5e-2
+        for a, g in zip(gp, ge):
+            assert float((a - g).norm()) <= rtol * float(g.norm()) + 1e-5 * scale
+        _sync_training_state(eager, planned)
+    assert ps.records >= 1 and ps.replays == steps - 3 - ps.records and ps.replays >= 3, ps.describe()
+    for info in ps.describe()["nodes"]:
+        assert info["launches"] > 100 and info["streams"] >= 3, info
+    assert planned._pai_opt_steps == eager._pai_opt_steps == 2 * steps
+    for oe, og in zip(eager._all_optimizers(), planned._all_optimizers()):
+        assert og.total_steps == oe.total_steps == steps
+        se, sg = oe.state_dict()["state"], og.state_dict()["state"]
+        assert int(next(iter(sg.values()))["step"]) == int(next(iter(se.values()))["step"]) == steps
+
+
+def test_plug_in_network_steps_aside(pai):
+    """A ``unet`` the library does not know (any nn.Module, reference README.md:23) launches torch's own kernels inside the
+    step: the recorder sees them, refuses, and every call runs the eager step -- never a partial replay."""
+    from thesis_pai_reconstruction_amd.plan import PlannedStep
+
+    class Plug(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(1, 1, 3, padding=1)
+
+        def forward(self, x):
+            return torch.tanh(self.c(x))
+
+    torch.manual_seed(0)
+    m = pai.UnetWrapper(Plug(), "gan")
+    m.to(DEV)
     m.train()
     ps = PlannedStep(m, warmup=3)
-    size = 64 if family == "resnext_unet" else 256
     for s in range(6):
-        ps(tuple(t.to(DEV) for t in synth_batch(300 + s, 2, size)), s)
+        ps(tuple(t.to(DEV) for t in synth_batch(300 + s, 2, 64)), s)
     torch.cuda.synchronize()
     assert ps.disabled is not None and ps.replays == 0 and not ps.plans, ps.describe()
     assert m._pai_opt_steps == 12 and np.isfinite(float(m.logged["loss"]))

@@ -728,3 +728,36 @@ extern "C" int pai_filter_grad_from_dense(const float* dense_dw, int Cout, int C
     PAI_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- [A][B][C][D] -> [A][C][B][D] ------------------------------------------------------------------------------------------
+// The patch rearrangement in front of and behind the ViT bottleneck (reference models/trans_unet.py:139-141,175-179:
+// "n c (h p1) (w p2) -> n (h w) (p1 p2 c)" and back) on NHWC storage is exactly this exchange of the two middle axes
+// of [n * grid][p1][grid][p2 * c]; D is moved in 16-byte pieces.
+__global__ __launch_bounds__(256) void swap_mid_k(const uint4* __restrict__ src, int64_t rows, int B, int Cc, int Dv,
+                                                  uint4* __restrict__ dst) {
+    const int64_t total = rows * Dv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int dv = (int)(i % Dv);
+        const int64_t r = i / Dv;               // destination row (a, c, b)
+        const int b = (int)(r % B);
+        const int c = (int)((r / B) % Cc);
+        const int64_t a = r / ((int64_t)B * Cc);
+        dst[i] = src[((a * B + b) * Cc + c) * Dv + dv];
+    }
+}
+
+extern "C" int pai_swap_mid(int elem_bytes, const void* src, int64_t A, int B, int Cc, int64_t D, void* dst, void* stream) {
+    PAI_CHECK(src && dst && src != dst && A > 0 && B > 0 && Cc > 0 && D > 0 && (elem_bytes == 2 || elem_bytes == 4),
+              "pai_swap_mid: bad arguments");
+    PAI_CHECK((D * elem_bytes) % 16 == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && D * elem_bytes / 16 < (1 << 30),
+              "pai_swap_mid: the inner extent (%lld elements of %d bytes) must be a multiple of 16 bytes, 16-byte aligned",
+              (long long)D, elem_bytes);
+    const int Dv = (int)(D * elem_bytes / 16);
+    const int64_t rows = A * B * Cc;
+    int64_t bx = (rows * Dv + 255) / 256;
+    if (bx > 16384) bx = 16384;
+    PAI_LAUNCH(swap_mid_k, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, rows, B, Cc, Dv, (uint4*)dst);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}

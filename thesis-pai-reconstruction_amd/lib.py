@@ -166,6 +166,7 @@ SIGNATURES = {
     "pai_cast_multi": (_I, [_I, _I, _P, _I, _P, _P, _P]),
     "pai_filter_to_dense": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pai_filter_grad_from_dense": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "pai_swap_mid": (_I, [_I, _P, C.c_int64, _I, _I, C.c_int64, _P, _P]),
 }
 
 _lib = None

@@ -38,6 +38,7 @@ class _Block(nn.Module):
 
     def run(self, x, ctx):
         mods = list(self.conv_block)
+        x, xs = nnops.fork(x)           # residual branch / skip branch
         h, i = x, 0
         while i < len(mods):
             conv = mods[i]
@@ -52,9 +53,9 @@ class _Block(nn.Module):
                 ctx["capture"][f"{ctx['name']}.conv_block.{i}"] = h.detach().float()
             i = j
         if isinstance(self.conv_skip, nn.Identity):
-            s = nnops.as_tensor(x)
+            s = nnops.as_tensor(xs)
         else:
-            s = nnops.conv_bn_act(x, self.conv_skip[0], self.conv_skip[1], ACT_NONE, ctx["training"], ctx["n_updates"],
+            s = nnops.conv_bn_act(xs, self.conv_skip[0], self.conv_skip[1], ACT_NONE, ctx["training"], ctx["n_updates"],
                                   ctx["dtype"])
         return nnops.AddAct.apply(h, s, ACT_RELU if self.post_relu else ACT_NONE)
 
@@ -214,7 +215,11 @@ class ResUnet(nn.Module):
             ctx["name"] = f"enc{i}"
             h = enc.encode[0].run(h, ctx)
             h = nnops.MaxPool2.apply(h)
-            skips.append(h)
+            if i + 1 < len(self.encoders):
+                h, sk = nnops.fork(h)     # next level / decoder
+                skips.append(sk)
+            else:
+                skips.append(h)
             if self.debug_capture is not None:
                 self.debug_capture[f"enc{len(skips) - 1}"] = h.detach().float()
         skips.pop()

@@ -58,12 +58,13 @@ class EncoderBlock(nn.Module):
     def run(self, x, ctx):
         tr, nu, dt = ctx["training"], ctx["n_updates"], ctx["dtype"]
         d = self.decode
+        x, xs = nnops.fork(x)           # residual branch / strided 1x1 skip
         h = nnops.conv_bn_act(x, d[0], d[1], ACT_RELU, tr, nu, dt)
         h = nnops.conv_bn_act(h, d[3], None, ACT_NONE, tr, 0, dt)          # 3x3 at stride 1 ...
         h = nnops.Subsample2.apply(h)                                      # ... its even pixels are the stride-2 result
         h = nnops.BNAct.apply(h, d[4].weight, d[4].bias, d[4], tr, nu, ACT_RELU)
         h = nnops.conv_bn_act(h, d[6], d[7], ACT_NONE, tr, nu, dt)
-        s = nnops.conv_bn_act(nnops.Subsample2.apply(x), self.skip[0], self.skip[1], ACT_NONE, tr, nu, dt)
+        s = nnops.conv_bn_act(nnops.Subsample2.apply(xs), self.skip[0], self.skip[1], ACT_NONE, tr, nu, dt)
         return nnops.AddAct.apply(h, s, ACT_RELU)
 
 
@@ -122,20 +123,22 @@ class VisionTransformer(nn.Module):
             return torch.bernoulli(torch.full(shape, 1.0 - pr, device=h.device)) / (1.0 - pr)
 
         # "n c (h p1) (w p2) -> n (h w) (p1 p2 c)" on the NHWC tensor: data movement only
-        t = h.view(n, g, p, g, p, c).permute(0, 1, 3, 2, 4, 5).reshape(n * P, D).contiguous()
+        t = nnops.SwapMid.apply(h, n * g, p, g, p * c).view(n * P, D)
         ln1, lin, ln2 = self.to_patch_embedding[1], self.to_patch_embedding[2], self.to_patch_embedding[3]
         t = nnops.LayerNorm.apply(t, None, ln1.weight, ln1.bias, ln1.eps, None)
         t = nnops.Linear.apply(t, lin.weight, lin.bias)
         t = nnops.LayerNorm.apply(t, None, ln2.weight, ln2.bias, ln2.eps, self.pos_embedding)      # ... += pos_embedding
         for li, layer in enumerate(self.transformer.layers):
             sa = layer.self_attn
+            t, t_res = nnops.fork(t)    # sublayer / its residual
             qkv = nnops.Linear.apply(t, sa.in_proj_weight, sa.in_proj_bias)
             # sequence axis = the image batch
             a = nnops.MHACore.apply(qkv, n, P, self.num_heads, mask("attn", li, P * self.num_heads, n, n) if drop else None)
             a = nnops.Linear.apply(a, sa.out_proj.weight, sa.out_proj.bias)
             if drop:
                 a = nnops.TokenDropout.apply(a, mask("sa", li, n * P, D))
-            t = nnops.LayerNorm.apply(t, a, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, None)
+            t = nnops.LayerNorm.apply(t_res, a, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, None)
+            t, t_res = nnops.fork(t)
             f = nnops.Linear.apply(t, layer.linear1.weight, layer.linear1.bias)
             f = nnops.GELU.apply(f)
             if drop:
@@ -143,11 +146,11 @@ class VisionTransformer(nn.Module):
             f = nnops.Linear.apply(f, layer.linear2.weight, layer.linear2.bias)
             if drop:
                 f = nnops.TokenDropout.apply(f, mask("out", li, n * P, D))
-            t = nnops.LayerNorm.apply(t, f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, None)
+            t = nnops.LayerNorm.apply(t_res, f, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, None)
             if ctx.get("capture") is not None:
                 ctx["capture"][f"vit{li}"] = t.detach().float()
         # "n (h w) (p1 p2 c) -> n c (h p1) (w p2)", as NHWC
-        return t.view(n, g, g, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(n, hs, ws, c).contiguous()
+        return nnops.SwapMid.apply(t, n * g, g, p, p * c).view(n, hs, ws, c)
 
 
 class TransUnet(nn.Module):
@@ -203,7 +206,11 @@ class TransUnet(nn.Module):
         skips = []
         for i, enc in enumerate(self.encoders):
             h = enc.run(h, ctx)
-            skips.append(h)
+            if i + 1 < len(self.encoders):
+                h, sk = nnops.fork(h)     # next level / decoder
+                skips.append(sk)
+            else:
+                skips.append(h)
             if cap is not None:
                 cap[f"enc{i}"] = h.detach().float()
         skips.pop()

@@ -247,7 +247,9 @@ class ConvBNAct(torch.autograd.Function):
 
         def wgrad():
             dw = torch.empty(Cout * k * k * Cin, **f32)
-            dbias = (torch.empty(Cout, **f32) if with_bias else torch.zeros(Cout, **f32)) if ctx.needs_input_grad[3] else None
+            dbias = torch.empty(Cout, **f32) if ctx.needs_input_grad[3] else None
+            if dbias is not None and not with_bias:
+                ops.zero_multi([dbias])
             ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
             return (_grad_from_fwd_pack(dw, weight, groups), dbias), (dw,)
 
@@ -346,6 +348,54 @@ class Dropout2d(torch.autograd.Function):
         out = torch.empty_like(g)
         ops.dropout2d(g.dtype, g.contiguous(), mask, N, H * W, C, out)
         return out, None
+
+
+class Fork(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (block input -> residual branch + skip branch, encoder feature ->
+    next level + decoder, token stream -> sublayer + its residual; reference models/res_unet.py:165-171,
+    models/trans_unet.py:227-236, nn.TransformerEncoderLayer).  Autograd would sum the two gradients with an aten add of
+    its own; here the sum is a library launch (``pai_add_act``), so a whole step consists of launches a plan can own."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g2 if g1 is None else g1
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        out = torch.empty_like(g1)
+        ops.add_act(g1.dtype, g1, g2, ACT_NONE, out)
+        return out
+
+
+def fork(x):
+    """Two handles of `x` (a tensor, or the pair a decoder block reads as a concatenation) for its two consumers."""
+    if isinstance(x, tuple):
+        a, b = zip(*(Fork.apply(t) for t in x))
+        return tuple(a), tuple(b)
+    return Fork.apply(x)
+
+
+class SwapMid(torch.autograd.Function):
+    """[A][B][C][D] -> [A][C][B][D] (``pai_swap_mid``): the patch rearrangement around the ViT bottleneck."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, Cc, D):
+        ctx.dims = (A, B, Cc, D)
+        out = torch.empty_like(x)
+        ops.swap_mid(x, A, B, Cc, D, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B, Cc, D = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        ops.swap_mid(g, A, Cc, B, D, dx)
+        return dx, None, None, None, None
 
 
 def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False):
@@ -533,7 +583,8 @@ class LayerNorm(torch.autograd.Function):
         ops.layernorm_bwd(xs.dtype, g, xs, M, D, gamma.detach(), mean, rstd, dx, dgb, part)
         dpost = None
         if ctx.has_post:
-            dpost = torch.zeros(ctx.P * D, **f32)
+            dpost = torch.empty(ctx.P * D, **f32)
+            ops.zero_multi([dpost])
             ops.colsum(g.dtype, g, M // ctx.P, ctx.P * D, dpost)
             dpost = dpost.view(ctx.post_shape)
         return dx, (dx if ctx.has_res else None), dgb[1], dgb[0], None, dpost

@@ -813,6 +813,14 @@ def filter_grad_from_dense(dense_dw, Cout, cig, taps, groups, dw_oihw) -> None:
                                                 _p(dw_oihw, torch.float32), _stream()), "pai_filter_grad_from_dense")
 
 
+def swap_mid(src, A, B, Cc, D, dst) -> None:
+    """dst[a][c][b][:] = src[a][b][c][:] (pai_swap_mid); src / dst contiguous, same dtype (bf16 or fp32)."""
+    if src.dtype != dst.dtype or src.numel() != A * B * Cc * D or dst.numel() != src.numel() \
+            or not src.is_contiguous() or not dst.is_contiguous():
+        raise PaiError("swap_mid: src / dst must be contiguous tensors of A * B * C * D elements of one dtype")
+    L.check(L.load().pai_swap_mid(src.element_size(), _p(src), A, B, Cc, D, _p(dst), _stream()), "pai_swap_mid")
+
+
 class ZeroList:
     """``zero_multi`` of a FIXED tensor list with the pointer tables built once (a gradient arena clears the same ~45
     segments in front of every backward pass)."""

@@ -353,6 +353,34 @@ class MultiAdam(torch.optim.Adam):
     def note_replays(self, n: int = 1):
         self._arena_steps += n
 
+    # ---- launch plans (plan.PlannedStep; same contract as ArenaAdam) ---------------------------------------------
+    @property
+    def total_steps(self) -> int:
+        return self._total_steps()
+
+    def plan_state(self):
+        """What a recorded step bakes in besides pointers that never move (parameters, moments): the hyper-parameters passed
+        by value.  None until the moments exist (first step) or while the fused update's preconditions do not hold."""
+        if len(self.param_groups) != 1 or self._dev_step is not None:
+            return None
+        group = self.param_groups[0]
+        if group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+            return None
+        ps = [p for p in group["params"] if p.requires_grad]
+        if not ps or any("exp_avg" not in self.state.get(p, ()) for p in ps):
+            return None
+        return ("multi", float(group["lr"]), tuple(float(b) for b in group["betas"]), float(group["eps"]), len(ps))
+
+    def plan_commits(self):
+        """The gradient tensors the recorded step produced: replays write the same memory."""
+        return [(p, p.grad) for p in self.param_groups[0]["params"] if p.grad is not None]
+
+    def plan_replayed(self, commits):
+        self._arena_steps += 1
+        for p, g in commits:
+            if p.grad is not g:
+                p.grad = g
+
     def _mirror_steps(self):
         if self._arena_steps:
             for st in self.state.values():

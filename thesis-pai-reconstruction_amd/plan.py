@@ -22,9 +22,11 @@ What a plan freezes, and how each piece stays valid:
     library.  Each collective (and the wait on it) is a HOST node (``host_op``): the recording is split into C-side
     segments around it and the replay alternates ``pai_plan_run`` with those ~2 x buckets Python calls.  With the
     C-ABI communicator (PAI_COMM=rccl, ``pai_allreduce``) the collectives are plan nodes themselves.
+The op-level networks of nnops.py (residual / Trans U-Nets) plan the same way: every launch of theirs is a library launch
+(gradient fan-in through ``nnops.Fork``, filter layout and patch rearrangement kernels), ``optim.MultiAdam`` is plan-aware.
 Anything the recorder cannot own makes it refuse (``disabled`` says why) and the step runs eagerly: kernels launched by
-torch itself inside the step (the op-level residual / Trans U-Nets of nnops.py, loss types other than "gan"), dropout
-masks drawn on the host side, per-launch profiling.
+torch itself inside the step (a plug-in ``unet`` module, ``torch.cat`` of the pre-activation residual blocks, loss types
+other than "gan"), dropout masks drawn on the host side, per-launch profiling.
 """
 from __future__ import annotations
 
@@ -112,7 +114,9 @@ class _Recorder(TorchDispatchMode):
             self.foreign.append(name)
         for t in touched:
             if t.is_cuda:
-                self.keep.append(t)
+                # the STORAGE is what replays need alive; holding the tensor itself would raise its use count, and autograd's
+                # AccumulateGrad then copies a gradient (a kernel of torch's) instead of adopting it as .grad
+                self.keep.append(t.untyped_storage())
         return out
 
 
