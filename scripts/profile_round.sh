@@ -29,3 +29,7 @@ timeout -k 10 300 python3 bench.py --model trans_unet --batch 32 --patch-size 2 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_trans -- python3 bench.py --model trans_unet --batch 32 --patch-size 4 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > /dev/null 2> $out/stats_trans.err
 cp $(ls $out/stats_trans/*/*_kernel_stats.csv | head -1) gpurun_out/profiles_$tag/${tag}_bench_trans_unet_p4_kernel_stats.csv
 rm -rf $out/stats_trans
+# ... and of the residual U-Net step (BASELINE configs[3])
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_res -- python3 bench.py --model resnext_unet --size 512 --batch 16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > /dev/null 2> $out/stats_res.err
+cp $(ls $out/stats_res/*/*_kernel_stats.csv | head -1) gpurun_out/profiles_$tag/${tag}_bench_resnext_unet_kernel_stats.csv
+rm -rf $out/stats_res
