@@ -376,7 +376,7 @@ class AttentionUnetEngine(UnetEngine):
             du, dz = G["ga"][i], G["dz_enc"][i]
             ops.bn_bwd_finalize(part, fused_rows, C, st.sums, A.seg(bn.weight), A.seg(bn.bias))
             ops.bn_bwd_apply(dtype, du, S["z"][i], M, C, st.mean, st.rstd, bn.weight, st.sums, dz)
-            wgrad(P["enc_wdesc"][i], S["a"][i - 1], None, dz, conv, False)
+            wgrad(P["enc_desc"][i], S["a"][i - 1], None, dz, conv, False)
             _, wd = self.enc_packs[i].get(dtype)
             fused_rows = enc_dgrad(i, dz, wd)
         conv0 = self.enc_conv[0]

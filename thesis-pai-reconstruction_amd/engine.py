@@ -290,31 +290,6 @@ def pack_targets(arena, packs):
     return out
 
 
-def solo_desc(d):
-    """A copy of a convolution descriptor with PAI_HINT_SOLO set: the launch geometry for a call that runs ALONE on the
-    device -- the weight gradient of the last dense layer of a backward pass, issued when the input-gradient chain is
-    about to end (the main stream then only waits for it)."""
-    c = type(d).from_buffer_copy(d)
-    c.hints |= ops.L.HINT_SOLO
-    return c
-
-
-def _defer_wgrad() -> int:
-    """How many of the first decoders' weight gradients UnetEngine.backward holds back until the main stream reaches the
-    bottleneck chain (PAI_DEFER_WGRAD; 3 = decoders[6], [5], [4] of the 8-level U-Net).  Default 0: measured round 4, same
-    box, three interleaved rounds: 6.25-6.27 ms/step as issued today, 6.40-6.42 with 3 held back, 6.34-6.36 with 2,
-    6.46-6.48 with 4 -- the chain's split-K launches want the whole chip too, and the side stream then ends later."""
-    import os
-    return int(os.environ.get("PAI_DEFER_WGRAD", "0"))
-
-
-def _solo_tail() -> int:
-    """How many trailing dense weight gradients of a backward pass get PAI_HINT_SOLO (PAI_SOLO_TAIL; default 0: measured
-    round 4, same box, 6.24-6.27 ms/step with 1 against 6.25-6.27 without -- within the noise)."""
-    import os
-    return int(os.environ.get("PAI_SOLO_TAIL", "0"))
-
-
 class _BNState:
     """Per-slot BatchNorm side tensors."""
 
@@ -511,7 +486,6 @@ class UnetEngine:
             cin = self.enc_c[i]
         # weight-gradient calls of the last dense layers of the backward pass (encoders[1], [2], ...): the input-gradient
         # chain ends while they run
-        P["enc_wdesc"] = [solo_desc(d) if 1 <= i <= _solo_tail() else d for i, d in enumerate(P["enc_desc"])]
         P["dec_desc"] = []
         for j in range(L):
             hin, win = eh[L - 1 - j], ew[L - 1 - j]
@@ -720,29 +694,14 @@ class UnetEngine:
         # segments GradArena.begin_backward cleared in one launch
         conv_wgrad = ops.conv_wgrad_overwrite_w if fresh else ops.conv_wgrad
 
-        # Experiment switch (PAI_DEFER_WGRAD, default 0 = off): hold the weight gradients of the first (largest) decoders
-        # back until the main stream enters the bottleneck chain (decoders[3] .. encoders[4]: ~0.75 ms of split-K
-        # launches) instead of issuing them beside their own input gradients, where two matrix-bound launches sharing
-        # every CU each run ~1.6x longer.  Measured SLOWER (see _defer_wgrad); same launches, same order on the side stream.
-        deferred = []
-        n_defer = min(_defer_wgrad(), max(L - 2, 0)) if side.on else 0
-
-        def wgrad(d, x1, x2, dz, conv, with_bias, defer=False):
-            """Weight (and bias) gradient of one layer on the side stream."""
-            def issue():
-                with torch.cuda.stream(side.fork(d)):
-                    fn = ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad
-                    fn(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
-                    done(conv.bias)
-            if defer:
-                deferred.append(issue)
-            else:
-                flush_deferred()
-                issue()
-
-        def flush_deferred():
-            while deferred:
-                deferred.pop(0)()
+        def wgrad(d, x1, x2, dz, conv, with_bias):
+            """Weight (and bias) gradient of one layer on the side stream, beside its own input gradient.  (Round 4 measured
+            the alternatives: holding the first decoders' weight gradients back until the main stream is in the bottleneck
+            chain, 6.34-6.48 against 6.25-6.27 ms/step; two workgroups per CU for the last one of a pass, no change.)"""
+            with torch.cuda.stream(side.fork(d)):
+                fn = ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad
+                fn(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
+                done(conv.bias)
 
         # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
         j = L - 1
@@ -797,7 +756,7 @@ class UnetEngine:
                 x1, x2 = S["r"][j - 1], (S["a"][skip] if skip > 0 else S["z"][0])
             # a conv bias in front of a BatchNorm has an identically zero gradient (BN subtracts the
             # batch mean); the arena already holds zeros for it, no reduction pass is spent on it
-            wgrad(d, x1, x2, dz, conv, False, defer=(j >= L - 1 - n_defer))
+            wgrad(d, x1, x2, dz, conv, False)
             _, wd = self.dec_packs[j].get(dtype)
             if j == 0:
                 # producer: the norm-free last encoder, consumed through ReLU -> dz_last = relu'(z_last) * g
@@ -814,7 +773,6 @@ class UnetEngine:
                                         ACT_NONE, pst.scale, pst.shift, pst.mean, pst.rstd, part, pbn.weight, pst.sums,
                                         A.seg(pbn.weight), A.seg(pbn.bias), G["dz_dec"][j - 1])
                 fused_rows = -1
-        flush_deferred()
         # last encoder (no norm)
         i = L - 1
         conv = self.enc_conv[i]
@@ -843,7 +801,7 @@ class UnetEngine:
             C = self.enc_c[i]
             dz = G["dz_enc"][i]       # written by encoder i+1's input-gradient call (pai_conv_dgrad_bn_apply)
             d = P["enc_desc"][i]
-            wgrad(P["enc_wdesc"][i], S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
+            wgrad(P["enc_desc"][i], S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)
             fused_rows = enc_dgrad(i, dz, wd)
         # encoder 0 (its dz came out of encoder 1's input gradient): on the tail stream, beside encoder 1's
@@ -907,7 +865,6 @@ class DiscEngine:
             P["desc"].append(ops.make_desc(dtype, 0, N, H >> k, W >> k, self.chans[k - 1], 0, self.chans[k], 2, 0, 0,
                                            ACT_LRELU))
         P["desc"].append(ops.make_desc(dtype, 0, N, H >> 4, W >> 4, self.chans[3], 0, 1, 1, 0, 0, ACT_NONE))
-        P["wdesc"] = [solo_desc(d) if 1 <= k <= _solo_tail() else d for k, d in enumerate(P["desc"])]
         P["oh"], P["ow"] = (H >> 4) - 1, (W >> 4) - 1
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, op) for d in P["desc"] for op in (0, 1)), device)
         ops.ensure_scratch(ops.scratch_bytes_for(P["desc"]), device)
@@ -1019,7 +976,7 @@ class DiscEngine:
                         d, S["xin"], S["yin"], G["du"][0], A.seg(conv.weight), A.seg(conv.bias))
             elif need_params:
                 with torch.cuda.stream(side.fork(d)):
-                    conv_wgrad(P["wdesc"][k], S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
+                    conv_wgrad(P["desc"][k], S["a"][k - 1], None, G["du"][k], A.seg(conv.weight), A.seg(conv.bias))
                     if hook is not None:
                         hook(A, A.end_of(conv.bias))
             if k > 0:
