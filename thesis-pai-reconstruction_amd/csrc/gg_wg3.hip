@@ -59,7 +59,7 @@ template <int BMC> __device__ __forceinline__ int yswz3(int row) {
 // BW: width of the K step's pixel block: 16 (4 x 16 pixels, images >= 16 wide) or 8 (8 x 8 pixels: 8 x 8 images)
 template <int BMC, int CI, int BW = 16>
 __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
-                                                            int splits, int blocks_per_split) {
+                                                            int splits, int blocks_per_split, int ph_inner) {
     static_assert((BMC == 128 && CI == 64) || (BMC == 64 && CI == 128), "wave tile 128 x 64 or 64 x 128");
     static_assert(BW == 16 || (BW == 8 && CI == 64), "8-wide blocks: 128-B patch pixels only");
     constexpr int LBW = BW == 16 ? 4 : 3;        // log2 BW
@@ -82,10 +82,15 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = tap of the window
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // transposed layers: the four output phases of one (column tile, pixel range) read the SAME X patches -- as neighbours in
+    // the tile order they run at the same time on one XCD and three of the four reads are L2 hits (decoders[6]: 804 MB of
+    // HBM traffic for 268 MB of operands with the phase outermost)
+    int ph = 0;
+    if (ph_inner) { ph = bid % g.nphase; bid /= g.nphase; }
     const int jt = bid % jtiles; bid /= jtiles;
     const int cot = bid % cotiles; bid /= cotiles;
     const int split = bid % splits;
-    const int ph = bid / splits;
+    if (!ph_inner) ph = bid / splits;
     const int co0 = cot * BMC;
     const int q = jt & (pg.groups - 1);
     const int ci0 = (jt >> (pg.groups == 4 ? 2 : 0)) * CI;
@@ -481,15 +486,16 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
         attr = true;
     }
     const dim3 grid(c.tiles * c.psplits);
+    const int ph_inner = g.nphase > 1 && pai_tunable("wgrad3_ph_inner", 1);
     if (variant == 1) {
         const size_t lds = 2 * (64 * 256 + 96 * 128);
-        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     } else if (variant == 2) {
         const size_t lds = 2 * (64 * 128 + 96 * 256);
-        PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     } else {
         const size_t lds = 2 * (64 * 256 + 128 * 128);
-        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per);
+        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     }
     PAI_LAUNCH_CHECK();
     if (slab) return launch_wgrad_slab_sum(a.dw, slab, c.psplits, dwn, a.overwrite, s);
