@@ -305,6 +305,13 @@ int pai_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float
 /* out = act(z*scale + shift), elementwise over [M][C]. */
 int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const float* scale,
                  const float* shift, int act, void* out, void* stream);
+/* out = act(act_a(za*scale_a + shift_a) + (zb*scale_b + shift_b)) over [M][C]: BatchNorm (+ its own ReLU: the ResNeXt
+ * block) of the residual branch + BatchNorm of the skip branch (scale_b = shift_b = NULL: identity skip, zb added as it is)
+ * + sum + activation, the tail of the residual blocks (reference models/res_unet.py:74,105,160-171,
+ * models/trans_unet.py:227-236), in one pass. */
+int pai_bn2_add_act(int dtype, const void* za, const float* scale_a, const float* shift_a, const void* zb,
+                    const float* scale_b, const float* shift_b, int64_t M, int C, int act_a, int act, void* out,
+                    void* stream);
 /* Backward, pass 1:  du = act1'(a)*g1 + act2'(a)*g2   (g2 may be NULL)
  *   a   : the stored activated output (its sign gives act'), or NULL when act1 = act2 = none
  *   sums[0][C] = sum(du), sums[1][C] = sum(du * xhat)   with xhat = (z-mean)*rstd

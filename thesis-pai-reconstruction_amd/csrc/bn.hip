@@ -218,6 +218,56 @@ extern "C" int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const fl
     return 0;
 }
 
+// out = act(act_a(za * sca + sha) + (zb * scb + shb)): the tail of a residual block -- BatchNorm (+ ReLU: the ResNeXt block,
+// reference models/res_unet.py:160-163) of the residual branch, BatchNorm of the skip branch (scb == NULL: the skip is the
+// identity, zb is added as it is), the sum and the ReLU behind it (models/res_unet.py:74,105,165-171,
+// models/trans_unet.py:227-236) in ONE pass over three tensors instead of bn_apply + bn_apply + add_act over seven.
+// fp32: the same roundings as the three passes (fma, fma, add).
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_add_act_k(const T* za, const float* sca, const float* sha, const T* zb,
+                                                     const float* scb, const float* shb, int64_t nvec, int C, int act_a,
+                                                     int act, T* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((i * 8) % C);
+        float a[8], b[8], s1[8], h1[8];
+        V8<T>::ld(za + i * 8, a);
+        V8<T>::ld(zb + i * 8, b);
+        V8<float>::ld(sca + c0, s1);
+        V8<float>::ld(sha + c0, h1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = act_apply(fmaf(a[k], s1[k], h1[k]), act_a);
+        if (scb) {
+            V8<float>::ld(scb + c0, s1);
+            V8<float>::ld(shb + c0, h1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = fmaf(b[k], s1[k], h1[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = act_apply(a[k] + b[k], act);
+        V8<T>::st(out + i * 8, a);
+    }
+}
+
+extern "C" int pai_bn2_add_act(int dtype, const void* za, const float* scale_a, const float* shift_a, const void* zb,
+                               const float* scale_b, const float* shift_b, int64_t M, int C, int act_a, int act, void* out,
+                               void* stream) {
+    PAI_CHECK(za && zb && out && scale_a && shift_a, "pai_bn2_add_act: null pointer");
+    PAI_CHECK((scale_b == nullptr) == (shift_b == nullptr), "pai_bn2_add_act: scale_b and shift_b go together");
+    PAI_CHECK(C % 8 == 0, "pai_bn2_add_act: C=%d must be a multiple of 8", C);
+    for (int t : {act_a, act})
+        PAI_CHECK(t == PAI_ACT_NONE || t == PAI_ACT_RELU || t == PAI_ACT_LRELU, "pai_bn2_add_act: act=%d", t);
+    const int64_t nvec = M * C / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PAI_F32)
+        PAI_LAUNCH(bn2_add_act_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)za, scale_a, shift_a,
+                   (const float*)zb, scale_b, shift_b, nvec, C, act_a, act, (float*)out);
+    else
+        PAI_LAUNCH(bn2_add_act_k<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const bf16_t*)za, scale_a, shift_a,
+                   (const bf16_t*)zb, scale_b, shift_b, nvec, C, act_a, act, (bf16_t*)out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- backward -------------------------------------------------------------------------------
 constexpr int BWD_MAX_PARTIAL = 2048;
 

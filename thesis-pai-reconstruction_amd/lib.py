@@ -96,6 +96,7 @@ SIGNATURES = {
     "pai_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "pai_bn_apply": (_I, [_I, _P, _L, _I, _P, _P, _I, _P, _P]),
+    "pai_bn2_add_act": (_I, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "pai_bn_bwd_partial_rows": (_I, [_L]),
     "pai_bn_bwd_reduce": (_I, [_I, _P, _I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_bn_bwd_reduce_affine": (_I, [_I, _P, _I, _P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -40,6 +40,8 @@ class _Block(nn.Module):
         mods = list(self.conv_block)
         x, xs = nnops.fork(x)           # residual branch / skip branch
         h, i = x, 0
+        ident = isinstance(self.conv_skip, nn.Identity)
+        post = ACT_RELU if self.post_relu else ACT_NONE
         while i < len(mods):
             conv = mods[i]
             assert isinstance(conv, nn.Conv2d)
@@ -48,16 +50,22 @@ class _Block(nn.Module):
             act = ACT_NONE
             if j < len(mods) and isinstance(mods[j], nn.ReLU):
                 act, j = ACT_RELU, j + 1
+            if j >= len(mods) and bn is not None and ctx.get("capture") is None and nnops.fuse_tail() \
+                    and not (ident and isinstance(xs, tuple)):
+                # last convolution of the block: its BatchNorm (+ ReLU), the skip branch's, the sum and the ReLU behind it in
+                # one pass
+                sk = (None, None) if ident else (self.conv_skip[0], self.conv_skip[1])
+                return nnops.bn_tail(h, conv, bn, act, xs, sk[0], sk[1], post, ctx["training"], ctx["n_updates"], ctx["dtype"])
             h = nnops.conv_bn_act(h, conv, bn, act, ctx["training"], ctx["n_updates"], ctx["dtype"])
             if ctx.get("capture") is not None:
                 ctx["capture"][f"{ctx['name']}.conv_block.{i}"] = h.detach().float()
             i = j
-        if isinstance(self.conv_skip, nn.Identity):
+        if ident:
             s = nnops.as_tensor(xs)
         else:
             s = nnops.conv_bn_act(xs, self.conv_skip[0], self.conv_skip[1], ACT_NONE, ctx["training"], ctx["n_updates"],
                                   ctx["dtype"])
-        return nnops.AddAct.apply(h, s, ACT_RELU if self.post_relu else ACT_NONE)
+        return nnops.AddAct.apply(h, s, post)
 
 
 def _skip(in_channels, out_channels):

@@ -63,6 +63,9 @@ class EncoderBlock(nn.Module):
         h = nnops.conv_bn_act(h, d[3], None, ACT_NONE, tr, 0, dt)          # 3x3 at stride 1 ...
         h = nnops.Subsample2.apply(h)                                      # ... its even pixels are the stride-2 result
         h = nnops.BNAct.apply(h, d[4].weight, d[4].bias, d[4], tr, nu, ACT_RELU)
+        if ctx.get("capture") is None and nnops.fuse_tail():      # BatchNorm of both branches + sum + ReLU in one pass
+            return nnops.bn_tail(h, d[6], d[7], ACT_NONE, nnops.Subsample2.apply(xs), self.skip[0], self.skip[1], ACT_RELU,
+                                 tr, nu, dt)
         h = nnops.conv_bn_act(h, d[6], d[7], ACT_NONE, tr, nu, dt)
         s = nnops.conv_bn_act(nnops.Subsample2.apply(xs), self.skip[0], self.skip[1], ACT_NONE, tr, nu, dt)
         return nnops.AddAct.apply(h, s, ACT_RELU)

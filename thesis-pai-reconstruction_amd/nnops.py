@@ -132,7 +132,7 @@ class ConvBNAct(torch.autograd.Function):
     blocks of reference models/res_unet.py:58-64,86-95,147-163,66-69 and the bare convolutions at :265,308."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, gamma, beta, bn, training, n_updates, act, groups, dtype, out_f32):
+    def forward(ctx, x, x2, weight, bias, gamma, beta, bn, training, n_updates, act, groups, dtype, out_f32, defer=None):
         # x2 (optional): a second NHWC tensor read as if concatenated behind x along C -- the torch.cat in front of the
         # decoder blocks (reference models/res_unet.py:327, models/trans_unet.py:113) never materialises
         _check(x)
@@ -168,6 +168,7 @@ class ConvBNAct(torch.autograd.Function):
         ctx.d, ctx.act, ctx.groups, ctx.dtype, ctx.has_bn, ctx.out_f32 = d, act, groups, dtype, bn is not None, out_f32
         ctx.has_x2 = x2 is not None
         ctx.bias_ref = bias
+        ctx.deferred = False
         extra = [x2] if x2 is not None else []
         if bn is None:
             if out_f32:                       # final conv + tanh (reference :307-315): fp32 NCHW-compatible output
@@ -196,6 +197,15 @@ class ConvBNAct(torch.autograd.Function):
             ops.conv_fwd(d, x, x2, wf, b32, y_raw=z)
             ops.bn_eval_coeffs(Cout, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, float(bn.eps),
                                scale, shift)
+        if defer is not None:
+            # the normalisation itself belongs to the caller's BNTail (residual sum): z goes out raw, its batch statistics in
+            # `defer`; the gradient that comes back is dz and gamma / beta are not this node's inputs
+            if act != ACT_NONE:
+                raise ops.PaiError("ConvBNAct: a deferred BatchNorm carries no activation of its own")
+            defer.update(mean=mean, rstd=rstd, scale=scale, shift=shift, training=training)
+            ctx.deferred = True
+            ctx.save_for_backward(x, z, wd, weight, *extra)
+            return z
         out = torch.empty_like(z)
         ops.bn_apply(dtype, z, M, Cout, scale, shift, act, out)
         ctx.training = training
@@ -213,7 +223,10 @@ class ConvBNAct(torch.autograd.Function):
         dev = g.device
         f32 = dict(dtype=torch.float32, device=dev)
         dgamma = dbeta = None
-        if not ctx.has_bn:
+        if ctx.deferred:
+            x, _, wd, weight = ctx.saved_tensors[:4]
+            dz = g
+        elif not ctx.has_bn:
             x, out, wd, weight = ctx.saved_tensors[:4]
             dz = torch.empty(N, H, W, Cout, dtype=dtype, device=dev)
             if ctx.out_f32:
@@ -259,7 +272,7 @@ class ConvBNAct(torch.autograd.Function):
             dx = torch.empty(N, H, W, C1, dtype=dtype, device=dev)
             dx2 = torch.empty(N, H, W, C2, dtype=dtype, device=dev) if ctx.has_x2 else None
             ops.conv_dgrad(d, dz, wd, dx, dx2)
-        return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class MaxPool2(torch.autograd.Function):
@@ -327,6 +340,82 @@ class AddAct(torch.autograd.Function):
         d = torch.empty_like(out)
         ops.act_bwd(out.dtype, g.contiguous(), ctx.act, None, ACT_NONE, out, out.numel(), d)
         return d, d, None
+
+
+class BNTail(torch.autograd.Function):
+    """act(act_a(BN_a(za)) + BN_b(zb)) -- the tail of a residual block (reference models/res_unet.py:74,105,160-171,
+    models/trans_unet.py:227-236): the BatchNorm (+ ReLU: ResNeXt) of the residual branch, the BatchNorm of the skip branch (``hb`` None: the
+    skip is the identity and ``zb`` is added as it is), the sum and the activation behind it in ONE pass over three tensors
+    (``pai_bn2_add_act``) instead of bn_apply + bn_apply + add_act over seven.  ``za`` / ``zb`` come out of
+    ``ConvBNAct(..., defer=ha / hb)``: raw convolution outputs with their batch statistics in the holder."""
+
+    @staticmethod
+    def forward(ctx, za, gamma_a, beta_a, ha, zb, gamma_b, beta_b, hb, act_a, act):
+        _check(za)
+        _check(zb)
+        if za.shape != zb.shape or za.dtype != zb.dtype:
+            raise ops.PaiError("BNTail: the two branches differ in shape or dtype")
+        N, H, W, Cc = za.shape
+        out = torch.empty_like(za)
+        ops.bn2_add_act(za.dtype, za, ha["scale"], ha["shift"], zb, hb["scale"] if hb else None, hb["shift"] if hb else None,
+                        N * H * W, Cc, act_a, act, out)
+        ctx.act_a, ctx.act, ctx.ha, ctx.hb = act_a, act, ha, hb
+        ctx.save_for_backward(za, zb, out if act != ACT_NONE else None, gamma_a, gamma_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        za, zb, out, gamma_a, gamma_b = ctx.saved_tensors
+        N, H, W, Cc = za.shape
+        M, dtype = N * H * W, za.dtype
+        f32 = dict(dtype=torch.float32, device=za.device)
+        g = g.contiguous()
+        if ctx.act != ACT_NONE:
+            d = torch.empty_like(out)
+            ops.act_bwd(dtype, g, ctx.act, None, ACT_NONE, out, out.numel(), d)
+        else:
+            d = g
+
+        def bn_bwd(z, h, gamma, act):
+            if not h["training"]:
+                raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
+            part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * Cc, **f32)
+            sums = torch.empty(2 * Cc, **f32)
+            dz = torch.empty_like(z)
+            if act != ACT_NONE:     # the branch's own activation: its sign from z * scale + shift, as in ConvBNAct.backward
+                ops.bn_bwd_reduce_affine(dtype, d, act, None, ACT_NONE, z, M, Cc, h["scale"], h["shift"], h["mean"], h["rstd"],
+                                         None, part, sums, None, None)
+                ops.bn_bwd_apply_affine(dtype, d, act, z, M, Cc, h["scale"], h["shift"], h["mean"], h["rstd"], gamma.detach(),
+                                        sums, dz)
+            else:
+                ops.bn_bwd_reduce(dtype, d, ACT_NONE, None, ACT_NONE, None, z, M, Cc, h["mean"], h["rstd"], None, part, sums,
+                                  None, None)
+                ops.bn_bwd_apply(dtype, d, z, M, Cc, h["mean"], h["rstd"], gamma.detach(), sums, dz)
+            return dz, sums[Cc:], sums[:Cc]
+
+        dza, dga, dba = bn_bwd(za, ctx.ha, gamma_a, ctx.act_a)
+        if ctx.hb is not None:
+            dzb, dgb, dbb = bn_bwd(zb, ctx.hb, gamma_b, ACT_NONE)
+        else:
+            dzb, dgb, dbb = d, None, None
+        return dza, dga, dba, None, dzb, dgb, dbb, None, None, None
+
+
+def fuse_tail() -> bool:
+    """PAI_NO_BN_TAIL=1: the residual blocks' tails as separate bn_apply / bn_apply / add_act passes (A/B switch)."""
+    import os
+    return os.environ.get("PAI_NO_BN_TAIL", "0") in ("", "0")
+
+
+def bn_tail(h, conv, bn, act_a, xs, skip_conv, skip_bn, act, training, n_updates, dtype):
+    """act(act_a(BN(conv(h))) + BN_skip(conv_skip(xs))) (``skip_conv`` None: + xs) through ``BNTail``."""
+    ha = {}
+    za = conv_bn_act(h, conv, bn, ACT_NONE, training, n_updates, dtype, defer=ha)
+    if skip_conv is None:
+        return BNTail.apply(za, bn.weight, bn.bias, ha, xs, None, None, None, act_a, act)
+    hb = {}
+    zb = conv_bn_act(xs, skip_conv, skip_bn, ACT_NONE, training, n_updates, dtype, defer=hb)
+    return BNTail.apply(za, bn.weight, bn.bias, ha, zb, skip_bn.weight, skip_bn.bias, hb, act_a, act)
 
 
 class Dropout2d(torch.autograd.Function):
@@ -398,14 +487,19 @@ class SwapMid(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False):
+def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False, defer=None):
     """Run an ``nn.Conv2d`` (+ ``nn.BatchNorm2d``) parameter container through ConvBNAct.  ``x``: an NHWC tensor, or a pair
-    ``(x1, x2)`` read as ``torch.cat([x1, x2], dim=3)`` without the concatenation being built."""
+    ``(x1, x2)`` read as ``torch.cat([x1, x2], dim=3)`` without the concatenation being built.  ``defer`` (a dict): the
+    BatchNorm is only measured (batch statistics, running averages), its normalisation is left to ``BNTail``."""
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
+    if defer is not None:
+        if bn is None:
+            raise ops.PaiError("conv_bn_act: defer needs a BatchNorm")
+        gamma, beta = gamma.detach(), beta.detach()       # their gradients come out of BNTail
     x1, x2 = x if isinstance(x, tuple) else (x, None)
     return ConvBNAct.apply(x1, x2, conv.weight, conv.bias, gamma, beta, bn, training, n_updates, act, conv.groups, dtype,
-                           out_f32)
+                           out_f32, defer)
 
 
 def as_tensor(x):

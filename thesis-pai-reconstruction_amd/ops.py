@@ -450,6 +450,14 @@ def bn_apply(dtype, z, M, C_, scale, shift, act, out):
                 "pai_bn_apply")
 
 
+def bn2_add_act(dtype, za, scale_a, shift_a, zb, scale_b, shift_b, M, C_, act_a, act, out):
+    """out = act(act_a(BN_a(za)) + BN_b(zb)) (scale_b None: + zb) in one pass (pai_bn2_add_act)."""
+    with _TimedBytes("bn_passes", 3 * M * C_ * _es(dtype)):
+        L.check(L.load().pai_bn2_add_act(code_of(dtype), _p(za), _p(scale_a, torch.float32), _p(shift_a, torch.float32), _p(zb),
+                                         _p(scale_b, torch.float32), _p(shift_b, torch.float32), M, C_, act_a, act, _p(out),
+                                         _stream()), "pai_bn2_add_act")
+
+
 def bn_bwd_partial_rows(M) -> int:
     return L.load().pai_bn_bwd_partial_rows(M)
 
