@@ -106,7 +106,10 @@ class _WgradStream:
                     t.record_stream(s)
         if not self.pending:
             # the backward pass ends with the join: callers of a bare loss.backward() read complete gradients as well
-            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+            except RuntimeError:
+                pass        # not inside an engine-driven backward pass (a Function's backward called by hand): the explicit joins remain
         self.pending.add(idx)
         return out
 
