@@ -217,27 +217,53 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         constexpr int ST = decltype(st_tag)::value;
         constexpr unsigned SB = (unsigned)(ST * STAGE);
         bf8_t fa[2][MT], fb[2][NT];
+        // The 8-byte halves the reads deliver.  The compiler knows nothing about WHEN an asm read delivers: anything it
+        // derives from these registers -- including the copies that assemble two halves into one operand tuple when the
+        // allocator did not place them side by side -- must come behind the wait.  So the halves stay as they are until
+        // `compose` (called right behind each lgkmcnt(0)) ties them to that point with empty asm statements and only then
+        // forms the fragments.  (Composed inside read_frag, an unrelated edit of the tile decode changed the allocation
+        // and the bias sums of the <64, 128> form came out wrong, differently from run to run.)
+        u2_t fal[2][MT], fah[2][MT], fbl[2][NT], fbh[2][NT];
         // fragment `i` of k-half KK: i < NT: X tile i, else dY tile i - NT (X first: every MFMA row needs all of them)
         auto read_frag = [&](auto kk_tag, int i) {
             constexpr int KK = decltype(kk_tag)::value;
-            u2_t lo, hi;
             if (i < NT) {
                 unsigned o0 = xbase[KK][0], o1 = xbase[KK][1];
                 if (i) { WG3_XOR(o0, xbase[KK][0], i << 5); WG3_XOR(o1, xbase[KK][1], i << 5); }
+                u2_t lo, hi;
                 WG3_RD(lo, o0, SB);
                 WG3_RD(hi, o1, SB);
-                fb[KK][i] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                fbl[KK][i] = lo;
+                fbh[KK][i] = hi;
             } else {
                 const int mt = i - NT;
                 unsigned a0 = ybase[0], a1 = ybase[1];
                 if (mt) { WG3_XOR(a0, ybase[0], mt << 5); WG3_XOR(a1, ybase[1], mt << 5); }
+                u2_t lo, hi;
                 WG3_RD(lo, a0, SB + KK * (32 * YROW));
                 WG3_RD(hi, a1, SB + KK * (32 * YROW));
-                fa[KK][mt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                fal[KK][mt] = lo;
+                fah[KK][mt] = hi;
             }
         };
         typedef std::integral_constant<int, 0> K0;
         typedef std::integral_constant<int, 1> K1;
+        auto compose = [&](auto kk_c) {
+            constexpr int KK = decltype(kk_c)::value;
+            if (WG3_ABL & 8) return;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u2_t lo = fbl[KK][nt], hi = fbh[KK][nt];
+                asm volatile("" : "+v"(lo), "+v"(hi));
+                fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                u2_t lo = fal[KK][mt], hi = fah[KK][mt];
+                asm volatile("" : "+v"(lo), "+v"(hi));
+                fa[KK][mt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+        };
         if (!(WG3_ABL & 8)) {
 #pragma unroll
             for (int i = 0; i < NT + MT; ++i) read_frag(K0{}, i);
@@ -256,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        compose(K0{});
         const bool bias_step = do_bias && (kb % jtiles) == jt;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -292,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
             if (kk == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                compose(K1{});
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
