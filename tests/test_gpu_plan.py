@@ -187,9 +187,11 @@ def test_composable_families_replay_from_a_plan(pai, family, dtype):
         scale = max(float(g.norm()) for g in ge)
         # (behind the discriminator's update, whose atomics-ordered bias gradients differ in the last bits: bf16 storage
         #  rounds those differences up to ~1 % at the far end of the generator's backward pass)
-        rtol = 1e-3 if dtype == torch.float32 else 5e-2
+        # (a bias in front of a BatchNorm-led block has a gradient that is rounding noise around zero -- in bf16 storage a
+        #  few 1e-3 of the largest gradient: absolute floor)
+        rtol, floor = (1e-3, 1e-5) if dtype == torch.float32 else (5e-2, 3e-3)
         for a, g in zip(gp, ge):
-            assert float((a - g).norm()) <= rtol * float(g.norm()) + 1e-5 * scale
+            assert float((a - g).norm()) <= rtol * float(g.norm()) + floor * scale
         _sync_training_state(eager, planned)
     assert ps.records >= 1 and ps.replays == steps - 3 - ps.records and ps.replays >= 3, ps.describe()
     for info in ps.describe()["nodes"]:
