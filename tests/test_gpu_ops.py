@@ -413,3 +413,70 @@ def test_filter_layout_kernels(pai, shape, groups):
     assert torch.equal(dw, want)
     with pytest.raises(ops.PaiError):
         ops.filter_to_dense(w, cout, cig, kh * kw, 5 if cout % 5 else 7, dense)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("skip_bn", [True, False], ids=["conv_skip", "identity_skip"])
+@pytest.mark.parametrize("act_a,act", [(0, 0), (2, 0), (0, 2)], ids=["plain", "relu_branch", "relu_sum"])
+def test_bn2_add_act(pai, dtype, skip_bn, act_a, act):
+    """pai_bn2_add_act against the three passes it replaces (bn_apply, bn_apply, add_act): fp32 bit for bit; bf16 against
+    the fp32 formula (the fused pass rounds once, the three passes three times)."""
+    from thesis_pai_reconstruction_amd import ops
+
+    M, C = 3 * 7 * 5, 24
+    g = torch.Generator().manual_seed(11)
+    za, zb = (torch.randn(M, C, generator=g).to(dev()).to(dtype) for _ in range(2))
+    sca, sha, scb, shb = (torch.randn(C, generator=g).to(dev()) for _ in range(4))
+    out = torch.empty_like(za)
+    ops.bn2_add_act(dtype, za, sca, sha, zb, scb if skip_bn else None, shb if skip_bn else None, M, C, act_a, act, out)
+    f = {0: lambda t: t, 2: torch.relu}
+    a = f[act_a](torch.addcmul(sha, za.float(), sca))
+    b = torch.addcmul(shb, zb.float(), scb) if skip_bn else zb.float()
+    want = f[act](a + b)
+    if dtype == torch.float32:
+        a3, b3 = torch.empty_like(za), torch.empty_like(zb)
+        ops.bn_apply(dtype, za, M, C, sca, sha, act_a, a3)
+        if skip_bn:
+            ops.bn_apply(dtype, zb, M, C, scb, shb, 0, b3)
+        else:
+            b3 = zb
+        three = torch.empty_like(za)
+        ops.add_act(dtype, a3, b3, act, three)
+        assert torch.equal(out, three)
+        assert rel_err(out, want) < 1e-6
+    else:
+        assert rel_err(out.float(), want) < 4e-3
+    with pytest.raises(ops.PaiError):
+        ops.bn2_add_act(dtype, za, sca, sha, zb, scb, None, M, C, act_a, act, out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_swap_mid_and_fork(pai, dtype):
+    """pai_swap_mid = permute(0, 2, 1, 3) (its own inverse with the middle extents exchanged); nnops.Fork hands the sum of
+    the two consumers' gradients to the producer."""
+    from thesis_pai_reconstruction_amd import nnops, ops
+
+    A, B, Cc, D = 6, 4, 3, 16
+    x = torch.randn(A, B, Cc, D, device=dev()).to(dtype)
+    y = torch.empty(A, Cc, B, D, device=dev(), dtype=dtype)
+    ops.swap_mid(x, A, B, Cc, D, y)
+    assert torch.equal(y, x.permute(0, 2, 1, 3).contiguous())
+    back = torch.empty_like(x)
+    ops.swap_mid(y, A, Cc, B, D, back)
+    assert torch.equal(back, x)
+    with pytest.raises(ops.PaiError):
+        ops.swap_mid(x, A, B, Cc, D + 1, y)
+    t = torch.randn(2, 5, 3, 8, device=dev()).to(dtype).requires_grad_(True)
+    s = nnops.SwapMid.apply(t.view(10, 3, 8), 2, 5, 3, 8)
+    w = torch.randn_like(s)
+    (s.float() * w.float()).sum().backward()
+    assert torch.equal(t.grad.view(2, 5, 3, 8), w.view(2, 3, 5, 8).permute(0, 2, 1, 3).contiguous().to(dtype))
+    u = torch.randn(2, 4, 4, 8, device=dev()).to(dtype).requires_grad_(True)
+    a, b = nnops.fork(u)
+    wa, wb = torch.randn_like(u), torch.randn_like(u)
+    ((a.float() * wa.float()).sum() + (b.float() * wb.float()).sum()).backward()
+    want = (wa.float() + wb.float()).to(dtype) if dtype == torch.float32 else None
+    if dtype == torch.float32:
+        assert torch.equal(u.grad, want)
+    else:
+        assert rel_err(u.grad.float(), wa.float() + wb.float()) < 4e-3
