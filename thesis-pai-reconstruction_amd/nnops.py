@@ -61,6 +61,21 @@ def _grad_from_fwd_pack(dw: torch.Tensor, weight: torch.Tensor, groups: int) -> 
     return out
 
 
+_ZEROS = {}
+
+
+def _zero_grad(n: int, device) -> torch.Tensor:
+    """The gradient of a conv bias in front of a BatchNorm: identically zero (the BatchNorm subtracts the batch mean).  A view
+    of one per-device buffer of zeros that nothing ever writes -- no fill launch per layer and step (59 of them in a
+    residual U-Net step).  In-place scaling of such a gradient (clipping, unscaling) leaves it what it is; code that ADDS
+    into ``.grad`` of these biases in place would have to replace the tensor first."""
+    key = str(device)
+    buf = _ZEROS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _ZEROS[key] = torch.zeros(max(n, 4096), dtype=torch.float32, device=device)
+    return buf[:n]
+
+
 class _WgradStream:
     """The weight gradients of the composable networks leave the critical path of the backward pass the way the Pix2Pix
     engine's do (engine._SideStream): each is issued on ONE second stream per device, ordered after the launch that produced
@@ -263,9 +278,9 @@ class ConvBNAct(torch.autograd.Function):
 
         def wgrad():
             dw = torch.empty(Cout * k * k * Cin, **f32)
-            dbias = torch.empty(Cout, **f32) if ctx.needs_input_grad[3] else None
-            if dbias is not None and not with_bias:
-                ops.zero_multi([dbias])
+            dbias = None
+            if ctx.needs_input_grad[3]:
+                dbias = torch.empty(Cout, **f32) if with_bias else _zero_grad(Cout, dev)
             ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
             return (_grad_from_fwd_pack(dw, weight, groups), dbias), (dw,)
 
