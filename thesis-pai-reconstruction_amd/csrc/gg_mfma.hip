@@ -1,22 +1,30 @@
-// bf16 MFMA gather-GEMM kernels for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+// bf16 MFMA gather-GEMM kernels for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  State at the end of round 4;
+// which kernel a call takes is decided in launch_fwd_mfma / launch_wgrad_mfma below and reported by pai_conv_kernel_name.
 //
 // Forward / input-gradient:  out[m][co] = sum_{t,ci} A(m,t,ci) * Wp[co][wt][ci]
-//   128 x BN x 64 tile, 4 waves (2 x 2).  Both operand tiles go HBM -> LDS directly
-//   (global_load_lds_dwordx4, no staging registers, no branches): one K-step = one tap x 64
-//   channels, so a tile row is one contiguous 128-B NHWC segment; out-of-image taps and rows
-//   beyond M fetch from a 128-B zero line instead.  The LDS image is lane-linear per load
-//   instruction and XOR-swizzled through the SOURCE address, every fragment is one conflict-free
-//   ds_read_b128.  One LDS buffer per workgroup (32-36 KB): latency is hidden by running 3-4
-//   workgroups per CU, not by a deep per-workgroup pipeline.  Layers with few output tiles and a
-//   long reduction (U-Net bottleneck) are split over K into an fp32 scratch buffer and finished
-//   by splitk_finish_k.
-// Weight gradient:           dW[co][wt][ci] += sum_m dY[m][co] * A(m,t,ci)
-//   both operands are pixel-major in HBM (NHWC), i.e. K-strided: they are staged row-major
-//   into LDS the same way and the MFMA fragments are fetched with ds_read_b64_tr_b16.
+//   gg_fwd_patch_k<256|128, 128|64> (+ gg_fwd_patch1_k<256, 64>, gg_fwd_patchw_k: tunable fwd_wide) -- the kernels of the
+//     k4 s2 layers, i.e. of nearly all the FLOPs: a workgroup owns a 16 x 16 (8 x 16) block of output pixels, keeps the
+//     source pixels its 2 x 2 tap windows touch in LDS (one patch fill serves four taps) and streams the 64-channel weight
+//     tiles through a one- or two-slot ring; LDS-DMA through buffer descriptors, fragments by conflict-free ds_read_b128,
+//     eight waves of 64 x 64; epilogue staged through LDS: bias, BatchNorm partial statistics, activation, the fused
+//     backward of the producing layer (pai_conv_dgrad_act / _bn).  18 launches per Pix2Pix step, 0.32-0.33 of the nominal
+//     bf16 peak in the step, 0.40-0.41 alone (DESIGN.md sections 9-11 for what bounds it).
+//   gg_fwd_mfma_k<128, 128|64, SPLITK, DB> -- the tile kernel everything else falls to (1 x 1 / 3 x 3 layers, nn.Linear as a
+//     one-tap convolution, shapes without a patch geometry): 128 x BN x 64 tile, both operand tiles HBM -> LDS directly
+//     (global_load_lds_dwordx4; out-of-image taps fetch a zero line), LDS image XOR-swizzled through the source address.
+//     Layers with few output tiles and a long reduction (the U-Net bottleneck, the ViT projections) are split over K into
+//     fp32 slabs of the handle's workspace and finished by splitk_finish_k (slab sum in split order + the same epilogue).
+//   pw_k<64, 32> / <32, 64> -- the finest attention gate's pointwise convolutions: no LDS, the filter in registers.
+// Weight gradient:           dW[co][wt][ci] (+)= sum_m dY[m][co] * A(m,t,ci)
+//   gg_wgrad_patch3_k (gg_wg3.hip) takes the k4 s2 layers; here: gg_wgrad_patch_k (its predecessor, tunable wgrad3 = 0)
+//   and gg_wgrad_mfma_k<128|64> for the rest -- both operands are pixel-major in HBM (NHWC), i.e. K-strided: staged
+//   row-major into LDS and fetched as MFMA fragments with ds_read_b64_tr_b16; pixel splits meet by fp32 atomics
+//   (un-split launches store).
 //
 // Serves the dense layers of the reference's hot path: EncoderBlock / DecoderBlock convs
-// (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232) and their
-// aten::convolution_backward calls.
+// (models/pix2pix.py:58-111), DiscriminatorBlock 1-3 (models/wrapper.py:229-232), the 1 x 1 / 3 x 3 convolutions and
+// nn.Linear layers of the other families (models/attention_unet.py:72-84, models/res_unet.py:147-163,
+// models/trans_unet.py:143-156) and their aten::convolution_backward calls.
 #include <stdlib.h>
 
 #include <type_traits>
