@@ -42,10 +42,33 @@ struct Tunable { char name[32]; int value; };
 static Tunable g_tunables[32];
 static int g_ntunables = 0;
 
+// Default of a tunable from the environment: PAI_TUNE_<name>=<int> (looked up once per name).  For whole-suite A/B runs
+// (pytest, bench.py) of a kernel-selection switch without touching the callers; pai_set_tunable still wins.
+struct TunableEnv { char name[32]; int has, value; };
+static TunableEnv g_tunable_env[48];
+static int g_ntunable_env = 0;
+static bool tunable_env(const char* name, int* value) {
+    for (int i = 0; i < g_ntunable_env; ++i)
+        if (!strcmp(g_tunable_env[i].name, name)) { *value = g_tunable_env[i].value; return g_tunable_env[i].has != 0; }
+    char key[64];
+    snprintf(key, sizeof(key), "PAI_TUNE_%s", name);
+    const char* e = getenv(key);
+    if (g_ntunable_env < 48 && strlen(name) < sizeof(g_tunable_env[0].name)) {
+        TunableEnv& t = g_tunable_env[g_ntunable_env];
+        strcpy(t.name, name);
+        t.has = e != nullptr;
+        t.value = e ? atoi(e) : 0;
+        ++g_ntunable_env;   // (published last: a racing reader sees either no entry or a complete one)
+    }
+    *value = e ? atoi(e) : 0;
+    return e != nullptr;
+}
+
 int pai_tunable(const char* name, int def) {
     for (int i = 0; i < g_ntunables; ++i)
         if (!strcmp(g_tunables[i].name, name)) return g_tunables[i].value;
-    return def;
+    int v;
+    return tunable_env(name, &v) ? v : def;
 }
 
 extern "C" int pai_set_tunable(const char* name, int value) {

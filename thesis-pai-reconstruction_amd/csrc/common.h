@@ -211,6 +211,12 @@ struct pai_handle_s {
 // active handle of the calling thread's current HIP device; never null (a device without a handle has an empty one:
 // no workspace, no scratch -> un-split / fallback kernels)
 const pai_handle_s* pai_ctx();
+// persistent patch-resident forward / input-gradient kernel (gg_pers.hip)
+struct PatchGeo;
+bool fwd_pers_ok(int bm, int bn);
+int fwd_pers_rows(const GG& g);
+const char* fwd_pers_kernel_name(int bm, int bn, bool db);
+int launch_fwd_pers(const GG& g, const FwdArgs& a, const PatchGeo& pg, int bm, int bn, bool db, hipStream_t s);
 int fwd_simt_mtiles(const GG& g);
 int fwd_mfma_mtiles(const GG& g);
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);

@@ -132,7 +132,10 @@ static int patch_rows(const GG& g, const FwdCfg& c);
 int fwd_mfma_mtiles(const GG& g) {
     if (fwd_effective_ksplit(g) > 1) return cdiv(g.M, FIN_ROWS);
     const FwdCfg c = fwd_cfg(g);
-    return patch_rows(g, c) == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
+    const int prow = patch_rows(g, c);
+    if (prow == 256 && c.bn == 128 && fwd_pers_ok(256, 128)) return fwd_pers_rows(g);
+    if (prow == 128 && fwd_pers_ok(128, c.bn)) return fwd_pers_rows(g);
+    return prow == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
 }
 
 
@@ -1149,6 +1152,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             }
             const int mt256 = g.M / 256;
             const dim3 grid256(mt256 * ntiles * g.nphase);
+            if (fwd_pers_ok(256, 128)) return launch_fwd_pers(g, a, pg, 256, 128, db, s);
             if (pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) {
                 static bool attrw = false;
                 if (!attrw) {
@@ -1166,6 +1170,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             const size_t lds = PD::BYTES + (size_t)c.bn * 128 * (db ? 2 : 1);
             const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 4 * 2 * c.bn * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
+            if (fwd_pers_ok(128, c.bn)) return launch_fwd_pers(g, a, pg, 128, c.bn, db, s);
             if (c.bn == 128) {
                 if (db) PAI_LAUNCH((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
                 else PAI_LAUNCH((gg_fwd_patch_k<128, 128, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
@@ -1194,6 +1199,8 @@ const char* fwd_mfma_kernel_name(const GG& g) {
     const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
     const int prow = patch_rows(g, c);
     if (prow == 256 && c.bn == 64) return (dbb & 4) ? "gg_fwd_patch1_k<256, 64, true>" : "gg_fwd_patch1_k<256, 64, false>";
+    if (prow == 256 && fwd_pers_ok(256, 128)) return fwd_pers_kernel_name(256, 128, (dbb & 1) != 0);
+    if (prow == 128 && fwd_pers_ok(128, c.bn)) return fwd_pers_kernel_name(128, c.bn, (dbb & (c.bn == 128 ? 2 : 4)) != 0);
     if (prow == 256 && pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) return "gg_fwd_patchw_k<256, 128, true>";
     if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";
     if (prow == 128) {
