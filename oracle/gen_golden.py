@@ -234,6 +234,18 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _REF = _import_reference()
+    if "--full-width" in sys.argv:    # BASELINE configs[3] / configs[4] at their REAL widths (kind 2: fingerprints)
+        # configs[3]: ResUnetGAN("next", class-default channel_mults (1, 2, 4, 8, 8, 8, 8, 8)) -- 256 x 256 keeps the
+        # fixture within CPU minutes; the network is fully convolutional (Q17), the width is what the tiny / mid fixtures miss
+        run_forward_case("ref_resnext_forward_full", (1, 2, 4, 8, 8, 8, 8, 8), 256, 2, seed=271, family="resnext")
+        run_case("ref_resnext_gan_full", (1, 2, 4, 8, 8, 8, 8, 8), 256, 2, "gan", seed=276, steps=1, full_tensors=False,
+                 search=False, family="resnext")
+        # configs[4]: TransUnetGAN((1, 2, 2, 4, 4), patch_size=4) as main.py:93-101 builds it: d_model 4096, 12 layers,
+        # 1.03 B parameters (Q16)
+        run_forward_case("ref_trans4_forward_full", (1, 2, 2, 4, 4), 256, 2, seed=281, family="trans4")
+        run_case("ref_trans4_gan_full", (1, 2, 2, 4, 4), 256, 2, "gan", seed=286, steps=1, full_tensors=False,
+                 search=False, family="trans4")
+        sys.exit(0)
     if "--trans" in sys.argv:         # TransUNet; image size is fixed at 256 by TransUnetGAN
         run_forward_case("ref_trans2_forward", (1, 1, 1, 2, 2), 256, 4, seed=211, family="trans2")
         run_forward_case("ref_trans4_forward", (1, 1, 1, 1, 1), 256, 3, seed=221, family="trans4")

@@ -130,15 +130,39 @@ def _worker(rank, world, port, q):
         wide = nn.Conv2d(4, 4, 3, padding=1)
         net2 = nn.Sequential(net[0], nn.ReLU(), wide, nn.ReLU(), net[2])
         pdist.broadcast_parameters(net2, src=0)
+        # the local gradients come from a twin without hooks: tensors of at least one bucket are all-reduced IN PLACE by the
+        # hook the moment they are final, i.e. while the backward pass is still running
+        import copy
+        twin = copy.deepcopy(net2)
+        twin(x).sum().backward()
+        local = [p.grad.clone() for p in twin.parameters()]
         red3.attach(net2)
         net2(x).sum().backward()
-        local = [p.grad.clone() for p in net2.parameters()]
+        assert red3.stats["buckets"] >= 3 and red3.stats["foreign_buckets"] >= 3     # issued before finish()
+        assert red3.plannable()
         red3.finish()
-        assert red3.stats["buckets"] >= 3
+        assert red3.stats["buckets"] >= 4
         for p, g in zip(net2.parameters(), local):
             both = [torch.zeros_like(g) for _ in range(world)]
             dist.all_gather(both, g)
             assert torch.allclose(p.grad, sum(both) / world, atol=1e-6)
+        # the same buckets with the bf16 wire format, and with the overlap off (everything issued in finish()): both must
+        # average to the fp32 result within bf16 rounding / exactly
+        for kwargs, tol in (({"grad_dtype": torch.bfloat16}, 2 ** -7), ({"overlap": False}, 1e-6)):
+            net3 = copy.deepcopy(twin)
+            net3.zero_grad(set_to_none=True)
+            red4 = pdist.GradReducer(bucket_bytes=64, **kwargs)
+            red4.attach(net3)
+            net3(x).sum().backward()
+            if not red4.overlap:
+                assert red4.stats["buckets"] == 0
+            red4.finish()
+            assert red4.stats["buckets"] >= 4
+            for p, g in zip(net3.parameters(), local):
+                both = [torch.zeros_like(g) for _ in range(world)]
+                dist.all_gather(both, g)
+                want = sum(both) / world
+                assert float((p.grad - want).abs().max()) <= tol * max(1.0, float(sum(b.abs() for b in both).max())), kwargs
         # permuted (fwd-pack) parameters are broadcast through their storage order
         ct = nn.ConvTranspose2d(8, 4, 4, 2, 1)
         E.to_fwd_pack_(ct)

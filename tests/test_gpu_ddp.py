@@ -52,16 +52,30 @@ def _worker(rank, world, port, precision, family, q, mode="gloo", grad_dtype=Non
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
         torch.manual_seed(100 + rank)                       # different initial weights per rank ...
+        composable = family in ("resnext_unet", "trans_unet")
         if family == "resnext_unet":                        # composable path: gradients outside the arenas (MultiAdam)
             m = pai.ResUnetGAN(1, 1, "next", (1, 2, 2), 0.0, "gan").to(dev)
+        elif family == "trans_unet":
+            m = pai.TransUnetGAN(1, 1, (1, 1, 1, 2, 2), 2, 0.0, "gan").to(dev)
         else:
             cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
             m = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
         m.set_precision(precision)
         m.train()
         pdist.broadcast_parameters(m)                       # ... aligned here
-        red = pdist.GradReducer(bucket_bytes=1 << 20, grad_dtype=grad_dtype)
+        red = pdist.GradReducer(bucket_bytes=(64 << 10) if composable else (1 << 20), grad_dtype=grad_dtype)
         red.attach(m)
+        # what finish() finds already issued: the composable networks' fixed buckets leave from post-accumulate hooks
+        # while the backward pass is still running, like the arena buckets of the engines
+        at_finish = []
+        orig_finish = red.finish
+
+        def counted_finish():
+            before = red.stats.get("foreign_buckets", 0)
+            orig_finish()
+            at_finish.append((before, red.stats.get("foreign_buckets", 0)))
+        red.finish = counted_finish
+        assert red.plannable()
         assert red.rccl_ranks() == (0 if mode == "gloo" else world), (mode, red.rccl_ranks())
         assert (red.comm is not None) == (mode == "rccl-abi")
 
@@ -70,12 +84,14 @@ def _worker(rank, world, port, precision, family, q, mode="gloo", grad_dtype=Non
             def _log(self, *a): pass
         m.trainer = T()
         rng = np.random.default_rng(7 + rank)               # different shard per rank
-        x = torch.from_numpy(rng.random((4, 1, 64, 64), dtype=np.float32) * 2 - 1).to(dev)
-        t = torch.from_numpy(rng.random((4, 1, 64, 64), dtype=np.float32) * 2 - 1).to(dev)
+        side = 256 if family == "trans_unet" else 64        # (the TransUNet's positional embedding fixes the image size)
+        nimg = 2 if family == "trans_unet" else 4
+        x = torch.from_numpy(rng.random((nimg, 1, side, side), dtype=np.float32) * 2 - 1).to(dev)
+        t = torch.from_numpy(rng.random((nimg, 1, side, side), dtype=np.float32) * 2 - 1).to(dev)
         before = torch.cat([p.detach().reshape(-1).clone() for p in m.parameters()])
         # a twin that takes the ordinary path (x 1/R pass and Adam behind the last bucket) on the same shards
         twin = None
-        if family != "resnext_unet":
+        if not composable:
             import copy
             twin = copy.deepcopy(m)
             red2 = pdist.GradReducer(bucket_bytes=1 << 20, grad_dtype=grad_dtype, comm=red.comm)
@@ -131,6 +147,13 @@ def _worker(rank, world, port, precision, family, q, mode="gloo", grad_dtype=Non
         assert torch.equal(both[0], both[1]), "replicas diverged"
         assert float((after - before.cpu()).abs().max()) > 0
         assert red.stats["buckets"] >= 2 * 2 * 2              # several buckets per network per step
+        if composable:
+            # (entry, exit) counts of the four finish() calls (two backward passes per GAN step; the discriminator's
+            # gradients live in an arena): most of the generator's buckets were in flight before finish() ran
+            assert len(at_finish) == 4, at_finish
+            early = sum(a - (at_finish[i - 1][1] if i else 0) for i, (a, _) in enumerate(at_finish))
+            total = red.stats["foreign_buckets"]
+            assert total >= 8 and early >= 0.7 * total, (at_finish, red.stats)
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -155,7 +178,7 @@ def _run_ranks(target, args, world=2):
         assert msg == "ok", f"rank {rank}:\n{msg}"
 
 
-@pytest.mark.parametrize("family", ["pix2pix", "attention_unet", "resnext_unet"])
+@pytest.mark.parametrize("family", ["pix2pix", "attention_unet", "resnext_unet", "trans_unet"])
 @pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
 def test_two_rank_step_keeps_replicas_identical(precision, family):
     _run_ranks(_worker, ((precision, family), ()))
@@ -167,7 +190,7 @@ needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL 
 @needs_two_gpus
 @pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16], ids=["f32buckets", "bf16buckets"])
 @pytest.mark.parametrize("mode", ["nccl", "rccl-abi"])
-@pytest.mark.parametrize("family", ["pix2pix", "attention_unet"])
+@pytest.mark.parametrize("family", ["pix2pix", "attention_unet", "resnext_unet", "trans_unet"])
 def test_two_rank_step_over_rccl(family, mode, grad_dtype):
     """The same invariants with the buckets travelling over RCCL / xGMI, one GPU per rank: torch.distributed's "nccl"
     backend and the C-ABI communicator (PAI_COMM=rccl -> pai_allreduce), fp32 and bf16 buckets, with the streamed

@@ -219,7 +219,9 @@ def test_state_dict_keys_match_reference_layout(pai):
         assert all(tuple(got[k].shape) == tuple(want[k].shape) for k in want)
 
 
-@pytest.mark.parametrize("name", ["ref_trans2_forward", "ref_trans4_forward"])
+@pytest.mark.parametrize("name", ["ref_trans2_forward", "ref_trans4_forward",
+                                  # BASELINE configs[4] as main.py:93-101 builds it: (1,2,2,4,4), patch_size 4, 1.03 B parameters
+                                  "ref_trans4_forward_full"])
 def test_forward_matches_reference_fixture(pai, golden_dir, name):
     z = _load(golden_dir, name)
     seed, n, size, fam = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), str(z["meta.family"])
@@ -270,7 +272,7 @@ def _check_step(m, z, s, gtol):
     assert not bad, (s, bad[:6])
 
 
-@pytest.mark.parametrize("name", ["ref_trans2_gan", "ref_trans2_ssim"])
+@pytest.mark.parametrize("name", ["ref_trans2_gan", "ref_trans2_ssim", "ref_trans4_gan_full"])
 def test_training_step_matches_reference_fixture(pai, golden_dir, name):
     z = _load(golden_dir, name)
     seed, n, size, steps = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"]), int(z["meta.steps"])

@@ -47,7 +47,9 @@ def _family(z):
 @pytest.mark.parametrize("name", ["ref_forward_tiny", "ref_forward_full", "ref_att_forward_tiny",
                                   "ref_att_forward_full", "ref_resnext_forward_tiny", "ref_res18_forward_tiny",
                                   "ref_res50_forward_tiny", "ref_resnext_forward_mid", "ref_resv2_forward_tiny", "ref_trans2_forward",
-                                  "ref_trans4_forward"])
+                                  "ref_trans4_forward",
+                                  # BASELINE configs[3] / configs[4] at their real widths (oracle/gen_golden.py --full-width)
+                                  "ref_resnext_forward_full", "ref_trans4_forward_full"])
 def test_forward_matches_reference(golden_dir, name):
     z = _load(golden_dir, name)
     seed, n, size = int(z["meta.seed"]), int(z["meta.n"]), int(z["meta.size"])
@@ -78,7 +80,8 @@ def test_forward_matches_reference(golden_dir, name):
                                   "ref_att_gan_tiny", "ref_att_ssim_tiny", "ref_att_gan_full",
                                   "ref_gan_dropout_tiny", "ref_att_gan_dropout_tiny", "ref_resnext_gan_tiny",
                                   "ref_res18_gan_tiny", "ref_res50_gan_tiny", "ref_resnext_gan_dropout_tiny",
-                                  "ref_resv2_gan_tiny", "ref_trans2_gan", "ref_trans2_ssim", "ref_trans4_gan_dropout"])
+                                  "ref_resv2_gan_tiny", "ref_trans2_gan", "ref_trans2_ssim", "ref_trans4_gan_dropout",
+                                  "ref_resnext_gan_full", "ref_trans4_gan_full"])
 def test_training_step_matches_reference(golden_dir, name, monkeypatch):
     z = _load(golden_dir, name)
     if name.startswith("ref_trans"):

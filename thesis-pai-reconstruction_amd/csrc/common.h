@@ -108,6 +108,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// "Once per DEVICE" flag for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, a process-wide
+// static bool leaves the second GPU of a process without it (the launch then fails: > 64 KB of dynamic LDS).
+struct PerDeviceOnce {
+    bool done[32] = {};
+    // true when the caller has to set the attributes for the current device now
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return true;   // unknown device: set every time (cheap)
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // ---- gather-GEMM problem ------------------------------------------------------
 // out[m, co] = sum_{t < ntaps} sum_{ci < Cin} A(m, t, ci) * Wp[co][wt[ph][t]][ci]
 //   m = (n, gy, gx) over the per-phase output grid OHg x OWg

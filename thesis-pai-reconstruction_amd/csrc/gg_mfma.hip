@@ -1092,13 +1092,12 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
     PAI_LAUNCH((gg_fwd_mfma_k<BM, BN, SK, DB>), grid, dim3(BM * 2), (fwd_lds_bytes<BM, BN, DB>()), s, g, \
                        a, mtiles, ntiles, c.ksplit, pai_ctx()->workspace)
     if (c.bm == 256) {
-        static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in
-        if (!attr_set) {
+        static PerDeviceOnce attr_set;   // > 64 KB of dynamic LDS needs an explicit opt-in
+        if (attr_set.first()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_mfma_k<256, 128, false, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)fwd_lds_bytes<256, 128, true>());
             PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            attr_set = true;
         }
         FWD_LAUNCH(256, 128, false, true);
     } else if (c.bm == -128) {
@@ -1140,26 +1139,24 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             const size_t lds = PD::BYTES + (size_t)128 * 128 * (db ? 2 : 1);
             const size_t epi = 256 * ((size_t)128 * 2 + 16) + 8 * 2 * 128 * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
-            static bool attr = false;
-            if (!attr) {
+            static PerDeviceOnce attr;
+            if (attr.first()) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patch_k<256, 128, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
                 if (e == hipSuccess)
                     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patch_k<256, 128, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
                 PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-                attr = true;
             }
             const int mt256 = g.M / 256;
             const dim3 grid256(mt256 * ntiles * g.nphase);
             if (fwd_pers_ok(256, 128)) return launch_fwd_pers(g, a, pg, 256, 128, db, s);
             if (pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) {
-                static bool attrw = false;
-                if (!attrw) {
+                static PerDeviceOnce attrw;
+                if (attrw.first()) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patchw_k<256, 128, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
                     PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-                    attrw = true;
                 }
                 PAI_LAUNCH((gg_fwd_patchw_k<256, 128, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
             } else if (db) PAI_LAUNCH((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);

@@ -545,14 +545,13 @@ template <int BM, int BN, bool DBB, int EPI>
 static int launch_pers_e(const GG& g, const FwdArgs& a, const PatchGeo& pg, int wgs_per_cu, hipStream_t s) {
     typedef PatchDims<BM, 2, 64> PD;
     const size_t lds = PD::BYTES + (size_t)BN * 128 * (DBB ? 2 : 1);
-    static bool attr[16] = {};
+    static PerDeviceOnce attr;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (lds > 64 * 1024 && dev >= 0 && dev < 16 && !attr[dev]) {
+    if (lds > 64 * 1024 && attr.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_pers_k<BM, BN, DBB, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-        attr[dev] = true;
     }
     const int mtiles = g.M / BM, ntiles = g.Cout / BN;
     const int total = mtiles * ntiles * g.nphase;

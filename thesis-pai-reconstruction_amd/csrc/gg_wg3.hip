@@ -500,8 +500,8 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
         hipError_t e = pai::memset_async(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
         PAI_CHECK(e == hipSuccess, "launch_wgrad3: hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess)
@@ -511,7 +511,6 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-        attr = true;
     }
     const dim3 grid(c.tiles * c.psplits);
     const int ph_inner = g.nphase > 1 && pai_tunable("wgrad3_ph_inner", 1);

@@ -311,6 +311,11 @@ extern "C" int pai_plan_run(pai_plan_t plan, int64_t step_delta) {
     Plan* p = (Plan*)plan;
     PAI_CHECK(p != nullptr && p->sealed, "pai_plan_run: the plan has not been recorded (pai_plan_begin / pai_plan_end)");
     PAI_CHECK(step_delta >= 0, "pai_plan_run: step_delta %lld < 0", (long long)step_delta);
+    // the recorded streams, events and function attributes belong to one device: replaying with another one current would
+    // launch on foreign streams
+    int dev = -1;
+    PAI_CHECK(hipGetDevice(&dev) == hipSuccess && (p->device < 0 || dev == p->device),
+              "pai_plan_run: the plan was recorded on device %d, the current device is %d", p->device, dev);
     const size_t n = p->ops.size();
     for (size_t i = 0; i < n; ++i) {
         const hipError_t e = p->ops[i]->run(step_delta);

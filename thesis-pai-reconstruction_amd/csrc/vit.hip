@@ -602,13 +602,12 @@ extern "C" int pai_mha_fwd(int dtype, const void* qkv, int S, int B, int heads, 
     const dim3 grid((unsigned)(S * B * heads));
     if (mha_mfma_ok(dtype, S, hd)) {
         const size_t ml = (size_t)32 * hd * 2 + 4 * 32 * 33 * sizeof(float) + 32 * 32 * 2;
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        if (attr.first()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_fwd_mfma_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_mfma_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            attr = true;
         }
         PAI_LAUNCH(mha_fwd_mfma_k, dim3((unsigned)(B * heads)), dim3(256), ml, s, (const bf16_t*)qkv, S, B, heads, hd, scale,
                    (bf16_t*)out, probs, mask);
@@ -635,11 +634,10 @@ extern "C" int pai_mha_bwd(int dtype, const void* dout, const void* qkv, const f
     const dim3 grid((unsigned)(S * B * heads));
     if (mha_mfma_ok(dtype, S, hd)) {
         const size_t ml = (size_t)3 * 32 * hd * 2 + 4 * 32 * 33 * sizeof(float) + 3 * 32 * 32 * 2;
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        if (attr.first()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_bwd_mfma_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            attr = true;
         }
         PAI_LAUNCH(mha_bwd_mfma_k, dim3((unsigned)(B * heads)), dim3(256), ml, s, (const bf16_t*)dout, (const bf16_t*)qkv, probs,
                    S, B, heads, hd, scale, (bf16_t*)dqkv, mask);

@@ -56,6 +56,17 @@ def _cast(src, dst):
         dst.copy_(src)
 
 
+def _cast_many(pairs):
+    """_cast for a list of (src, dst) pairs: eight per launch on the HIP device (pai_cast_multi)."""
+    if pairs and pairs[0][0].is_cuda:
+        from . import ops
+        for i in range(0, len(pairs), 8):
+            ops.cast_multi(pairs[i:i + 8])
+    else:
+        for src, dst in pairs:
+            dst.copy_(src)
+
+
 def _scale(t, f):
     if t.is_cuda:
         from . import ops
@@ -111,13 +122,16 @@ class GradReducer:
         self._post_stream = None
         self._engines = []
         self._foreign_params: List[torch.nn.Parameter] = []
+        self._foreign_hooks, self._fbuckets, self._fmap = [], [], {}
+        self._f32_scratch = None
         self.stats = {"buckets": 0, "bytes": 0}
 
     def plannable(self) -> bool:
-        """plan.PlannedStep: the arena buckets are exchanged with C-ABI launches (cast, scale, pai_allreduce) plus, on the
-        torch.distributed path, host nodes for the collectives; gradients OUTSIDE the arenas (the composable networks)
-        go through torch-launched staging kernels and cannot be replayed."""
-        return not self._foreign_params
+        """plan.PlannedStep: arena buckets and the fixed buckets of the gradients outside the arenas (the composable
+        residual / Trans U-Nets) are exchanged with C-ABI launches (cast, scale, pai_allreduce) plus, on the
+        torch.distributed path, host nodes for the collectives.  What cannot be replayed is a gradient the staging
+        launches cannot read as it stands: not fp32, or not contiguous (``torch`` would copy it first)."""
+        return all(p.dtype == torch.float32 and p.is_contiguous() for p in self._foreign_params)
 
     def rccl_ranks(self) -> int:
         """Ranks of the RCCL communicator the buckets actually travel over: the C-ABI communicator's own count, or the
@@ -139,7 +153,139 @@ class GradReducer:
             if eng is not None and hasattr(eng, "arena"):
                 self.attach_engine(eng)
                 covered.update(id(p) for p, _ in eng.ordered_params())
-        self._foreign_params = [p for p in model.parameters() if id(p) not in covered]
+        self._attach_foreign([p for p in model.parameters() if id(p) not in covered])
+
+    # ---- gradients outside the arenas: fixed buckets fed by post-accumulate-grad hooks ---------------
+    def _attach_foreign(self, params):
+        """Parameters whose gradients are ordinary tensors (the composable residual / Trans U-Nets of ``nnops``, plug-in
+        ``unet`` modules).  What Lightning-DDP does for the reference (``main.py:123-136``): fixed buckets in reverse
+        registration order -- the order the backward pass finishes them in -- each all-reduced the moment its last
+        gradient is final, i.e. beside the rest of the backward pass.  A tensor of at least one bucket is reduced in
+        place (bf16 wire: through a persistent staging buffer); smaller ones are gathered into a persistent bucket buffer
+        by the hook (``pai_cast``: a node of the launch plan, not ``torch.cat``) and scattered back in ``finish()``."""
+        for h in self._foreign_hooks:
+            h.remove()
+        self._foreign_hooks = []
+        self._foreign_params = list(params)
+        self._fbuckets, self._fmap = [], {}
+        cur = None
+        for p in reversed(self._foreign_params):
+            if not p.requires_grad:
+                continue
+            n = p.numel()
+            if n >= self.bucket_elems:
+                b = {"solo": True, "members": [(p, 0, n)], "numel": n, "buf": None, "work": None, "have": set()}
+                self._fbuckets.append(b)
+            else:
+                if cur is None or cur["numel"] >= self.bucket_elems:
+                    cur = {"solo": False, "members": [], "numel": 0, "buf": None, "work": None, "have": set()}
+                    self._fbuckets.append(cur)
+                b = cur
+                off = (b["numel"] + 7) // 8 * 8          # 32-byte pieces: the multi-tensor scatter's contract
+                b["members"].append((p, off, n))
+                b["numel"] = off + n
+            self._fmap[id(p)] = (b, len(b["members"]) - 1)
+            if hasattr(p, "register_post_accumulate_grad_hook"):
+                self._foreign_hooks.append(p.register_post_accumulate_grad_hook(self._foreign_ready))
+
+    def _fbuf(self, b, like, dtype):
+        if b["buf"] is None or b["buf"].device != like.device or b["buf"].dtype != dtype:
+            b["buf"] = torch.zeros(b["numel"], dtype=dtype, device=like.device)
+        return b["buf"]
+
+    def _foreign_ready(self, p):
+        """post-accumulate-grad hook: ``p.grad`` is final for this backward pass."""
+        if self.world < 2 or not self.overlap or p.grad is None:
+            return
+        ent = self._fmap.get(id(p))
+        if ent is not None:
+            self._foreign_stage(*ent)
+
+    def _foreign_stage(self, b, k):
+        """Member k of bucket b has its gradient: stage it; all-reduce the bucket when it is complete."""
+        if k in b["have"]:
+            raise RuntimeError("GradReducer: a second backward pass produced a gradient whose bucket was already "
+                               "filled; use one backward per optimizer step")
+        b["have"].add(k)
+        p, off, n = b["members"][k]
+        g = p.grad
+        if b["solo"]:
+            if self.grad_dtype == torch.float32 and g.dtype == torch.float32 and g.is_contiguous():
+                b["work"], b["inplace"] = self._all_reduce_async(g), g
+            else:
+                stage = self._fbuf(b, g, self.grad_dtype)
+                _cast(g.contiguous().view(-1), stage)
+                b["work"], b["inplace"] = self._all_reduce_async(stage), None
+            self._count(n)
+            return
+        buf = self._fbuf(b, g, self.grad_dtype)
+        _cast(g.contiguous().view(-1), buf[off:off + n])
+        if len(b["have"]) == len(b["members"]):
+            b["work"] = self._all_reduce_async(buf)
+            self._count(b["numel"])
+
+    def _count(self, numel):
+        self.stats["buckets"] += 1
+        self.stats["foreign_buckets"] = self.stats.get("foreign_buckets", 0) + 1
+        self.stats["bytes"] += numel * (4 if self.grad_dtype == torch.float32 else 2)
+
+    def _finish_foreign(self):
+        scale = 1.0 / self.world
+        # buckets the backward pass left incomplete (parameters without a gradient in this pass, or hooks that do not
+        # exist in this torch): gather what is there now; every rank issues the same collectives in the same order
+        for b in self._fbuckets:
+            if b["work"] is not None:
+                continue
+            todo = [k for k, (p, _, _) in enumerate(b["members"]) if k not in b["have"] and p.grad is not None]
+            if not todo and not b["have"]:
+                continue                                     # nothing of this bucket took part in the pass (on any rank)
+            for k in todo:
+                self._foreign_stage(b, k)
+            if b["work"] is None:                            # members without a gradient: their pieces travel as zeros
+                buf = b["buf"]
+                for k, (p, off, n) in enumerate(b["members"]):
+                    if k not in b["have"]:
+                        _cast(torch.zeros(n, dtype=buf.dtype, device=buf.device), buf[off:off + n])
+                b["work"] = self._all_reduce_async(buf)
+                self._count(b["numel"])
+        for b in self._fbuckets:
+            if b["work"] is None:
+                continue
+            b["work"].wait()
+            if b["solo"]:
+                p = b["members"][0][0]
+                g = b.get("inplace")
+                if g is None:
+                    g = p.grad
+                    if g.dtype == torch.float32 and g.is_contiguous():
+                        _cast(b["buf"], g.view(-1))
+                    else:
+                        g.copy_(b["buf"].to(g.dtype).view_as(g))
+                if g.dtype == torch.float32 and g.is_contiguous():
+                    _scale(g.view(-1), scale)
+                else:
+                    g.mul_(scale)
+            else:
+                buf = b["buf"]
+                if buf.dtype != torch.float32:
+                    if self._f32_scratch is None or self._f32_scratch.numel() < buf.numel() or self._f32_scratch.device != buf.device:
+                        self._f32_scratch = torch.empty(max(buf.numel(), self.bucket_elems + 8), dtype=torch.float32, device=buf.device)
+                    wide = self._f32_scratch[:buf.numel()]
+                    _cast(buf, wide)
+                    buf = wide
+                _scale(buf, scale)
+                pairs = []
+                for p, off, n in b["members"]:
+                    g = p.grad
+                    if g is None:
+                        continue
+                    if g.dtype == torch.float32 and g.is_contiguous():
+                        pairs.append((buf[off:off + n], g.view(-1)))
+                    else:
+                        g.copy_(buf[off:off + n].to(g.dtype).view_as(g))
+                _cast_many(pairs)
+            b["work"], b["have"] = None, set()
+            b.pop("inplace", None)
 
     def attach_engine(self, eng):
         eng.grad_ready_hook = self._on_ready
@@ -253,48 +399,8 @@ class GradReducer:
             self._subs.pop(id(st["arena"]), None)
             st["sent"], st["works"], st["active"], st["post"] = 0, [], False, False
         self._ev_next = 0
-        grads = [p.grad for p in self._foreign_params if p.requires_grad and p.grad is not None]
-        if grads and self.world > 1:
-            self._reduce_foreign(grads)
-
-    def _reduce_foreign(self, grads):
-        """Gradients that do not live in an arena (the composable residual / Trans U-Nets, plug-in ``unet`` modules):
-        tensors of at least one bucket are all-reduced in place, the small ones coalesced into buckets of
-        ``bucket_bytes`` -- never one concatenation of everything (the TransUNet of ``patch_size = 4`` has 1.03 B
-        parameters).  All collectives are issued asynchronously, then waited for and averaged."""
-        scale = 1.0 / self.world
-        pending = []                                   # (work, flat buffer, tensors it was gathered from | None)
-        bucket, size = [], 0
-
-        def flush():
-            nonlocal bucket, size
-            if bucket:
-                flat = torch.cat([g.reshape(-1) for g in bucket])
-                pending.append((self._all_reduce_async(flat), flat, bucket))
-                self.stats["buckets"] += 1
-                self.stats["bytes"] += flat.numel() * 4
-            bucket, size = [], 0
-
-        for g in grads:
-            if g.numel() >= self.bucket_elems and g.is_contiguous():
-                pending.append((self._all_reduce_async(g), g, None))
-                self.stats["buckets"] += 1
-                self.stats["bytes"] += g.numel() * 4
-            else:
-                bucket.append(g)
-                size += g.numel()
-                if size >= self.bucket_elems:
-                    flush()
-        flush()
-        for work, flat, members in pending:
-            work.wait()
-            flat.mul_(scale)
-            if members is not None:
-                off = 0
-                for g in members:
-                    n = g.numel()
-                    g.copy_(flat[off:off + n].view_as(g))
-                    off += n
+        if self._fbuckets and self.world > 1:
+            self._finish_foreign()
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=None):

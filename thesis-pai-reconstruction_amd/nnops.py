@@ -84,7 +84,7 @@ class _WgradStream:
     the stream the backward pass was started from wait for them.  One
     stream: the library's weight-gradient slab buffer is used by one launch at a time.  PAI_NO_OVERLAP=1 turns it off."""
 
-    KEEP_BYTES = 48 << 30
+    KEEP_BYTES = 48 << 30       # upper bound; per backward pass the budget is also half of the free device memory
 
     def __init__(self):
         import os
@@ -92,15 +92,42 @@ class _WgradStream:
         self.streams = {}
         self.pending = set()
         self.keep, self.kept_bytes = [], 0
+        self.budget = self.KEEP_BYTES
+        self.seen = set()           # id() of the parameters whose gradient this backward pass has already produced
+        self.queued = False         # the join is queued as this backward pass's end-of-pass callback
+
+    @staticmethod
+    def _hooked(p) -> bool:
+        return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
 
     def run(self, device, reads, fn, params=()):
         """fn() -> (results, temporaries) with the library's launches on the side stream.  `reads`: the tensors those
         launches read; they and the temporaries were allocated on the main stream and must outlive the side stream's use.
         A parameter that already HAS a gradient makes autograd add the new one to it on the main stream, during the backward
-        pass: such a layer's weight gradient stays on the main stream."""
-        if not self.on or any(p is not None and p.grad is not None for p in params):
+        pass: such a layer's weight gradient stays on the main stream.  So does that of a parameter used by a SECOND node
+        of this graph (autograd sums the two gradients on the main stream before the join) and of one with tensor /
+        post-accumulate hooks (they read the gradient the moment it is returned)."""
+        if not self.on:
+            return fn()[0]
+        if not self.queued:
+            # the backward pass ends with the join: callers of a bare loss.backward() read complete gradients as well, and
+            # the per-pass bookkeeping (`seen`) is reset there
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+                self.queued = True
+            except RuntimeError:
+                self.seen.clear()   # not inside an engine-driven backward pass (a Function's backward called by hand): the explicit joins remain
+        live = [p for p in params if p is not None]
+        again = any(id(p) in self.seen for p in live)
+        self.seen.update(id(p) for p in live)
+        if again or any(p.grad is not None or self._hooked(p) for p in live):
             return fn()[0]
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        if not self.pending:
+            try:
+                self.budget = min(self.KEEP_BYTES, torch.cuda.mem_get_info(idx)[0] // 2)
+            except RuntimeError:
+                self.budget = self.KEEP_BYTES
         s = self.streams.get(idx)
         if s is None:
             s = self.streams[idx] = torch.cuda.Stream(device=idx)
@@ -112,19 +139,13 @@ class _WgradStream:
         # stream before anything can reuse their memory) -- record_stream costs an allocator event per tensor, ~8 ms of host
         # time per residual U-Net step; past KEEP_BYTES it is used after all
         nbytes = sum(t.numel() * t.element_size() for t in reads if t is not None)
-        if self.kept_bytes + nbytes <= self.KEEP_BYTES:
+        if self.kept_bytes + nbytes <= self.budget:
             self.keep.append(reads)
             self.kept_bytes += nbytes
         else:
             for t in reads:
                 if t is not None:
                     t.record_stream(s)
-        if not self.pending:
-            # the backward pass ends with the join: callers of a bare loss.backward() read complete gradients as well
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(self.join)
-            except RuntimeError:
-                pass        # not inside an engine-driven backward pass (a Function's backward called by hand): the explicit joins remain
         self.pending.add(idx)
         return out
 
@@ -133,6 +154,8 @@ class _WgradStream:
             ops.stream_wait_last(torch.cuda.current_stream(idx), self.streams[idx])
         self.pending.clear()
         self.keep, self.kept_bytes = [], 0
+        self.seen.clear()
+        self.queued = False
 
 
 WGRAD = _WgradStream()

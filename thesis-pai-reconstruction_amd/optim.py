@@ -28,12 +28,9 @@ class ArenaAdam(torch.optim.Adam):
         self._streamed = None          # streaming step armed: elements of the arena already updated by the hook
         self._stream_step = 0
         self._reducer = None           # the GradReducer the armed step subscribed to (data parallel)
-        # PAI_ADAM_STREAM=1: streamed ranges on a stream of their own instead of the stream that produced the gradients.
-        # Measured (round 3, same box, three interleaved runs): 7.17-7.27 ms/step against 6.31-6.35 -- a third concurrent
-        # stream takes CUs and HBM from two matrix-bound ones; off.
-        self._own_stream = os.environ.get("PAI_ADAM_STREAM", "0") not in ("", "0")
-        self._adam_stream = None
-        self._adam_pending = False
+        # (Streamed ranges always run on the stream that produced their gradients.  A stream of their own was measured in
+        #  round 3 -- 7.17-7.27 ms/step against 6.31-6.35: a third concurrent stream takes CUs and HBM from two matrix-bound
+        #  ones -- and removed in round 5: its two torch-level stream edges were not nodes of a launch plan.)
         # PAI_ADAM_PACK=0: never write filter packs from the streamed update (A/B switch; default on)
         self._fuse_packs = os.environ.get("PAI_ADAM_PACK", "1") not in ("", "0")
         self._pack_targets = None      # armed step without a reducer: the engine's pack_targets()
@@ -188,17 +185,7 @@ class ArenaAdam(torch.optim.Adam):
             raise ops.PaiError("ArenaAdam: a streaming step is armed and a second backward pass reached this arena "
                                "before step(); use one backward pass per optimizer step or do not arm_streaming()")
         with torch.no_grad():
-            if self._own_stream:
-                # a stream of its own, behind the one that produced the gradients: the 28 B/parameter pass then runs beside
-                # BOTH the input-gradient chain and the next weight gradients instead of in front of the latter
-                if self._adam_stream is None:
-                    self._adam_stream = torch.cuda.Stream(device=arena.flat.device)
-                self._adam_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._adam_stream):
-                    self._adam_range_packing(arena, self._streamed, int(end_offset), self._stream_step)
-                self._adam_pending = True
-            else:
-                self._adam_range_packing(arena, self._streamed, int(end_offset), self._stream_step)
+            self._adam_range_packing(arena, self._streamed, int(end_offset), self._stream_step)
         self._streamed = max(self._streamed, int(end_offset))
 
     def _on_reduced(self, arena, lo, hi):
@@ -258,9 +245,6 @@ class ArenaAdam(torch.optim.Adam):
         streamed = self._streamed
         if streamed is not None:
             self._disarm()
-        if self._adam_pending:
-            torch.cuda.current_stream().wait_stream(self._adam_stream)     # everything behind step() sees the updated ranges
-            self._adam_pending = False
         self._last_commits = []
         arena = self._arena_ready()
         if arena is None:

@@ -121,7 +121,7 @@ class _Recorder(TorchDispatchMode):
 
 
 class _Recorded:
-    __slots__ = ("items", "keep", "logs", "step0", "commits", "opt_steps", "static")
+    __slots__ = ("items", "keep", "logs", "step0", "commits", "opt_steps", "static", "last_use")
 
     def info(self):
         out = {"launches": 0, "waits": 0, "streams": 0, "runs": 0, "segments": 0, "host_nodes": 0}
@@ -154,6 +154,7 @@ class PlannedStep:
         self.replays = 0
         self.records = 0
         self.max_plans = 8
+        self.evictions = 0
 
     # ---- eligibility ------------------------------------------------------------------------------------
     def _why_not(self, batch):
@@ -198,15 +199,29 @@ class PlannedStep:
             self.disabled = self._why_not(batch)
         if self.disabled is not None or self.calls <= self.warmup:
             return m.training_step(batch, batch_idx)
+        # conditions that may change between calls (profiling switched on, eval mode, a host batch): this call runs eagerly,
+        # the recorded plans stay
+        if ops.PROFILE is not None or ops.PROFILE_HBM is not None or not m.training or \
+                not all(torch.is_tensor(b) and b.is_cuda for b in batch):
+            return m.training_step(batch, batch_idx)
         sig = self._signature(batch)
         if sig is None or any(s is None for s in sig):
             return m.training_step(batch, batch_idx)       # an optimizer is not in its steady state yet
         rec = self.plans.get(sig)
         if rec is None:
             if len(self.plans) >= self.max_plans:
-                self.disabled = f"more than {self.max_plans} distinct buffer states: the step is not periodic"
-                return m.training_step(batch, batch_idx)
+                # a learning-rate schedule (the rate is part of the signature) or a re-registered workspace retires old
+                # states for good: drop the least recently used plan -- with the activations and static batches it holds --
+                # instead of giving up
+                oldest = min(self.plans, key=lambda k: self.plans[k].last_use)
+                del self.plans[oldest]
+                self.evictions += 1
             return self._record(sig, batch, batch_idx)
+        rec.last_use = self.calls
+        if not self._replayable(rec):
+            # the optimizers' step counts moved apart from the recorded ones (a state reload): the plans are stale
+            self.plans.clear()
+            return m.training_step(batch, batch_idx)
         return self._replay(rec, batch)
 
     def _total_steps(self):
@@ -256,8 +271,14 @@ class PlannedStep:
             self.disabled = "an optimizer did not take exactly one step in the recorded call"
             self.plans.clear()
             return out
+        rec.last_use = self.calls
         self.plans[sig] = rec
         return out
+
+    def _replayable(self, rec) -> bool:
+        now = self._total_steps()
+        delta = now[0] - rec.step0[0]
+        return delta >= 0 and all(n - s0 == delta for n, s0 in zip(now, rec.step0))
 
     def _replay(self, rec, batch):
         m = self.model
@@ -286,7 +307,8 @@ class PlannedStep:
         return None
 
     def describe(self) -> dict:
-        return {"plans": len(self.plans), "records": self.records, "replays": self.replays, "disabled": self.disabled,
+        return {"plans": len(self.plans), "records": self.records, "replays": self.replays, "evictions": self.evictions,
+                "disabled": self.disabled,
                 "nodes": [r.info() for r in self.plans.values()]}
 
 
