@@ -52,7 +52,8 @@ const char* pai_last_error(void);
  * 121: pai_adam_pack, pai_bn_bwd_apply_affine (pai_bn_bwd_reduce_affine accepts du = NULL); with groups > 1 the weight
  * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only.  130: launch plans (pai_plan_*,
  * pai_stream_wait, pai_event_*), pai_zero_multi, pai_scale; pai_pack_frag and the pack_flags bits are gone (removed
- * experiment kernels: pack_flags MUST be zero); pai_conv_desc.reserved became .hints (PAI_HINT_SOLO). */
+ * experiment kernels: pack_flags MUST be zero); pai_conv_desc.reserved became .hints (PAI_HINT_SOLO).
+ * 131: pai_lerp_multi (the EMA update of callbacks/ema.py), PAI_TUNE_<name> environment defaults of the tunables. */
 int pai_version(void);
 /* Build-option bits.  0 since ABI 130: bit 0 used to announce the round-2 experiment kernels (and pai_pack_frag), which
  * were removed from the library. */
@@ -607,6 +608,13 @@ int pai_zero_multi(int count, void* const* ptrs, const int64_t* numels, void* st
  * of the conditioning image and the real / generated one) were four 7-12 us launches. */
 int pai_cast_multi(int count, int src_dtype, const void* const* srcs, int dst_dtype, void* const* dsts,
                    const int64_t* numels, void* stream);
+/* dst[i][k] += weight * (src[i][k] - dst[i][k]) for `count` pairs of fp32 buffers (host pointer tables), one launch per 48
+ * pairs: the exponential-moving-average update the reference runs after every training batch over ALL module parameters
+ * (callbacks/ema.py:24-33 -> torch_ema.ExponentialMovingAverage.update: shadow -= (1 - decay) * (shadow - param)).
+ * Written as that subtraction (s - w * (s - p), one rounding per operation, no contraction), so that it matches torch_ema's
+ * in-place sub_ / mul_ sequence bit for bit.  Callers pass whole arena ranges where parameters are adjacent in memory (one
+ * pair per network then); 16-byte alignment is not required. */
+int pai_lerp_multi(int count, void* const* dsts, const void* const* srcs, const int64_t* numels, float weight, void* stream);
 
 /* nn.Conv2d filters ([Cout][Cin / groups][kh][kw] fp32; reference models/res_unet.py:147-151 uses groups = 32) to and from
  * the dense tap-major fp32 layout [Cout][kh * kw][Cin] of pai_pack_weights / pai_conv_wgrad (groups as diagonal blocks,

@@ -36,6 +36,19 @@ def main(name):
     g = type(g)((k, v.double() if v.is_floating_point() else v) for k, v in g.items())
     d = type(d)((k, v.double()) for k, v in d.items())
     x, t = synth_batch(seed + 100, n, size)
+    if "pred_full" in z.files:
+        # forward fixture (oracle/gen_golden.py run_forward_case): distance of the reference's fp32 prediction from the fp64
+        # one, relative to max |pred| -- BatchNorm over the TWO samples of a 1 x 1 bottleneck (the 8-level residual U-Net
+        # at N = 2) turns fp32 rounding of nearly equal pairs into percent-level noise in the reference itself
+        fwd = oracle.res_unet_forward if fam.startswith("res") else \
+            (oracle.attention_unet_forward if fam == "attention" else oracle.unet_forward)
+        with torch.no_grad():
+            pred = fwd(g, x.double(), training=True)
+        want = torch.from_numpy(z["pred_full"]).double()
+        floor = float((pred - want).abs().max() / want.abs().max())
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_f64floor.npz"), **{"floor.pred": np.array(floor)})
+        print("wrote", name + "_f64floor", {"floor.pred": floor})
+        return
     _, grads = oracle.gan_training_step(g, d, oracle.AdamState(), oracle.AdamState(), x.double(), t.double(),
                                         loss_type=str(z["meta.loss_type"]), return_grads=True)
     rec = {}

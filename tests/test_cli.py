@@ -39,15 +39,18 @@ def test_train_and_report_flags_match_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["pix2pix", "attention_unet", "resnext_unet", "trans_unet"])
+@pytest.mark.parametrize("model", ["pix2pix", "attention_unet", "resnext_unet", "trans_unet", "pix2pix+ema", "resnext_unet+ema"])
 def test_train_then_report_roundtrip(tmp_path, model):
+    # "+ema": --ema (reference main.py:175-178 -> callbacks/ema.py): the shadow parameters are updated after every batch
+    # by the fused C-ABI lerp and swapped in around every validation run
+    model, ema = (model[:-4], ["--ema"]) if model.endswith("+ema") else (model, [])
     env = dict(os.environ, PYTHONPATH=ROOT)
     # TransUnetGAN fixes image_size = 256 (reference models/trans_unet.py:22) and needs a channel_mults that leaves patches
     shape = (["--synthetic", "8", "--batch-size", "4", "--channel-mults", "1,1,1,1,1", "--image-size", "256"]
              if model == "trans_unet" else
              ["--synthetic", "24", "--batch-size", "8", "--channel-mults", "1,2,2,4", "--image-size", "64"])
     run = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "cli_run", *shape, "-e", "2", "--val-epochs", "1",
-                          "-m", model], cwd=tmp_path, env=env, capture_output=True, text=True,
+                          "-m", model, *ema], cwd=tmp_path, env=env, capture_output=True, text=True,
                          timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     vdir = tmp_path / "logs" / "cli_run" / "version_0"
@@ -68,3 +71,69 @@ def test_train_then_report_roundtrip(tmp_path, model):
     assert set(stats) == {"SSIM", "PSNR", "RMSE", "FLOPs", "Parameter count"}
     assert int(stats["Parameter count"]) > 2_000_000 and 0 < float(stats["SSIM"]) <= 1
     assert len(open(rdir / "depth_ssim.csv").read().strip().splitlines()) == 17
+
+
+def _write_pairs(root, n, seed):
+    """n PNG pairs (sizes that do and do not need the resize) + a YAML list in the reference's format (dataset.py:22-32)."""
+    import numpy as np
+    import yaml
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(root / "img", exist_ok=True)
+    items = []
+    for i in range(n):
+        h, w = ((256, 256), (300, 280), (200, 333), (512, 512))[i % 4]
+        for kind in ("in", "gt"):
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = (127 + 90 * np.sin(xx / (7.0 + i) + (kind == "gt")) * np.cos(yy / (11.0 + i)) + rng.normal(0, 12, (h, w)))
+            Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), mode="L").save(root / "img" / f"{kind}_{i:03d}.png")
+        items.append({"input": f"img/in_{i:03d}.png", "ground_truth": f"img/gt_{i:03d}.png"})
+    return items
+
+
+@pytest.mark.gpu
+def test_yaml_png_pipeline_on_the_gpu_box(tmp_path):
+    """The reference's input path end to end on the GPU box (dataset.py:11-134: YAML list -> GRAY decode -> antialiased
+    resize to 256 -> [-1, 1]; main.py:106-111): 16 PNG pairs + two YAML lists written here, decoded by two worker
+    processes, staged through pinned memory and copied on the prefetcher's stream -- the batch that reaches the device is
+    bit for bit ``load_gray_256`` of the files -- and ``main.py -d ... -vd ... --num-workers 2`` trains from them."""
+    import torch
+    import yaml
+    sys.path.insert(0, ROOT)
+    import pai_bootstrap
+    pai_bootstrap.load()
+    from thesis_pai_reconstruction_amd.dataset import ImageDataModule, load_gray_256
+    from thesis_pai_reconstruction_amd.lightning import DevicePrefetcher
+    items = _write_pairs(tmp_path, 16, seed=3)
+    with open(tmp_path / "train.yaml", "w") as f:
+        yaml.safe_dump(items[:12], f)
+    with open(tmp_path / "val.yaml", "w") as f:
+        yaml.safe_dump(items[12:], f)
+    dm = ImageDataModule(str(tmp_path / "train.yaml"), str(tmp_path / "val.yaml"), batch_size=4, num_workers=2)
+    dm.setup("fit")
+    dev = torch.device("cuda", 0)
+    seen = 0
+    for loader, part in ((dm.val_dataloader(), items[12:]), (dm._loader(dm.train_split, False), items[:12])):
+        for b, (x, t) in enumerate(DevicePrefetcher(loader, dev)):
+            assert x.is_cuda and tuple(x.shape) == (4, 1, 256, 256) and x.dtype == torch.float32
+            for k in range(x.shape[0]):
+                it = part[4 * b + k]
+                assert torch.equal(x[k].cpu(), load_gray_256(str(tmp_path / it["input"])))
+                assert torch.equal(t[k].cpu(), load_gray_256(str(tmp_path / it["ground_truth"])))
+                seen += 1
+            assert float(x.min()) >= -1 and float(x.max()) <= 1
+    assert seen == 16
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "png_run", "-d", str(tmp_path / "train.yaml"),
+                          "-vd", str(tmp_path / "val.yaml"), "--batch-size", "4", "--channel-mults", "1,2,2,4,4", "-e", "2",
+                          "--val-epochs", "1", "--num-workers", "2", "-m", "pix2pix"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    vdir = tmp_path / "logs" / "png_run" / "version_0"
+    rows = open(vdir / "metrics.csv").read().strip().splitlines()
+    assert "val_ssim" in rows[0] and len(rows) >= 3 and (vdir / "checkpoints" / "best.ckpt").exists()
+    rep = subprocess.run([sys.executable, os.path.join(ROOT, "report.py"), "png_rep", "-c",
+                          str(vdir / "checkpoints" / "best.ckpt"), "-d", str(tmp_path / "val.yaml"), "-bs", "2", "-m", "pix2pix"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert rep.returncode == 0, rep.stdout[-2000:] + rep.stderr[-2000:]
+    assert len(os.listdir(tmp_path / "reports" / "png_rep" / "outputs")) == 4

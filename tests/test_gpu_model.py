@@ -460,3 +460,51 @@ def test_dropout2d_step_matches_reference_fixture(pai, golden_dir):
     m.train()
     with torch.no_grad():
         m.unet(batch[0])
+
+
+@pytest.mark.parametrize("family", ["pix2pix", "resnext_unet"])
+def test_ema_update_is_a_fused_pass_with_torch_ema_arithmetic(pai, family):
+    """callbacks.EMACallback on the device (reference callbacks/ema.py:24-52 -> torch_ema): pai_lerp_multi over memory
+    segments -- the parameters of a HIP engine are one segment once its optimizer has adopted them into the arena -- with
+    torch_ema's own arithmetic (shadow -= (1 - d) * (shadow - p), warm-up decay), bit for bit; swap-in / restore around
+    validation keeps the engines' packs current (the eval forward really runs on the shadow weights)."""
+    from thesis_pai_reconstruction_amd.callbacks import EMACallback
+    seed = 77
+    x, t = synth_batch(seed + 100, 4, 32)
+    batch = (x.to(DEV), t.to(DEV))
+    if family == "pix2pix":
+        m, _, _ = build(pai, (1, 2, 2, 4), "gan", seed)
+    else:
+        m = pai.ResUnetGAN(1, 1, "next", (1, 2, 2), 0.0, "gan").to(DEV)
+        m.set_precision("32")
+        m.train()
+    cb = EMACallback(decay=0.9)
+    cb.on_fit_start(None, m)
+    ref = [p.detach().cpu().clone() for p in cb.params]
+    for n in range(1, 5):
+        m.training_step(batch, n - 1)
+        cb.on_train_batch_end(None, m)
+        w = 1.0 - min(0.9, (1 + n) / (10 + n))
+        for r, p in zip(ref, cb.params):
+            tmp = r - p.detach().cpu()
+            tmp.mul_(w)
+            r.sub_(tmp)
+    torch.cuda.synchronize()
+    for k, (s, r) in enumerate(zip(cb.shadow, ref)):
+        assert torch.equal(s.cpu(), r), k
+    nseg, npar = len(cb._segments), len(cb.params)
+    # the two engines' arenas (pix2pix), or the generator's separately allocated tensors + the discriminator's arena
+    assert nseg <= (4 if family == "pix2pix" else npar) and nseg < npar, (nseg, npar)
+    live = [p.detach().clone() for p in cb.params]
+    m.eval()
+    with torch.no_grad():
+        out_live = m(batch[0]).clone()
+        cb.on_validation_start(None, m)
+        for p, r in zip(cb.params, ref):
+            assert torch.equal(p.detach().cpu(), r)
+        out_ema = m(batch[0]).clone()
+        cb.on_validation_end(None, m)
+        out_back = m(batch[0]).clone()
+    for p, l in zip(cb.params, live):
+        assert torch.equal(p.detach(), l)
+    assert torch.equal(out_back, out_live) and not torch.equal(out_ema, out_live)

@@ -54,12 +54,15 @@ def test_forward_matches_reference_fixture(pai, golden_dir, name):
         lf = m.discriminator(x, pred)
     want = torch.from_numpy(z["pred_full"])
     # 3-level fixtures at 1e-4; the 5-level one (10 residual blocks, BatchNorm over 32 samples at the bottom) at 5e-4; the
-    # 8-level one (16 residual blocks, BatchNorm over TWO samples at the 1 x 1 bottom) at 2e-3
-    ftol = 1e-4 if name.endswith("tiny") else (2e-3 if name.endswith("full") else 5e-4)
+    # 8-level one at 512 x 512 (16 residual blocks, 32 samples at the bottom) at 5e-4 + 3 x the distance of the reference's
+    # OWN fp32 prediction from its fp64 one (oracle/gen_f64_floor.py: 1.1e-3 -- fp32 rounding through 16 BatchNorms)
+    ftol = 1e-4 if name.endswith("tiny") else 5e-4
+    if os.path.exists(os.path.join(golden_dir, name + "_f64floor.npz")):
+        ftol += 3.0 * float(_load(golden_dir, name + "_f64floor")["floor.pred"])
     assert float((pred.cpu() - want).abs().max()) < ftol * float(want.abs().max())
     w = torch.from_numpy(z["logits_fake_full"])
     # (the 32 x 32 fixtures give one logit of ~1e-3 per sample: bound relative to the activations that form it)
-    assert float((lf.cpu() - w).norm()) < 1e-4 * max(float(w.norm()), 1e-2)
+    assert float((lf.cpu() - w).norm()) < max(ftol / 5, 1e-4) * max(float(w.norm()), 1e-2)     # (logits of the noisy prediction)
     m.eval()                                   # eval mode (running statistics) against the live oracle
     g = {k: v.detach().cpu().clone() for k, v in m.unet.state_dict().items()}
     with torch.no_grad():

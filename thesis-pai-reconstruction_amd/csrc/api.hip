@@ -14,7 +14,7 @@ void pai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pai_last_error(void) { return g_err; }
-extern "C" int pai_version(void) { return 130; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine; 130: launch plans
+extern "C" int pai_version(void) { return 131; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine; 130: launch plans; 131: pai_lerp_multi
 
 // build-option bits; none since ABI 130 (bit 0 announced the round-2 experiment kernels, which were removed)
 extern "C" int pai_build_flags(void) { return 0; }

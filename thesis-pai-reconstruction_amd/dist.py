@@ -174,11 +174,11 @@ class GradReducer:
                 continue
             n = p.numel()
             if n >= self.bucket_elems:
-                b = {"solo": True, "members": [(p, 0, n)], "numel": n, "buf": None, "work": None, "have": set()}
+                b = {"solo": True, "members": [(p, 0, n)], "numel": n, "buf": None, "work": None, "have": set(), "touched": set()}
                 self._fbuckets.append(b)
             else:
                 if cur is None or cur["numel"] >= self.bucket_elems:
-                    cur = {"solo": False, "members": [], "numel": 0, "buf": None, "work": None, "have": set()}
+                    cur = {"solo": False, "members": [], "numel": 0, "buf": None, "work": None, "have": set(), "touched": set()}
                     self._fbuckets.append(cur)
                 b = cur
                 off = (b["numel"] + 7) // 8 * 8          # 32-byte pieces: the multi-tensor scatter's contract
@@ -195,11 +195,13 @@ class GradReducer:
 
     def _foreign_ready(self, p):
         """post-accumulate-grad hook: ``p.grad`` is final for this backward pass."""
-        if self.world < 2 or not self.overlap or p.grad is None:
-            return
         ent = self._fmap.get(id(p))
-        if ent is not None:
-            self._foreign_stage(*ent)
+        if self.world < 2 or ent is None or p.grad is None:
+            return
+        b, k = ent
+        b["touched"].add(k)
+        if self.overlap:
+            self._foreign_stage(b, k)
 
     def _foreign_stage(self, b, k):
         """Member k of bucket b has its gradient: stage it; all-reduce the bucket when it is complete."""
@@ -231,12 +233,15 @@ class GradReducer:
 
     def _finish_foreign(self):
         scale = 1.0 / self.world
-        # buckets the backward pass left incomplete (parameters without a gradient in this pass, or hooks that do not
-        # exist in this torch): gather what is there now; every rank issues the same collectives in the same order
+        # buckets the backward pass left incomplete (some members got no gradient in this pass), or everything when the
+        # overlap is off: gather what this pass produced; every rank issues the same collectives in the same order.  A
+        # gradient left over from an EARLIER pass (the generator's, while the discriminator steps) is not touched.
+        hooks = bool(self._foreign_hooks)
         for b in self._fbuckets:
             if b["work"] is not None:
                 continue
-            todo = [k for k, (p, _, _) in enumerate(b["members"]) if k not in b["have"] and p.grad is not None]
+            todo = [k for k, (p, _, _) in enumerate(b["members"])
+                    if k not in b["have"] and p.grad is not None and (k in b["touched"] or not hooks)]
             if not todo and not b["have"]:
                 continue                                     # nothing of this bucket took part in the pass (on any rank)
             for k in todo:
@@ -286,6 +291,8 @@ class GradReducer:
                 _cast_many(pairs)
             b["work"], b["have"] = None, set()
             b.pop("inplace", None)
+        for b in self._fbuckets:
+            b["touched"] = set()
 
     def attach_engine(self, eng):
         eng.grad_ready_hook = self._on_ready

@@ -163,6 +163,7 @@ SIGNATURES = {
     "pai_profile_arm": (_I, [_P, _P]),
     "pai_stream_wait_event": (_I, [_P, _P]),
     "pai_zero_multi": (_I, [_I, _P, _P, _P]),
+    "pai_lerp_multi": (_I, [_I, _P, _P, _P, _F, _P]),
     "pai_scale": (_I, [_P, _L, _F, _P]),
     "pai_cast_multi": (_I, [_I, _I, _P, _I, _P, _P, _P]),
     "pai_filter_to_dense": (_I, [_P, _I, _I, _I, _I, _P, _P]),

@@ -803,6 +803,18 @@ def zero_multi(tensors) -> None:
     L.check(L.load().pai_zero_multi(n, ptrs, numels, _stream()), "pai_zero_multi")
 
 
+def lerp_multi(segments, weight: float) -> None:
+    """dst -= weight * (dst - src) over (dst_ptr, src_ptr, numel) fp32 segments (pai_lerp_multi): the EMA update."""
+    n = len(segments)
+    if n == 0:
+        return
+    dsts = (C.c_void_p * n)(*[int(d) for d, _, _ in segments])
+    srcs = (C.c_void_p * n)(*[int(s_) for _, s_, _ in segments])
+    numels = (C.c_int64 * n)(*[int(k) for _, _, k in segments])
+    with _TimedBytes("ema", 12 * sum(int(k) for _, _, k in segments)):
+        L.check(L.load().pai_lerp_multi(n, dsts, srcs, numels, float(weight), _stream()), "pai_lerp_multi")
+
+
 def scale_(t, factor: float) -> None:
     """t *= factor for a contiguous fp32 HIP tensor (pai_scale)."""
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
