@@ -229,16 +229,21 @@ def _planned_worker(rank, world, port, family, q, mode="gloo"):
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
         torch.manual_seed(100)
-        cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
-        eager = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
+        composable = family == "resnext_unet"      # gradients outside the arenas: the reducer's hook-fed fixed buckets
+        if composable:
+            eager = pai.ResUnetGAN(1, 1, "next", (1, 2, 2), 0.0, "gan").to(dev)
+        else:
+            cls = pai.AttentionUnetGAN if family == "attention_unet" else pai.Pix2Pix
+            eager = cls(1, 1, (1, 2, 2, 4), 0.0, "gan").to(dev)
         eager.set_precision("bf16-mixed")
         eager.train()
         pdist.broadcast_parameters(eager)
         planned = copy.deepcopy(eager)
         reds = []
         for m in (eager, planned):
-            red = pdist.GradReducer(bucket_bytes=1 << 20, comm=reds[0].comm if reds else None)
+            red = pdist.GradReducer(bucket_bytes=(64 << 10) if composable else (1 << 20), comm=reds[0].comm if reds else None)
             red.attach(m)
+            assert red.plannable()
             reds.append(red)
 
             class T:
@@ -261,11 +266,14 @@ def _planned_worker(rank, world, port, family, q, mode="gloo"):
             assert ps.disabled is None, ps.disabled
             for k, v in logs["e"].items():
                 a, g = float(v), float(logs["p"][k])
-                assert (abs(a - g) <= 1e-4 * max(1.0, abs(a))) if k == "loss" else a == g, (s, k, a, g)
+                # (the composable networks' forward passes have fp32 atomics in the BatchNorm statistics of their thin
+                #  layers: noise-level differences between any two runs)
+                assert (abs(a - g) <= (2e-3 if composable else 1e-4) * max(1.0, abs(a))) if (k == "loss" or composable) else a == g, (s, k, a, g)
             for (k, p), (_, q2) in zip(eager.state_dict().items(), planned.state_dict().items()):
                 if not k.endswith("num_batches_tracked"):
                     d = (p.float() - q2.float()).abs()
-                    assert float(d.max()) <= 4.1e-4 and (d.numel() < 64 or float(d.mean()) <= 1e-5), (s, k, float(d.max()))
+                    assert float(d.max()) <= (2e-3 if composable else 4.1e-4) and \
+                        (d.numel() < 64 or float(d.mean()) <= (1e-4 if composable else 1e-5)), (s, k, float(d.max()))
             after = torch.cat([p.detach().reshape(-1) for p in planned.parameters()]).cpu()
             both = [torch.zeros_like(after) for _ in range(world)]
             dist.all_gather(both, after)
@@ -277,6 +285,8 @@ def _planned_worker(rank, world, port, family, q, mode="gloo"):
             assert node["launches"] > 50, node
             assert (node["host_nodes"] == 0) == (mode == "rccl-abi"), node      # torch collectives are host nodes
         assert reds[1].stats["buckets"] >= steps * 2 * 2
+        if composable:
+            assert reds[1].stats["foreign_buckets"] >= steps * 4, reds[1].stats
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -287,15 +297,16 @@ def _planned_worker(rank, world, port, family, q, mode="gloo"):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("family", ["pix2pix", "attention_unet"])
+@pytest.mark.parametrize("family", ["pix2pix", "attention_unet", "resnext_unet"])
 def test_two_rank_planned_step(family):
     _run_ranks(_planned_worker, ((family,), ()))
 
 
 @needs_two_gpus
+@pytest.mark.parametrize("family", ["pix2pix", "resnext_unet"])
 @pytest.mark.parametrize("mode", ["nccl", "rccl-abi"])
-def test_two_rank_planned_step_over_rccl(mode):
-    _run_ranks(_planned_worker, (("pix2pix",), (mode,)))
+def test_two_rank_planned_step_over_rccl(mode, family):
+    _run_ranks(_planned_worker, ((family,), (mode,)))
 
 
 def _mean_worker(rank, world, port, family, q, mode="gloo", grad_dtype=None):
