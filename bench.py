@@ -154,11 +154,6 @@ def main():
                     help="plan (default): the step is recorded once into a C-side launch plan (plan.PlannedStep -> "
                          "pai_plan_run) and replayed with ONE C call per step -- same kernels, arguments, streams and "
                          "order as the eager step; eager: every launch issued from Python (PAI_PLAN=0 does the same)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as ONE hipGraph launch (graph.GraphedStep; single process only) instead of issuing "
-                         "every launch from Python.  EXPERIMENTAL.  Measured on MI355X (round 3): host time per step 4.4 -> 0.66 ms, but the "
-                         "step itself 6.64 -> 7.02 ms -- the replay overlaps the three streams of the step less well than "
-                         "eager submission does, and the run is GPU-bound -- so eager stays the default")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="wire format of the gradient buckets (dist.GradReducer)")
     ap.add_argument("--precision", default="bf16-mixed")
@@ -236,19 +231,13 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    # --graph: one hipGraph launch per step (the same kernels on the same three streams, captured after three eager
-    # steps); with more than one rank the bucketed RCCL exchange is not captured and the step is issued from Python.
-    from thesis_pai_reconstruction_amd.graph import GraphedStep
     from thesis_pai_reconstruction_amd import plan as pplan
-    graphed = GraphedStep(model, warmup=3) if (world == 1 and args.graph) else None
     planned = None
-    if graphed is None and args.launch == "plan" and pplan.enabled_by_default():
+    if args.launch == "plan" and pplan.enabled_by_default():
         planned = pplan.PlannedStep(model, warmup=3)
 
     def run_step(b, i):
-        if graphed is not None:
-            graphed(b, i)
-        elif planned is not None:
+        if planned is not None:
             planned(b, i)
         else:
             model.training_step(b, i)
@@ -421,10 +410,8 @@ def main():
                    **({"backend": torch.distributed.get_backend(), "gpus_visible": torch.cuda.device_count(),
                        "rccl_ranks": reducer.rccl_ranks() if reducer is not None else 0} if world > 1 else {})},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
-        "launch_mode": ("hipGraph replay (one launch per step)" if graphed is not None and graphed.graph is not None else
-                        "launch plan (pai_plan_run: one C call per step)" if planned is not None and planned.replays > 0 else
-                        "eager" + (f" ({graphed.disabled})" if graphed is not None and graphed.disabled else "")
-                        + (f" (plan refused: {planned.disabled})" if planned is not None and planned.disabled else "")),
+        "launch_mode": ("launch plan (pai_plan_run: one C call per step)" if planned is not None and planned.replays > 0 else
+                        "eager" + (f" (plan refused: {planned.disabled})" if planned is not None and planned.disabled else "")),
         "launch_plan": planned.describe() if planned is not None else None,
         "clock_ramp_steps": prewarm_steps,
         "step_conv_gflop_per_image": None if gflop != gflop else round(gflop, 2),

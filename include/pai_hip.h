@@ -241,9 +241,9 @@ int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const void* w_dgra
 /* Convolution + BatchNorm2d in training mode + activation (Conv2d / ConvTranspose2d -> nn.BatchNorm2d -> ReLU /
  * LeakyReLU, reference models/pix2pix.py:63-70,99-106) as ONE call: z = conv + bias (storage dtype, kept for the
  * backward pass), batch statistics of z, running statistics advanced n_updates times, a = act(z * scale + shift).
- * Same results as pai_conv_fwd(stats) -> pai_bn_finalize -> pai_bn_apply, which is what runs for most layers; layers
- * whose split-K output has <= 4096 rows (the U-Net bottleneck) end in one column-owner finish launch instead of three
- * dependent ones (pai_conv_bn_fused says which).  `stats`: the buffer pai_conv_fwd would take. */
+ * Same results as pai_conv_fwd(stats) -> pai_bn_finalize -> pai_bn_apply, which is what runs (ABI 120-130 ended the
+ * U-Net bottleneck's split-K layers in one column-owner finish launch instead; measured slower, removed in 131).
+ * `stats`: the buffer pai_conv_fwd would take. */
 typedef struct pai_bn_train {
     const float* gamma;            /* or NULL (= 1) */
     const float* beta;             /* or NULL (= 0) */
@@ -258,11 +258,12 @@ int pai_conv_fwd_bn(const pai_conv_desc* d, const void* x1, const void* x2, cons
                     void* z, void* a, int act, const pai_bn_train* bn, float* stats, void* stream);
 /* Input gradient + the whole BatchNorm backward of the producer layer: like pai_conv_dgrad_bn, but carried through to
  * dz = gamma * rstd * (du - sum(du) / M - xhat * sum(du xhat) / M), with sums [2][C1], dgamma += , dbeta += written on
- * the way.  `du_scratch` (shaped like dx1) and e->partials are only used when the layer is not fused. */
+ * the way.  `du_scratch` (shaped like dx1) and e->partials are workspace of the call. */
 int pai_conv_dgrad_bn_apply(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* du_scratch, void* dx2,
                             const pai_bwd_epilogue* e, const float* gamma, float* sums, float* dgamma, float* dbeta,
                             void* dz, void* stream);
-/* 1: the two calls above end in the single fused finish launch for this layer (op 0 forward, 1 input gradient). */
+/* Always 0 since ABI 131 (-1: bad descriptor); ABI 120-130: 1 when the two calls above ended in the single fused finish
+ * launch for this layer (op 0 forward, 1 input gradient). */
 int pai_conv_bn_fused(const pai_conv_desc* d, int op);
 
 /* dw += conv_backward_weight(act(x1|x2), dy)   (fp32, fwd pack; caller zeroes it first)

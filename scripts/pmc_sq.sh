@@ -7,7 +7,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${tag}_sq
 rm -rf $out && mkdir -p $out gpurun_out/profiles_$tag
-B="scripts/micro/convbench --iters 3 --rounds 1 --ops fdw $PMC_SQ_ARGS"   # PMC_SQ_ARGS: e.g. "--set fwd_wide=1"
+B="scripts/micro/convbench --iters 3 --rounds 1 --ops fdw $PMC_SQ_ARGS"   # PMC_SQ_ARGS: e.g. "--set wgrad3=0"
 pass() {   # name, counters...
   n=$1; shift
   for f in enc2 dec4 dec5 dec6 D1x2 enc4; do

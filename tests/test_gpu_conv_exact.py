@@ -149,18 +149,6 @@ def test_mfma_kernels_bit_exact_on_integer_data(pai, case, workspace):
         assert used[0] == SPLIT[0] and used[1] == SPLIT[0], used
 
 
-P2_CASES = [c for c in CASES if c[0] in ("enc_patch256", "dec_patch256", "enc_dgrad256", "cfg2_enc2", "cfg2_dec4", "cfg2_dec5", "cfg2_D3")]
-
-
-@pytest.mark.parametrize("case", P2_CASES, ids=[c[0] for c in P2_CASES])
-def test_wide_wave_tile_form_of_the_256_row_tile_bit_exact(pai, case):
-    """gg_fwd_patchw_k<256, 128> (four waves of 128 x 64, round-3 operand addressing; tunable fwd_wide = 1: faster than the
-    default alone on the chip, slower beside the weight-gradient stream of the training step) against the same cases as
-    gg_fwd_patch_k<256, 128> (eight waves of 64 x 64), which the named run above pins."""
-    used = _run_case(pai, case, tunables=(("fwd_wide", 1),))
-    assert any(u == "gg_fwd_patchw_k<256, 128, true>" for u in used[:2]), used
-
-
 OLD_WGRAD = {"enc_patch": "gg_wgrad_patch_k<128>", "dec_patch": "gg_wgrad_patch_k<128>", "dec_patch256x64": "gg_wgrad_patch_k<64>",
              "cfg2_dec5": "gg_wgrad_patch_k<128>"}
 

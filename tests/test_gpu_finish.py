@@ -1,11 +1,11 @@
-"""GPU: the column-owner finish of small split-K outputs (csrc/gg_finish.hip) behind pai_conv_fwd_bn /
-pai_conv_dgrad_bn_apply -- convolution + BatchNorm2d(train) + activation, and input gradient + the producer's whole
-BatchNorm backward, each ending in ONE launch for the U-Net bottleneck layers (reference models/pix2pix.py:63-70,
-99-106; aten::native_batch_norm / native_batch_norm_backward behind nn.BatchNorm2d).
+"""GPU: the composite entry points pai_conv_fwd_bn / pai_conv_dgrad_bn_apply on the split-K layers of the U-Net bottleneck
+-- convolution + BatchNorm2d(train) + activation, and input gradient + the producer's whole BatchNorm backward (reference
+models/pix2pix.py:63-70,99-106; aten::native_batch_norm / native_batch_norm_backward behind nn.BatchNorm2d).
 
-Checked three ways: against PyTorch-CPU fp32 autograd (integer inputs: the convolution part is exact, the BatchNorm
-part is held to fp32 rounding), against the three-launch path of the same entry points (tunable finish_fused = 0: z and
-the slab sums must be IDENTICAL, everything behind the statistics within rounding), and at BASELINE configs[1] layer shapes."""
+Against PyTorch-CPU fp32 autograd on integer inputs (the convolution part is exact, the BatchNorm part is held to fp32
+rounding), at BASELINE configs[1] layer shapes.  (Rounds 3-4 also ran these layers through a single column-owner finish
+launch, csrc/gg_finish.hip, tunable finish_fused; it was slower than the three launches it replaced -- 6.64-6.65 against
+6.52-6.56 ms/step -- and was removed in round 5; pai_conv_bn_fused now always answers 0.)"""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -66,10 +66,9 @@ def test_conv_bn_act_forward_fused_finish(pai, case):
     X1, X2 = nhwc(x1, dt), (nhwc(x2, dt) if C2 else None)
     stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, device=dev())
     out = {}
-    for fused in (1, 0):
-        ops.set_tunable("finish_fused", fused)
+    for fused in (0,):
         try:
-            assert ops.conv_bn_fused(d, 0) == bool(fused), (name, fused)
+            assert ops.conv_bn_fused(d, 0) is False
             z = torch.empty(M * Cout, dtype=dt, device=dev())
             a = torch.empty_like(z)
             rm, rv = torch.zeros(Cout, device=dev()), torch.ones(Cout, device=dev())
@@ -80,7 +79,7 @@ def test_conv_bn_act_forward_fused_finish(pai, case):
             torch.cuda.synchronize()
             out[fused] = (from_nhwc(z, N, OH, OH, Cout), from_nhwc(a, N, OH, OH, Cout), [t.cpu() for t in st], rm.cpu(), rv.cpu(), int(nbt))
         finally:
-            ops.set_tunable("finish_fused")
+            pass
     for fused, (z, a, st, rm, rv, nbt) in out.items():
         assert torch.equal(z, zb), (name, fused, "z")                       # integer data: exact
         assert torch.allclose(st[0].double(), mean_ref, rtol=1e-6, atol=1e-6), (name, fused, "mean")
@@ -94,11 +93,6 @@ def test_conv_bn_act_forward_fused_finish(pai, case):
             rm_ref = 0.9 * rm_ref + 0.1 * mean_ref
             rv_ref = 0.9 * rv_ref + 0.1 * unb
         assert torch.allclose(rm.double(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rv.double(), rv_ref, rtol=1e-5), (name, fused)
-    # the two launch sequences: same z, statistics equal to fp32 rounding, a equal up to a rounding flip of bf16
-    assert torch.equal(out[1][0], out[0][0])
-    for k in range(4):
-        assert torch.allclose(out[1][2][k], out[0][2][k], rtol=2e-6, atol=1e-6), (name, k)
-    assert float((out[1][1] - out[0][1]).abs().max()) <= 2.0 ** -7 * max(1.0, float(a_ref.abs().max()))
 
 
 @pytest.mark.parametrize("enc_form", [False, True], ids=["decoder_form", "encoder_form"])
@@ -143,10 +137,9 @@ def test_dgrad_with_producer_batchnorm_backward_fused_finish(pai, case, enc_form
     f = lambda t: None if t is None else t.to(dev())
     part = torch.empty(ops.conv_dgrad_bn_rows_max(d) * 2 * C1, device=dev())
     res = {}
-    for fused in (1, 0):
-        ops.set_tunable("finish_fused", fused)
+    for fused in (0,):
         try:
-            assert ops.conv_bn_fused(d, 1) == bool(fused), (name, fused)
+            assert ops.conv_bn_fused(d, 1) is False
             du = torch.empty(M * C1, dtype=dt, device=dev())
             dx2 = torch.empty(M * C2, dtype=dt, device=dev()) if C2 else None
             dz = torch.empty(M * C1, dtype=dt, device=dev())
@@ -159,7 +152,7 @@ def test_dgrad_with_producer_batchnorm_backward_fused_finish(pai, case, enc_form
             res[fused] = (from_nhwc(dz, N, H, H, C1), dgamma.cpu() - 1.0, dbeta.cpu() + 1.0, sums.cpu(),
                           from_nhwc(dx2, N, H, H, C2) if C2 else None)
         finally:
-            ops.set_tunable("finish_fused")
+            pass
     scale_dz = float(zr.grad.abs().max())
     for fused, (dz, dg, db, sums, dx2) in res.items():
         # bf16 storage of du and dz: two roundings of 2^-9 relative each, on values up to max|dz|
@@ -171,6 +164,3 @@ def test_dgrad_with_producer_batchnorm_backward_fused_finish(pai, case, enc_form
             yy = F.conv_transpose2d(xg, w, None, stride=2, padding=1) if tr else F.conv2d(xg, w, None, stride=2, padding=1)
             yy.backward(dy)
             assert torch.equal(dx2, xg.grad[:, C1:].bfloat16().float()), (name, fused, "dx2")
-    # fused against three launches: same du (bit for bit, inside), sums to fp32 rounding, dz up to a bf16 rounding flip
-    assert torch.allclose(res[1][3], res[0][3], rtol=1e-5, atol=1e-5 * float(res[0][3].abs().max())), name
-    assert float((res[1][0] - res[0][0]).abs().max()) <= 2.0 ** -7 * scale_dz, name

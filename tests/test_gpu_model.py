@@ -508,3 +508,34 @@ def test_ema_update_is_a_fused_pass_with_torch_ema_arithmetic(pai, family):
     for p, l in zip(cb.params, live):
         assert torch.equal(p.detach(), l)
     assert torch.equal(out_back, out_live) and not torch.equal(out_ema, out_live)
+
+
+def test_device_side_step_count_equals_host_side(pai):
+    """ArenaAdam.enable_device_step (pai_adam_dev: the step count in device memory, for callers that capture step() into
+    a hipGraph of their own) against the ordinary host-side count: same parameters and moments after three steps."""
+    mults, seed = (1, 2, 2, 4), 41
+    x, t = synth_batch(seed + 100, 4, 32)
+    batch = (x.to(DEV), t.to(DEV))
+    ma, _, _ = build(pai, mults, "gan", seed)
+    mb, _, _ = build(pai, mults, "gan", seed)
+    os.environ["PAI_NO_STREAM_ADAM"] = "1"        # the streamed update needs the host-side count
+    try:
+        for m in (ma, mb):
+            m.training_step(batch, 0)                 # the first fused step adopts the parameters into the arenas
+        from _gpu_util import sync_training_state
+        sync_training_state(ma, mb)
+        for opt in mb.optimizers():
+            opt.enable_device_step()
+        for s in range(1, 4):
+            ma.training_step(batch, s)
+            mb.training_step(batch, s)
+    finally:
+        os.environ.pop("PAI_NO_STREAM_ADAM", None)
+    torch.cuda.synchronize()
+    for oa, ob in zip(ma.optimizers(), mb.optimizers()):
+        assert int(ob._dev_step) == 4 and ob.total_steps == oa.total_steps == 4
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        if sa[k].is_floating_point():
+            err = float((sa[k].double() - sb[k].double()).norm())
+            assert err <= 1e-4 * max(float(sb[k].double().norm()), 1e-3), (k, err)

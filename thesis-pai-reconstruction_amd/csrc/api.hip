@@ -634,16 +634,8 @@ extern "C" int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const v
     return pai_act_bwd(d->dtype, dx1, e->act1, e->add, e->act2, e->z, M * g.D1, dx1, stream);
 }
 
-// the call runs on the tile kernels of gg_mfma.hip (the family with the split-K launches)
-static bool runs_tile_mfma(const pai_conv_desc* d, const GG& g, const FwdArgs& a) {
-    return !grouped3_ok(d->dtype, g, a) && !pw_ok(d->dtype, g, a) && !thin_fwd_ok(d->dtype, g, a) &&
-           !thin_dgrad_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) && use_mfma(d->dtype, g, a);
-}
-
-// Convolution + BatchNorm2d(train) + activation.  One entry point so that the library may pick the launch sequence:
-// small split-K outputs (the U-Net bottleneck) end in ONE column-owner finish (gg_finish.hip) instead of
-// splitk_finish_k -> bn_finalize_wide_k -> bn_apply_k; every other layer runs pai_conv_fwd(stats) -> pai_bn_finalize
-// -> pai_bn_apply exactly as the three separate calls would.
+// Convolution + BatchNorm2d(train) + activation.  One entry point so that the library may pick the launch sequence; today
+// every layer runs pai_conv_fwd(stats) -> pai_bn_finalize -> pai_bn_apply exactly as the three separate calls would.
 extern "C" int pai_conv_fwd_bn(const pai_conv_desc* d, const void* x1, const void* x2, const void* w_fwd, const float* bias,
                                void* z, void* a_out, int act, const pai_bn_train* bn, float* stats, void* stream) {
     GG g;
@@ -659,17 +651,6 @@ extern "C" int pai_conv_fwd_bn(const pai_conv_desc* d, const void* x1, const voi
     a.eact = PAI_ACT_NONE;
     hipStream_t s = (hipStream_t)stream;
     const int64_t count = (int64_t)g.N * g.OH * g.OW;
-    if (d->dtype == PAI_BF16 && runs_tile_mfma(d, g, a) && finish_fused_ok(g, g.Cout)) {
-        a.skip_finish = 1;
-        if (int rc = launch_fwd_mfma(g, a, s)) return rc;
-        FinishBnArgs f;
-        f.ws = pai_ctx()->workspace; f.ksplit = fwd_mfma_ksplit_effective(g); f.bias = bias;
-        f.z = (bf16_t*)z; f.a = (bf16_t*)a_out; f.act = act;
-        f.gamma = bn->gamma; f.beta = bn->beta; f.eps = bn->eps; f.momentum = bn->momentum; f.n_updates = bn->n_updates;
-        f.running_mean = bn->running_mean; f.running_var = bn->running_var; f.nbt = bn->num_batches_tracked;
-        f.mean = bn->mean; f.rstd = bn->rstd; f.scale = bn->scale; f.shift = bn->shift;
-        return launch_finish_bn(g, f, s);
-    }
     if (int rc = run_fwd(d->dtype, g, a, s)) return rc;
     const int rows = pai_conv_fwd_stats_rows(d);
     if (int rc = pai_bn_finalize(stats, rows, g.Cout, count, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->n_updates,
@@ -678,19 +659,16 @@ extern "C" int pai_conv_fwd_bn(const pai_conv_desc* d, const void* x1, const voi
     return pai_bn_apply(d->dtype, z, count, g.Cout, bn->scale, bn->shift, act, a_out, stream);
 }
 
-// 1 when pai_conv_fwd_bn / pai_conv_dgrad_bn_apply of this layer end in the single column-owner finish launch
+// Always 0 since ABI 131: the single column-owner finish launch of rounds 3-4 (gg_finish.hip) was slower than the three
+// launches it replaced and is gone; the entry point stays so that ABI-130 callers link.
 extern "C" int pai_conv_bn_fused(const pai_conv_desc* d, int op) {
     GG g;
     if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
-    FwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.y1 = (void*)1;
-    if (op == 1) a.y2 = (void*)1;
-    return d->dtype == PAI_BF16 && runs_tile_mfma(d, g, a) && finish_fused_ok(g, op == 1 ? g.D1 : g.Cout) ? 1 : 0;
+    return 0;
 }
 
 // Input gradient + the COMPLETE BatchNorm backward of the layer that produced the input: dz (gradient w.r.t. that
-// layer's convolution output), sums, dgamma / dbeta.  Small split-K outputs: one column-owner finish; otherwise
+// layer's convolution output), sums, dgamma / dbeta:
 // pai_conv_dgrad_bn (du into `du_scratch`, partial rows into e->partials) -> pai_bn_bwd_finalize -> pai_bn_bwd_apply.
 extern "C" int pai_conv_dgrad_bn_apply(const pai_conv_desc* d, const void* dy, const void* w_dgrad, void* du_scratch,
                                        void* dx2, const pai_bwd_epilogue* e, const float* gamma, float* sums,
@@ -706,17 +684,6 @@ extern "C" int pai_conv_dgrad_bn_apply(const pai_conv_desc* d, const void* dy, c
     a.x1 = dy; a.w = w_dgrad;
     a.y1 = du_scratch; a.y2 = dx2;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == PAI_BF16 && runs_tile_mfma(d, g, a) && finish_fused_ok(g, g.D1)) {
-        a.bz = e->z; a.badd = e->add;
-        a.bscale = e->scale; a.bshift = e->shift; a.bmean = e->mean; a.brstd = e->rstd;
-        a.bact1 = e->act1; a.bact2 = e->act2;
-        a.skip_finish = 1;
-        if (int rc = launch_fwd_mfma(g, a, s)) return rc;
-        FinishBwdArgs f;
-        f.ws = pai_ctx()->workspace; f.ksplit = fwd_mfma_ksplit_effective(g);
-        f.gamma = gamma; f.sums = sums; f.dgamma = dgamma; f.dbeta = dbeta; f.dz = (bf16_t*)dz;
-        return launch_finish_bnbwd(g, a, f, s);
-    }
     int rows = 0;
     if (int rc = pai_conv_dgrad_bn(d, dy, w_dgrad, du_scratch, dx2, e, &rows, stream)) return rc;
     if (int rc = pai_bn_bwd_finalize(e->partials, rows, g.D1, sums, dgamma, dbeta, stream)) return rc;

@@ -173,34 +173,7 @@ struct FwdArgs {
     const float *bscale, *bshift, *bmean, *brstd;
     int bact1, bact2;
     float* bpart;
-    int skip_finish;   // split-K launches: leave the slabs in the workspace, the caller runs its own finish (gg_finish.hip)
 };
-// column-owner finish kernels of small split-K outputs (gg_finish.hip)
-struct FinishBnArgs {
-    const float* ws;              // slabs [split][phase][M][Cout]
-    int ksplit;
-    const float* bias;            // conv bias or NULL
-    bf16_t* z;                    // raw output (what the BatchNorm backward reads), or NULL
-    bf16_t* a;                    // act(BN(z))
-    int act;
-    const float *gamma, *beta;
-    float eps, momentum;
-    int n_updates;
-    float *running_mean, *running_var;
-    int64_t* nbt;
-    float *mean, *rstd, *scale, *shift;
-};
-struct FinishBwdArgs {
-    const float* ws;
-    int ksplit;
-    const float* gamma;           // of the producer's BatchNorm, or NULL (= 1)
-    float* sums;                  // [2][D1]: sum du, sum du * xhat
-    float *dgamma, *dbeta;        // += (gradient arena)
-    bf16_t* dz;                   // gradient w.r.t. the producer's convolution output [rows][D1]
-};
-bool finish_fused_ok(const GG& g, int d1_cols);
-int launch_finish_bn(const GG& g, const FinishBnArgs& f, hipStream_t s);
-int launch_finish_bnbwd(const GG& g, const FwdArgs& a, const FinishBwdArgs& f, hipStream_t s);
 int fwd_mfma_ksplit_effective(const GG& g);     // the K split launch_fwd_mfma uses with the registered workspace
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
@@ -225,12 +198,6 @@ struct pai_handle_s {
 // active handle of the calling thread's current HIP device; never null (a device without a handle has an empty one:
 // no workspace, no scratch -> un-split / fallback kernels)
 const pai_handle_s* pai_ctx();
-// persistent patch-resident forward / input-gradient kernel (gg_pers.hip)
-struct PatchGeo;
-bool fwd_pers_ok(int bm, int bn);
-int fwd_pers_rows(const GG& g);
-const char* fwd_pers_kernel_name(int bm, int bn, bool db);
-int launch_fwd_pers(const GG& g, const FwdArgs& a, const PatchGeo& pg, int bm, int bn, bool db, hipStream_t s);
 int fwd_simt_mtiles(const GG& g);
 int fwd_mfma_mtiles(const GG& g);
 bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);

@@ -2,7 +2,7 @@
 // which kernel a call takes is decided in launch_fwd_mfma / launch_wgrad_mfma below and reported by pai_conv_kernel_name.
 //
 // Forward / input-gradient:  out[m][co] = sum_{t,ci} A(m,t,ci) * Wp[co][wt][ci]
-//   gg_fwd_patch_k<256|128, 128|64> (+ gg_fwd_patch1_k<256, 64>, gg_fwd_patchw_k: tunable fwd_wide) -- the kernels of the
+//   gg_fwd_patch_k<256|128, 128|64> (+ gg_fwd_patch1_k<256, 64>) -- the kernels of the
 //     k4 s2 layers, i.e. of nearly all the FLOPs: a workgroup owns a 16 x 16 (8 x 16) block of output pixels, keeps the
 //     source pixels its 2 x 2 tap windows touch in LDS (one patch fill serves four taps) and streams the 64-channel weight
 //     tiles through a one- or two-slot ring; LDS-DMA through buffer descriptors, fragments by conflict-free ds_read_b128,
@@ -49,11 +49,10 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a) {
 // double-buffered, one 512-thread workgroup per CU) when that still gives every CU a workgroup,
 // else 128 x 128 / 128 x 64 (single buffer, 3-4 workgroups per CU), split over K when even that
 // leaves CUs idle.
-// gg_fwd_patchw_k (128 x 64 wave tiles) for the 256-row tiles: tunable fwd_wide.  5-9 % faster when a launch has the GPU to
-// itself, 1 % slower over the step as the default -- and no faster either when only the launches that DO run alone (the
-// forward passes, the generator step's pass through the discriminator) take it: 6.36-6.39 ms/step with and without,
-// three interleaved runs (round 3).
-constexpr int FWD_WIDE_DEFAULT = 0;
+// (A 128 x 64 wave-tile form of the 256-row kernel, gg_fwd_patchw_k / tunable fwd_wide, lived here in rounds 3-4: 5-9 %
+// faster when a launch has the GPU to itself, 1 % slower over the step -- beside the weight-gradient stream a CU holds one
+// forward workgroup, and eight 64 x 64 waves hide more latency than four 128 x 64 ones.  Removed in round 5; the body
+// still takes WPX = 128.)
 struct FwdCfg { int bm, bn, ksplit; };
 
 static FwdCfg fwd_cfg(const GG& g) {
@@ -132,10 +131,7 @@ static int patch_rows(const GG& g, const FwdCfg& c);
 int fwd_mfma_mtiles(const GG& g) {
     if (fwd_effective_ksplit(g) > 1) return cdiv(g.M, FIN_ROWS);
     const FwdCfg c = fwd_cfg(g);
-    const int prow = patch_rows(g, c);
-    if (prow == 256 && c.bn == 128 && fwd_pers_ok(256, 128)) return fwd_pers_rows(g);
-    if (prow == 128 && fwd_pers_ok(128, c.bn)) return fwd_pers_rows(g);
-    return prow == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
+    return patch_rows(g, c) == 256 ? g.M / 256 : cdiv(g.M, abs(c.bm));
 }
 
 
@@ -334,27 +330,6 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
         // run at ~1.3 TB/s chip-wide against ~6 TB/s for stores, and at 16-64 splits the added bytes
         // (splits x output) were the whole cost of the bottleneck layers.  splitk_finish_k sums the slabs
         // in a fixed order (deterministic) and applies the epilogue.
-        if (a.skip_finish) {
-            // the caller's column-owner finish (gg_finish.hip) reads 8-channel groups over ALL rows: slab layout
-            // [split][channel group][phase * M + m][8] -- a 16 x 16 accumulator tile is two contiguous 512-B blocks, and
-            // the finish reads 32 B per thread, contiguous across its threads
-            const size_t rows_all = (size_t)g.nphase * g.M;
-            float* sl = ws + (size_t)ks * rows_all * g.Cout;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wm * WR + mt * 16 + fq * 4 + r;
-                    if (m0 + row < g.M) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const int col = n0 + wn * (BN / 2) + nt * 16 + fr;
-                            sl[((size_t)(col >> 3) * rows_all + (size_t)ph * g.M + m0 + row) * 8 + (col & 7)] = acc[mt][nt][r];
-                        }
-                    }
-                }
-            return;
-        }
         float* dst = ws + ((size_t)(ks * g.nphase + ph) * g.M + m0) * g.Cout + n0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -1065,11 +1040,6 @@ __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)
     // (BM, BN, DBB) = (256, 128, *) and (128, 128, false) are the configurations at the register line, see COLSWZ
     gg_fwd_patch_body<BM, BN, DBB, 2, 64, !(BN == 128 && (BM == 256 || !DBB))>(g, a, pg, mtiles, ntiles);
 }
-// 128 x 64 wave tiles: BM / 128 x 2 waves (see gg_fwd_patch_body, WPX = 128)
-template <int BM, int BN, bool DBB>
-__global__ __launch_bounds__(BM, 2) void gg_fwd_patchw_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
-    gg_fwd_patch_body<BM, BN, DBB, 2, 128>(g, a, pg, mtiles, ntiles);
-}
 // 64 output channels, one wave column: BM / 64 waves of 64 x 64 (see gg_fwd_patch_body, WN = 1)
 template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM, 3) void gg_fwd_patch1_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
@@ -1113,7 +1083,6 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             if (pai_tunable("fwd_splitk_db", 1)) FWD_LAUNCH(128, 128, true, true); else FWD_LAUNCH(128, 128, true, false);
         } else FWD_LAUNCH(128, 64, true, false);
         PAI_LAUNCH_CHECK();
-        if (a.skip_finish) return 0;      // the caller finishes the slabs itself (gg_finish.hip)
         const int ftiles = cdiv(g.M, FIN_ROWS);
         PAI_LAUNCH(splitk_finish_k, dim3(ftiles, g.nphase, cdiv(g.Cout, FIN_COLS)), dim3(256), 0, s, g, a,
                            pai_ctx()->workspace, ftiles, c.ksplit);
@@ -1150,16 +1119,7 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             }
             const int mt256 = g.M / 256;
             const dim3 grid256(mt256 * ntiles * g.nphase);
-            if (fwd_pers_ok(256, 128)) return launch_fwd_pers(g, a, pg, 256, 128, db, s);
-            if (pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) {
-                static PerDeviceOnce attrw;
-                if (attrw.first()) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_fwd_patchw_k<256, 128, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                    PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-                }
-                PAI_LAUNCH((gg_fwd_patchw_k<256, 128, true>), grid256, dim3(256), need, s, g, a, pg, mt256, ntiles);
-            } else if (db) PAI_LAUNCH((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
+            if (db) PAI_LAUNCH((gg_fwd_patch_k<256, 128, true>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
             else PAI_LAUNCH((gg_fwd_patch_k<256, 128, false>), grid256, dim3(512), need, s, g, a, pg, mt256, ntiles);
         } else if (prow == 128 && patch_geo(g, 8, &pg)) {
             typedef PatchDims<128> PD;
@@ -1167,7 +1127,6 @@ int launch_fwd_mfma(const GG& g, const FwdArgs& a, hipStream_t s) {
             const size_t lds = PD::BYTES + (size_t)c.bn * 128 * (db ? 2 : 1);
             const size_t epi = 128 * ((size_t)c.bn * 2 + 16) + 4 * 2 * c.bn * sizeof(float);
             const size_t need = lds > epi ? lds : epi;
-            if (fwd_pers_ok(128, c.bn)) return launch_fwd_pers(g, a, pg, 128, c.bn, db, s);
             if (c.bn == 128) {
                 if (db) PAI_LAUNCH((gg_fwd_patch_k<128, 128, true>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
                 else PAI_LAUNCH((gg_fwd_patch_k<128, 128, false>), grid, dim3(256), need, s, g, a, pg, mtiles, ntiles);
@@ -1196,9 +1155,6 @@ const char* fwd_mfma_kernel_name(const GG& g) {
     const int dbb = getenv("PAI_PATCH_DBB") ? atoi(getenv("PAI_PATCH_DBB")) : 3;
     const int prow = patch_rows(g, c);
     if (prow == 256 && c.bn == 64) return (dbb & 4) ? "gg_fwd_patch1_k<256, 64, true>" : "gg_fwd_patch1_k<256, 64, false>";
-    if (prow == 256 && fwd_pers_ok(256, 128)) return fwd_pers_kernel_name(256, 128, (dbb & 1) != 0);
-    if (prow == 128 && fwd_pers_ok(128, c.bn)) return fwd_pers_kernel_name(128, c.bn, (dbb & (c.bn == 128 ? 2 : 4)) != 0);
-    if (prow == 256 && pai_tunable("fwd_wide", FWD_WIDE_DEFAULT)) return "gg_fwd_patchw_k<256, 128, true>";
     if (prow == 256) return (dbb & 1) ? "gg_fwd_patch_k<256, 128, true>" : "gg_fwd_patch_k<256, 128, false>";
     if (prow == 128) {
         if (c.bn == 128) return (dbb & 2) ? "gg_fwd_patch_k<128, 128, true>" : "gg_fwd_patch_k<128, 128, false>";

@@ -174,11 +174,8 @@ class UnetWrapper(LightningModule):
         self.log("loss", loss, prog_bar=True)
         if metrics_early is not None:
             s, p, r = self._metrics_join(metrics_early)
-        elif pred.is_cuda:
-            s, p, r = PF.metrics_of_normalized(pred, target)
         else:
-            den_pred, den_target = denormalize(pred), denormalize(target)
-            s, p, r = ssim(den_pred, den_target), psnr(den_pred, den_target), rmse(den_pred, den_target)
+            s, p, r = PF.metrics_of_normalized(pred, target)      # (raises on host tensors: there is no CPU path)
         self.log("train_ssim", s, prog_bar=True)
         self.log("train_psnr", p, prog_bar=True)
         self.log("train_rmse", r, prog_bar=True)

@@ -215,7 +215,7 @@ class Handle:
         self.workspace = None
         self.scratch = None
         self.wgrad_workspace = None
-        # bumped whenever a registered buffer is replaced: a captured hipGraph (graph.GraphedStep) or a recorded launch
+        # bumped whenever a registered buffer is replaced: a caller's captured hipGraph or a recorded launch
         # plan holds the OLD addresses in its kernel arguments and must not be replayed past such a change
         self.epoch = 0
 

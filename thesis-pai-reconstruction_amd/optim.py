@@ -23,7 +23,7 @@ class ArenaAdam(torch.optim.Adam):
         super().__init__(list(params), lr=lr, betas=betas, eps=eps, foreach=True)
         self._engine = engine
         self._arena_steps = 0          # steps taken on the fused path and not yet mirrored into `state`
-        self._dev_step = None          # graph mode: int64 device scalar holding the step count (see graph.py)
+        self._dev_step = None          # device-step mode: int64 device scalar holding the step count (a caller's hipGraph capture of step())
         self._dev_coeff = None
         self._streamed = None          # streaming step armed: elements of the arena already updated by the hook
         self._stream_step = 0
@@ -319,7 +319,7 @@ class MultiAdam(torch.optim.Adam):
 
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-7):
         super().__init__(list(params), lr=lr, betas=betas, eps=eps, foreach=True)
-        self._dev_step = None          # graph mode: int64 device scalar holding the step count (graph.GraphedStep)
+        self._dev_step = None          # device-step mode: int64 device scalar holding the step count
         self._dev_coeff = None
         self._arena_steps = 0          # replays not yet mirrored into the per-parameter `step` entries
 
@@ -388,7 +388,7 @@ class MultiAdam(torch.optim.Adam):
         nnops.join_wgrads()      # weight gradients of the composable networks run on a second stream; no-op after manual_backward
 
         def stock(*a):
-            # a captured step (device-side count, graph.GraphedStep) must never reach the stock implementation: it would
+            # a captured step (device-side count) must never reach the stock implementation: it would
             # bake the HOST step count of the capture into the graph and every replay would reuse one bias correction
             if self._dev_step is not None:
                 raise ops.PaiError("MultiAdam: the fused update's preconditions do not hold (closure / several param groups / "

@@ -4,7 +4,7 @@ launch plan (``ops.Plan`` -> pai_plan_*, include/pai_hip.h) and replays it.
 The reference's step is one Python call dispatching ~170 ATen operators (reference models/wrapper.py:117-162).  The
 eager step of this package issues ~205 kernel launches one by one from Python through ctypes: 5.5 ms of host time under
 a 6.4 ms GPU step at batch 64 (round 3), host-bound outright for the smaller per-rank batches of strong scaling.  A
-hipGraph of the step (``graph.GraphedStep``) replays 4-6 % SLOWER than eager issue, because the replay serialises the
+hipGraph of the step (``graph.GraphedStep``, rounds 2-4; removed in round 5) replayed 4-6 % SLOWER than eager issue, because the replay serialises the
 weight-gradient stream.  A launch plan keeps the eager schedule exactly -- same kernels, same arguments, same three
 streams, same fork / join edges -- and only moves the issue loop from Python into ``pai_plan_run``.
 
