@@ -327,7 +327,14 @@ def main():
                      "launches_per_step": f["launches"] / nsteps,
                      "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                      "gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 3),
-                     "kernel_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())}}
+                     "kernel_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items())},
+                     # every matrix-core kernel family of the step against the same peak: launches, time and algorithmic
+                     # FLOPs per step, fraction of the dense bf16 peak
+                     "per_kernel": {k: {"launches_per_step": round(v["launches"] / nsteps, 1),
+                                        "ms_per_step": round(v["ms"] / nsteps, 3),
+                                        "gflop_per_step": round(v["flops"] / nsteps / 1e9, 1),
+                                        "frac": round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4)}
+                                    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
 
     def roofline_hbm_of(prof_hbm, nsteps):
         """The HBM-bound passes issued through ops (BatchNorm apply / backward passes of the composable networks, Adam):
