@@ -5,7 +5,11 @@ models/pix2pix.py:63-70,99-106; aten::native_batch_norm / native_batch_norm_back
 Against PyTorch-CPU fp32 autograd on integer inputs (the convolution part is exact, the BatchNorm part is held to fp32
 rounding), at BASELINE configs[1] layer shapes.  (Rounds 3-4 also ran these layers through a single column-owner finish
 launch, csrc/gg_finish.hip, tunable finish_fused; it was slower than the three launches it replaced -- 6.64-6.65 against
-6.52-6.56 ms/step -- and was removed in round 5; pai_conv_bn_fused now always answers 0.)"""
+6.52-6.56 ms/step -- and was removed in round 5; pai_conv_bn_fused now always answers 0.)
+
+Round 5: for these small layers BatchNorm finalize + apply (forward and backward) run as ONE launch
+(bn_fin_apply_k / bn_bwd_fin_apply_k, tunable bn_fuse_small) that sums the partial rows in the order of the finalize
+kernels: every output must be BIT-IDENTICAL to the two-launch form."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -66,7 +70,8 @@ def test_conv_bn_act_forward_fused_finish(pai, case):
     X1, X2 = nhwc(x1, dt), (nhwc(x2, dt) if C2 else None)
     stats = torch.zeros(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, device=dev())
     out = {}
-    for fused in (0,):
+    for fused in (1, 0):
+        ops.set_tunable("bn_fuse_small", fused)
         try:
             assert ops.conv_bn_fused(d, 0) is False
             z = torch.empty(M * Cout, dtype=dt, device=dev())
@@ -79,7 +84,7 @@ def test_conv_bn_act_forward_fused_finish(pai, case):
             torch.cuda.synchronize()
             out[fused] = (from_nhwc(z, N, OH, OH, Cout), from_nhwc(a, N, OH, OH, Cout), [t.cpu() for t in st], rm.cpu(), rv.cpu(), int(nbt))
         finally:
-            pass
+            ops.set_tunable("bn_fuse_small")
     for fused, (z, a, st, rm, rv, nbt) in out.items():
         assert torch.equal(z, zb), (name, fused, "z")                       # integer data: exact
         assert torch.allclose(st[0].double(), mean_ref, rtol=1e-6, atol=1e-6), (name, fused, "mean")
@@ -93,6 +98,11 @@ def test_conv_bn_act_forward_fused_finish(pai, case):
             rm_ref = 0.9 * rm_ref + 0.1 * mean_ref
             rv_ref = 0.9 * rv_ref + 0.1 * unb
         assert torch.allclose(rm.double(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rv.double(), rv_ref, rtol=1e-5), (name, fused)
+    # one launch against two: the same summation order, so everything is bit-identical
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1]), name
+    for k in range(4):
+        assert torch.equal(out[1][2][k], out[0][2][k]), (name, k)
+    assert torch.equal(out[1][3], out[0][3]) and torch.equal(out[1][4], out[0][4]) and out[1][5] == out[0][5], name
 
 
 @pytest.mark.parametrize("enc_form", [False, True], ids=["decoder_form", "encoder_form"])
@@ -137,7 +147,8 @@ def test_dgrad_with_producer_batchnorm_backward_fused_finish(pai, case, enc_form
     f = lambda t: None if t is None else t.to(dev())
     part = torch.empty(ops.conv_dgrad_bn_rows_max(d) * 2 * C1, device=dev())
     res = {}
-    for fused in (0,):
+    for fused in (1, 0):
+        ops.set_tunable("bn_fuse_small", fused)
         try:
             assert ops.conv_bn_fused(d, 1) is False
             du = torch.empty(M * C1, dtype=dt, device=dev())
@@ -152,7 +163,7 @@ def test_dgrad_with_producer_batchnorm_backward_fused_finish(pai, case, enc_form
             res[fused] = (from_nhwc(dz, N, H, H, C1), dgamma.cpu() - 1.0, dbeta.cpu() + 1.0, sums.cpu(),
                           from_nhwc(dx2, N, H, H, C2) if C2 else None)
         finally:
-            pass
+            ops.set_tunable("bn_fuse_small")
     scale_dz = float(zr.grad.abs().max())
     for fused, (dz, dg, db, sums, dx2) in res.items():
         # bf16 storage of du and dz: two roundings of 2^-9 relative each, on values up to max|dz|
@@ -164,3 +175,5 @@ def test_dgrad_with_producer_batchnorm_backward_fused_finish(pai, case, enc_form
             yy = F.conv_transpose2d(xg, w, None, stride=2, padding=1) if tr else F.conv2d(xg, w, None, stride=2, padding=1)
             yy.backward(dy)
             assert torch.equal(dx2, xg.grad[:, C1:].bfloat16().float()), (name, fused, "dx2")
+    for k in range(4):      # dz, dgamma, dbeta, sums: one launch against two, bit for bit
+        assert torch.equal(res[1][k], res[0][k]), (name, k)

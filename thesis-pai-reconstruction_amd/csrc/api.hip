@@ -653,6 +653,10 @@ extern "C" int pai_conv_fwd_bn(const pai_conv_desc* d, const void* x1, const voi
     const int64_t count = (int64_t)g.N * g.OH * g.OW;
     if (int rc = run_fwd(d->dtype, g, a, s)) return rc;
     const int rows = pai_conv_fwd_stats_rows(d);
+    if (bn_fuse_small_ok(rows, count, g.Cout))      // the U-Net bottleneck: finalize + apply as ONE launch, same results
+        return launch_bn_fin_apply(d->dtype, stats, rows, g.Cout, count, bn->gamma, bn->beta, bn->eps, bn->momentum,
+                                   bn->n_updates, bn->running_mean, bn->running_var, bn->num_batches_tracked, bn->mean,
+                                   bn->rstd, bn->scale, bn->shift, z, act, a_out, s);
     if (int rc = pai_bn_finalize(stats, rows, g.Cout, count, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->n_updates,
                                  bn->running_mean, bn->running_var, bn->num_batches_tracked, bn->mean, bn->rstd, bn->scale,
                                  bn->shift, stream)) return rc;
@@ -686,8 +690,12 @@ extern "C" int pai_conv_dgrad_bn_apply(const pai_conv_desc* d, const void* dy, c
     hipStream_t s = (hipStream_t)stream;
     int rows = 0;
     if (int rc = pai_conv_dgrad_bn(d, dy, w_dgrad, du_scratch, dx2, e, &rows, stream)) return rc;
+    const int64_t Mo = (int64_t)g.N * g.OH * g.OW;
+    if (bn_fuse_small_ok(rows, Mo, g.D1))
+        return launch_bn_bwd_fin_apply(d->dtype, e->partials, rows, g.D1, sums, dgamma, dbeta, du_scratch, e->z, Mo, e->mean,
+                                       e->rstd, gamma, dz, s);
     if (int rc = pai_bn_bwd_finalize(e->partials, rows, g.D1, sums, dgamma, dbeta, stream)) return rc;
-    return pai_bn_bwd_apply(d->dtype, du_scratch, e->z, (int64_t)g.N * g.OH * g.OW, g.D1, e->mean, e->rstd, gamma, sums, dz, stream);
+    return pai_bn_bwd_apply(d->dtype, du_scratch, e->z, Mo, g.D1, e->mean, e->rstd, gamma, sums, dz, stream);
 }
 
 static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,

@@ -579,6 +579,198 @@ extern "C" int pai_bn_bwd_apply_affine(int dtype, const void* g1, int act1, cons
     return 0;
 }
 
+// ---- finalize + apply in ONE launch for the small layers (the U-Net bottleneck: <= 4096 rows, <= 256 partial rows) -------
+// pai_bn_finalize -> pai_bn_apply and pai_bn_bwd_finalize -> pai_bn_bwd_apply are two dependent launches of 5-9 us each
+// around tensors of 0.1-4 MB: twelve such pairs per Pix2Pix step (encoders[4-6], decoders[0-2], forward and backward).
+// Here every workgroup (64 channels x a block of rows) first re-derives the per-channel totals of its 64 channels from the
+// partial rows -- <= 128 KB from L2, summed in EXACTLY the order of bn_finalize_wide_k / bn_finalize_k / bn_bwd_finalize_k
+// (128 row lanes, 8-lane butterflies, 16 waves in order; <= 16 rows: one sequential sum), so the statistics, and with
+// them every output, are bit-identical to the two-launch form -- and then applies them to its rows.  The workgroups of
+// row block 0 write the per-channel outputs and advance the running statistics.
+constexpr int FA_ROWS = 128;      // rows of the tensor per workgroup
+
+// totals of channel c over the partial rows [R][2][C], component `comp`, in the finalize kernels' summation order
+__device__ __forceinline__ void fa_wave_partials(const float* part, int R, int C, int c, int w, double (*Wl)[16][64]) {
+    // thread (c, w): "wave" w of the finalize kernel = the butterfly of its 8 row lanes
+    const int cl = threadIdx.x & 63;
+    {
+        double P[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rl = 8 * w + j;
+            double a = 0.0, b = 0.0;
+            for (int r = rl; r < R; r += 128) {
+                a += (double)part[((size_t)r * 2 + 0) * C + c];
+                b += (double)part[((size_t)r * 2 + 1) * C + c];
+            }
+            P[0][j] = a;
+            P[1][j] = b;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            Wl[k][w][cl] = ((P[k][0] + P[k][1]) + (P[k][2] + P[k][3])) + ((P[k][4] + P[k][5]) + (P[k][6] + P[k][7]));
+    }
+}
+__device__ __forceinline__ void fa_totals(const float* part, int R, int C, int c, bool wide, double (*Wl)[16][64], double& s, double& q) {
+    const int cl = threadIdx.x & 63;
+    s = q = 0.0;
+    if (wide) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l) { s += Wl[0][l][cl]; q += Wl[1][l][cl]; }
+    } else {
+        for (int r = 0; r < R; ++r) {
+            s += (double)part[((size_t)r * 2 + 0) * C + c];
+            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_fin_apply_k(const float* stats, int R, int wide, int C, double count, const float* gamma,
+                                                      const float* beta, float eps, float momentum, int n_updates,
+                                                      float* running_mean, float* running_var, int64_t* nbt, float* mean_o,
+                                                      float* rstd_o, float* scale_o, float* shift_o, const T* z, int64_t M,
+                                                      int act, T* out) {
+    __shared__ double Wl[2][16][64];
+    __shared__ float coef[2][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (wide) fa_wave_partials(stats, R, C, c, g, Wl);
+    __syncthreads();
+    if (g == 0) {
+        double s, q;
+        fa_totals(stats, R, C, c, wide != 0, Wl, s, q);
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float gm = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = gm * rstd;
+        const float sh = b - (float)mean * sc;
+        coef[0][cl] = sc;
+        coef[1][cl] = sh;
+        if (blockIdx.y == 0) {
+            if (blockIdx.x == 0 && cl == 0 && nbt) *nbt += n_updates;
+            mean_o[c] = (float)mean;
+            rstd_o[c] = rstd;
+            scale_o[c] = sc;
+            shift_o[c] = sh;
+            if (running_mean && running_var) {
+                const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+                float rm = running_mean[c], rv = running_var[c];
+                for (int u = 0; u < n_updates; ++u) {
+                    rm = (1.f - momentum) * rm + momentum * (float)mean;
+                    rv = (1.f - momentum) * rv + momentum * unbiased;
+                }
+                running_mean[c] = rm;
+                running_var[c] = rv;
+            }
+        }
+    }
+    __syncthreads();
+    // apply: thread = (row lane, 8-channel group) of the workgroup's FA_ROWS x 64 block; same arithmetic as bn_apply_k
+    const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = coef[0][cg * 8 + k]; sh[k] = coef[1][cg * 8 + k]; }
+    const int64_t m0 = (int64_t)blockIdx.y * FA_ROWS;
+    for (int r = r0; r < FA_ROWS; r += 128) {
+        const int64_t m = m0 + r;
+        if (m >= M) break;
+        const size_t off = (size_t)m * C + blockIdx.x * 64 + cg * 8;
+        float v[8];
+        V8<T>::ld(z + off, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act);
+        V8<T>::st(out + off, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_bwd_fin_apply_k(const float* partials, int R, int C, float* sums, float* dgamma,
+                                                          float* dbeta, const T* du, const T* z, int64_t M, float inv_m,
+                                                          const float* mean, const float* rstd, const float* gamma, T* dz) {
+    __shared__ double Wl[2][16][64];
+    __shared__ float coef[2][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    fa_wave_partials(partials, R, C, c, g, Wl);
+    __syncthreads();
+    if (g == 0) {
+        double s1, s2;
+        fa_totals(partials, R, C, c, true, Wl, s1, s2);
+        coef[0][cl] = (float)s1;
+        coef[1][cl] = (float)s2;
+        if (blockIdx.y == 0) {
+            sums[c] = (float)s1;
+            sums[C + c] = (float)s2;
+            if (dbeta) dbeta[c] += (float)s1;
+            if (dgamma) dgamma[c] += (float)s2;
+        }
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    const int cb = blockIdx.x * 64 + cg * 8;
+    float mu[8], rs[8], gm[8], sb[8], sg[8];
+    V8<float>::ld(mean + cb, mu);
+    V8<float>::ld(rstd + cb, rs);
+    if (gamma) V8<float>::ld(gamma + cb, gm);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sb[k] = coef[0][cg * 8 + k]; sg[k] = coef[1][cg * 8 + k]; }
+    const int64_t m0 = (int64_t)blockIdx.y * FA_ROWS;
+    for (int r = r0; r < FA_ROWS; r += 128) {
+        const int64_t m = m0 + r;
+        if (m >= M) break;
+        const size_t off = (size_t)m * C + cb;
+        float d[8], zv[8];
+        V8<T>::ld(du + off, d);
+        V8<T>::ld(z + off, zv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {      // (same expression as bn_bwd_apply_k)
+            const float xh = (zv[k] - mu[k]) * rs[k];
+            const float gk = gamma ? gm[k] : 1.f;
+            d[k] = gk * rs[k] * (d[k] - sb[k] * inv_m - xh * sg[k] * inv_m);
+        }
+        V8<T>::st(dz + off, d);
+    }
+}
+
+// the layers the fused launches take: channel groups of 64, a small tensor, few partial rows (tunable bn_fuse_small)
+bool bn_fuse_small_ok(int rows, int64_t M, int C) {
+    return pai_tunable("bn_fuse_small", 1) && (C % 64) == 0 && M > 0 && M <= 4096 && rows > 0 && rows <= 256;
+}
+
+int launch_bn_fin_apply(int dtype, const float* stats, int rows, int C, int64_t count, const float* gamma, const float* beta,
+                        float eps, float momentum, int n_updates, float* running_mean, float* running_var, int64_t* nbt,
+                        float* mean, float* rstd, float* scale, float* shift, const void* z, int act, void* out,
+                        hipStream_t s) {
+    const dim3 grid(C / 64, cdiv(count, FA_ROWS));
+    const int wide = rows > 16;      // pai_bn_finalize: more than 16 partial rows go through bn_finalize_wide_k's tree
+    if (dtype == PAI_F32)
+        PAI_LAUNCH(bn_fin_apply_k<float>, grid, dim3(1024), 0, s, stats, rows, wide, C, (double)count, gamma, beta, eps, momentum,
+                   n_updates, running_mean, running_var, nbt, mean, rstd, scale, shift, (const float*)z, count, act, (float*)out);
+    else
+        PAI_LAUNCH(bn_fin_apply_k<bf16_t>, grid, dim3(1024), 0, s, stats, rows, wide, C, (double)count, gamma, beta, eps, momentum,
+                   n_updates, running_mean, running_var, nbt, mean, rstd, scale, shift, (const bf16_t*)z, count, act, (bf16_t*)out);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bn_bwd_fin_apply(int dtype, const float* partials, int rows, int C, float* sums, float* dgamma, float* dbeta,
+                            const void* du, const void* z, int64_t M, const float* mean, const float* rstd,
+                            const float* gamma, void* dz, hipStream_t s) {
+    const dim3 grid(C / 64, cdiv(M, FA_ROWS));
+    const float inv_m = (float)(1.0 / (double)M);
+    if (dtype == PAI_F32)
+        PAI_LAUNCH(bn_bwd_fin_apply_k<float>, grid, dim3(1024), 0, s, partials, rows, C, sums, dgamma, dbeta, (const float*)du,
+                   (const float*)z, M, inv_m, mean, rstd, gamma, (float*)dz);
+    else
+        PAI_LAUNCH(bn_bwd_fin_apply_k<bf16_t>, grid, dim3(1024), 0, s, partials, rows, C, sums, dgamma, dbeta, (const bf16_t*)du,
+                   (const bf16_t*)z, M, inv_m, mean, rstd, gamma, (bf16_t*)dz);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- activation backward without a norm ------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_k(const T* g1, int act1, const T* g2, int act2, const T* a,

@@ -174,6 +174,15 @@ struct FwdArgs {
     int bact1, bact2;
     float* bpart;
 };
+// BatchNorm finalize + apply in one launch for small layers (bn.hip)
+bool bn_fuse_small_ok(int rows, int64_t M, int C);
+int launch_bn_fin_apply(int dtype, const float* stats, int rows, int C, int64_t count, const float* gamma, const float* beta,
+                        float eps, float momentum, int n_updates, float* running_mean, float* running_var, int64_t* nbt,
+                        float* mean, float* rstd, float* scale, float* shift, const void* z, int act, void* out,
+                        hipStream_t s);
+int launch_bn_bwd_fin_apply(int dtype, const float* partials, int rows, int C, float* sums, float* dgamma, float* dbeta,
+                            const void* du, const void* z, int64_t M, const float* mean, const float* rstd,
+                            const float* gamma, void* dz, hipStream_t s);
 int fwd_mfma_ksplit_effective(const GG& g);     // the K split launch_fwd_mfma uses with the registered workspace
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
