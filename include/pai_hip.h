@@ -571,6 +571,10 @@ int pai_comm_destroy(void* comm);
  *     eager launch of that step.  Everything else step-dependent already lives on the device.
  *   - pai_allreduce calls are recorded too (the data-parallel step as one plan per rank).
  *   - one plan may be recorded at a time per process; replay is not re-entrant per plan.
+ *   - while a plan is being recorded EVERY launch of the library in the process is appended, whichever thread or device
+ *     made it: keep unrelated users of the library (a metrics / validation thread, a second model, another in-process
+ *     rank) quiet between pai_plan_begin and pai_plan_end.  pai_plan_run must be called with the device current on
+ *     which the plan was recorded (checked since ABI 131).
  * pai_plan_info: launches = kernel + memset + collective nodes, waits = stream-wait edges, streams = distinct streams.
  * ------------------------------------------------------------------------- */
 typedef struct pai_plan_s* pai_plan_t;
