@@ -436,14 +436,20 @@ TILE = ("gg_fwd_mfma_k<128, 128, false, false, 64>", "gg_fwd_mfma_k<128, 64, fal
         "gg_fwd_mfma_k<128, 128, true, true, 64>", "gg_fwd_mfma_k<128, 64, true, false, 64>")
 WG = ("gg_wgrad_mfma_k<128>", "gg_wgrad_mfma_k<64>")
 SAME_CASES = [
-    ("res_1x1_64_128", 1, 4, 256, 256, 64, 0, 128, TILE, TILE, WG),           # ResidualBlockNeXt: 1 x 1 up / down projections
-    ("res_1x1_128_64", 1, 4, 256, 256, 128, 0, 64, TILE, TILE, WG),
-    ("res_1x1_cat", 1, 4, 128, 128, 64, 64, 128, TILE, TILE, WG),             # decoder: two sources read as one concatenation
+    # ResidualBlockNeXt 1 x 1 up / down projections and skips at the fine levels: the streaming pointwise kernel (gg_pw.hip)
+    ("res_1x1_64_128", 1, 4, 256, 256, 64, 0, 128, ("pwx_k<64, 128>",), ("pwx_k<128, 64>",), WG),
+    ("res_1x1_128_64", 1, 4, 256, 256, 128, 0, 64, ("pwx_k<128, 64>",), ("pwx_k<64, 128>",), WG),
+    ("res_1x1_cat", 1, 4, 128, 128, 64, 64, 128, ("pwx_k<128, 128>",), ("pwx_k<128, 128>",), WG),   # decoder: two sources read as one concatenation
+    ("res_1x1_cat_64", 1, 4, 128, 128, 64, 64, 64, ("pwx_k<128, 64>",), ("pwx_k<64, 128>",), WG),   # its skip convolution
+    ("res_1x1_256_64", 1, 2, 128, 128, 128, 128, 64, ("pwx_k<256, 64>",), ("pwx_k<64, 256>",), WG), # level-1 decoder skip (128 | 128 -> 64)
+    ("res_1x1_64_64", 1, 2, 128, 128, 64, 0, 64, ("pwx_k<64, 64>",), ("pwx_k<64, 64>",), WG),
+    ("res_1x1_ragged", 1, 5, 100, 37, 64, 64, 128, ("pwx_k<128, 128>",), ("pwx_k<128, 128>",), WG + ("gg_simt",)),   # 18500 pixels: partial group, partial batch
+    ("res_1x1_small", 1, 4, 32, 32, 64, 0, 128, TILE, TILE, WG),              # < 16384 pixels: the tile kernels
     ("tr_3x3_cat", 3, 8, 128, 128, 64, 64, 64, TILE, TILE, WG),               # TransUNet decoder block, configs[4] width
     ("tr_3x3_128", 3, 8, 32, 32, 128, 128, 128, TILE, TILE, WG),
     ("tr_3x3_16", 3, 4, 256, 256, 16, 0, 16, ("small_mfma_bf16",), ("small_mfma_bf16",), WG),      # 16-channel encoder block
     ("gate_1x1_64_32", 1, 8, 128, 128, 64, 0, 32, ("thin_mfma_bf16",), ("thin_mfma_bf16",), WG),   # AttentionBlock W_x / W_g (pw_k)
-    ("gate_1x1_128_64", 1, 8, 64, 64, 128, 0, 64, TILE, TILE, WG),
+    ("gate_1x1_128_64", 1, 8, 64, 64, 128, 0, 64, ("pwx_k<128, 64>",), ("pwx_k<64, 128>",), WG),
     ("in_conv_3x3", 3, 4, 256, 256, 1, 0, 64, ("thin_mfma_bf16",), None, ("thin_mfma_bf16",)),   # 1 -> 64 in_conv (no dgrad)
     ("out_conv_3x3", 3, 4, 256, 256, 64, 0, 1, ("thin_mfma_bf16",), ("thin_mfma_bf16",), ("thin_mfma_bf16",)),
 ]
@@ -483,6 +489,17 @@ def test_same_convolutions_of_the_other_families_bit_exact(pai, case):
         yo = torch.full((N * H * W * K,), 7.0, dtype=dtype, device=dev())
         ops.conv_fwd(d, X1, X2, wf, b.detach().to(dev()), y_raw=yo)
         got_y = from_nhwc(yo, N, H, W, K)
+        # the same launch with BatchNorm partial statistics (fp32 accumulators: integers)
+        yo2 = torch.full_like(yo, 7.0)
+        stats = torch.full((ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * K,), float("nan"), device=dev())
+        ops.conv_fwd(d, X1, X2, wf, b.detach().to(dev()), y_raw=yo2, stats=stats)
+        torch.cuda.synchronize()
+        assert torch.equal(yo2, yo), name
+        rows = ops.conv_fwd_stats_rows(d)
+        st = stats[:rows * 2 * K].view(rows, 2, K).double().sum(0).cpu()
+        yd = y.detach().double()
+        assert float((st[0] - yd.sum((0, 2, 3))).abs().max()) <= 1e-6 * float(yd.abs().sum()), name
+        assert float((st[1] - (yd * yd).sum((0, 2, 3))).abs().max()) <= 1e-6 * float((yd * yd).sum()), name
     else:       # 1-channel outputs leave in fp32 (the head of the network)
         yo = torch.full((N * H * W * K,), 7.0, dtype=torch.float32, device=dev())
         ops.conv_fwd(d, X1, X2, wf, b.detach().to(dev()), y_f32=yo)

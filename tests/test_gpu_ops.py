@@ -92,10 +92,12 @@ def test_batchnorm_forward_backward(pai, dtype, shape):
     assert rel_err(from_nhwc(A, N, H, W, C), want) < tol
 
 
-def test_bn_finalize_two_stage_reduction(pai):
-    """More than 64 partial rows takes the two-stage fp64 path."""
+@pytest.mark.parametrize("C,R", [(64, 300), (128, 2049), (128, 32768), (64, 10007), (8, 5000)], ids=str)
+def test_bn_finalize_many_partial_rows(pai, C, R):
+    """More than 16 partial rows: the wide fp64 tree; more than 2048 (the 1 x 1 convolutions of the residual U-Net at
+    512 x 512 write 32768): chunk sums over the whole chip first, in the scratch rows behind the partials."""
     from thesis_pai_reconstruction_amd import ops
-    C, R, M = 64, 300, 300 * 128
+    M = R * 128
     rng = np.random.default_rng(0)
     parts = rng.standard_normal((R, 2, C)).astype(np.float32)
     parts[:, 1] = np.abs(parts[:, 1]) * 200 + 300

@@ -440,6 +440,7 @@ extern "C" int pai_conv_fwd_stats_rows(const pai_conv_desc* d) {
     a.stats = (float*)1;
     if (grouped3_ok(d->dtype, g, a)) return grouped3_rows(g);
     if (pw_ok(d->dtype, g, a)) return pw_rows(g);
+    if (pwx_ok(d->dtype, g, a)) return pwx_rows(g);
     if (!thin_fwd_ok(d->dtype, g, a) && !fwd_rowdot_ok(g, a) && !use_mfma(d->dtype, g, a) && small_ok(d->dtype, g, a))
         return small_rows(g);
     int mt = use_mfma(d->dtype, g, a) ? fwd_mfma_mtiles(g) : fwd_simt_mtiles(g);
@@ -476,6 +477,7 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
         if (head_dgrad_ok(d->dtype, g, a1)) return 4;
     }
     if (fwd_rowdot_ok(g, a)) return 1;
+    if (pwx_ok(d->dtype, g, a)) return 7;
     if (fwd_mfma_ok(d->dtype, g, a))
         return ((g.Cout % 128) == 0 && (g.D2 == 0 || (g.D1 % 128) == 0)) ? 2 : 3;
     if (small_ok(d->dtype, g, a)) return 5;
@@ -483,7 +485,8 @@ extern "C" int pai_conv_kernel_id(const pai_conv_desc* d, int op) {
 }
 
 extern "C" int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, int name_len) {
-    static const char* fam[7] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16", "small_mfma_bf16", "grouped3_k"};
+    static const char* fam[8] = {"gg_simt", "gg_rowdot", "gg_mfma", "gg_mfma", "thin_mfma_bf16", "small_mfma_bf16", "grouped3_k",
+                                 "pwx_k"};
     const int id = pai_conv_kernel_id(d, op);
     if (id < 0 || !name || name_len <= 0) return -1;
     const char* n = (id == 6 && op == 2) ? "grouped3_wgrad_k" : fam[id];
@@ -491,6 +494,11 @@ extern "C" int pai_conv_kernel_name(const pai_conv_desc* d, int op, char* name, 
         GG g;
         if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
         n = op == 2 ? wgrad_mfma_kernel_name(g) : fwd_mfma_kernel_name(g);
+    }
+    if (id == 7) {
+        GG g;
+        if (op == 1 ? gg_build_dgrad(d, &g) : gg_build_fwd(d, &g)) return -1;
+        n = pwx_kernel_name(g);
     }
     strncpy(name, n, name_len - 1);
     name[name_len - 1] = 0;
@@ -512,6 +520,7 @@ static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     if (head_dgrad_ok(dtype, g, a)) return launch_head_dgrad(g, a, s);
     if (thin_dgrad_ok(dtype, g, a)) return launch_thin_dgrad(g, a, s);
     if (fwd_rowdot_ok(g, a)) return launch_fwd_rowdot(dtype, g, a, s);
+    if (pwx_ok(dtype, g, a)) return launch_pwx(g, a, s);             // big pointwise layers: streaming kernel
     if (use_mfma(dtype, g, a)) return launch_fwd_mfma(g, a, s);
     if (small_ok(dtype, g, a)) return launch_small(g, a, s);
     return launch_fwd_simt(dtype, g, a, s);

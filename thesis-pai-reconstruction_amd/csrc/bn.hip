@@ -5,19 +5,30 @@
 // compute them.
 #include "common.h"
 
-constexpr int STAGE_ROWS = 64;
+constexpr int STAGE_ROWS = 64;        // (scratch rows behind the partials: pai_bn_stats_buffer_rows keeps the old 2 x 64)
+constexpr int BIG_ROWS = 2048;        // more partial rows than this: chunk sums first
+constexpr int BIG_CHUNKS = 256;
 
 // ---- forward statistics --------------------------------------------------------------
-__global__ void bn_stats_stage1_k(const float* stats, int R, int C2, int per, double* out) {
+// Partial rows of a big layer (32768 rows of 2 x 128 floats behind a 1 x 1 convolution of the residual U-Net at 512 x 512:
+// 33 MB) summed into BIG_CHUNKS fp64 rows by the whole chip, coalesced -- bn_finalize_wide_k alone walks them with C / 8
+// workgroups (16 CUs, 149 us).
+__global__ __launch_bounds__(256) void bn_stats_chunks_k(const float* stats, int R, int C2, int per, double* out) {
     const int col = blockIdx.y * 256 + threadIdx.x;
     if (col >= C2) return;
     const int r0 = blockIdx.x * per, r1 = min(R, r0 + per);
-    double s = 0.0;
-    for (int r = r0; r < r1; ++r) s += (double)stats[(size_t)r * C2 + col];
-    out[(size_t)blockIdx.x * C2 + col] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        const float a = stats[(size_t)r * C2 + col], b = stats[(size_t)(r + 1) * C2 + col];
+        const float c = stats[(size_t)(r + 2) * C2 + col], d = stats[(size_t)(r + 3) * C2 + col];
+        s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+    }
+    for (; r < r1; ++r) s0 += (double)stats[(size_t)r * C2 + col];
+    out[(size_t)blockIdx.x * C2 + col] = (s0 + s1) + (s2 + s3);
 }
 
-__global__ void bn_finalize_k(const float* stats, const double* stage, int R, int C, double count,
+__global__ void bn_finalize_k(const float* stats, int R, int C, double count,
                               const float* gamma, const float* beta, float eps, float momentum,
                               int n_updates, float* running_mean, float* running_var,
                               int64_t* nbt, float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
@@ -25,16 +36,9 @@ __global__ void bn_finalize_k(const float* stats, const double* stage, int R, in
     if (c == 0 && nbt) *nbt += n_updates;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    if (stage) {
-        for (int r = 0; r < STAGE_ROWS; ++r) {
-            s += stage[(size_t)r * 2 * C + c];
-            q += stage[(size_t)r * 2 * C + C + c];
-        }
-    } else {
-        for (int r = 0; r < R; ++r) {
-            s += (double)stats[(size_t)r * 2 * C + c];
-            q += (double)stats[(size_t)r * 2 * C + C + c];
-        }
+    for (int r = 0; r < R; ++r) {
+        s += (double)stats[(size_t)r * 2 * C + c];
+        q += (double)stats[(size_t)r * 2 * C + C + c];
     }
     const double mean = s / count;
     double var = q / count - mean * mean;
@@ -58,12 +62,14 @@ __global__ void bn_finalize_k(const float* stats, const double* stage, int R, in
     }
 }
 
-extern "C" int pai_bn_stats_buffer_rows(int rows) { return rows + 2 * STAGE_ROWS; }
+// rows of the partial-sum buffer: the partials + scratch (BIG_CHUNKS fp64 rows for the chunk sums of a big layer)
+extern "C" int pai_bn_stats_buffer_rows(int rows) { return rows + (rows > BIG_ROWS ? 2 * BIG_CHUNKS : 2 * STAGE_ROWS); }
 
 // One-launch finalize for many partial rows: 8 channels x 128 row lanes per block sum the rows in fp64 (as the
 // backward finalize does), then 8 threads turn the totals into mean / rstd / scale / shift and advance the running
 // statistics.  Replaces the stage-1 + finalize pair (two dependent tiny launches per BatchNorm layer).
-__global__ __launch_bounds__(1024) void bn_finalize_wide_k(const float* stats, int R, int C, double count,
+template <typename P>     // P: float partial rows, or the fp64 chunk sums of bn_stats_chunks_k
+__global__ __launch_bounds__(1024) void bn_finalize_wide_k(const P* stats, int R, int C, double count,
                                                            const float* gamma, const float* beta, float eps,
                                                            float momentum, int n_updates, float* running_mean,
                                                            float* running_var, int64_t* nbt, float* mean_o,
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_wide_k(const float* stats, i
     if (c < C) {
         int r = rl;
         for (; r + 7 * 128 < R; r += 8 * 128) {      // eight rows in flight per lane (see bn_bwd_finalize_k)
-            float a[8], b[8];
+            P a[8], b[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 a[u] = stats[(size_t)(r + u * 128) * 2 * C + c];
@@ -133,24 +139,26 @@ extern "C" int pai_bn_finalize(const float* stats, int rows, int C, int64_t coun
     PAI_CHECK(stats && mean && rstd && scale && shift, "pai_bn_finalize: null pointer");
     PAI_CHECK(rows > 0 && C > 0 && count > 0, "pai_bn_finalize: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    const double* stage = nullptr;
+    if (rows > BIG_ROWS) {
+        // scratch = the 2 * BIG_CHUNKS float rows that follow the partials (pai_bn_stats_buffer_rows)
+        double* chunks = (double*)(stats + (size_t)rows * 2 * C);
+        const int per = cdiv(rows, BIG_CHUNKS);
+        PAI_LAUNCH(bn_stats_chunks_k, dim3(BIG_CHUNKS, cdiv(2 * C, 256)), dim3(256), 0, s, stats, rows, 2 * C, per, chunks);
+        PAI_LAUNCH_CHECK();
+        PAI_LAUNCH(bn_finalize_wide_k<double>, dim3(cdiv(C, 8)), dim3(1024), 0, s, (const double*)chunks, cdiv(rows, per), C,
+                   (double)count, gamma, beta, eps, momentum, n_updates, running_mean, running_var, num_batches_tracked, mean,
+                   rstd, scale, shift);
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     if (rows > 16) {
-        PAI_LAUNCH(bn_finalize_wide_k, dim3(cdiv(C, 8)), dim3(1024), 0, s, stats, rows, C, (double)count, gamma,
+        PAI_LAUNCH(bn_finalize_wide_k<float>, dim3(cdiv(C, 8)), dim3(1024), 0, s, stats, rows, C, (double)count, gamma,
                            beta, eps, momentum, n_updates, running_mean, running_var, num_batches_tracked, mean, rstd,
                            scale, shift);
         PAI_LAUNCH_CHECK();
         return 0;
     }
-    if (rows > STAGE_ROWS) {
-        // scratch = the 2*STAGE_ROWS float rows that follow the partials (pai_bn_stats_buffer_rows)
-        double* scratch = (double*)(stats + (size_t)rows * 2 * C);
-        const int per = cdiv(rows, STAGE_ROWS);
-        PAI_LAUNCH(bn_stats_stage1_k, dim3(STAGE_ROWS, cdiv(2 * C, 256)), dim3(256), 0, s, stats,
-                           rows, 2 * C, per, scratch);
-        PAI_LAUNCH_CHECK();
-        stage = scratch;
-    }
-    PAI_LAUNCH(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, s, stats, stage, rows, C,
+    PAI_LAUNCH(bn_finalize_k, dim3(cdiv(C, 64)), dim3(64), 0, s, stats, rows, C,
                        (double)count, gamma, beta, eps, momentum, n_updates, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift);
     PAI_LAUNCH_CHECK();
@@ -208,6 +216,7 @@ extern "C" int pai_bn_apply(int dtype, const void* z, int64_t M, int C, const fl
     PAI_CHECK(C % 8 == 0, "pai_bn_apply: C=%d must be a multiple of 8", C);
     const int64_t nvec = M * C / 8;
     hipStream_t s = (hipStream_t)stream;
+    if (const int r = ew_stream_bn_apply(dtype, z, M, C, scale, shift, act, out, s); r >= 0) return r;
     if (dtype == PAI_F32)
         PAI_LAUNCH(bn_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)z, nvec, C,
                            scale, shift, act, (float*)out);
@@ -258,6 +267,8 @@ extern "C" int pai_bn2_add_act(int dtype, const void* za, const float* scale_a, 
         PAI_CHECK(t == PAI_ACT_NONE || t == PAI_ACT_RELU || t == PAI_ACT_LRELU, "pai_bn2_add_act: act=%d", t);
     const int64_t nvec = M * C / 8;
     hipStream_t s = (hipStream_t)stream;
+    if (const int r = ew_stream_bn2_add_act(dtype, za, scale_a, shift_a, zb, scale_b, shift_b, M, C, act_a, act, out, s); r >= 0)
+        return r;
     if (dtype == PAI_F32)
         PAI_LAUNCH(bn2_add_act_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)za, scale_a, shift_a,
                    (const float*)zb, scale_b, shift_b, nvec, C, act_a, act, (float*)out);
@@ -460,7 +471,11 @@ extern "C" int pai_bn_bwd_reduce(int dtype, const void* g1, int act1, const void
     hipStream_t s = (hipStream_t)stream;
     const int rows = pai_bn_bwd_partial_rows(M);
     const int64_t rpb = (M + rows - 1) / rows;
-    if (dtype == PAI_F32)
+    int taken = -1;
+    if (!g2 && !a && !du) taken = ew_stream_bn_bwd_reduce(dtype, g1, PAI_ACT_NONE, z, M, C, nullptr, nullptr, mean, rstd, partials, rows, s);
+    if (taken > 0) return taken;
+    if (taken == 0) {
+    } else if (dtype == PAI_F32)
         PAI_LAUNCH(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
                            (const float*)g2, act2, (const float*)a, (const float*)z, M, C, rpb, mean, rstd,
                            (float*)du, partials, nullptr, nullptr);
@@ -488,7 +503,11 @@ extern "C" int pai_bn_bwd_reduce_affine(int dtype, const void* g1, int act1, con
     hipStream_t s = (hipStream_t)stream;
     const int rows = pai_bn_bwd_partial_rows(M);
     const int64_t rpb = (M + rows - 1) / rows;
-    if (dtype == PAI_F32)
+    int taken = -1;
+    if (!g2 && !du) taken = ew_stream_bn_bwd_reduce(dtype, g1, act1, z, M, C, scale, shift, mean, rstd, partials, rows, s);
+    if (taken > 0) return taken;
+    if (taken == 0) {
+    } else if (dtype == PAI_F32)
         PAI_LAUNCH(bn_bwd_reduce_k<float>, dim3(rows), dim3(256), 0, s, (const float*)g1, act1,
                            (const float*)g2, act2, (const float*)nullptr, (const float*)z, M, C, rpb, mean, rstd,
                            (float*)du, partials, scale, shift);
@@ -548,6 +567,8 @@ extern "C" int pai_bn_bwd_apply(int dtype, const void* du, const void* z, int64_
     const int64_t nvec = M * C / 8;
     const float inv_m = (float)(1.0 / (double)M);
     hipStream_t s = (hipStream_t)stream;
+    if (const int r = ew_stream_bn_bwd_apply(dtype, du, PAI_ACT_NONE, z, M, C, nullptr, nullptr, mean, rstd, gamma, sums, dz, s); r >= 0)
+        return r;
     if (dtype == PAI_F32)
         PAI_LAUNCH(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)du,
                            (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz, -1, nullptr, nullptr);
@@ -569,6 +590,7 @@ extern "C" int pai_bn_bwd_apply_affine(int dtype, const void* g1, int act1, cons
     const int64_t nvec = M * C / 8;
     const float inv_m = (float)(1.0 / (double)M);
     hipStream_t s = (hipStream_t)stream;
+    if (const int r = ew_stream_bn_bwd_apply(dtype, g1, act1, z, M, C, scale, shift, mean, rstd, gamma, sums, dz, s); r >= 0) return r;
     if (dtype == PAI_F32)
         PAI_LAUNCH(bn_bwd_apply_k<float>, dim3(ew_grid(nvec)), dim3(256), 0, s, (const float*)g1,
                            (const float*)z, nvec, C, inv_m, mean, rstd, gamma, sums, (float*)dz, act1, scale, shift);

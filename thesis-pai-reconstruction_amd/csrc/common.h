@@ -183,6 +183,17 @@ int launch_bn_fin_apply(int dtype, const float* stats, int rows, int C, int64_t 
 int launch_bn_bwd_fin_apply(int dtype, const float* partials, int rows, int C, float* sums, float* dgamma, float* dbeta,
                             const void* du, const void* z, int64_t M, const float* mean, const float* rstd,
                             const float* gamma, void* dz, hipStream_t s);
+// streaming forms of the big bf16 tensor passes (ew_stream.hip): 0 = launched, > 0 = error, -1 = not taken
+int ew_stream_bn_apply(int dtype, const void* z, int64_t M, int C, const float* scale, const float* shift, int act, void* out,
+                       hipStream_t s);
+int ew_stream_bn2_add_act(int dtype, const void* za, const float* sca, const float* sha, const void* zb, const float* scb,
+                          const float* shb, int64_t M, int C, int act_a, int act, void* out, hipStream_t s);
+int ew_stream_add_act(int dtype, const void* a, const void* b, int64_t numel, int act, void* out, hipStream_t s);
+int ew_stream_bn_bwd_reduce(int dtype, const void* g, int act, const void* z, int64_t M, int C, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, float* partials, int rows, hipStream_t s);
+int ew_stream_bn_bwd_apply(int dtype, const void* g, int act, const void* z, int64_t M, int C, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                           void* dz, hipStream_t s);
 int fwd_mfma_ksplit_effective(const GG& g);     // the K split launch_fwd_mfma uses with the registered workspace
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
@@ -214,6 +225,11 @@ bool fwd_mfma_ok(int dtype, const GG& g, const FwdArgs& a);
 bool pw_ok(int dtype, const GG& g, const FwdArgs& a);
 int pw_rows(const GG& g);
 int launch_pw(const GG& g, const FwdArgs& a, hipStream_t s);
+// streaming pointwise convolution of the residual blocks' fine levels (gg_pw.hip)
+bool pwx_ok(int dtype, const GG& g, const FwdArgs& a);
+int pwx_rows(const GG& g);
+int launch_pwx(const GG& g, const FwdArgs& a, hipStream_t s);
+const char* pwx_kernel_name(const GG& g);
 bool fwd_rowdot_ok(const GG& g, const FwdArgs& a);
 // 16- / 32-channel 1x1 and 3x3 convolutions on the matrix cores, no LDS (gg_small.hip)
 bool small_ok(int dtype, const GG& g, const FwdArgs& a);

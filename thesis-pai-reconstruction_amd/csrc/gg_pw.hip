@@ -1,0 +1,194 @@
+// Streaming pointwise (1 x 1) convolution: forward and input gradient of the bottleneck / expansion / skip convolutions of
+// the residual blocks at the fine levels (reference models/res_unet.py:143-147, 74: ResidualBlockNeXt 1x1 -> grouped 3x3 ->
+// 1x1, conv_skip), bf16.
+//
+//   out[M][COUT] = in[M][CIN] x W[COUT][CIN]^T (+ bias)        CIN x COUT <= 128 x 128
+//
+// At 512 x 512 x 16 images these layers move 1.6 GB for 69-137 GFLOP: HBM-bound by 5-10x.  The 128 x 128 tile kernel
+// (gg_fwd_mfma_k: operands through LDS, a staged epilogue, one tile per workgroup) ran them at 2.2-2.6 TB/s; this one
+// follows pw_k (the attention gate's kernel, gg_mfma.hip) and the streaming rules of ew_stream.hip:
+//   * no LDS for the operands: a wave keeps the WHOLE filter in registers as the MFMA's A operand (rows permuted so that a
+//     lane ends up with COUT / 4 consecutive channels of one pixel) and streams groups of 16 pixels as the B operand -- one
+//     16-byte load per lane and 32 input channels, whole rows per instruction;
+//   * T groups per batch and the NEXT batch's loads issued before the current batch's MFMAs: 16-64 KB in flight per CU;
+//   * the input may be two tensors read as one concatenation (decoder blocks), the output may split into two (their input
+//     gradients);
+//   * bias, BatchNorm partial statistics (one row per workgroup: <= 2048 rows instead of one per 128 pixels).
+#include "common.h"
+#include "gg_tile.h"
+
+namespace {
+constexpr int PWX_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ float dpp_add16(float u) {      // sum over the 16 lanes of a row (all lanes get the total)
+    u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, false));
+    u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x4E, 0xF, 0xF, false));
+    u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x141, 0xF, 0xF, false));
+    u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0x140, 0xF, 0xF, false));
+    return u;
+}
+}  // namespace
+
+// the instantiations of launch_pwx: the filter fits the registers of a wave (CIN x COUT <= 128 x 128)
+bool pwx_shape_ok(int cin, int cout) {
+    return (cin == 64 && (cout == 64 || cout == 128 || cout == 256)) || (cin == 128 && (cout == 64 || cout == 128)) ||
+           (cin == 256 && cout == 64);
+}
+
+bool pwx_ok(int dtype, const GG& g, const FwdArgs& a) {
+    if (dtype != PAI_BF16 || g.ntaps != 1 || g.nphase != 1 || g.S != 1 || g.OS != 1 || g.gslice) return false;
+    if (!pwx_shape_ok(g.Cin, g.Cout) || (g.C1 % 32) || (g.C2 % 32)) return false;
+    if (g.D2 ? ((g.D1 % 8) || (g.D2 % 8) || g.D1 + g.D2 != g.Cout) : false) return false;
+    if (g.relu1 || g.relu2 || a.yf32 || a.skip_d1 || a.bz) return false;
+    if (!a.y1 || a.yact) return false;                              // the raw output only (what a BatchNorm or a sum follows)
+    if ((int64_t)g.M < 16384) return false;                         // small images: the tile kernels (split-K) do better
+    return pai_tunable("pwx", 1) != 0;
+}
+
+int pwx_rows(const GG& g) {
+    const int64_t b = ((int64_t)g.M + 255) / 256;
+    return (int)(b > PWX_MAX_BLOCKS ? PWX_MAX_BLOCKS : (b < 1 ? 1 : b));
+}
+
+template <int CIN, int COUT, int T, bool STATS>
+__global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wave) {
+    constexpr int KB = CIN / 32, NTT = COUT / 16, CL = COUT / 4, NCH = CL / 8;
+    __shared__ __attribute__((aligned(16))) float sbias[COUT];
+    __shared__ float sred[4][2][STATS ? COUT : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* x1 = (const bf16_t*)a.x1;
+    const bf16_t* x2 = (const bf16_t*)a.x2;
+    const bf16_t* w = (const bf16_t*)a.w;
+    const int C1 = g.C1, C2 = g.C2;
+    for (int c = tid; c < COUT; c += 256) sbias[c] = a.bias ? a.bias[c] : 0.f;
+    // filter: MFMA row (nt, i = fr) carries output channel CL (i >> 2) + 4 nt + (i & 3)
+    bf8_t wf[NTT][KB];
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            wf[nt][kb] = *(const bf8_t*)(w + (size_t)(CL * (fr >> 2) + 4 * nt + (fr & 3)) * CIN + kb * 32 + fq * 8);
+    const int c0 = CL * fq;                  // this lane's first output channel
+    // destination of this lane's 8-channel chunks (the raw output, split D1 | D2 for the input gradient of a concatenation)
+    bf16_t* dst[NCH];
+    int dstride[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+        const int ch = c0 + 8 * h;
+        if (g.D2 && ch >= g.D1) { dst[h] = (bf16_t*)a.y2 + (ch - g.D1); dstride[h] = g.D2; }
+        else { dst[h] = (bf16_t*)a.y1 + ch; dstride[h] = g.D2 ? g.D1 : COUT; }
+    }
+    float s1[STATS ? CL : 1], s2[STATS ? CL : 1];
+    if (STATS) {
+#pragma unroll
+        for (int c = 0; c < CL; ++c) s1[c] = s2[c] = 0.f;
+    }
+    __syncthreads();
+    const int64_t ngroups = ((int64_t)g.M + 15) / 16;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wid) * groups_per_wave;
+    const int64_t g1 = min(ngroups, g0 + groups_per_wave);
+
+    auto load = [&](int64_t gb, bf8_t (*xb)[KB]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t pix = (gb + t) * 16 + fr;
+            const int64_t pc = (gb + t < g1 && pix < g.M) ? pix : 0;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const bf16_t* src = kb * 32 < C1 ? x1 + pc * C1 + kb * 32 + fq * 8 : x2 + pc * C2 + (kb * 32 - C1) + fq * 8;
+                xb[t][kb] = *(const bf8_t*)src;
+            }
+        }
+    };
+    auto compute = [&](int64_t gb, bf8_t (*xb)[KB]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (gb + t >= g1) break;
+            const int64_t pix = (gb + t) * 16 + fr;
+            const bool valid = pix < g.M;
+            f4_t acc[NTT];
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                acc[nt] = *(const f4_t*)&sbias[c0 + 4 * nt];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kb], xb[t][kb], acc[nt], 0, 0, 0);
+            }
+            // lane: pixel `pix`, channels c0 + 4 nt + r
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) {
+                unsigned pk[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nt = 2 * h + j;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[nt][r];
+                        if (STATS && valid) { s1[4 * nt + r] += v[r]; s2[4 * nt + r] = fmaf(v[r], v[r], s2[4 * nt + r]); }
+                    }
+                    pk[2 * j] = pk2bf(v[0], v[1]);
+                    pk[2 * j + 1] = pk2bf(v[2], v[3]);
+                }
+                if (valid) *(uint4*)(dst[h] + pix * dstride[h]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        }
+    };
+
+    bf8_t xa[T][KB], xc[T][KB];
+    if (g0 < g1) load(g0, xa);
+    for (int64_t gb = g0; gb < g1; gb += 2 * T) {
+        if (gb + T < g1) load(gb + T, xc);
+        compute(gb, xa);
+        if (gb + 2 * T < g1) load(gb + 2 * T, xa);
+        if (gb + T < g1) compute(gb + T, xc);
+    }
+    if (!STATS) return;
+    // sum over the 16 pixels of each lane row (DPP), then over the 4 waves; one partial row per workgroup
+#pragma unroll
+    for (int c = 0; c < CL; ++c) {
+        const float u = dpp_add16(s1[c]), q = dpp_add16(s2[c]);
+        if (fr == 0) { sred[wid][0][c0 + c] = u; sred[wid][1][c0 + c] = q; }
+    }
+    __syncthreads();
+    for (int c = tid; c < COUT; c += 256) {
+        float u = 0.f, q = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { u += sred[wv][0][c]; q += sred[wv][1][c]; }
+        float* row = a.stats + (size_t)blockIdx.x * 2 * COUT;
+        row[c] = u;
+        row[COUT + c] = q;
+    }
+}
+
+template <int CIN, int COUT, int T>
+static void pwx_launch(const GG& g, const FwdArgs& a, int blocks, int gpw, hipStream_t s) {
+    if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    else PAI_LAUNCH((pwx_k<CIN, COUT, T, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+}
+
+int launch_pwx(const GG& g, const FwdArgs& a, hipStream_t s) {
+    const int blocks = pwx_rows(g);
+    const int64_t ngroups = ((int64_t)g.M + 15) / 16;
+    const int gpw = (int)((ngroups + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4));
+    const int ci = g.Cin, co = g.Cout;
+    if (ci == 64 && co == 64) pwx_launch<64, 64, 4>(g, a, blocks, gpw, s);
+    else if (ci == 64 && co == 128) pwx_launch<64, 128, 4>(g, a, blocks, gpw, s);
+    else if (ci == 128 && co == 64) pwx_launch<128, 64, 4>(g, a, blocks, gpw, s);
+    else if (ci == 128 && co == 128) pwx_launch<128, 128, 2>(g, a, blocks, gpw, s);
+    else if (ci == 256 && co == 64) pwx_launch<256, 64, 2>(g, a, blocks, gpw, s);
+    else if (ci == 64 && co == 256) pwx_launch<64, 256, 2>(g, a, blocks, gpw, s);
+    else {
+        pai_set_error("launch_pwx: no instantiation for %d -> %d channels", ci, co);
+        return 1;
+    }
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+const char* pwx_kernel_name(const GG& g) {
+    static thread_local char buf[48];
+    snprintf(buf, sizeof(buf), "pwx_k<%d, %d>", g.Cin, g.Cout);
+    return buf;
+}

@@ -182,6 +182,7 @@ extern "C" int pai_add_act(int dtype, const void* a, const void* b, int64_t nume
     PAI_CHECK(a && b && out && numel % 8 == 0, "pai_add_act: bad arguments");
     PAI_CHECK(act == PAI_ACT_NONE || act == PAI_ACT_RELU || act == PAI_ACT_LRELU, "pai_add_act: act=%d", act);
     const dim3 grid(ew_blocks(numel / 8));
+    if (const int r = ew_stream_add_act(dtype, a, b, numel, act, out, (hipStream_t)stream); r >= 0) return r;
     if (dtype == PAI_F32)
         PAI_LAUNCH(add_act_k<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, numel / 8, act, (float*)out);
     else
