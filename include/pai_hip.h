@@ -53,7 +53,9 @@ const char* pai_last_error(void);
  * gradient of a 3 x 3 layer defines the diagonal 16-channel blocks of dw only.  130: launch plans (pai_plan_*,
  * pai_stream_wait, pai_event_*), pai_zero_multi, pai_scale; pai_pack_frag and the pack_flags bits are gone (removed
  * experiment kernels: pack_flags MUST be zero); pai_conv_desc.reserved became .hints (PAI_HINT_SOLO).
- * 131: pai_lerp_multi (the EMA update of callbacks/ema.py), PAI_TUNE_<name> environment defaults of the tunables. */
+ * 131: pai_lerp_multi (the EMA update of callbacks/ema.py), PAI_TUNE_<name> environment defaults of the tunables.
+ * 132: input prologue (pai_conv_prologue_ok, pai_conv_fwd_pro, pai_conv_wgrad_pro); pai_bn_stats_buffer_rows grows for
+ * layers with more than 2048 partial rows (callers that size the buffer through it need no change). */
 int pai_version(void);
 /* Build-option bits.  0 since ABI 130: bit 0 used to announce the round-2 experiment kernels (and pai_pack_frag), which
  * were removed from the library. */
@@ -278,6 +280,20 @@ int pai_conv_wgrad_overwrite(const pai_conv_desc* d, const void* x1, const void*
 /* dw = ..., dbias += ...: as above for the weights; the bias gradient is added to what the caller cleared. */
 int pai_conv_wgrad_overwrite_w(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy,
                                float* dw, float* dbias, void* stream);
+
+/* ---- input prologue: Conv2d -> BatchNorm2d -> ReLU -> Conv2d without the tensor in the middle
+ * (reference models/res_unet.py:143-147, the ResNeXt block).  The SECOND convolution and its weight gradient read the raw
+ * output z of the first one as act(z * scale[c] + shift[c]) (scale / shift of pai_bn_finalize or pai_bn_eval_coeffs, act =
+ * PAI_ACT_NONE | PAI_ACT_RELU) on load: same roundings as pai_bn_apply followed by the plain call (fma, max, storage-type
+ * rounding), one tensor write and two tensor reads less per layer.  bf16, one source tensor, raw output only.
+ * pai_conv_prologue_ok: 1 when BOTH calls below serve this layer (today: pointwise layers of 64-256 channels with at least
+ * 16384 pixels and power-of-two image sizes); otherwise apply the BatchNorm as a pass of its own. */
+int pai_conv_prologue_ok(const pai_conv_desc* d);
+int pai_conv_fwd_pro(const pai_conv_desc* d, const void* x1, const void* w_fwd, const float* bias, void* y_raw,
+                     float* stats, const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
+/* overwrite: 0 = accumulate into dw / dbias, 1 = dw = ..., dbias = ... (as pai_conv_wgrad_overwrite) */
+int pai_conv_wgrad_pro(const pai_conv_desc* d, const void* x1, const void* dy, float* dw, float* dbias, int overwrite,
+                       const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
 
 /* fp32 master weights (fwd pack) -> storage-dtype fwd pack and/or dgrad pack. */
 int pai_pack_weights(int dtype, const float* w_master, int Cout, int taps, int Cin,

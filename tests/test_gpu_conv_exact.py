@@ -522,3 +522,70 @@ def test_same_convolutions_of_the_other_families_bit_exact(pai, case):
     assert torch.equal(dw.cpu().view(K, k, k, Cin).permute(0, 3, 1, 2), w.grad), name
     assert torch.equal(db.cpu(), b.grad), name
 
+
+
+# (N, H, W, Cin, Cout): pointwise layers of the ResNeXt blocks that read their input through a prologue
+PRO_CASES = [(4, 128, 128, 128, 64), (2, 128, 128, 128, 128), (4, 64, 64, 64, 128), (2, 128, 64, 64, 256), (1, 128, 128, 256, 64)]
+
+
+@pytest.mark.parametrize("act", ["relu", "none"])
+@pytest.mark.parametrize("case", PRO_CASES, ids=str)
+def test_input_prologue_equals_batchnorm_pass_then_plain_call(pai, case, act):
+    """pai_conv_fwd_pro / pai_conv_wgrad_pro (Conv2d -> BatchNorm2d -> ReLU -> Conv2d of reference models/res_unet.py:143-147
+    without the activated tensor in the middle) against pai_bn_apply followed by the plain calls, on random data: the prologue
+    forms the same bf16 values on load, so outputs and BatchNorm partial statistics are BIT-IDENTICAL and the weight / bias gradients equal up to the order of their fp32 atomics."""
+    from thesis_pai_reconstruction_amd import ops
+    N, H, W, Cin, K = case
+    dt, M = torch.bfloat16, N * H * W
+    d = ops.make_desc(dt, 0, N, H, W, Cin, 0, K, 1, 0, 0, ops.ACT_NONE, kernel=1)
+    assert ops.conv_prologue_ok(d)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    ops.ensure_wgrad_workspace([d], dev())
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(M, Cin, generator=g) * 1.3 + 0.2).to(dt).to(dev())
+    dy = torch.randn(M, K, generator=g).to(dt).to(dev())
+    w = (torch.randn(K * Cin, generator=g) * 0.1).to(dt).to(dev())
+    bias = torch.randn(K, generator=g).to(dev())
+    scale = (0.5 + torch.rand(Cin, generator=g)).to(dev())
+    shift = (torch.randn(Cin, generator=g) * 0.3).to(dev())
+    a_code = ops.ACT_RELU if act == "relu" else ops.ACT_NONE
+    rows = ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * K
+    # reference: the BatchNorm + activation as a pass of its own
+    a = torch.empty_like(z)
+    ops.bn_apply(dt, z, M, Cin, scale, shift, a_code, a)
+    y0, st0 = torch.empty(M, K, dtype=dt, device=dev()), torch.zeros(rows, device=dev())
+    ops.conv_fwd(d, a, None, w, bias, y_raw=y0, stats=st0)
+    dw0, db0 = torch.empty(K * Cin, device=dev()), torch.empty(K, device=dev())
+    ops.conv_wgrad_overwrite(d, a, None, dy, dw0, db0)
+    # prologue
+    y1, st1 = torch.empty(M, K, dtype=dt, device=dev()), torch.zeros(rows, device=dev())
+    ops.conv_fwd_pro(d, z, w, bias, y1, st1, scale, shift, a_code)
+    dw1, db1 = torch.full((K * Cin,), float("nan"), device=dev()), torch.full((K,), float("nan"), device=dev())
+    ops.conv_wgrad_pro(d, z, dy, dw1, db1, True, scale, shift, a_code)
+    y2 = torch.empty(M, K, dtype=dt, device=dev())
+    ops.conv_fwd_pro(d, z, w, bias, y2, None, scale, shift, a_code)          # without statistics
+    dw2 = torch.ones(K * Cin, device=dev())
+    ops.conv_wgrad_pro(d, z, dy, dw2, None, False, scale, shift, a_code)     # accumulating
+    torch.cuda.synchronize()
+    n = ops.conv_fwd_stats_rows(d) * 2 * K
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
+    assert torch.equal(y2.view(torch.int16), y0.view(torch.int16))
+    assert torch.equal(st1[:n], st0[:n])
+    # (the pixel splits of the weight gradient meet through fp32 atomics: equal up to their summation order)
+    tol = 2e-6 * float(dw0.abs().max()) * 8
+    assert float((dw1 - dw0).abs().max()) <= tol and float((db1 - db0).abs().max()) <= 2e-6 * float(db0.abs().max()) * 8
+    assert float((dw2 - 1.0 - dw0).abs().max()) <= tol
+    # and against fp64 on the bf16 activation (the plain call's own tolerance)
+    af = a.double()
+    want = af @ w.double().view(K, Cin).t() + bias.double()
+    assert float((y1.double() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+
+
+def test_prologue_is_refused_where_no_kernel_takes_it(pai):
+    from thesis_pai_reconstruction_amd import ops
+    dt = torch.bfloat16
+    for args, kw in (((dt, 0, 2, 32, 32, 128, 0, 64, 1, 0, 0, ops.ACT_NONE), dict(kernel=1)),        # < 16384 pixels
+                     ((dt, 0, 2, 128, 128, 64, 64, 64, 1, 0, 0, ops.ACT_NONE), dict(kernel=1)),      # two sources
+                     ((dt, 0, 2, 128, 128, 64, 0, 64, 1, 0, 0, ops.ACT_NONE), dict(kernel=3)),       # 3 x 3
+                     ((torch.float32, 0, 2, 128, 128, 64, 0, 64, 1, 0, 0, ops.ACT_NONE), dict(kernel=1))):
+        assert not ops.conv_prologue_ok(ops.make_desc(*args, **kw))

@@ -231,3 +231,40 @@ def test_side_stream_weight_gradients_equal_main_stream_ones(pai, golden_dir, dt
         # BatchNorm buffers moved between the two passes of the accumulate run, so only the scale is compared
         ratio = float(grads["accumulate"][k].norm() / g.norm().clamp_min(1e-30))
         assert g.norm() == 0 or 0.5 < ratio < 4.0, (k, ratio)
+
+
+def test_batchnorm_on_load_equals_batchnorm_as_a_pass(pai, monkeypatch, res_type="next"):
+    """bf16: where the next convolution of a block can read its input through a prologue (``nnops.can_prologue``: the 1 x 1
+    behind the grouped 3 x 3 of a ResNeXt block at >= 16384 pixels; reference models/res_unet.py:143-147), the BatchNorm + ReLU
+    in between never writes its tensor.  Against PAI_NO_PROLOGUE=1 (every BatchNorm a pass of its own): the prediction bit
+    for bit (the prologue forms the same bf16 values), the gradients up to the atomics of the weight-gradient splits."""
+    from thesis_pai_reconstruction_amd import nnops, ops
+
+    mults, n, size, seed = (1, 2), 2, 128, 5
+    x, t = synth_batch(seed + 3, n, size)
+    x, t = x.to(DEV), t.to(DEV)
+    out, grads, calls = {}, {}, {}
+    real = ops.conv_fwd_pro
+    for mode in ("pass", "load"):
+        monkeypatch.setenv("PAI_NO_PROLOGUE", "1" if mode == "pass" else "0")
+        count = [0]
+
+        def counted(*a, **k):
+            count[0] += 1
+            return real(*a, **k)
+        monkeypatch.setattr(ops, "conv_fwd_pro", counted)
+        m, _, _ = build(pai, res_type, mults, "mse", seed, dtype=torch.bfloat16)
+        pred = m.unet(x)
+        m.loss(x, pred, t).backward()
+        nnops.join_wgrads()
+        torch.cuda.synchronize()
+        out[mode], calls[mode] = pred.detach().clone(), count[0]
+        grads[mode] = {k: p.grad.detach().clone() for k, p in m.unet.named_parameters() if p.grad is not None}
+    assert calls["pass"] == 0
+    assert calls["load"] >= 1, calls       # the level-0 encoder block (2 x 128 x 128 pixels)
+    assert torch.equal(out["load"], out["pass"])
+    assert grads["load"].keys() == grads["pass"].keys()
+    scale = max(float(g.norm()) for g in grads["pass"].values())
+    for k, g in grads["pass"].items():
+        err = float((grads["load"][k] - g).norm())
+        assert err <= 1e-5 * float(g.norm()) + 1e-6 * scale, (k, err, float(g.norm()), scale)

@@ -14,7 +14,7 @@ void pai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pai_last_error(void) { return g_err; }
-extern "C" int pai_version(void) { return 131; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine; 130: launch plans; 131: pai_lerp_multi
+extern "C" int pai_version(void) { return 132; }   // 110: handles, tunables, device-side Adam step, *_take, pack multi; 120: weight-gradient workspace; 121: pai_adam_pack, pai_bn_bwd_apply_affine; 130: launch plans; 131: pai_lerp_multi; 132: input prologue (pai_conv_fwd_pro / pai_conv_wgrad_pro)
 
 // build-option bits; none since ABI 130 (bit 0 announced the round-2 experiment kernels, which were removed)
 extern "C" int pai_build_flags(void) { return 0; }
@@ -514,6 +514,11 @@ extern "C" int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d) {
 }
 
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
+    if (a.pscale) {                     // prologue on x1: only the kernels that apply it on load
+        if (pwx_ok(dtype, g, a)) return launch_pwx(g, a, s);
+        pai_set_error("pai_conv_fwd_pro: this layer takes no prologue (ask pai_conv_prologue_ok)");
+        return 1;
+    }
     if (grouped3_ok(dtype, g, a)) return launch_grouped3(g, a, s);   // grouped 3x3: 16-channel slices, patch in LDS
     if (pw_ok(dtype, g, a)) return launch_pw(g, a, s);
     if (thin_fwd_ok(dtype, g, a)) return launch_thin_fwd(g, a, s);
@@ -540,6 +545,52 @@ extern "C" int pai_conv_fwd(const pai_conv_desc* d, const void* x1, const void* 
     a.y1 = y_raw; a.y2 = nullptr; a.yact = y_act; a.yf32 = y_f32; a.stats = stats;
     a.eact = d->epilogue_act;
     return run_fwd(d->dtype, g, a, (hipStream_t)stream);
+}
+
+static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
+                           float* dbias, int overwrite, void* stream, const float* pscale = nullptr,
+                           const float* pshift = nullptr, int pact = 0);
+
+// ---- prologue: the input read as act(x * scale[c] + shift[c]) -- the BatchNorm + activation of the producing layer applied
+// on load, so that its activated tensor is never written (reference models/res_unet.py:143-147: Conv2d -> BatchNorm2d -> ReLU ->
+// Conv2d; the second convolution and its weight gradient read the first one's raw output)
+static bool prologue_fwd_ok(const pai_conv_desc* d, const GG& g) {
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y1 = (void*)1;
+    a.pscale = a.pshift = (const float*)1;
+    a.pact = PAI_ACT_RELU;
+    return pwx_ok(d->dtype, g, a);
+}
+
+extern "C" int pai_conv_prologue_ok(const pai_conv_desc* d) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return 0;
+    return prologue_fwd_ok(d, g) && wgrad_pro_ok(d->dtype, g);
+}
+
+extern "C" int pai_conv_fwd_pro(const pai_conv_desc* d, const void* x1, const void* w_fwd, const float* bias, void* y_raw,
+                                float* stats, const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
+    GG g;
+    if (gg_build_fwd(d, &g)) return 1;
+    PAI_CHECK(x1 && w_fwd && y_raw && pre_scale && pre_shift, "pai_conv_fwd_pro: null pointer");
+    PAI_CHECK(pre_act == PAI_ACT_NONE || pre_act == PAI_ACT_RELU, "pai_conv_fwd_pro: pre_act=%d (none or ReLU)", pre_act);
+    PAI_CHECK(d->C2 == 0, "pai_conv_fwd_pro: one source tensor only");
+    FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x1 = x1; a.w = w_fwd; a.bias = bias;
+    a.y1 = y_raw;
+    a.stats = stats;
+    a.pscale = pre_scale; a.pshift = pre_shift; a.pact = pre_act;
+    return run_fwd(d->dtype, g, a, (hipStream_t)stream);
+}
+
+extern "C" int pai_conv_wgrad_pro(const pai_conv_desc* d, const void* x1, const void* dy, float* dw, float* dbias,
+                                  int overwrite, const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
+    PAI_CHECK(pre_scale && pre_shift, "pai_conv_wgrad_pro: null prologue");
+    PAI_CHECK(pre_act == PAI_ACT_NONE || pre_act == PAI_ACT_RELU, "pai_conv_wgrad_pro: pre_act=%d (none or ReLU)", pre_act);
+    PAI_CHECK(d->C2 == 0, "pai_conv_wgrad_pro: one source tensor only");
+    return conv_wgrad_impl(d, x1, nullptr, dy, dw, dbias, overwrite ? 1 : 0, stream, pre_scale, pre_shift, pre_act);
 }
 
 extern "C" int pai_conv_dgrad(const pai_conv_desc* d, const void* dy, const void* w_dgrad,
@@ -707,8 +758,6 @@ extern "C" int pai_conv_dgrad_bn_apply(const pai_conv_desc* d, const void* dy, c
     return pai_bn_bwd_apply(d->dtype, du_scratch, e->z, Mo, g.D1, e->mean, e->rstd, gamma, sums, dz, stream);
 }
 
-static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
-                           float* dbias, int overwrite, void* stream);
 
 extern "C" int pai_conv_wgrad(const pai_conv_desc* d, const void* x1, const void* x2,
                               const void* dy, float* dw, float* dbias, void* stream) {
@@ -728,14 +777,30 @@ extern "C" int pai_conv_wgrad_overwrite_w(const pai_conv_desc* d, const void* x1
 }
 
 static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
-                           float* dbias, int overwrite, void* stream) {
+                           float* dbias, int overwrite, void* stream, const float* pscale, const float* pshift, int pact) {
     GG g;
     if (gg_build_fwd(d, &g)) return 1;
     PAI_CHECK(x1 && dy && dw, "pai_conv_wgrad: null pointer");
     PAI_CHECK(d->C2 == 0 || x2, "pai_conv_wgrad: C2 > 0 but x2 is null");
     WgradArgs a;
     a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0; a.overwrite_bias = 0; a.slab = nullptr;
+    a.pscale = pscale; a.pshift = pshift; a.pact = pact;
     hipStream_t s = (hipStream_t)stream;
+    if (pscale) {
+        PAI_CHECK(wgrad_pro_ok(d->dtype, g), "pai_conv_wgrad_pro: this layer takes no prologue (ask pai_conv_prologue_ok)");
+        if (overwrite && wgrad_mfma_can_overwrite(g)) {
+            a.overwrite = 1;
+            a.overwrite_bias = overwrite == 1;
+        } else if (overwrite) {
+            hipError_t e = pai::memset_async(dw, 0, (size_t)g.Cout * g.wtaps * g.Cin * sizeof(float), s);
+            PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_pro: hipMemsetAsync: %s", hipGetErrorString(e));
+            if (dbias && overwrite == 1) {
+                e = pai::memset_async(dbias, 0, (size_t)g.Cout * sizeof(float), s);
+                PAI_CHECK(e == hipSuccess, "pai_conv_wgrad_pro: hipMemsetAsync: %s", hipGetErrorString(e));
+            }
+        }
+        return launch_wgrad_mfma(g, a, s);
+    }
     if (grouped3_wgrad_ok(d->dtype, g, dbias)) {      // block-diagonal 3 x 3 filter: the diagonal blocks only (gg_group.hip)
         float* part = wgrad_slab_acquire(grouped3_wgrad_part_bytes(g));
         if (part) {

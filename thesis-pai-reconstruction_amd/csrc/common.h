@@ -173,6 +173,10 @@ struct FwdArgs {
     const float *bscale, *bshift, *bmean, *brstd;
     int bact1, bact2;
     float* bpart;
+    // Prologue (pai_conv_fwd_pro): x1 is read as pact(x1 * pscale[c] + pshift[c]) -- the BatchNorm + activation of the layer
+    // that produced it, applied on load (zero padding stays zero).  Kernels that take it: pwx_k, grouped3_k.
+    const float *pscale, *pshift;
+    int pact;
 };
 // BatchNorm finalize + apply in one launch for small layers (bn.hip)
 bool bn_fuse_small_ok(int rows, int64_t M, int C);
@@ -203,6 +207,7 @@ int pai_tunable(const char* name, int def);
 int fwd_mfma_ksplit(const GG& g);
 const char* fwd_mfma_kernel_name(const GG& g);
 const char* wgrad_mfma_kernel_name(const GG& g);
+bool wgrad_pro_ok(int dtype, const GG& g);
 int64_t fwd_mfma_workspace_bytes(const GG& g);
 // Per-device handle (pai_create / pai_bind): owner of the caller-provided split-K workspace and general scratch.
 // Entry points use the ACTIVE handle of the current HIP device (pai_ctx()); there is no process-wide buffer.
@@ -259,6 +264,9 @@ struct WgradArgs {
     int overwrite;   // dw = instead of +=; honoured by gg_wgrad_mfma_k when wgrad_mfma_can_overwrite(g)
     int overwrite_bias;   // dbias = instead of += (pai_conv_wgrad_overwrite; 0 for pai_conv_wgrad_overwrite_w: the caller cleared dbias)
     float* slab;     // set by the launcher: pixel split `s` stores its tile into slab + s * |dW| (plain stores, no atomics)
+    // prologue of x1 as in FwdArgs (pai_conv_wgrad_pro): gg_wgrad_mfma_k on pointwise layers, grouped3_wgrad_k
+    const float *pscale, *pshift;
+    int pact;
 };
 // the handle's weight-gradient workspace if it holds `bytes`, else NULL (the launch then adds with fp32 atomics)
 float* wgrad_slab_acquire(int64_t bytes);

@@ -1401,6 +1401,18 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
         const int ci = jcol % g.Cin;
         nt_relu[nt] = jcol < J && (ci < g.C1 ? g.relu1 != 0 : g.relu2 != 0);
     }
+    // prologue (pai_conv_wgrad_pro, pointwise layers): x is read as pact(x * pscale[c] + pshift[c]).  A B fragment is 8
+    // pixels of ONE input channel per lane (column j0 + 64 wn + 16 nt + fi), so scale and shift are lane scalars.  Rows past
+    // the end come from the zero line, turn into pact(pshift) and meet a zero dY row: no contribution.
+    const bool pre = a.pscale != nullptr;
+    float psc[4], psh[4];
+    const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int jcol = j0 + wn * 64 + nt * 16 + fi;
+        psc[nt] = (pre && jcol < J) ? a.pscale[jcol] : 0.f;
+        psh[nt] = (pre && jcol < J) ? a.pshift[jcol] : 0.f;
+    }
 
     // bias gradient: the workgroups of the first column tile (and first tap of each phase) see every
     // dY row of their channel tile exactly once -> column sums straight from the staged LDS tile
@@ -1475,6 +1487,21 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     if (nt_relu[nt]) bfr[nt] = relu_frag(bfr[nt]);
+            }
+            if (pre) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const uint4 u = __builtin_bit_cast(uint4, bfr[nt]);
+                    const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float lo = fmaxf(fmaf(__uint_as_float(wv[i] << 16), psc[nt], psh[nt]), plo);
+                        const float hi = fmaxf(fmaf(__uint_as_float(wv[i] & 0xffff0000u), psc[nt], psh[nt]), plo);
+                        o[i] = pk2bf(lo, hi);
+                    }
+                    bfr[nt] = __builtin_bit_cast(bf8_t, make_uint4(o[0], o[1], o[2], o[3]));
+                }
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -1849,7 +1876,16 @@ static int wgrad_mfma_splits(const GG& g, int* rows_out) {
     return splits;
 }
 
+// pointwise layers whose weight gradient can read x through a prologue (gg_wgrad_mfma_k only)
+bool wgrad_pro_ok(int dtype, const GG& g) {
+    return wgrad_mfma_ok(dtype, g) && g.ntaps == 1 && g.nphase == 1 && g.C2 == 0 && !g.gslice && !g.relu1 && !wgrad3_ok(g);
+}
+
 int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
+    if (a.pscale && !wgrad_pro_ok(PAI_BF16, g)) {
+        pai_set_error("launch_wgrad_mfma: this layer's weight gradient takes no prologue");
+        return 1;
+    }
     if (wgrad3_ok(g)) return launch_wgrad3(g, a, s);
     const bool big = (g.Cout % 128) == 0;
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
@@ -1859,7 +1895,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
     const int splits = wgrad_mfma_splits(g, &rows);
     static const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;
-    if (!no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg)) {
+    if (!a.pscale && !no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg)) {
         const int kblocks = g.M / 64;
         const int per = rows / 64;
         const int psplits = cdiv(kblocks, per);

@@ -40,6 +40,7 @@ bool pwx_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (!pwx_shape_ok(g.Cin, g.Cout) || (g.C1 % 32) || (g.C2 % 32)) return false;
     if (g.D2 ? ((g.D1 % 8) || (g.D2 % 8) || g.D1 + g.D2 != g.Cout) : false) return false;
     if (g.relu1 || g.relu2 || a.yf32 || a.skip_d1 || a.bz) return false;
+    if (a.pscale && (g.C2 || !a.pshift || (a.pact != PAI_ACT_NONE && a.pact != PAI_ACT_RELU))) return false;
     if (!a.y1 || a.yact) return false;                              // the raw output only (what a BatchNorm or a sum follows)
     if ((int64_t)g.M < 16384) return false;                         // small images: the tile kernels (split-K) do better
     return pai_tunable("pwx", 1) != 0;
@@ -50,11 +51,12 @@ int pwx_rows(const GG& g) {
     return (int)(b > PWX_MAX_BLOCKS ? PWX_MAX_BLOCKS : (b < 1 ? 1 : b));
 }
 
-template <int CIN, int COUT, int T, bool STATS>
+template <int CIN, int COUT, int T, bool STATS, bool PRE>
 __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wave) {
     constexpr int KB = CIN / 32, NTT = COUT / 16, CL = COUT / 4, NCH = CL / 8;
     __shared__ __attribute__((aligned(16))) float sbias[COUT];
     __shared__ float sred[4][2][STATS ? COUT : 1];
+    __shared__ __attribute__((aligned(16))) float spre[2][PRE ? CIN : 4];      // prologue: scale | shift per input channel
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16_t* x1 = (const bf16_t*)a.x1;
@@ -62,20 +64,25 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
     const bf16_t* w = (const bf16_t*)a.w;
     const int C1 = g.C1, C2 = g.C2;
     for (int c = tid; c < COUT; c += 256) sbias[c] = a.bias ? a.bias[c] : 0.f;
-    // filter: MFMA row (nt, i = fr) carries output channel CL (i >> 2) + 4 nt + (i & 3)
+    if (PRE) {
+        for (int c = tid; c < CIN; c += 256) { spre[0][c] = a.pscale[c]; spre[1][c] = a.pshift[c]; }
+    }
+    const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;      // prologue activation: ReLU or none
+    // filter: MFMA row (nt, i = fr) carries output channel 32 (nt >> 1) + 8 (i >> 2) + 4 (nt & 1) + (i & 3): lane (fr, fq)
+    // ends up with channels 32 h + 8 fq + [0, 8) of pixel fr for h = 0 .. NCH - 1, so that ONE store instruction (fixed h)
+    // writes 64 contiguous bytes per pixel (CL fq + 8 h, pw_k's order, gives 16-byte pieces 64 bytes apart)
     bf8_t wf[NTT][KB];
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
-            wf[nt][kb] = *(const bf8_t*)(w + (size_t)(CL * (fr >> 2) + 4 * nt + (fr & 3)) * CIN + kb * 32 + fq * 8);
-    const int c0 = CL * fq;                  // this lane's first output channel
+            wf[nt][kb] = *(const bf8_t*)(w + (size_t)(32 * (nt >> 1) + 8 * (fr >> 2) + 4 * (nt & 1) + (fr & 3)) * CIN + kb * 32 + fq * 8);
     // destination of this lane's 8-channel chunks (the raw output, split D1 | D2 for the input gradient of a concatenation)
     bf16_t* dst[NCH];
     int dstride[NCH];
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-        const int ch = c0 + 8 * h;
+        const int ch = 32 * h + 8 * fq;
         if (g.D2 && ch >= g.D1) { dst[h] = (bf16_t*)a.y2 + (ch - g.D1); dstride[h] = g.D2; }
         else { dst[h] = (bf16_t*)a.y1 + ch; dstride[h] = g.D2 ? g.D1 : COUT; }
     }
@@ -107,15 +114,35 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
             if (gb + t >= g1) break;
             const int64_t pix = (gb + t) * 16 + fr;
             const bool valid = pix < g.M;
+            if (PRE) {
+                // the producer's BatchNorm + ReLU on the fragment: the same fma -> max -> bf16 rounding as bn_apply_k
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const uint4 u = __builtin_bit_cast(uint4, xb[t][kb]);
+                    const unsigned wv[4] = {u.x, u.y, u.z, u.w};
+                    const f4_t sc0 = *(const f4_t*)&spre[0][kb * 32 + fq * 8], sc1 = *(const f4_t*)&spre[0][kb * 32 + fq * 8 + 4];
+                    const f4_t sh0 = *(const f4_t*)&spre[1][kb * 32 + fq * 8], sh1 = *(const f4_t*)&spre[1][kb * 32 + fq * 8 + 4];
+                    const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+                    const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+                    unsigned o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float lo = fmaxf(fmaf(__uint_as_float(wv[i] << 16), sc[2 * i], sh[2 * i]), plo);
+                        const float hi = fmaxf(fmaf(__uint_as_float(wv[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), plo);
+                        o[i] = pk2bf(lo, hi);
+                    }
+                    xb[t][kb] = __builtin_bit_cast(bf8_t, make_uint4(o[0], o[1], o[2], o[3]));
+                }
+            }
             f4_t acc[NTT];
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt) {
-                acc[nt] = *(const f4_t*)&sbias[c0 + 4 * nt];
+                acc[nt] = *(const f4_t*)&sbias[32 * (nt >> 1) + 8 * fq + 4 * (nt & 1)];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kb], xb[t][kb], acc[nt], 0, 0, 0);
             }
-            // lane: pixel `pix`, channels c0 + 4 nt + r
+            // lane: pixel `pix`, channels 32 (nt >> 1) + 8 fq + 4 (nt & 1) + r
 #pragma unroll
             for (int h = 0; h < NCH; ++h) {
                 unsigned pk[4];
@@ -131,6 +158,8 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
                     pk[2 * j] = pk2bf(v[0], v[1]);
                     pk[2 * j + 1] = pk2bf(v[2], v[3]);
                 }
+                // (non-temporal loads / stores, which help the elementwise passes of ew_stream.hip, cost this kernel 5-15 %:
+                //  396 against 346 us for 64 -> 128 channels at 512 x 512 x 16)
                 if (valid) *(uint4*)(dst[h] + pix * dstride[h]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
         }
@@ -149,7 +178,8 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
 #pragma unroll
     for (int c = 0; c < CL; ++c) {
         const float u = dpp_add16(s1[c]), q = dpp_add16(s2[c]);
-        if (fr == 0) { sred[wid][0][c0 + c] = u; sred[wid][1][c0 + c] = q; }
+        const int ch = 32 * (c >> 3) + 8 * fq + (c & 7);       // c = 4 nt + r
+        if (fr == 0) { sred[wid][0][ch] = u; sred[wid][1][ch] = q; }
     }
     __syncthreads();
     for (int c = tid; c < COUT; c += 256) {
@@ -164,21 +194,37 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
 
 template <int CIN, int COUT, int T>
 static void pwx_launch(const GG& g, const FwdArgs& a, int blocks, int gpw, hipStream_t s) {
-    if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
-    else PAI_LAUNCH((pwx_k<CIN, COUT, T, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    if (a.pscale) {         // forward with the producer's BatchNorm on load (always with statistics or without: both exist)
+        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, true, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        else PAI_LAUNCH((pwx_k<CIN, COUT, T, false, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    } else {
+        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, true, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        else PAI_LAUNCH((pwx_k<CIN, COUT, T, false, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    }
+}
+template <int CIN, int COUT>
+static void pwx_launch_t(const GG& g, const FwdArgs& a, int blocks, int gpw, int t, hipStream_t s) {
+    if (t >= 4) pwx_launch<CIN, COUT, 4>(g, a, blocks, gpw, s);
+    else if (t >= 2) pwx_launch<CIN, COUT, 2>(g, a, blocks, gpw, s);
+    else pwx_launch<CIN, COUT, 1>(g, a, blocks, gpw, s);
 }
 
 int launch_pwx(const GG& g, const FwdArgs& a, hipStream_t s) {
-    const int blocks = pwx_rows(g);
+    const int cap = pai_tunable("pwx_blocks", PWX_MAX_BLOCKS);
+    int blocks = pwx_rows(g);
+    if (!a.stats && cap < blocks) blocks = cap;          // (the number of statistics rows is part of the interface)
     const int64_t ngroups = ((int64_t)g.M + 15) / 16;
     const int gpw = (int)((ngroups + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4));
     const int ci = g.Cin, co = g.Cout;
-    if (ci == 64 && co == 64) pwx_launch<64, 64, 4>(g, a, blocks, gpw, s);
-    else if (ci == 64 && co == 128) pwx_launch<64, 128, 4>(g, a, blocks, gpw, s);
-    else if (ci == 128 && co == 64) pwx_launch<128, 64, 4>(g, a, blocks, gpw, s);
-    else if (ci == 128 && co == 128) pwx_launch<128, 128, 2>(g, a, blocks, gpw, s);
-    else if (ci == 256 && co == 64) pwx_launch<256, 64, 2>(g, a, blocks, gpw, s);
-    else if (ci == 64 && co == 256) pwx_launch<64, 256, 2>(g, a, blocks, gpw, s);
+    const int big = ci * co > 64 * 128;
+    int t = pai_tunable("pwx_t", big ? 2 : 4);
+    if (co == 256 && a.stats) t = 1;                     // (the 64-register statistics on top of a 128-register filter)
+    if (ci == 64 && co == 64) pwx_launch_t<64, 64>(g, a, blocks, gpw, t, s);
+    else if (ci == 64 && co == 128) pwx_launch_t<64, 128>(g, a, blocks, gpw, t, s);
+    else if (ci == 128 && co == 64) pwx_launch_t<128, 64>(g, a, blocks, gpw, t, s);
+    else if (ci == 128 && co == 128) pwx_launch_t<128, 128>(g, a, blocks, gpw, t, s);
+    else if (ci == 256 && co == 64) pwx_launch_t<256, 64>(g, a, blocks, gpw, t, s);
+    else if (ci == 64 && co == 256) pwx_launch_t<64, 256>(g, a, blocks, gpw, t, s);
     else {
         pai_set_error("launch_pwx: no instantiation for %d -> %d channels", ci, co);
         return 1;

@@ -90,6 +90,9 @@ SIGNATURES = {
     "pai_conv_wgrad": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_conv_wgrad_overwrite": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "pai_conv_wgrad_overwrite_w": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "pai_conv_prologue_ok": (_I, [_D]),
+    "pai_conv_fwd_pro": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "pai_conv_wgrad_pro": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "pai_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _P, _P]),
     "pai_build_flags": (_I, []),
     "pai_pack_weights_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),

@@ -42,6 +42,7 @@ class _Block(nn.Module):
         h, i = x, 0
         ident = isinstance(self.conv_skip, nn.Identity)
         post = ACT_RELU if self.post_relu else ACT_NONE
+        pre = None          # (holder, BatchNorm2d, act) of the previous convolution when ITS normalisation is left to the next one
         while i < len(mods):
             conv = mods[i]
             assert isinstance(conv, nn.Conv2d)
@@ -55,8 +56,19 @@ class _Block(nn.Module):
                 # last convolution of the block: its BatchNorm (+ ReLU), the skip branch's, the sum and the ReLU behind it in
                 # one pass
                 sk = (None, None) if ident else (self.conv_skip[0], self.conv_skip[1])
-                return nnops.bn_tail(h, conv, bn, act, xs, sk[0], sk[1], post, ctx["training"], ctx["n_updates"], ctx["dtype"])
-            h = nnops.conv_bn_act(h, conv, bn, act, ctx["training"], ctx["n_updates"], ctx["dtype"])
+                return nnops.bn_tail(h, conv, bn, act, xs, sk[0], sk[1], post, ctx["training"], ctx["n_updates"], ctx["dtype"],
+                                     pre=pre)
+            if j < len(mods) and bn is not None and ctx.get("capture") is None \
+                    and nnops.can_prologue(h, mods[j], ctx["dtype"], act):
+                # the next convolution (and its weight gradient) reads this one's raw output through the BatchNorm + ReLU:
+                # the activated tensor is never written (one tensor write and two reads less)
+                hold = {}
+                h = nnops.conv_bn_act(h, conv, bn, ACT_NONE, ctx["training"], ctx["n_updates"], ctx["dtype"], defer=hold, pre=pre)
+                pre = (hold, bn, act)
+                i = j
+                continue
+            h = nnops.conv_bn_act(h, conv, bn, act, ctx["training"], ctx["n_updates"], ctx["dtype"], pre=pre)
+            pre = None
             if ctx.get("capture") is not None:
                 ctx["capture"][f"{ctx['name']}.conv_block.{i}"] = h.detach().float()
             i = j

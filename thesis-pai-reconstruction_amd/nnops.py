@@ -173,9 +173,13 @@ class ConvBNAct(torch.autograd.Function):
     blocks of reference models/res_unet.py:58-64,86-95,147-163,66-69 and the bare convolutions at :265,308."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, gamma, beta, bn, training, n_updates, act, groups, dtype, out_f32, defer=None):
+    def forward(ctx, x, x2, weight, bias, gamma, beta, bn, training, n_updates, act, groups, dtype, out_f32, defer=None,
+                pre=None, pre_gamma=None, pre_beta=None, pre_act=ACT_NONE):
         # x2 (optional): a second NHWC tensor read as if concatenated behind x along C -- the torch.cat in front of the
         # decoder blocks (reference models/res_unet.py:327, models/trans_unet.py:113) never materialises
+        # pre (optional): x is the RAW output of the producing convolution and `pre` the holder of its BatchNorm (a
+        # ``defer`` dict): this layer and its weight gradient read pre_act(BN(x)) on load (``ops.conv_fwd_pro``), the activated
+        # tensor is never written, and the producer's BatchNorm backward happens HERE (pre_gamma / pre_beta get its gradients)
         _check(x)
         N, H, W, C1 = x.shape
         C2 = 0
@@ -210,14 +214,26 @@ class ConvBNAct(torch.autograd.Function):
         ctx.has_x2 = x2 is not None
         ctx.bias_ref = bias
         ctx.deferred = False
+        ctx.pre_act = pre_act if pre is not None else None
         extra = [x2] if x2 is not None else []
+        if pre is not None:
+            if x2 is not None or out_f32 or (bn is None and act != ACT_NONE) or not ops.conv_prologue_ok(d):
+                raise ops.PaiError("ConvBNAct: this layer cannot read its input through a prologue")
+            ctx.pre_training = pre["training"]
+            extra = [pre["scale"], pre["shift"], pre["mean"], pre["rstd"], pre_gamma]
+
+        def conv(**kw):        # the convolution proper: raw output (+ statistics) through the prologue, or the plain call
+            if pre is None:
+                return ops.conv_fwd(d, x, x2, wf, b32, **kw)
+            return ops.conv_fwd_pro(d, x, wf, b32, kw["y_raw"], kw.get("stats"), pre["scale"], pre["shift"], pre_act)
+
         if bn is None:
             if out_f32:                       # final conv + tanh (reference :307-315): fp32 NCHW-compatible output
                 out = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
                 ops.conv_fwd(d, x, x2, wf, b32, y_f32=out)
             elif act == ACT_NONE:
                 out = torch.empty(N, H, W, Cout, dtype=dtype, device=x.device)
-                ops.conv_fwd(d, x, x2, wf, b32, y_raw=out)
+                conv(y_raw=out)
             else:
                 out = torch.empty(N, H, W, Cout, dtype=dtype, device=x.device)
                 ops.conv_fwd(d, x, x2, wf, b32, y_act=out)
@@ -230,12 +246,12 @@ class ConvBNAct(torch.autograd.Function):
         if training:
             rows = ops.conv_fwd_stats_rows(d)
             stats = torch.empty(ops.bn_stats_buffer_rows(ops.conv_fwd_stats_rows_max(d)) * 2 * Cout, **f32)
-            ops.conv_fwd(d, x, x2, wf, b32, y_raw=z, stats=stats)
+            conv(y_raw=z, stats=stats)
             mom = bn.momentum if bn.momentum is not None else 0.1
             ops.bn_finalize(stats, rows, Cout, M, gamma.detach(), beta.detach(), float(bn.eps), float(mom), n_updates,
                             bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, rstd, scale, shift)
         else:
-            ops.conv_fwd(d, x, x2, wf, b32, y_raw=z)
+            conv(y_raw=z)
             ops.bn_eval_coeffs(Cout, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, float(bn.eps),
                                scale, shift)
         if defer is not None:
@@ -298,22 +314,44 @@ class ConvBNAct(torch.autograd.Function):
         # a conv bias in front of a BatchNorm has an identically zero gradient
         with_bias = ctx.needs_input_grad[3] and not ctx.has_bn       # inputs: x, x2, weight, bias, gamma, beta, ...
         groups = ctx.groups
+        pre = ctx.pre_act is not None
+        if pre:
+            psc, psh, pmean, prstd, pgam = ctx.saved_tensors[-5:]
 
         def wgrad():
             dw = torch.empty(Cout * k * k * Cin, **f32)
             dbias = None
             if ctx.needs_input_grad[3]:
                 dbias = torch.empty(Cout, **f32) if with_bias else _zero_grad(Cout, dev)
-            ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
+            if pre:         # x is the producer's raw output: its BatchNorm + activation on load, as in the forward pass
+                ops.conv_wgrad_pro(d, x, dz, dw, dbias if with_bias else None, True, psc, psh, ctx.pre_act)
+            else:
+                ops.conv_wgrad_overwrite(d, x, x2, dz, dw, dbias if with_bias else None)
             return (_grad_from_fwd_pack(dw, weight, groups), dbias), (dw,)
 
-        gw, dbias = WGRAD.run(dev, (x, x2, dz), wgrad, (weight, ctx.bias_ref))
-        dx = dx2 = None
+        gw, dbias = WGRAD.run(dev, (x, x2, dz) + ((psc, psh) if pre else ()), wgrad, (weight, ctx.bias_ref))
+        dx = dx2 = dpg = dpb = None
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
             dx = torch.empty(N, H, W, C1, dtype=dtype, device=dev)
             dx2 = torch.empty(N, H, W, C2, dtype=dtype, device=dev) if ctx.has_x2 else None
             ops.conv_dgrad(d, dz, wd, dx, dx2)
-        return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+        if pre and dx is not None:
+            # dx is the gradient behind the producer's BatchNorm + activation: its backward (two passes over dx and x = z),
+            # the producing convolution gets dz and the BatchNorm parameters their gradients from here
+            if not ctx.pre_training:
+                raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
+            part = torch.empty(ops.bn_bwd_partial_rows(M) * 2 * C1, **f32)
+            sums = torch.empty(2 * C1, **f32)
+            dzp = torch.empty_like(dx)
+            if ctx.pre_act != ACT_NONE:
+                ops.bn_bwd_reduce_affine(dtype, dx, ctx.pre_act, None, ACT_NONE, x, M, C1, psc, psh, pmean, prstd, None, part,
+                                         sums, None, None)
+                ops.bn_bwd_apply_affine(dtype, dx, ctx.pre_act, x, M, C1, psc, psh, pmean, prstd, pgam.detach(), sums, dzp)
+            else:
+                ops.bn_bwd_reduce(dtype, dx, ACT_NONE, None, ACT_NONE, None, x, M, C1, pmean, prstd, None, part, sums, None, None)
+                ops.bn_bwd_apply(dtype, dx, x, M, C1, pmean, prstd, pgam.detach(), sums, dzp)
+            dx, dpb, dpg = dzp, sums[:C1], sums[C1:]
+        return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dpg, dpb, None
 
 
 class MaxPool2(torch.autograd.Function):
@@ -448,10 +486,10 @@ def fuse_tail() -> bool:
     return os.environ.get("PAI_NO_BN_TAIL", "0") in ("", "0")
 
 
-def bn_tail(h, conv, bn, act_a, xs, skip_conv, skip_bn, act, training, n_updates, dtype):
+def bn_tail(h, conv, bn, act_a, xs, skip_conv, skip_bn, act, training, n_updates, dtype, pre=None):
     """act(act_a(BN(conv(h))) + BN_skip(conv_skip(xs))) (``skip_conv`` None: + xs) through ``BNTail``."""
     ha = {}
-    za = conv_bn_act(h, conv, bn, ACT_NONE, training, n_updates, dtype, defer=ha)
+    za = conv_bn_act(h, conv, bn, ACT_NONE, training, n_updates, dtype, defer=ha, pre=pre)
     if skip_conv is None:
         return BNTail.apply(za, bn.weight, bn.bias, ha, xs, None, None, None, act_a, act)
     hb = {}
@@ -528,7 +566,27 @@ class SwapMid(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False, defer=None):
+def no_prologue() -> bool:
+    """PAI_NO_PROLOGUE=1: every BatchNorm + activation as a pass of its own (A/B switch)."""
+    import os
+    return os.environ.get("PAI_NO_PROLOGUE", "0") not in ("", "0")
+
+
+def can_prologue(x, nxt, dtype, act) -> bool:
+    """Can convolution ``nxt`` read the NHWC tensor ``x`` (the raw output of the layer in front of it) through that layer's
+    BatchNorm + activation (``ops.conv_prologue_ok``)?"""
+    if dtype != torch.bfloat16 or act not in (ACT_NONE, ACT_RELU) or no_prologue():
+        return False
+    if isinstance(x, tuple):        # (the producer's own input may be a pair; its output is one tensor of the same extent)
+        x = x[0]
+    if not isinstance(nxt, torch.nn.Conv2d) or nxt.groups != 1 or nxt.kernel_size != (1, 1) or nxt.stride != (1, 1):
+        return False
+    N, H, W, _ = x.shape
+    d = ops.make_desc(dtype, 0, N, H, W, nxt.in_channels, 0, nxt.out_channels, 1, 0, 0, ACT_NONE, kernel=1)
+    return ops.conv_prologue_ok(d)
+
+
+def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False, defer=None, pre=None):
     """Run an ``nn.Conv2d`` (+ ``nn.BatchNorm2d``) parameter container through ConvBNAct.  ``x``: an NHWC tensor, or a pair
     ``(x1, x2)`` read as ``torch.cat([x1, x2], dim=3)`` without the concatenation being built.  ``defer`` (a dict): the
     BatchNorm is only measured (batch statistics, running averages), its normalisation is left to ``BNTail``."""
@@ -539,6 +597,10 @@ def conv_bn_act(x, conv, bn, act, training, n_updates, dtype, out_f32=False, def
             raise ops.PaiError("conv_bn_act: defer needs a BatchNorm")
         gamma, beta = gamma.detach(), beta.detach()       # their gradients come out of BNTail
     x1, x2 = x if isinstance(x, tuple) else (x, None)
+    if pre is not None:         # (holder, BatchNorm2d, activation) of the producing layer, see ConvBNAct.forward
+        hold, pbn, pact = pre
+        return ConvBNAct.apply(x1, x2, conv.weight, conv.bias, gamma, beta, bn, training, n_updates, act, conv.groups, dtype,
+                               out_f32, defer, hold, pbn.weight, pbn.bias, pact)
     return ConvBNAct.apply(x1, x2, conv.weight, conv.bias, gamma, beta, bn, training, n_updates, act, conv.groups, dtype,
                            out_f32, defer)
 

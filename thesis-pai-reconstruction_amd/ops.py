@@ -95,7 +95,8 @@ def bn_stats_buffer_rows(rows: int) -> int:
 # the stream the kernel is launched on, and (kernel family, op, algorithmic FLOPs, events) is
 # appended.  Off (None) in normal operation.
 PROFILE = None
-KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16", 5: "small_mfma_bf16", 6: "grouped3_k"}
+KERNEL_NAMES = {0: "gg_simt", 1: "gg_rowdot", 2: "gg_mfma_bf16_t128", 3: "gg_mfma_bf16_t64", 4: "thin_mfma_bf16", 5: "small_mfma_bf16", 6: "grouped3_k",
+                7: "pwx_k"}
 
 
 def conv_kernel_id(d: ConvDesc, op: int) -> int:
@@ -316,6 +317,26 @@ def conv_fwd(d, x1, x2, w, bias, y_raw=None, y_act=None, y_f32=None, stats=None)
         L.check(L.load().pai_conv_fwd(C.byref(d), _p(x1), _p(x2), _p(w), _p(bias, torch.float32), _p(y_raw),
                                       _p(y_act), _p(y_f32, torch.float32), _p(stats, torch.float32),
                                       _stream()), "pai_conv_fwd")
+
+
+def conv_prologue_ok(d) -> bool:
+    """Forward and weight gradient of this layer can read their input through a prologue (pai_conv_prologue_ok)."""
+    return bool(L.load().pai_conv_prologue_ok(C.byref(d)))
+
+
+def conv_fwd_pro(d, x1, w, bias, y_raw, stats, pre_scale, pre_shift, pre_act):
+    """y_raw = conv(act(x1 * pre_scale + pre_shift)): the producer's BatchNorm + activation applied on load."""
+    with _Timed(d, 0):
+        L.check(L.load().pai_conv_fwd_pro(C.byref(d), _p(x1), _p(w), _p(bias, torch.float32), _p(y_raw),
+                                          _p(stats, torch.float32), _p(pre_scale, torch.float32), _p(pre_shift, torch.float32),
+                                          int(pre_act), _stream()), "pai_conv_fwd_pro")
+
+
+def conv_wgrad_pro(d, x1, dy, dw, dbias, overwrite, pre_scale, pre_shift, pre_act):
+    with _Timed(d, 2):
+        L.check(L.load().pai_conv_wgrad_pro(C.byref(d), _p(x1), _p(dy), _p(dw, torch.float32), _p(dbias, torch.float32),
+                                            int(overwrite), _p(pre_scale, torch.float32), _p(pre_shift, torch.float32),
+                                            int(pre_act), _stream()), "pai_conv_wgrad_pro")
 
 
 def conv_dgrad(d, dy, w_dgrad, dx1, dx2=None, only_c2=False):
