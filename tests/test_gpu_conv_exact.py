@@ -524,8 +524,10 @@ def test_same_convolutions_of_the_other_families_bit_exact(pai, case):
 
 
 
-# (N, H, W, Cin, Cout): pointwise layers of the ResNeXt blocks that read their input through a prologue
-PRO_CASES = [(4, 128, 128, 128, 64), (2, 128, 128, 128, 128), (4, 64, 64, 64, 128), (2, 128, 64, 64, 256), (1, 128, 128, 256, 64)]
+# (N, H, W, Cin, Cout, k, groups): layers of the ResNeXt blocks that read their input through a prologue -- the pointwise
+# ones (pwx_k / gg_wgrad_mfma_k) and the grouped 3 x 3 (grouped3_k / grouped3_wgrad_k: zero padding must stay zero)
+PRO_CASES = [(4, 128, 128, 128, 64, 1, 1), (2, 128, 128, 128, 128, 1, 1), (4, 64, 64, 64, 128, 1, 1), (2, 128, 64, 64, 256, 1, 1),
+             (1, 128, 128, 256, 64, 1, 1), (2, 64, 64, 128, 128, 3, 32), (1, 16, 32, 128, 128, 3, 32)]
 
 
 @pytest.mark.parametrize("act", ["relu", "none"])
@@ -535,16 +537,16 @@ def test_input_prologue_equals_batchnorm_pass_then_plain_call(pai, case, act):
     without the activated tensor in the middle) against pai_bn_apply followed by the plain calls, on random data: the prologue
     forms the same bf16 values on load, so outputs and BatchNorm partial statistics are BIT-IDENTICAL and the weight / bias gradients equal up to the order of their fp32 atomics."""
     from thesis_pai_reconstruction_amd import ops
-    N, H, W, Cin, K = case
+    N, H, W, Cin, K, k, groups = case
     dt, M = torch.bfloat16, N * H * W
-    d = ops.make_desc(dt, 0, N, H, W, Cin, 0, K, 1, 0, 0, ops.ACT_NONE, kernel=1)
-    assert ops.conv_prologue_ok(d)
+    d = ops.make_desc(dt, 0, N, H, W, Cin, 0, K, 1, 0, 0, ops.ACT_NONE, kernel=k, groups=groups)
     ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
     ops.ensure_wgrad_workspace([d], dev())
+    assert ops.conv_prologue_ok(d)
     g = torch.Generator().manual_seed(11)
     z = (torch.randn(M, Cin, generator=g) * 1.3 + 0.2).to(dt).to(dev())
     dy = torch.randn(M, K, generator=g).to(dt).to(dev())
-    w = (torch.randn(K * Cin, generator=g) * 0.1).to(dt).to(dev())
+    w = (torch.randn(K * k * k * Cin, generator=g) * 0.1).to(dt).to(dev())
     bias = torch.randn(K, generator=g).to(dev())
     scale = (0.5 + torch.rand(Cin, generator=g)).to(dev())
     shift = (torch.randn(Cin, generator=g) * 0.3).to(dev())
@@ -555,16 +557,18 @@ def test_input_prologue_equals_batchnorm_pass_then_plain_call(pai, case, act):
     ops.bn_apply(dt, z, M, Cin, scale, shift, a_code, a)
     y0, st0 = torch.empty(M, K, dtype=dt, device=dev()), torch.zeros(rows, device=dev())
     ops.conv_fwd(d, a, None, w, bias, y_raw=y0, stats=st0)
-    dw0, db0 = torch.empty(K * Cin, device=dev()), torch.empty(K, device=dev())
+    nw = K * k * k * Cin
+    with_db = groups == 1                 # (the grouped layer feeds a BatchNorm: its kernel forms no bias gradient)
+    dw0, db0 = torch.zeros(nw, device=dev()), (torch.empty(K, device=dev()) if with_db else None)
     ops.conv_wgrad_overwrite(d, a, None, dy, dw0, db0)
     # prologue
     y1, st1 = torch.empty(M, K, dtype=dt, device=dev()), torch.zeros(rows, device=dev())
     ops.conv_fwd_pro(d, z, w, bias, y1, st1, scale, shift, a_code)
-    dw1, db1 = torch.full((K * Cin,), float("nan"), device=dev()), torch.full((K,), float("nan"), device=dev())
+    dw1, db1 = torch.zeros(nw, device=dev()), (torch.full((K,), float("nan"), device=dev()) if with_db else None)
     ops.conv_wgrad_pro(d, z, dy, dw1, db1, True, scale, shift, a_code)
     y2 = torch.empty(M, K, dtype=dt, device=dev())
     ops.conv_fwd_pro(d, z, w, bias, y2, None, scale, shift, a_code)          # without statistics
-    dw2 = torch.ones(K * Cin, device=dev())
+    dw2 = torch.ones(nw, device=dev())
     ops.conv_wgrad_pro(d, z, dy, dw2, None, False, scale, shift, a_code)     # accumulating
     torch.cuda.synchronize()
     n = ops.conv_fwd_stats_rows(d) * 2 * K
@@ -573,12 +577,18 @@ def test_input_prologue_equals_batchnorm_pass_then_plain_call(pai, case, act):
     assert torch.equal(st1[:n], st0[:n])
     # (the pixel splits of the weight gradient meet through fp32 atomics: equal up to their summation order)
     tol = 2e-6 * float(dw0.abs().max()) * 8
-    assert float((dw1 - dw0).abs().max()) <= tol and float((db1 - db0).abs().max()) <= 2e-6 * float(db0.abs().max()) * 8
-    assert float((dw2 - 1.0 - dw0).abs().max()) <= tol
+    assert float((dw1 - dw0).abs().max()) <= tol
+    if with_db:
+        assert float((db1 - db0).abs().max()) <= 2e-6 * float(db0.abs().max()) * 8
+    else:
+        assert torch.equal(dw1, dw0)          # the grouped kernel sums its partial blocks in a fixed order
+    written = dw0 != 0 if groups > 1 else torch.ones_like(dw0, dtype=torch.bool)     # (diagonal blocks only)
+    assert float(((dw2 - 1.0 - dw0) * written).abs().max()) <= tol
     # and against fp64 on the bf16 activation (the plain call's own tolerance)
-    af = a.double()
-    want = af @ w.double().view(K, Cin).t() + bias.double()
-    assert float((y1.double() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+    if k == 1:
+        af = a.double()
+        want = af @ w.double().view(K, Cin).t() + bias.double()
+        assert float((y1.double() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
 
 
 def test_prologue_is_refused_where_no_kernel_takes_it(pai):

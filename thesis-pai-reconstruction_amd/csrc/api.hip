@@ -515,6 +515,7 @@ extern "C" int pai_conv_fwd_stats_rows_max(const pai_conv_desc* d) {
 
 static int run_fwd(int dtype, const GG& g, const FwdArgs& a, hipStream_t s) {
     if (a.pscale) {                     // prologue on x1: only the kernels that apply it on load
+        if (grouped3_ok(dtype, g, a)) return launch_grouped3(g, a, s);
         if (pwx_ok(dtype, g, a)) return launch_pwx(g, a, s);
         pai_set_error("pai_conv_fwd_pro: this layer takes no prologue (ask pai_conv_prologue_ok)");
         return 1;
@@ -560,13 +561,19 @@ static bool prologue_fwd_ok(const pai_conv_desc* d, const GG& g) {
     a.y1 = (void*)1;
     a.pscale = a.pshift = (const float*)1;
     a.pact = PAI_ACT_RELU;
-    return pwx_ok(d->dtype, g, a);
+    return grouped3_ok(d->dtype, g, a) || pwx_ok(d->dtype, g, a);
+}
+
+// weight gradient through a prologue: the pointwise tile kernel, or the grouped 3 x 3 kernel with its workspace registered
+static bool prologue_wgrad_ok(const pai_conv_desc* d, const GG& g) {
+    if (grouped3_wgrad_ok(d->dtype, g, nullptr)) return wgrad_slab_acquire(grouped3_wgrad_part_bytes(g)) != nullptr;
+    return wgrad_pro_ok(d->dtype, g);
 }
 
 extern "C" int pai_conv_prologue_ok(const pai_conv_desc* d) {
     GG g;
     if (gg_build_fwd(d, &g)) return 0;
-    return prologue_fwd_ok(d, g) && wgrad_pro_ok(d->dtype, g);
+    return prologue_fwd_ok(d, g) && prologue_wgrad_ok(d, g);
 }
 
 extern "C" int pai_conv_fwd_pro(const pai_conv_desc* d, const void* x1, const void* w_fwd, const float* bias, void* y_raw,
@@ -786,6 +793,12 @@ static int conv_wgrad_impl(const pai_conv_desc* d, const void* x1, const void* x
     a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw; a.dbias = dbias; a.overwrite = 0; a.overwrite_bias = 0; a.slab = nullptr;
     a.pscale = pscale; a.pshift = pshift; a.pact = pact;
     hipStream_t s = (hipStream_t)stream;
+    if (pscale && grouped3_wgrad_ok(d->dtype, g, dbias)) {
+        float* part = wgrad_slab_acquire(grouped3_wgrad_part_bytes(g));
+        PAI_CHECK(part, "pai_conv_wgrad_pro: the grouped 3 x 3 weight gradient needs its workspace (pai_set_wgrad_workspace)");
+        a.overwrite = overwrite != 0;
+        return launch_grouped3_wgrad(g, a, part, s);
+    }
     if (pscale) {
         PAI_CHECK(wgrad_pro_ok(d->dtype, g), "pai_conv_wgrad_pro: this layer takes no prologue (ask pai_conv_prologue_ok)");
         if (overwrite && wgrad_mfma_can_overwrite(g)) {

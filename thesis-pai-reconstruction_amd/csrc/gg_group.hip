@@ -33,6 +33,20 @@ constexpr int PW = TW + 2, PH = TH + 2; // patch
 constexpr int PATCH_PIXELS = PW * PH;   // 180
 constexpr int MAX_BLOCKS = 2048;
 
+// prologue (pai_conv_fwd_pro / pai_conv_wgrad_pro): eight channels of one pixel through the producer's BatchNorm + ReLU --
+// the same fma -> max -> bf16 rounding as bn_apply_k
+__device__ __forceinline__ uint4 pre_chunk(uint4 v, const float* sc, const float* sh, float plo) {
+    const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = fmaxf(fmaf(__uint_as_float(wv[i] << 16), sc[2 * i], sh[2 * i]), plo);
+        const float hi = fmaxf(fmaf(__uint_as_float(wv[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]), plo);
+        o[i] = pk2bf(lo, hi);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 __device__ __forceinline__ bf8_t relu8g(bf8_t f) {
     s8_t x = __builtin_bit_cast(s8_t, f);
     const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -47,6 +61,7 @@ bool grouped3_ok(int dtype, const GG& g, const FwdArgs& a) {
     if ((g.OHg % TH) || (g.OWg % TW) || g.H != g.OHg || g.W != g.OWg) return false;
     if (a.yf32 || a.skip_d1 || a.bz) return false;
     if (a.yact && a.eact != PAI_ACT_NONE && a.eact != PAI_ACT_LRELU && a.eact != PAI_ACT_RELU) return false;
+    if (a.pscale && (!a.pshift || g.relu1 || (a.pact != PAI_ACT_NONE && a.pact != PAI_ACT_RELU))) return false;
     return true;
 }
 
@@ -57,7 +72,7 @@ int grouped3_rows(const GG& g) {
     return t < MAX_BLOCKS ? t : MAX_BLOCKS;
 }
 
-template <bool STATS>
+template <bool STATS, bool PRE>
 __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[PATCH_PIXELS * 128];
     const int c0 = blockIdx.y * (HS * 16);      // first channel of this workgroup
@@ -123,6 +138,13 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
             if (!inb) pre[j] = make_uint4(0, 0, 0, 0);
         }
     };
+    // prologue: this thread's chunk column c = tid & 7 is the same for every patch chunk it moves
+    float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
+    const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;
+    if (PRE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { psc[e] = a.pscale[c0 + (tid & 7) * 8 + e]; psh[e] = a.pshift[c0 + (tid & 7) * 8 + e]; }
+    }
     if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int n = tile / tpi, rem = tile - n * tpi;
@@ -132,7 +154,13 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
         for (int j = 0; j < NF; ++j) {
             const int i = tid + 256 * j;
             const int p = i >> 3, c = i & 7;
-            if (i < PATCH_PIXELS * 8) *(uint4*)(patch + p * 128 + ((c ^ (((p >> 1) & 3) << 1)) << 4)) = pre[j];
+            uint4 v = pre[j];
+            if (PRE) {          // the producer's BatchNorm + ReLU on the way into LDS; the zero padding stays zero
+                const int py = p / PW, px = p - py * PW;
+                const bool inb = (unsigned)(y0 - 1 + py) < (unsigned)g.H && (unsigned)(x0 - 1 + px) < (unsigned)g.W;
+                if (inb) v = pre_chunk(v, psc, psh, plo);
+            }
+            if (i < PATCH_PIXELS * 8) *(uint4*)(patch + p * 128 + ((c ^ (((p >> 1) & 3) << 1)) << 4)) = v;
         }
         __syncthreads();
         if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
@@ -197,8 +225,13 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
 int launch_grouped3(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int tiles = grouped3_tiles(g);
     const dim3 grid(grouped3_rows(g), GC / (HS * 16));
-    if (a.stats) PAI_LAUNCH(grouped3_k<true>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
-    else PAI_LAUNCH(grouped3_k<false>, grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    if (a.pscale) {
+        if (a.stats) PAI_LAUNCH((grouped3_k<true, true>), grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+        else PAI_LAUNCH((grouped3_k<false, true>), grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    } else {
+        if (a.stats) PAI_LAUNCH((grouped3_k<true, false>), grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+        else PAI_LAUNCH((grouped3_k<false, false>), grid, dim3(256), 0, s, g, a, tiles, g.OWg / TW, g.OHg / TH);
+    }
     PAI_LAUNCH_CHECK();
     return 0;
 }
@@ -265,6 +298,7 @@ static int grouped3_wgrad_blocks(const GG& g) {
 
 int64_t grouped3_wgrad_part_bytes(const GG& g) { return (int64_t)grouped3_wgrad_blocks(g) * WPART * sizeof(float); }
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void grouped3_wgrad_k(GG g, WgradArgs a, float* part, int tiles, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) unsigned char xp[WPATCH * 128];
     __shared__ __attribute__((aligned(16))) unsigned char dyt[WDY * 128];
@@ -306,13 +340,27 @@ __global__ __launch_bounds__(256, 2) void grouped3_wgrad_k(GG g, WgradArgs a, fl
             pre[NX + j] = *(const uint4*)(dy + ((size_t)(n * g.H + y0 + py) * g.W + x0 + px) * GC + c0 + c * 8);
         }
     };
+    float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];          // prologue of x, as in grouped3_k
+    const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;
+    if (PRE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { psc[e] = a.pscale[c0 + (tid & 7) * 8 + e]; psh[e] = a.pshift[c0 + (tid & 7) * 8 + e]; }
+    }
     if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int rem = tile % tpi;
+        const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * WTW;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int i = tid + 256 * j;
             const int p = i >> 3, c = i & 7;
-            if (i < WPATCH * 8) *(uint4*)(xp + p * 128 + ((c ^ gsw(p)) << 4)) = pre[j];
+            uint4 v = pre[j];
+            if (PRE) {
+                const int py = p / WPW, px = p - py * WPW;
+                const bool inb = (unsigned)(y0 - 1 + py) < (unsigned)g.H && (unsigned)(x0 - 1 + px) < (unsigned)g.W;
+                if (inb) v = pre_chunk(v, psc, psh, plo);
+            }
+            if (i < WPATCH * 8) *(uint4*)(xp + p * 128 + ((c ^ gsw(p)) << 4)) = v;
         }
 #pragma unroll
         for (int j = 0; j < NY; ++j) {
@@ -372,7 +420,8 @@ __global__ __launch_bounds__(256) void grouped3_wgrad_reduce_k(float* dw, const 
 int launch_grouped3_wgrad(const GG& g, const WgradArgs& a, float* part, hipStream_t s) {
     const int tiles = g.N * (g.OHg / WTH) * (g.OWg / WTW);
     const int nblk = grouped3_wgrad_blocks(g);
-    PAI_LAUNCH(grouped3_wgrad_k, dim3(nblk, GC / (HS * 16)), dim3(256), 0, s, g, a, part, tiles, g.OWg / WTW, g.OHg / WTH);
+    if (a.pscale) PAI_LAUNCH(grouped3_wgrad_k<true>, dim3(nblk, GC / (HS * 16)), dim3(256), 0, s, g, a, part, tiles, g.OWg / WTW, g.OHg / WTH);
+    else PAI_LAUNCH(grouped3_wgrad_k<false>, dim3(nblk, GC / (HS * 16)), dim3(256), 0, s, g, a, part, tiles, g.OWg / WTW, g.OHg / WTH);
     PAI_LAUNCH_CHECK();
     GroupWt wt;
     for (int t = 0; t < 9; ++t) wt.wt[t] = g.wt[0][t];

@@ -191,7 +191,7 @@ class ConvBNAct(torch.autograd.Function):
         Cin = C1 + C2
         Cout, _, k, _ = weight.shape
         # grouped 3x3 (ResNeXt): block-diagonal dense packs + the groups hint (16-channel slices skip the zero blocks)
-        hint = groups if (groups > 1 and k == 3 and Cin == Cout and Cin % 16 == 0 and 16 % (Cin // groups) == 0) else 1
+        hint = _groups_hint(groups, k, Cin, Cout)
         d = ops.make_desc(dtype, 0, N, H, W, C1, C2, Cout, 1, 0, 0, act if bn is None else ACT_NONE, kernel=k,
                           groups=hint)
         ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
@@ -572,17 +572,27 @@ def no_prologue() -> bool:
     return os.environ.get("PAI_NO_PROLOGUE", "0") not in ("", "0")
 
 
+def _groups_hint(groups, k, cin, cout) -> int:
+    """pai_conv_desc.groups for a grouped 3 x 3 layer whose groups tile into 16-channel slices (ResNeXt), else 1 (dense)."""
+    return groups if (groups > 1 and k == 3 and cin == cout and cin % 16 == 0 and 16 % (cin // groups) == 0) else 1
+
+
 def can_prologue(x, nxt, dtype, act) -> bool:
     """Can convolution ``nxt`` read the NHWC tensor ``x`` (the raw output of the layer in front of it) through that layer's
-    BatchNorm + activation (``ops.conv_prologue_ok``)?"""
+    BatchNorm + activation (``ops.conv_prologue_ok``: forward AND weight gradient)?"""
     if dtype != torch.bfloat16 or act not in (ACT_NONE, ACT_RELU) or no_prologue():
         return False
     if isinstance(x, tuple):        # (the producer's own input may be a pair; its output is one tensor of the same extent)
         x = x[0]
-    if not isinstance(nxt, torch.nn.Conv2d) or nxt.groups != 1 or nxt.kernel_size != (1, 1) or nxt.stride != (1, 1):
+    if not isinstance(nxt, torch.nn.Conv2d) or nxt.stride != (1, 1) or nxt.kernel_size not in ((1, 1), (3, 3)):
+        return False
+    k = nxt.kernel_size[0]
+    hint = _groups_hint(nxt.groups, k, nxt.in_channels, nxt.out_channels)
+    if nxt.padding != (k // 2, k // 2) or (nxt.groups > 1 and hint == 1):
         return False
     N, H, W, _ = x.shape
-    d = ops.make_desc(dtype, 0, N, H, W, nxt.in_channels, 0, nxt.out_channels, 1, 0, 0, ACT_NONE, kernel=1)
+    d = ops.make_desc(dtype, 0, N, H, W, nxt.in_channels, 0, nxt.out_channels, 1, 0, 0, ACT_NONE, kernel=k, groups=hint)
+    ops.ensure_wgrad_workspace([d], x.device)       # (the grouped weight gradient needs its workspace to say yes)
     return ops.conv_prologue_ok(d)
 
 
