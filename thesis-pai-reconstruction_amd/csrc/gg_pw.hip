@@ -18,7 +18,7 @@
 #include "gg_tile.h"
 
 namespace {
-constexpr int PWX_MAX_BLOCKS = 2048;
+constexpr int PWX_MAX_BLOCKS = 4096;
 
 __device__ __forceinline__ float dpp_add16(float u) {      // sum over the 16 lanes of a row (all lanes get the total)
     u += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, false));
@@ -48,7 +48,11 @@ bool pwx_ok(int dtype, const GG& g, const FwdArgs& a) {
 
 int pwx_rows(const GG& g) {
     const int64_t b = ((int64_t)g.M + 255) / 256;
-    return (int)(b > PWX_MAX_BLOCKS ? PWX_MAX_BLOCKS : (b < 1 ? 1 : b));
+    // one resident workgroup per CU walks its share of a mid-size tensor (16 x 256 x 256: 116 against 129 us for 128 -> 128
+    // channels, 32 against 43 us for 256 -> 64 at 128 x 128); the 4 M-pixel layers do better in many short workgroups
+    // (299 against 315 us) -- scripts/bench_pw.py pwx_blocks=...
+    const int64_t cap = pai_tunable("pwx_blocks", g.M >= (1 << 21) ? PWX_MAX_BLOCKS : 256);
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 template <int CIN, int COUT, int T, bool STATS, bool PRE>
@@ -210,9 +214,7 @@ static void pwx_launch_t(const GG& g, const FwdArgs& a, int blocks, int gpw, int
 }
 
 int launch_pwx(const GG& g, const FwdArgs& a, hipStream_t s) {
-    const int cap = pai_tunable("pwx_blocks", PWX_MAX_BLOCKS);
-    int blocks = pwx_rows(g);
-    if (!a.stats && cap < blocks) blocks = cap;          // (the number of statistics rows is part of the interface)
+    const int blocks = pwx_rows(g);
     const int64_t ngroups = ((int64_t)g.M + 15) / 16;
     const int gpw = (int)((ngroups + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4));
     const int ci = g.Cin, co = g.Cout;
