@@ -268,3 +268,28 @@ def test_batchnorm_on_load_equals_batchnorm_as_a_pass(pai, monkeypatch, res_type
     for k, g in grads["pass"].items():
         err = float((grads["load"][k] - g).norm())
         assert err <= 1e-5 * float(g.norm()) + 1e-6 * scale, (k, err, float(g.norm()), scale)
+
+
+def test_one_pack_launch_per_forward_equals_a_pack_per_layer(pai, monkeypatch):
+    """``nnops.prepack``: the bf16 packs of all dense pointwise convolutions from ONE pai_pack_weights_multi launch at the start
+    of the forward pass -- same packs, so the same prediction and gradients as with a pack launch in front of each layer, and
+    the table is empty again when the pass is over (nothing stale can be picked up later)."""
+    from thesis_pai_reconstruction_amd import nnops
+
+    mults, n, size, seed = (1, 2, 4), 2, 64, 9
+    x, t = synth_batch(seed, n, size)
+    x, t = x.to(DEV), t.to(DEV)
+    res = {}
+    for mode in ("multi", "single"):
+        monkeypatch.setenv("PAI_NO_PREPACK", "0" if mode == "multi" else "1")
+        m, _, _ = build(pai, "next", mults, "mse", seed, dtype=torch.bfloat16)
+        pred = m.unet(x)
+        assert not nnops._PREPACK
+        m.loss(x, pred, t).backward()
+        nnops.join_wgrads()
+        torch.cuda.synchronize()
+        res[mode] = (pred.detach().clone(), {k: p.grad.detach().clone() for k, p in m.unet.named_parameters()})
+    assert torch.equal(res["multi"][0], res["single"][0])
+    scale = max(float(g.norm()) for g in res["single"][1].values())
+    for k, g in res["single"][1].items():
+        assert float((res["multi"][1][k] - g).norm()) <= 2e-6 * float(g.norm()) + 1e-7 * scale, k

@@ -226,6 +226,7 @@ class ResUnet(nn.Module):
         dtype = self.compute_dtype
         ctx = {"training": self.training, "n_updates": self.bn_updates_per_forward, "dtype": dtype,
                "capture": self.debug_capture, "name": ""}
+        nnops.prepack(self, dtype)          # the pointwise layers' bf16 packs: one launch for the whole pass
         h = nnops.to_nhwc(x, dtype)
         h = nnops.conv_bn_act(h, self.in_conv, None, ACT_NONE, self.training, 0, dtype)
         skips = []

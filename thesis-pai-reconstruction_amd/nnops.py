@@ -12,6 +12,8 @@ expansion / extraction of the filter is host-side plumbing on a 147 K-element te
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -59,6 +61,38 @@ def _grad_from_fwd_pack(dw: torch.Tensor, weight: torch.Tensor, groups: int) -> 
     out = torch.empty(cout, cig, kh, kw, dtype=torch.float32, device=dw.device)
     ops.filter_grad_from_dense(dw, cout, cig, kh * kw, groups, out)
     return out
+
+
+_PREPACK = {}       # id(weight) -> (w_fwd, w_dgrad) bf16 packs made by prepack() for the forward pass that follows; single use
+
+
+def prepack(module: torch.nn.Module, dtype) -> None:
+    """bf16 packs of EVERY dense pointwise convolution of ``module`` in one launch (``pai_pack_weights_multi``) at the start
+    of a forward pass, instead of one ``pack64_k`` launch in front of each convolution (40 of the ~600 launches on the main
+    stream of a residual U-Net step, each 5 us + a launch gap in the launch-bound coarse levels).  The packs live for this
+    forward pass only -- ``ConvBNAct.forward`` takes its layer's pair out of the table -- so a weight changed by anything
+    (optimizer, ``load_state_dict``, an EMA swap) is simply packed again by the next call."""
+    _PREPACK.clear()
+    if dtype != torch.bfloat16 or os.environ.get("PAI_NO_PREPACK", "0") not in ("", "0"):
+        return
+    convs = getattr(module, "_pai_pointwise", None)
+    if convs is None:
+        convs = [m for m in module.modules()
+                 if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (1, 1) and m.groups == 1 and m.stride == (1, 1)
+                 and m.in_channels % 64 == 0 and m.out_channels % 64 == 0]
+        object.__setattr__(module, "_pai_pointwise", convs)
+    convs = [c for c in convs if c.weight.dtype == torch.float32 and c.weight.is_contiguous() and c.weight.is_cuda]
+    if not convs:
+        return
+    buf = torch.empty(2 * sum(c.weight.numel() for c in convs), dtype=dtype, device=convs[0].weight.device)
+    items, off = [], 0
+    for c in convs:
+        n = c.weight.numel()
+        wf, wd = buf[off:off + n], buf[off + n:off + 2 * n]
+        off += 2 * n
+        items.append((c.weight.detach(), c.out_channels, 1, c.in_channels, wf, wd))
+        _PREPACK[id(c.weight)] = (wf, wd)
+    ops.pack_weights_multi(items)
 
 
 _ZEROS = {}
@@ -199,8 +233,11 @@ class ConvBNAct(torch.autograd.Function):
             ops.ensure_scratch(ops.scratch_bytes_for([d]), x.device)
         # weight-gradient workspace: pixel-split slabs of the patch kernels, partial blocks of the grouped 3 x 3 gradient
         ops.ensure_wgrad_workspace([d], x.device)
+        packed = _PREPACK.pop(id(weight), None) if (k == 1 and groups == 1 and dtype == torch.bfloat16) else None
         wm = _dense_fwd_pack(weight, groups)
-        if dtype == torch.float32:
+        if packed is not None:
+            wf, wd = packed
+        elif dtype == torch.float32:
             wf = wm
             wd = torch.empty_like(wm)
             ops.pack_weights(dtype, wm, Cout, k * k, Cin, None, wd)
