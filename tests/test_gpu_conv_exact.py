@@ -599,3 +599,54 @@ def test_prologue_is_refused_where_no_kernel_takes_it(pai):
                      ((dt, 0, 2, 128, 128, 64, 0, 64, 1, 0, 0, ops.ACT_NONE), dict(kernel=3)),       # 3 x 3
                      ((torch.float32, 0, 2, 128, 128, 64, 0, 64, 1, 0, 0, ops.ACT_NONE), dict(kernel=1))):
         assert not ops.conv_prologue_ok(ops.make_desc(*args, **kw))
+
+
+# (N, H, W, Cin, Cout): the input gradient of a pointwise layer (dx has Cin channels) with the producer's backward in the store
+PWX_BWD = [(2, 128, 128, 128, 64), (2, 128, 128, 64, 128), (1, 128, 128, 128, 128), (5, 100, 37, 64, 128), (1, 128, 128, 64, 256)]
+
+
+@pytest.mark.parametrize("act1", [2, 0], ids=["relu", "none"])
+@pytest.mark.parametrize("case", PWX_BWD, ids=str)
+def test_fused_producer_backward_of_the_streaming_pointwise_kernel_bit_exact(pai, case, act1):
+    """pai_conv_dgrad_bn on pwx_k (the 1 x 1 behind the grouped 3 x 3 of a ResNeXt block hands its input gradient to that
+    layer's BatchNorm, reference models/res_unet.py:143-147): du = act1'(z * scale + shift) * dgrad and the partial sums
+    (sum du, sum du * xhat) on integer data against the PyTorch-CPU restatement, bit for bit."""
+    from thesis_pai_reconstruction_amd import ops
+    N, H, W, Cin, K = case
+    dt = torch.bfloat16
+    w = _ints((K, Cin, 1, 1), 3)
+    dy = _ints((N, K, H, W), 5)
+    x = torch.zeros(N, Cin, H, W, requires_grad=True)
+    F.conv2d(x, w).backward(dy)
+    g = x.grad.bfloat16().float()
+    z = _ints((N, Cin, H, W), 11, -3, 3)
+    scale = torch.tensor([1.0, 2.0, 0.5, -1.0]).repeat(Cin // 4)
+    shift = torch.tensor([0.0, 1.0, -1.0, 2.0, -2.0, 0.5, 3.0, -0.5]).repeat(Cin // 8)
+    mean = torch.tensor([1.0, -1.0, 0.0, 2.0]).repeat(Cin // 4)
+    rstd = torch.tensor([0.5, 1.0, 2.0, 0.25]).repeat(Cin // 4)
+    pre = z * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    du = torch.where(pre > 0, g, torch.zeros_like(g)) if act1 else g
+    du_bf = du.bfloat16().float()
+    d = ops.make_desc(dt, 0, N, H, W, Cin, 0, K, 1, 0, 0, ops.ACT_NONE, kernel=1)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    assert ops.conv_kernel_name(d, 1) == f"pwx_k<{K}, {Cin}>"
+    wm = w.permute(0, 2, 3, 1).contiguous().to(dev())
+    wd = torch.empty(wm.numel(), dtype=dt, device=dev())
+    ops.pack_weights(dt, wm, K, 1, Cin, None, wd)
+    dx = torch.full((N * H * W * Cin,), 7.0, dtype=dt, device=dev())
+    part = torch.full((ops.conv_dgrad_bn_rows_max(d) * 2 * Cin,), float("nan"), device=dev())
+    f = lambda t: t.to(dev())
+    rows = ops.conv_dgrad_bn(d, nhwc(dy, dt), wd, dx, None, nhwc(z, dt), act1, None, ops.ACT_NONE, f(scale), f(shift), f(mean),
+                             f(rstd), part)
+    torch.cuda.synchronize()
+    assert 0 < rows <= 4096
+    assert torch.equal(from_nhwc(dx, N, H, W, Cin), du_bf)
+    P = part[: rows * 2 * Cin].view(rows, 2, Cin).double().sum(0).cpu()
+    s1 = du_bf.double().sum((0, 2, 3))
+    s2 = (du_bf.double() * ((z.double() - mean.view(1, -1, 1, 1).double()) * rstd.view(1, -1, 1, 1).double())).sum((0, 2, 3))
+    assert torch.equal(P[0], s1) and torch.equal(P[1], s2)
+    # without partial sums: the store alone
+    dx2 = torch.full_like(dx, 7.0)
+    assert ops.conv_dgrad_bn(d, nhwc(dy, dt), wd, dx2, None, nhwc(z, dt), act1, None, ops.ACT_NONE, f(scale), f(shift)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)

@@ -648,6 +648,7 @@ extern "C" int pai_conv_dgrad_bn_rows_max(const pai_conv_desc* d) {
     if (gg_build_dgrad(d, &g)) return -1;
     int fused = cdiv(g.M, 16) * g.nphase;
     if (pw_rows(g) > fused) fused = pw_rows(g);
+    if (pwx_rows(g) > fused) fused = pwx_rows(g);
     const int twopass = pai_bn_bwd_partial_rows((int64_t)g.N * g.OH * g.OW);
     return fused > twopass ? fused : twopass;
 }
@@ -677,7 +678,9 @@ extern "C" int pai_conv_dgrad_bn(const pai_conv_desc* d, const void* dy, const v
         a.bscale = e->scale; a.bshift = e->shift; a.bmean = e->mean; a.brstd = e->rstd;
         a.bact1 = e->act1; a.bact2 = e->act2;
         a.bpart = e->partials;
-        if (partial_rows) *partial_rows = !e->partials ? 0 : (pw_ok(d->dtype, g, a) ? pw_rows(g) : fwd_mfma_mtiles(g) * g.nphase);
+        if (partial_rows)
+            *partial_rows = !e->partials ? 0 : (pw_ok(d->dtype, g, a) ? pw_rows(g) : pwx_ok(d->dtype, g, a) ? pwx_rows(g)
+                                                                                      : fwd_mfma_mtiles(g) * g.nphase);
         return run_fwd(d->dtype, g, a, s);
     }
     if (e->partials) {

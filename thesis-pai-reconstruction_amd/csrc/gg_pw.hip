@@ -39,7 +39,12 @@ bool pwx_ok(int dtype, const GG& g, const FwdArgs& a) {
     if (dtype != PAI_BF16 || g.ntaps != 1 || g.nphase != 1 || g.S != 1 || g.OS != 1 || g.gslice) return false;
     if (!pwx_shape_ok(g.Cin, g.Cout) || (g.C1 % 32) || (g.C2 % 32)) return false;
     if (g.D2 ? ((g.D1 % 8) || (g.D2 % 8) || g.D1 + g.D2 != g.Cout) : false) return false;
-    if (g.relu1 || g.relu2 || a.yf32 || a.skip_d1 || a.bz) return false;
+    if (g.relu1 || g.relu2 || a.yf32 || a.skip_d1) return false;
+    // fused producer backward (pai_conv_dgrad_bn): du = act1'(bz * bscale + bshift) * dgrad with the BatchNorm partial sums;
+    // one destination, no second gradient, ReLU or none, no forward statistics / prologue at the same time
+    if (a.bz && (g.D2 || a.badd || !a.bscale || !a.bshift || a.stats || a.pscale ||
+                 (a.bpart && !(a.bmean && a.brstd)) || (a.bact1 != PAI_ACT_NONE && a.bact1 != PAI_ACT_RELU)))
+        return false;
     if (a.pscale && (g.C2 || !a.pshift || (a.pact != PAI_ACT_NONE && a.pact != PAI_ACT_RELU))) return false;
     if (!a.y1 || a.yact) return false;                              // the raw output only (what a BatchNorm or a sum follows)
     if ((int64_t)g.M < 16384) return false;                         // small images: the tile kernels (split-K) do better
@@ -55,11 +60,15 @@ int pwx_rows(const GG& g) {
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
-template <int CIN, int COUT, int T, bool STATS, bool PRE>
+// MODE 0: plain; 1: BatchNorm partial statistics of the output (forward); 2: the producer's backward in the store
+// (input gradient: du = act'(bz * bscale + bshift) * dgrad, partial sums of du and du * (bz - bmean))
+template <int CIN, int COUT, int T, int MODE, bool PRE>
 __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wave) {
+    constexpr bool STATS = MODE != 0;
     constexpr int KB = CIN / 32, NTT = COUT / 16, CL = COUT / 4, NCH = CL / 8;
     __shared__ __attribute__((aligned(16))) float sbias[COUT];
     __shared__ float sred[4][2][STATS ? COUT : 1];
+    __shared__ __attribute__((aligned(16))) float sbwd[3][MODE == 2 ? COUT : 4];      // bscale | bshift | bmean
     __shared__ __attribute__((aligned(16))) float spre[2][PRE ? CIN : 4];      // prologue: scale | shift per input channel
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -72,6 +81,15 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
         for (int c = tid; c < CIN; c += 256) { spre[0][c] = a.pscale[c]; spre[1][c] = a.pshift[c]; }
     }
     const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;      // prologue activation: ReLU or none
+    if (MODE == 2) {
+        for (int c = tid; c < COUT; c += 256) {
+            sbwd[0][c] = a.bscale[c];
+            sbwd[1][c] = a.bshift[c];
+            sbwd[2][c] = a.bmean ? a.bmean[c] : 0.f;
+        }
+    }
+    const bf16_t* bzp = (const bf16_t*)a.bz;
+    const bool brelu = a.bact1 == PAI_ACT_RELU;
     // filter: MFMA row (nt, i = fr) carries output channel 32 (nt >> 1) + 8 (i >> 2) + 4 (nt & 1) + (i & 3): lane (fr, fq)
     // ends up with channels 32 h + 8 fq + [0, 8) of pixel fr for h = 0 .. NCH - 1, so that ONE store instruction (fixed h)
     // writes 64 contiguous bytes per pixel (CL fq + 8 h, pw_k's order, gives 16-byte pieces 64 bytes apart)
@@ -138,6 +156,12 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
                     xb[t][kb] = __builtin_bit_cast(bf8_t, make_uint4(o[0], o[1], o[2], o[3]));
                 }
             }
+            uint4 zq[MODE == 2 ? NCH : 1];
+            if (MODE == 2) {        // the producer's raw output for this lane's chunks: in flight under the MFMAs
+                const int64_t pc = valid ? pix : 0;
+#pragma unroll
+                for (int h = 0; h < NCH; ++h) zq[h] = *(const uint4*)(bzp + pc * COUT + 32 * h + 8 * fq);
+            }
             f4_t acc[NTT];
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt) {
@@ -150,6 +174,8 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
 #pragma unroll
             for (int h = 0; h < NCH; ++h) {
                 unsigned pk[4];
+                const unsigned zw[4] = {zq[MODE == 2 ? h : 0].x, zq[MODE == 2 ? h : 0].y, zq[MODE == 2 ? h : 0].z,
+                                        zq[MODE == 2 ? h : 0].w};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nt = 2 * h + j;
@@ -157,7 +183,19 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = acc[nt][r];
-                        if (STATS && valid) { s1[4 * nt + r] += v[r]; s2[4 * nt + r] = fmaf(v[r], v[r], s2[4 * nt + r]); }
+                        if (MODE == 1 && valid) { s1[4 * nt + r] += v[r]; s2[4 * nt + r] = fmaf(v[r], v[r], s2[4 * nt + r]); }
+                    }
+                    if (MODE == 2) {
+                        const int cb = 32 * h + 8 * fq + 4 * j;        // this tile's 4 channels
+                        const f4_t bsc = *(const f4_t*)&sbwd[0][cb], bsh = *(const f4_t*)&sbwd[1][cb], bmu = *(const f4_t*)&sbwd[2][cb];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned w2 = zw[2 * j + (r >> 1)];
+                            const float z = __uint_as_float((r & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+                            if (brelu && !(fmaf(z, bsc[r], bsh[r]) > 0.f)) v[r] = 0.f;
+                            const float dr = bf2f(f2bf(v[r]));          // sums of the value as stored (what pass 2 reads back)
+                            if (valid) { s1[4 * nt + r] += dr; s2[4 * nt + r] = fmaf(dr, z - bmu[r], s2[4 * nt + r]); }
+                        }
                     }
                     pk[2 * j] = pk2bf(v[0], v[1]);
                     pk[2 * j + 1] = pk2bf(v[2], v[3]);
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
         if (gb + 2 * T < g1) load(gb + 2 * T, xa);
         if (gb + T < g1) compute(gb + T, xc);
     }
-    if (!STATS) return;
+    if (!STATS || (MODE == 2 && !a.bpart)) return;
     // sum over the 16 pixels of each lane row (DPP), then over the 4 waves; one partial row per workgroup
 #pragma unroll
     for (int c = 0; c < CL; ++c) {
@@ -190,20 +228,22 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
         float u = 0.f, q = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) { u += sred[wv][0][c]; q += sred[wv][1][c]; }
-        float* row = a.stats + (size_t)blockIdx.x * 2 * COUT;
+        float* row = (MODE == 2 ? a.bpart : a.stats) + (size_t)blockIdx.x * 2 * COUT;
         row[c] = u;
-        row[COUT + c] = q;
+        row[COUT + c] = MODE == 2 ? a.brstd[c] * q : q;       // producer backward: sum du * xhat = rstd * sum du * (z - mean)
     }
 }
 
 template <int CIN, int COUT, int T>
 static void pwx_launch(const GG& g, const FwdArgs& a, int blocks, int gpw, hipStream_t s) {
-    if (a.pscale) {         // forward with the producer's BatchNorm on load (always with statistics or without: both exist)
-        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, true, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
-        else PAI_LAUNCH((pwx_k<CIN, COUT, T, false, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    if (a.bz) {             // input gradient with the producer's backward in its store
+        PAI_LAUNCH((pwx_k<CIN, COUT, T, 2, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+    } else if (a.pscale) {  // forward with the producer's BatchNorm on load
+        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, 1, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        else PAI_LAUNCH((pwx_k<CIN, COUT, T, 0, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
     } else {
-        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, true, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
-        else PAI_LAUNCH((pwx_k<CIN, COUT, T, false, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, 1, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        else PAI_LAUNCH((pwx_k<CIN, COUT, T, 0, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
     }
 }
 template <int CIN, int COUT>
@@ -220,7 +260,7 @@ int launch_pwx(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int ci = g.Cin, co = g.Cout;
     const int big = ci * co > 64 * 128;
     int t = pai_tunable("pwx_t", big ? 2 : 4);
-    if (co == 256 && a.stats) t = 1;                     // (the 64-register statistics on top of a 128-register filter)
+    if (co == 256 && (a.stats || a.bz)) t = 1;                     // (the 64-register statistics on top of a 128-register filter)
     if (ci == 64 && co == 64) pwx_launch_t<64, 64>(g, a, blocks, gpw, t, s);
     else if (ci == 64 && co == 128) pwx_launch_t<64, 128>(g, a, blocks, gpw, t, s);
     else if (ci == 128 && co == 64) pwx_launch_t<128, 64>(g, a, blocks, gpw, t, s);

@@ -368,11 +368,25 @@ class ConvBNAct(torch.autograd.Function):
 
         gw, dbias = WGRAD.run(dev, (x, x2, dz) + ((psc, psh) if pre else ()), wgrad, (weight, ctx.bias_ref))
         dx = dx2 = dpg = dpb = None
-        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
+        fused_bwd = pre and ctx.needs_input_grad[0] and ctx.pre_training and fuse_dgrad_bn() \
+            and ops.conv_kernel_name(d, 1).startswith("pwx_k")
+        if fused_bwd:
+            # the streaming pointwise kernel forms du = act'(x * scale + shift) * dgrad and the BatchNorm partial sums in its
+            # store (pai_conv_dgrad_bn): pass 1 of the producer's BatchNorm backward costs one read of x instead of a read of
+            # dx and x; pass 2 turns du into dz in place
+            part = torch.empty(ops.conv_dgrad_bn_rows_max(d) * 2 * C1, **f32)
+            sums = torch.empty(2 * C1, **f32)
+            dx = torch.empty(N, H, W, C1, dtype=dtype, device=dev)
+            rows = ops.conv_dgrad_bn(d, dz, wd, dx, None, x, ctx.pre_act, scale=psc, shift=psh, mean=pmean, rstd=prstd,
+                                     partials=part)
+            ops.bn_bwd_finalize(part, rows, C1, sums, None, None)
+            ops.bn_bwd_apply(dtype, dx, x, M, C1, pmean, prstd, pgam.detach(), sums, dx)
+            dpb, dpg = sums[:C1], sums[C1:]
+        elif ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
             dx = torch.empty(N, H, W, C1, dtype=dtype, device=dev)
             dx2 = torch.empty(N, H, W, C2, dtype=dtype, device=dev) if ctx.has_x2 else None
             ops.conv_dgrad(d, dz, wd, dx, dx2)
-        if pre and dx is not None:
+        if pre and dx is not None and not fused_bwd:
             # dx is the gradient behind the producer's BatchNorm + activation: its backward (two passes over dx and x = z),
             # the producing convolution gets dz and the BatchNorm parameters their gradients from here
             if not ctx.pre_training:
@@ -601,6 +615,11 @@ class SwapMid(torch.autograd.Function):
         dx = torch.empty_like(g)
         ops.swap_mid(g, A, Cc, B, D, dx)
         return dx, None, None, None, None
+
+
+def fuse_dgrad_bn() -> bool:
+    """PAI_NO_DGRAD_BN=1: the producer's BatchNorm backward always as two passes behind a plain input gradient (A/B switch)."""
+    return os.environ.get("PAI_NO_DGRAD_BN", "0") in ("", "0")
 
 
 def no_prologue() -> bool:
