@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
                     pk[2 * j] = pk2bf(v[0], v[1]);
                     pk[2 * j + 1] = pk2bf(v[2], v[3]);
                 }
-                // (non-temporal loads / stores, which help the elementwise passes of ew_stream.hip, cost this kernel 5-15 %:
+                // (eight groups per batch for the 64-channel inputs, i.e. twice the loads in flight: 350 against 339 us -- the launch is not
+                //  bound by the latency of its reads; non-temporal loads / stores, which help the elementwise passes of ew_stream.hip, cost this kernel 5-15 %:
                 //  396 against 346 us for 64 -> 128 channels at 512 x 512 x 16)
                 if (valid) *(uint4*)(dst[h] + pix * dstride[h]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
