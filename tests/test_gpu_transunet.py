@@ -132,7 +132,7 @@ def test_mha_matrix_core_path_against_the_vector_path(pai, S, B, heads, hd, drop
 
 
 @DTYPES
-@pytest.mark.parametrize("M,K,O", [(16, 96, 40), (64, 512, 1536), (128, 1024, 2048), (12, 256, 256)])
+@pytest.mark.parametrize("M,K,O", [(16, 96, 40), (64, 512, 1536), (128, 1024, 2048), (12, 256, 256), (128, 4096, 2048), (100, 132, 72)])
 def test_linear(pai, dtype, M, K, O):
     from thesis_pai_reconstruction_amd import nnops
     x, w, b = q(rnd((M, K), 11), dtype), q(rnd((O, K), 12) * 0.05, dtype), rnd((O,), 13) * 0.1

@@ -1340,7 +1340,7 @@ __device__ __forceinline__ unsigned tr_off(int row, int ch) { return (unsigned)(
 
 template <int BMC>  // output-channel tile: 128 or 64
 __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int cotiles, int jtiles,
-                                                       int splits, int rows_per_split) {
+                                                       int splits, int rows_per_split, int stage_lds) {
     constexpr int MT = BMC / 32;   // 16-row MFMA tiles per wave along co
     constexpr int BUF = 64 * 256;  // one staged operand tile: 64 pixel rows x 256 B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1356,6 +1356,8 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     const int split = bid % splits;
     const int ph = bid / splits;
     const int co0 = cot * BMC, j0 = jt * 128;
+    // one writer per element of a pointwise layer's [Cout][Cin] gradient: the tile leaves through LDS as whole rows
+    const bool stage_out = stage_lds != 0;
 
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
@@ -1534,6 +1536,48 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
                 atomicAdd(a.dbias + co0 + tid, t);
             }
         }
+    }
+
+    // ---- un-split pointwise layers (nn.Linear of the ViT bottleneck: 128 token rows, 4096 x 4096 .. 12288 weights; the
+    // launch is the store of dW): the tile goes through LDS in two 64-row halves and leaves as 512-byte rows -- 32 lanes x
+    // 16 bytes per row instead of 16 scalar stores of 64 bytes per MFMA tile (28 -> ~14 us at 4096 x 4096, 2.4 -> ~5 TB/s)
+    if (stage_out) {
+        constexpr int SP = 132;                                // padded row: 128 columns + 4
+        float* st = (float*)smem;                              // 64 x 132 x 4 B = 33 KB (the launch asks for it)
+        constexpr int HALVES = BMC / 64;
+#pragma unroll
+        for (int hpass = 0; hpass < HALVES; ++hpass) {
+            __syncthreads();                                   // the K loop / the previous half is done with smem
+            if (HALVES == 1 || wm == hpass) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = (HALVES == 1 ? wm * (BMC / 2) : 0) + mt * 16 + fg * 4 + r;
+                            st[row * SP + wn * 64 + nt * 16 + fi] = acc[mt][nt][r];
+                        }
+            }
+            __syncthreads();
+            const int c4 = (tid & 31) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (tid >> 5) + 8 * i;
+                const int co = co0 + hpass * 64 + row, jcol = j0 + c4;
+                if (co < g.Cout && jcol < g.Cin) {
+                    const float4 v = *(const float4*)(st + row * SP + c4);
+                    float* pw = a.dw + (size_t)co * g.Cin + jcol;
+                    if (a.overwrite) *(float4*)pw = v;
+                    else {
+                        float4 o = *(float4*)pw;
+                        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                        *(float4*)pw = o;
+                    }
+                }
+            }
+        }
+        return;
     }
 
     // ---- accumulate into the fp32 gradient (fwd pack) ------------------------------
@@ -1908,16 +1952,19 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
         PAI_LAUNCH_CHECK();
         return 0;
     }
-    const size_t lds = 2 * 64 * 256;
+    // un-split pointwise layers store their tile as whole rows through LDS (see the kernel)
+    const int stage = splits == 1 && g.ntaps == 1 && g.nphase == 1 && (g.Cin % 4) == 0 && !g.gslice &&
+                      pai_tunable("wgrad_stage", 1) != 0;
+    const size_t lds = stage ? 64 * 132 * 4 : 2 * 64 * 256;
     dim3 grid(tiles * splits);
     if (a.overwrite_bias && a.dbias && g.nphase > 1) {
         hipError_t e = pai::memset_async(a.dbias, 0, (size_t)g.Cout * sizeof(float), s);
         PAI_CHECK(e == hipSuccess, "launch_wgrad_mfma: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     if (big)
-        PAI_LAUNCH(gg_wgrad_mfma_k<128>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
+        PAI_LAUNCH(gg_wgrad_mfma_k<128>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows, stage);
     else
-        PAI_LAUNCH(gg_wgrad_mfma_k<64>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows);
+        PAI_LAUNCH(gg_wgrad_mfma_k<64>, grid, dim3(256), lds, s, g, a, cotiles, jtiles, splits, rows, stage);
     PAI_LAUNCH_CHECK();
     return 0;
 }
