@@ -54,7 +54,7 @@ const char* pai_last_error(void);
  * pai_stream_wait, pai_event_*), pai_zero_multi, pai_scale; pai_pack_frag and the pack_flags bits are gone (removed
  * experiment kernels: pack_flags MUST be zero); pai_conv_desc.reserved became .hints (PAI_HINT_SOLO).
  * 131: pai_lerp_multi (the EMA update of callbacks/ema.py), PAI_TUNE_<name> environment defaults of the tunables.
- * 132: input prologue (pai_conv_prologue_ok, pai_conv_fwd_pro, pai_conv_wgrad_pro); pai_bn_stats_buffer_rows grows for
+ * 132: input prologue (pai_conv_prologue_ok, pai_conv_fwd_pro, pai_conv_wgrad_pro); pai_instnorm_fwd / _bwd; pai_bn_stats_buffer_rows grows for
  * layers with more than 2048 partial rows (callers that size the buffer through it need no change). */
 int pai_version(void);
 /* Build-option bits.  0 since ABI 130: bit 0 used to announce the round-2 experiment kernels (and pai_pack_frag), which
@@ -389,6 +389,14 @@ int pai_maxpool2_bwd(int dtype, const void* dout, const unsigned char* idx, int 
 int pai_upsample2(int dtype, const void* x, int N, int H, int W, int C, void* out, void* stream);
 int pai_upsample2_bwd(int dtype, const void* dout, int N, int H, int W, int C, void* dx, void* stream);
 int pai_add_act(int dtype, const void* a, const void* b, int64_t numel, int act, void* out, void* stream);
+/* nn.InstanceNorm2d(C) (affine=False, no running statistics) with the activation behind it -- DiscriminatorBlock(norm=True),
+ * reference models/wrapper.py:203-205; x, y: NHWC [N][HW][C], C a multiple of 8; mean, rstd: fp32 [N][C] (kept for the backward
+ * pass).  y = act((x - mean[n][c]) * rstd[n][c]) with the biased variance over the HW pixels of sample n;
+ * backward: du = g * act'(y), dx = rstd * (du - mean(du) - xhat * mean(du * xhat)).  ABI 132. */
+int pai_instnorm_fwd(int dtype, const void* x, int N, int HW, int C, float eps, int act, void* y, float* mean, float* rstd,
+                     void* stream);
+int pai_instnorm_bwd(int dtype, const void* g, const void* x, int N, int HW, int C, int act, const float* mean,
+                     const float* rstd, void* dx, void* stream);
 
 /* ---------------------------------------------------------------------------
  * TransUNet (models/trans_unet.py) pieces besides its convolutions / BatchNorms / Upsample (above) and its

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpai_hip.so")
 STAMPS = os.path.join(CSRC, ".build_stamps.json")     # object / library -> content hash of what it was built from
-SOURCES = ["api.hip", "gg_simt.hip", "gg_mfma.hip", "gg_wg3.hip", "gg_thin.hip", "gg_small.hip", "gg_group.hip", "gg_pw.hip", "bn.hip", "ew_stream.hip", "gate.hip", "resnet.hip", "vit.hip", "loss.hip", "ssim.hip", "misc.hip", "comm.hip", "plan.hip"]
+SOURCES = ["api.hip", "gg_simt.hip", "gg_mfma.hip", "gg_wg3.hip", "gg_thin.hip", "gg_small.hip", "gg_group.hip", "gg_pw.hip", "bn.hip", "ew_stream.hip", "gate.hip", "resnet.hip", "inorm.hip", "vit.hip", "loss.hip", "ssim.hip", "misc.hip", "comm.hip", "plan.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "plan.h"), os.path.join(CSRC, "gg_tile.h"), os.path.join(HERE, "..", "include", "pai_hip.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in the (unified) VGPR file.  Without it hipcc 7.2
 # put the wgrad accumulators in AGPRs with a different source/destination register per MFMA and

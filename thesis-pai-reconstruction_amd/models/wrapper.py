@@ -198,19 +198,37 @@ class UnetWrapper(LightningModule):
 
 class DiscriminatorBlock(nn.Module):
     """Conv2d(k4,s2,p1) -> (InstanceNorm2d | Identity) -> LeakyReLU(0.2)
-    (reference models/wrapper.py:176-209).  Parameter container; the arithmetic runs in
-    ``Discriminator.forward`` through DiscEngine.  ``norm=True`` is dead code in the reference
-    (never enabled) and is rejected here."""
+    (reference models/wrapper.py:176-209).  Inside ``Discriminator`` it is a parameter container whose arithmetic runs
+    through DiscEngine; used on its own (``forward``) it runs through the op-level kernels -- including ``norm=True``
+    (``nn.InstanceNorm2d``), which the reference's Discriminator never enables but its class offers."""
 
     def __init__(self, in_channels: int, out_channels: int, norm: bool = False):
         super().__init__()
-        if norm:
-            raise NotImplementedError("DiscriminatorBlock(norm=True) is never used by the reference")
+        self.compute_dtype = torch.float32
         self.block = nn.Sequential(
             nn.Conv2d(in_channels, out_channels, kernel_size=4, stride=2, padding=1),
-            nn.Identity(),
+            nn.InstanceNorm2d(out_channels) if norm else nn.Identity(),
             nn.LeakyReLU(0.2),
         )
+
+    def forward(self, x):
+        """:input: [N x in_channels x H x W]   :output: [N x out_channels x H/2 x W/2] (fp32)"""
+        from .. import nnops
+        from ..ops import ACT_LRELU, ACT_NONE, PaiError
+        if not x.is_cuda:
+            raise PaiError("DiscriminatorBlock (HIP) needs a HIP device tensor; there is no CPU path")
+        conv, norm = self.block[0], self.block[1]
+        dtype = self.compute_dtype
+        h = x.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        h = nnops.ToStorage.apply(h, dtype)
+        if isinstance(norm, nn.InstanceNorm2d):
+            if norm.affine or norm.track_running_stats:
+                raise PaiError("DiscriminatorBlock: InstanceNorm2d with affine parameters / running statistics is not built")
+            h = nnops.ConvK4S2.apply(h, conv.weight, conv.bias, ACT_NONE, dtype)
+            h = nnops.InstanceNormAct.apply(h, float(norm.eps), ACT_LRELU)
+        else:
+            h = nnops.ConvK4S2.apply(h, conv.weight, conv.bias, ACT_LRELU, dtype)
+        return h.float().permute(0, 3, 1, 2)
 
 
 class Discriminator(nn.Module):

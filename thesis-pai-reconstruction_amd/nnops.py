@@ -405,6 +405,102 @@ class ConvBNAct(torch.autograd.Function):
         return dx, dx2, gw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, dpg, dpb, None
 
 
+class ConvK4S2(torch.autograd.Function):
+    """act(nn.Conv2d(k4, s2, p1)(x)) on an NHWC tensor: the convolution of DiscriminatorBlock as a stand-alone op (reference
+    models/wrapper.py:196-203).  The networks of this package run these layers inside their engines; this Function exists
+    for a DiscriminatorBlock used on its own (``norm=True`` included, which the reference's Discriminator never builds)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, dtype):
+        _check(x)
+        N, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        if H % 2 or W % 2 or tuple(weight.shape[1:]) != (Cin, 4, 4):
+            raise ops.PaiError("ConvK4S2: even image sizes and a [Cout, Cin, 4, 4] filter")
+        d = ops.make_desc(dtype, 0, N, H, W, Cin, 0, Cout, 2, 0, 0, act)
+        ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), x.device)
+        ops.ensure_scratch(ops.scratch_bytes_for([d]), x.device)
+        ops.ensure_wgrad_workspace([d], x.device)
+        wm = _dense_fwd_pack(weight, 1)
+        if dtype == torch.float32:
+            wf, wd = wm, torch.empty_like(wm)
+            ops.pack_weights(dtype, wm, Cout, 16, Cin, None, wd)
+        else:
+            wf = torch.empty(wm.numel(), dtype=dtype, device=x.device)
+            wd = torch.empty(wm.numel(), dtype=dtype, device=x.device)
+            ops.pack_weights(dtype, wm, Cout, 16, Cin, wf, wd)
+        out = torch.empty(N, H // 2, W // 2, Cout, dtype=dtype, device=x.device)
+        b32 = None if bias is None else bias.detach().float()
+        if act == ACT_NONE:
+            ops.conv_fwd(d, x, None, wf, b32, y_raw=out)
+        else:
+            ops.conv_fwd(d, x, None, wf, b32, y_act=out)
+        ctx.d, ctx.act, ctx.dtype = d, act, dtype
+        ctx.save_for_backward(x, out, wd, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out, wd, weight = ctx.saved_tensors
+        d, act, dtype = ctx.d, ctx.act, ctx.dtype
+        g = g.contiguous()
+        dz = g
+        if act != ACT_NONE:
+            dz = torch.empty_like(out)
+            ops.act_bwd(dtype, g, act, None, ACT_NONE, out, g.numel(), dz)
+        f32 = dict(dtype=torch.float32, device=g.device)
+        dw = torch.empty(weight.numel(), **f32)
+        dbias = torch.empty(d.Cout, **f32) if ctx.needs_input_grad[2] else None
+        ops.conv_wgrad_overwrite(d, x, None, dz, dw, dbias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ops.conv_dgrad(d, dz, wd, dx, None)
+        return dx, _grad_from_fwd_pack(dw, weight, 1), dbias, None, None
+
+
+class InstanceNormAct(torch.autograd.Function):
+    """act(nn.InstanceNorm2d(C)(x)) on an NHWC tensor (affine=False, no running statistics: the module DiscriminatorBlock
+    builds for ``norm=True``, reference models/wrapper.py:203)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, act):
+        _check(x)
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N * C, dtype=torch.float32, device=x.device)
+        ops.instnorm_fwd(x.dtype, x, N, H * W, C, eps, act, y, mean, rstd)
+        ctx.act = act
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        ops.instnorm_bwd(x.dtype, g.contiguous(), x, N, H * W, C, ctx.act, mean, rstd, dx)
+        return dx, None, None
+
+
+class ToStorage(torch.autograd.Function):
+    """fp32 NHWC -> storage dtype (``pai_cast``) with the gradient cast back: the differentiable form of ``to_nhwc``'s last
+    step, for stand-alone blocks whose input needs a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        if dtype == torch.float32:
+            return x
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+        ops.cast(x.contiguous(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float(), None
+
+
 class MaxPool2(torch.autograd.Function):
     """nn.MaxPool2d(2) (reference models/res_unet.py:199)."""
 

@@ -540,6 +540,17 @@ def add_act(dtype, a, b, act, out):
     L.check(L.load().pai_add_act(code_of(dtype), _p(a), _p(b), a.numel(), int(act), _p(out), _stream()), "pai_add_act")
 
 
+def instnorm_fwd(dtype, x, N, HW, C_, eps, act, y, mean, rstd):
+    """y = act(InstanceNorm2d(x)) over an NHWC tensor; mean / rstd [N][C] are kept for the backward pass."""
+    L.check(L.load().pai_instnorm_fwd(code_of(dtype), _p(x), N, HW, C_, float(eps), int(act), _p(y), _p(mean, torch.float32),
+                                      _p(rstd, torch.float32), _stream()), "pai_instnorm_fwd")
+
+
+def instnorm_bwd(dtype, g, x, N, HW, C_, act, mean, rstd, dx):
+    L.check(L.load().pai_instnorm_bwd(code_of(dtype), _p(g), _p(x), N, HW, C_, int(act), _p(mean, torch.float32),
+                                      _p(rstd, torch.float32), _p(dx), _stream()), "pai_instnorm_bwd")
+
+
 def dropout2d(dtype, x, mask, N, HW, C_, out):
     """out = x * mask[n][c] over an NHWC tensor (nn.Dropout2d forward, and its backward on gradients)."""
     L.check(L.load().pai_dropout2d(code_of(dtype), _p(x), _p(mask, torch.float32), N, HW, C_, _p(out), _stream()),
