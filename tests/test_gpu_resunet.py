@@ -260,6 +260,10 @@ def test_batchnorm_on_load_equals_batchnorm_as_a_pass(pai, monkeypatch, res_type
         torch.cuda.synchronize()
         out[mode], calls[mode] = pred.detach().clone(), count[0]
         grads[mode] = {k: p.grad.detach().clone() for k, p in m.unet.named_parameters() if p.grad is not None}
+        m.eval()                         # eval mode: the prologue carries the running statistics' scale / shift
+        with torch.no_grad():
+            out[mode + "_eval"] = m.unet(x).detach().clone()
+    assert torch.equal(out["load_eval"], out["pass_eval"])
     assert calls["pass"] == 0
     assert calls["load"] >= 2, calls       # the level-0 encoder block (2 x 128 x 128 pixels): grouped 3 x 3 and the last 1 x 1
     assert torch.equal(out["load"], out["pass"])
