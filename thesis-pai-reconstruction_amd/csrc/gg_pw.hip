@@ -8,12 +8,14 @@
 // (gg_fwd_mfma_k: operands through LDS, a staged epilogue, one tile per workgroup) ran them at 2.2-2.6 TB/s; this one
 // follows pw_k (the attention gate's kernel, gg_mfma.hip) and the streaming rules of ew_stream.hip:
 //   * no LDS for the operands: a wave keeps the WHOLE filter in registers as the MFMA's A operand (rows permuted so that a
-//     lane ends up with COUT / 4 consecutive channels of one pixel) and streams groups of 16 pixels as the B operand -- one
-//     16-byte load per lane and 32 input channels, whole rows per instruction;
+//     lane ends up with 8-channel chunks of one pixel and a store instruction writes 64 contiguous bytes per pixel) and
+//     streams groups of 16 pixels as the B operand -- one 16-byte load per lane and 32 input channels;
 //   * T groups per batch and the NEXT batch's loads issued before the current batch's MFMAs: 16-64 KB in flight per CU;
 //   * the input may be two tensors read as one concatenation (decoder blocks), the output may split into two (their input
 //     gradients);
-//   * bias, BatchNorm partial statistics (one row per workgroup: <= 2048 rows instead of one per 128 pixels).
+//   * bias; BatchNorm partial statistics (one row per workgroup: 256 or 4096 rows instead of one per 128 pixels); the input
+//     read through the producer's BatchNorm + ReLU (pai_conv_fwd_pro); the producer's BatchNorm backward, first pass, in
+//     the store of an input gradient (pai_conv_dgrad_bn).
 #include "common.h"
 #include "gg_tile.h"
 
