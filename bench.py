@@ -317,8 +317,10 @@ def main():
         f = fam[dom]
         achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
         traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))[dom]["hbm_bytes_per_launch"]
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/): they were taken on the DEFAULT
+            # workload (BASELINE configs[1]); a kernel of that name in another family's step runs other layers
+            if args.model == "pix2pix" and args.batch == 64:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))[dom]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         return dom, {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
