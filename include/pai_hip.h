@@ -54,7 +54,7 @@ const char* pai_last_error(void);
  * pai_stream_wait, pai_event_*), pai_zero_multi, pai_scale; pai_pack_frag and the pack_flags bits are gone (removed
  * experiment kernels: pack_flags MUST be zero); pai_conv_desc.reserved became .hints (PAI_HINT_SOLO).
  * 131: pai_lerp_multi (the EMA update of callbacks/ema.py), PAI_TUNE_<name> environment defaults of the tunables.
- * 132: input prologue (pai_conv_prologue_ok, pai_conv_fwd_pro, pai_conv_wgrad_pro); pai_instnorm_fwd / _bwd; pai_bn_stats_buffer_rows grows for
+ * 132: input prologue (pai_conv_prologue_ok, pai_conv_fwd_pro, pai_conv_wgrad_pro); pai_instnorm_fwd / _bwd; pai_bn2_bwd_reduce / _apply; pai_bn_stats_buffer_rows grows for
  * layers with more than 2048 partial rows (callers that size the buffer through it need no change). */
 int pai_version(void);
 /* Build-option bits.  0 since ABI 130: bit 0 used to announce the round-2 experiment kernels (and pai_pack_frag), which
@@ -389,6 +389,20 @@ int pai_maxpool2_bwd(int dtype, const void* dout, const unsigned char* idx, int 
 int pai_upsample2(int dtype, const void* x, int N, int H, int W, int C, void* out, void* stream);
 int pai_upsample2_bwd(int dtype, const void* dout, int N, int H, int W, int C, void* dx, void* stream);
 int pai_add_act(int dtype, const void* a, const void* b, int64_t numel, int act, void* out, void* stream);
+/* The tail of a residual block, backward (reference models/res_unet.py:165-171: conv_block(x) + conv_skip(x), both ending in
+ * a BatchNorm2d): the two BatchNorms read the SAME incoming gradient d.  pai_bn2_bwd_reduce = pai_bn_bwd_reduce(_affine)
+ * for both branches (branch a through its activation act_a: du_a = d * act_a'(za * scale_a + shift_a), not stored; branch b
+ * without one) + the two pai_bn_bwd_finalize (sums_x = [sum du | sum du * xhat], fp32 [2 C]); pai_bn2_bwd_apply = the two
+ * pai_bn_bwd_apply(_affine).  Big bf16 tensors take one pass over (d, za, zb) each -- 3 + 5 tensor passes instead of
+ * 4 + 6; everything else runs the one-branch calls twice.  part_x: fp32 [pai_bn_bwd_partial_rows(M)][2][C].  ABI 132. */
+int pai_bn2_bwd_reduce(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                       const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                       const float* mean_b, const float* rstd_b, float* part_a, float* part_b, float* sums_a, float* sums_b,
+                       void* stream);
+int pai_bn2_bwd_apply(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                      const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                      const float* gamma_a, const float* sums_a, const float* mean_b, const float* rstd_b,
+                      const float* gamma_b, const float* sums_b, void* dza, void* dzb, void* stream);
 /* nn.InstanceNorm2d(C) (affine=False, no running statistics) with the activation behind it -- DiscriminatorBlock(norm=True),
  * reference models/wrapper.py:203-205; x, y: NHWC [N][HW][C], C a multiple of 8; mean, rstd: fp32 [N][C] (kept for the backward
  * pass).  y = act((x - mean[n][c]) * rstd[n][c]) with the biased variance over the HW pixels of sample n;

@@ -176,3 +176,59 @@ def test_small_and_odd_layers_stay_on_the_generic_kernels(both):
             return dz
         a, b = run(fn)
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("act", ["relu", "none"])
+@pytest.mark.parametrize("shape", [(40000 + 3, 128), (9001, 64), (4096, 64), (20000, 24)], ids=str)
+def test_block_tail_backward_both_branches_in_one_pass(both, shape, act):
+    """pai_bn2_bwd_reduce / pai_bn2_bwd_apply (both BatchNorms of a residual block's tail read the same gradient) against the
+    two one-branch call pairs they stand for: sums to fp32 summation error, dz to bf16 rounding.  Small / odd shapes run the
+    one-branch kernels inside the entry point: bit-identical."""
+    ops, run = both
+    M, C = shape
+    dt = torch.bfloat16
+    za, d, mean_a, rstd_a, gamma_a, scale_a, shift_a = _data(M, C, 7)
+    zb, _, mean_b, rstd_b, gamma_b, _, _ = _data(M, C, 8)
+    f32 = dict(dtype=torch.float32, device=dev())
+    a = _act(ops, act)
+    rows = ops.bn_bwd_partial_rows(M)
+    if C / 8 not in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        pytest.skip("pai_bn_bwd_reduce needs C = 8 * 2^k")
+
+    def pair():
+        pa, pb = torch.empty(rows * 2 * C, **f32), torch.empty(rows * 2 * C, **f32)
+        sa, sb = torch.empty(2 * C, **f32), torch.empty(2 * C, **f32)
+        dza, dzb = torch.empty_like(za), torch.empty_like(zb)
+        ops.bn2_bwd_reduce(dt, d, a, za, zb, M, C, scale_a, shift_a, mean_a, rstd_a, mean_b, rstd_b, pa, pb, sa, sb)
+        ops.bn2_bwd_apply(dt, d, a, za, zb, M, C, scale_a, shift_a, mean_a, rstd_a, gamma_a, sa, mean_b, rstd_b, gamma_b, sb, dza, dzb)
+        return sa.clone(), sb.clone(), dza, dzb
+
+    def single():
+        pa, pb = torch.empty(rows * 2 * C, **f32), torch.empty(rows * 2 * C, **f32)
+        sa, sb = torch.empty(2 * C, **f32), torch.empty(2 * C, **f32)
+        dza, dzb = torch.empty_like(za), torch.empty_like(zb)
+        if act == "none":
+            ops.bn_bwd_reduce(dt, d, ops.ACT_NONE, None, ops.ACT_NONE, None, za, M, C, mean_a, rstd_a, None, pa, sa, None, None)
+            ops.bn_bwd_apply(dt, d, za, M, C, mean_a, rstd_a, gamma_a, sa, dza)
+        else:
+            ops.bn_bwd_reduce_affine(dt, d, a, None, ops.ACT_NONE, za, M, C, scale_a, shift_a, mean_a, rstd_a, None, pa, sa, None, None)
+            ops.bn_bwd_apply_affine(dt, d, a, za, M, C, scale_a, shift_a, mean_a, rstd_a, gamma_a, sa, dza)
+        ops.bn_bwd_reduce(dt, d, ops.ACT_NONE, None, ops.ACT_NONE, None, zb, M, C, mean_b, rstd_b, None, pb, sb, None, None)
+        ops.bn_bwd_apply(dt, d, zb, M, C, mean_b, rstd_b, gamma_b, sb, dzb)
+        return sa.clone(), sb.clone(), dza, dzb
+
+    got = pair()
+    want = single()
+    torch.cuda.synchronize()
+    big = M > 4096
+    for g_, w_ in zip(got[:2], want[:2]):
+        if big:
+            assert float((g_ - w_).abs().max()) <= 2e-5 * float(w_.abs().max()) + 1e-3
+        else:
+            assert torch.equal(g_, w_)
+    for g_, w_ in zip(got[2:], want[2:]):
+        if big:
+            fa, fb = g_.float(), w_.float()
+            assert bool(((fa - fb).abs() <= 2 ** -7 * torch.maximum(fa.abs(), fb.abs()) + 4e-6 * (d.abs().float() + 1)).all())
+        else:
+            assert torch.equal(g_.view(torch.int16), w_.view(torch.int16))

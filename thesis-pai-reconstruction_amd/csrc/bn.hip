@@ -601,6 +601,56 @@ extern "C" int pai_bn_bwd_apply_affine(int dtype, const void* g1, int act1, cons
     return 0;
 }
 
+// ---- the tail of a residual block, backward (reference models/res_unet.py:165-171: conv_block(x) + conv_skip(x), both ending
+// in a BatchNorm): the residual branch's BatchNorm (with its ReLU, act_a) and the skip branch's read the SAME gradient d.
+// pai_bn2_bwd_reduce = pai_bn_bwd_reduce(_affine) for both (du not stored) + the two finalizes; pai_bn2_bwd_apply = both
+// pai_bn_bwd_apply(_affine).  Big bf16 tensors: one pass over (d, za, zb) each (3 + 5 tensor passes instead of 4 + 6);
+// everything else: the one-branch calls, twice.
+extern "C" int pai_bn2_bwd_reduce(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                                  const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                                  const float* mean_b, const float* rstd_b, float* part_a, float* part_b, float* sums_a,
+                                  float* sums_b, void* stream) {
+    PAI_CHECK(d && za && zb && mean_a && rstd_a && mean_b && rstd_b && part_a && part_b && sums_a && sums_b,
+              "pai_bn2_bwd_reduce: null pointer");
+    PAI_CHECK(C % 8 == 0 && ((C / 8) & (C / 8 - 1)) == 0, "pai_bn2_bwd_reduce: C=%d must be 8 * 2^k", C);
+    PAI_CHECK(act_a == PAI_ACT_NONE || (scale_a && shift_a), "pai_bn2_bwd_reduce: an activation needs scale_a / shift_a");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = pai_bn_bwd_partial_rows(M);
+    const int r = ew_stream_bn2_bwd_reduce(dtype, d, act_a, za, zb, M, C, scale_a, shift_a, mean_a, rstd_a, mean_b, rstd_b, part_a,
+                                           part_b, rows, s);
+    if (r > 0) return r;
+    if (r == 0) {
+        if (int rc = pai_bn_bwd_finalize(part_a, rows, C, sums_a, nullptr, nullptr, stream)) return rc;
+        return pai_bn_bwd_finalize(part_b, rows, C, sums_b, nullptr, nullptr, stream);
+    }
+    int rc = act_a != PAI_ACT_NONE
+                 ? pai_bn_bwd_reduce_affine(dtype, d, act_a, nullptr, PAI_ACT_NONE, za, M, C, scale_a, shift_a, mean_a, rstd_a,
+                                            nullptr, part_a, sums_a, nullptr, nullptr, stream)
+                 : pai_bn_bwd_reduce(dtype, d, PAI_ACT_NONE, nullptr, PAI_ACT_NONE, nullptr, za, M, C, mean_a, rstd_a, nullptr,
+                                     part_a, sums_a, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return pai_bn_bwd_reduce(dtype, d, PAI_ACT_NONE, nullptr, PAI_ACT_NONE, nullptr, zb, M, C, mean_b, rstd_b, nullptr, part_b,
+                             sums_b, nullptr, nullptr, stream);
+}
+
+extern "C" int pai_bn2_bwd_apply(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                                 const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                                 const float* gamma_a, const float* sums_a, const float* mean_b, const float* rstd_b,
+                                 const float* gamma_b, const float* sums_b, void* dza, void* dzb, void* stream) {
+    PAI_CHECK(d && za && zb && dza && dzb && mean_a && rstd_a && mean_b && rstd_b && sums_a && sums_b,
+              "pai_bn2_bwd_apply: null pointer");
+    PAI_CHECK(C % 8 == 0, "pai_bn2_bwd_apply: C=%d must be a multiple of 8", C);
+    PAI_CHECK(act_a == PAI_ACT_NONE || (scale_a && shift_a), "pai_bn2_bwd_apply: an activation needs scale_a / shift_a");
+    const int r = ew_stream_bn2_bwd_apply(dtype, d, act_a, za, zb, M, C, scale_a, shift_a, mean_a, rstd_a, gamma_a, sums_a, mean_b,
+                                          rstd_b, gamma_b, sums_b, dza, dzb, (hipStream_t)stream);
+    if (r >= 0) return r;
+    int rc = act_a != PAI_ACT_NONE
+                 ? pai_bn_bwd_apply_affine(dtype, d, act_a, za, M, C, scale_a, shift_a, mean_a, rstd_a, gamma_a, sums_a, dza, stream)
+                 : pai_bn_bwd_apply(dtype, d, za, M, C, mean_a, rstd_a, gamma_a, sums_a, dza, stream);
+    if (rc) return rc;
+    return pai_bn_bwd_apply(dtype, d, zb, M, C, mean_b, rstd_b, gamma_b, sums_b, dzb, stream);
+}
+
 // ---- finalize + apply in ONE launch for the small layers (the U-Net bottleneck: <= 4096 rows, <= 256 partial rows) -------
 // pai_bn_finalize -> pai_bn_apply and pai_bn_bwd_finalize -> pai_bn_bwd_apply are two dependent launches of 5-9 us each
 // around tensors of 0.1-4 MB: twelve such pairs per Pix2Pix step (encoders[4-6], decoders[0-2], forward and backward).

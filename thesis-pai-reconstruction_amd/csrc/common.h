@@ -198,6 +198,13 @@ int ew_stream_bn_bwd_reduce(int dtype, const void* g, int act, const void* z, in
 int ew_stream_bn_bwd_apply(int dtype, const void* g, int act, const void* z, int64_t M, int C, const float* scale,
                            const float* shift, const float* mean, const float* rstd, const float* gamma, const float* sums,
                            void* dz, hipStream_t s);
+int ew_stream_bn2_bwd_reduce(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                             const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                             const float* mean_b, const float* rstd_b, float* part_a, float* part_b, int rows, hipStream_t s);
+int ew_stream_bn2_bwd_apply(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                            const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                            const float* gamma_a, const float* sums_a, const float* mean_b, const float* rstd_b,
+                            const float* gamma_b, const float* sums_b, void* dza, void* dzb, hipStream_t s);
 int fwd_mfma_ksplit_effective(const GG& g);     // the K split launch_fwd_mfma uses with the registered workspace
 int launch_fwd_simt(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);
 int launch_fwd_rowdot(int dtype, const GG& g, const FwdArgs& a, hipStream_t s);

@@ -234,6 +234,123 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_k(const u32x4* g, con
     }
 }
 
+// ---- the tail of a residual block, backward: BOTH BatchNorms (residual branch with its activation, skip branch without) read
+// the same incoming gradient d -- one pass over (d, za, zb) for the two sets of partial sums, one for the two dz
+template <int ACT, bool NT>
+__global__ __launch_bounds__(256) void bn2_bwd_reduce_stream_k(const u32x4* d, const u32x4* za, const u32x4* zb, int64_t M, int G,
+                                                               int64_t rows_per_block, const float* mean_a, const float* rstd_a,
+                                                               const float* scale_a, const float* shift_a, const float* mean_b,
+                                                               const float* rstd_b, float* part_a, float* part_b) {
+    __shared__ float red[4][256][8];
+    const int tid = threadIdx.x, cg = tid & (G - 1);
+    float mua[8], mub[8], sc[8], sh[8], a1[8], a2[8], b1[8], b2[8];
+    ld8(mean_a + cg * 8, mua);
+    ld8(mean_b + cg * 8, mub);
+    if (ACT != PAI_ACT_NONE) { ld8(scale_a + cg * 8, sc); ld8(shift_a + cg * 8, sh); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a1[e] = a2[e] = b1[e] = b2[e] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    const int64_t i1 = r1 * G;
+    constexpr int V = 2;           // three tensors: two vectors each in flight
+    for (int64_t i = r0 * G + tid; i < i1; i += 256 * V) {
+        u32x4 wd[V], wa[V], wb[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (i + k * 256 < i1) { wd[k] = ldv<NT>(d + i + k * 256); wa[k] = ldv<NT>(za + i + k * 256); wb[k] = ldv<NT>(zb + i + k * 256); }
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (i + k * 256 < i1) {
+                float dv[8], av[8], bv[8];
+                unpack8(wd[k], dv);
+                unpack8(wa[k], av);
+                unpack8(wb[k], bv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float du = ACT == PAI_ACT_NONE ? dv[e] : actg<ACT>(fmaf(av[e], sc[e], sh[e]), dv[e]);
+                    a1[e] += du;
+                    a2[e] = fmaf(du, av[e] - mua[e], a2[e]);
+                    b1[e] += dv[e];
+                    b2[e] = fmaf(dv[e], bv[e] - mub[e], b2[e]);
+                }
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = a1[e]; red[1][tid][e] = a2[e]; red[2][tid][e] = b1[e]; red[3][tid][e] = b2[e]; }
+    __syncthreads();
+    if (tid < G) {
+        const int lanes = 256 / G, C = G * 8;
+        float ra[8], rb[8];
+        ld8(rstd_a + cg * 8, ra);
+        ld8(rstd_b + cg * 8, rb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int l = 0; l < lanes; ++l)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] += red[q][tid + l * G][e];
+            part_a[((size_t)blockIdx.x * 2 + 0) * C + cg * 8 + e] = t[0];
+            part_a[((size_t)blockIdx.x * 2 + 1) * C + cg * 8 + e] = t[1] * ra[e];
+            part_b[((size_t)blockIdx.x * 2 + 0) * C + cg * 8 + e] = t[2];
+            part_b[((size_t)blockIdx.x * 2 + 1) * C + cg * 8 + e] = t[3] * rb[e];
+        }
+    }
+}
+
+template <int ACT, bool NT>
+__global__ __launch_bounds__(256) void bn2_bwd_apply_stream_k(const u32x4* d, const u32x4* za, const u32x4* zb, int64_t nvec, int G,
+                                                              float inv_m, const float* mean_a, const float* rstd_a,
+                                                              const float* gamma_a, const float* sums_a, const float* scale_a,
+                                                              const float* shift_a, const float* mean_b, const float* rstd_b,
+                                                              const float* gamma_b, const float* sums_b, u32x4* dza, u32x4* dzb) {
+    const int cg = threadIdx.x & (G - 1), C = G * 8;
+    float Aa[8], Ba[8], Ka[8], mua[8], Ab[8], Bb[8], Kb[8], mub[8], sc[8], sh[8];
+    {
+        float rs[8], gm[8], sb[8], sg[8];
+        ld8(mean_a + cg * 8, mua); ld8(rstd_a + cg * 8, rs); ld8(sums_a + cg * 8, sb); ld8(sums_a + C + cg * 8, sg);
+        if (gamma_a) ld8(gamma_a + cg * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            Aa[e] = (gamma_a ? gm[e] : 1.f) * rs[e];
+            Ba[e] = -Aa[e] * rs[e] * (sg[e] * inv_m);
+            Ka[e] = -Aa[e] * (sb[e] * inv_m);
+        }
+        ld8(mean_b + cg * 8, mub); ld8(rstd_b + cg * 8, rs); ld8(sums_b + cg * 8, sb); ld8(sums_b + C + cg * 8, sg);
+        if (gamma_b) ld8(gamma_b + cg * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            Ab[e] = (gamma_b ? gm[e] : 1.f) * rs[e];
+            Bb[e] = -Ab[e] * rs[e] * (sg[e] * inv_m);
+            Kb[e] = -Ab[e] * (sb[e] * inv_m);
+        }
+    }
+    if (ACT != PAI_ACT_NONE) { ld8(scale_a + cg * 8, sc); ld8(shift_a + cg * 8, sh); }
+    constexpr int V = 2;
+    const int64_t step = (int64_t)gridDim.x * 256 * V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 * V + threadIdx.x; i < nvec; i += step) {
+        u32x4 wd[V], wa[V], wb[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (i + k * 256 < nvec) { wd[k] = ldv<NT>(d + i + k * 256); wa[k] = ldv<NT>(za + i + k * 256); wb[k] = ldv<NT>(zb + i + k * 256); }
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (i + k * 256 < nvec) {
+                float dv[8], av[8], bv[8], oa[8], ob[8];
+                unpack8(wd[k], dv);
+                unpack8(wa[k], av);
+                unpack8(wb[k], bv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float du = ACT == PAI_ACT_NONE ? dv[e] : actg<ACT>(fmaf(av[e], sc[e], sh[e]), dv[e]);
+                    oa[e] = fmaf(Aa[e], du, fmaf(Ba[e], av[e] - mua[e], Ka[e]));
+                    ob[e] = fmaf(Ab[e], dv[e], fmaf(Bb[e], bv[e] - mub[e], Kb[e]));
+                }
+                stv<NT>(dza + i + k * 256, pack8(oa));
+                stv<NT>(dzb + i + k * 256, pack8(ob));
+            }
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------
 // which calls take the streaming form: bf16, more than 4096 rows (the small layers keep the arithmetic of their one-launch
 // forms), at least 32768 vectors, C / 8 a power of two <= 256
@@ -338,6 +455,34 @@ int ew_stream_bn_bwd_apply(int dtype, const void* g, int act, const void* z, int
     const float inv_m = (float)(1.0 / (double)M);
     EW_ACT_NT(bn_bwd_apply_stream_k, act, nt, dim3(sweep_grid(nvec)), s, (const u32x4*)g, (const u32x4*)z, nvec, C / 8, inv_m, mean,
               rstd, gamma, sums, scale, shift, (u32x4*)dz);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+// both BatchNorms of a residual block's tail (see the kernels): -1 when the shape keeps the generic one-branch kernels
+int ew_stream_bn2_bwd_reduce(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                             const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                             const float* mean_b, const float* rstd_b, float* part_a, float* part_b, int rows, hipStream_t s) {
+    if (!stream_ok(dtype, M, C) || !act3(act_a) || (act_a != PAI_ACT_NONE && !(scale_a && shift_a))) return -1;
+    const int64_t rpb = (M + rows - 1) / rows;
+    const bool nt = stream_nt(M * (C / 8));
+    EW_ACT_NT(bn2_bwd_reduce_stream_k, act_a, nt, dim3(rows), s, (const u32x4*)d, (const u32x4*)za, (const u32x4*)zb, M, C / 8, rpb,
+              mean_a, rstd_a, scale_a, shift_a, mean_b, rstd_b, part_a, part_b);
+    PAI_LAUNCH_CHECK();
+    return 0;
+}
+
+int ew_stream_bn2_bwd_apply(int dtype, const void* d, int act_a, const void* za, const void* zb, int64_t M, int C,
+                            const float* scale_a, const float* shift_a, const float* mean_a, const float* rstd_a,
+                            const float* gamma_a, const float* sums_a, const float* mean_b, const float* rstd_b,
+                            const float* gamma_b, const float* sums_b, void* dza, void* dzb, hipStream_t s) {
+    if (!stream_ok(dtype, M, C) || !act3(act_a) || (act_a != PAI_ACT_NONE && !(scale_a && shift_a))) return -1;
+    const int64_t nvec = M * (C / 8);
+    const bool nt = stream_nt(nvec);
+    const float inv_m = (float)(1.0 / (double)M);
+    EW_ACT_NT(bn2_bwd_apply_stream_k, act_a, nt, dim3(sweep_grid(nvec)), s, (const u32x4*)d, (const u32x4*)za, (const u32x4*)zb, nvec,
+              C / 8, inv_m, mean_a, rstd_a, gamma_a, sums_a, scale_a, shift_a, mean_b, rstd_b, gamma_b, sums_b, (u32x4*)dza,
+              (u32x4*)dzb);
     PAI_LAUNCH_CHECK();
     return 0;
 }

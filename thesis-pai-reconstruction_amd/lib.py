@@ -111,6 +111,8 @@ SIGNATURES = {
     "pai_upsample2": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "pai_upsample2_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "pai_add_act": (_I, [_I, _P, _P, _L, _I, _P, _P]),
+    "pai_bn2_bwd_reduce": (_I, [_I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pai_bn2_bwd_apply": (_I, [_I, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pai_instnorm_fwd": (_I, [_I, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
     "pai_instnorm_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pai_dropout2d": (_I, [_I, _P, _P, _I, _L, _I, _P, _P]),

@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_RELU, ACT_TANH
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
 
 
 def _check(x):
@@ -619,11 +619,27 @@ class BNTail(torch.autograd.Function):
                 ops.bn_bwd_apply(dtype, d, z, M, Cc, h["mean"], h["rstd"], gamma.detach(), sums, dz)
             return dz, sums[Cc:], sums[:Cc]
 
-        dza, dga, dba = bn_bwd(za, ctx.ha, gamma_a, ctx.act_a)
-        if ctx.hb is not None:
-            dzb, dgb, dbb = bn_bwd(zb, ctx.hb, gamma_b, ACT_NONE)
+        if ctx.hb is not None and ctx.act_a in (ACT_NONE, ACT_RELU, ACT_LRELU):
+            # both BatchNorms read the same gradient d: one pass over (d, za, zb) for the two sets of sums, one for the two dz
+            # (pai_bn2_bwd_*; 3 + 5 tensor passes instead of 4 + 6)
+            ha, hb = ctx.ha, ctx.hb
+            if not (ha["training"] and hb["training"]):
+                raise ops.PaiError("backward through an eval-mode BatchNorm block is not supported")
+            rows = ops.bn_bwd_partial_rows(M)
+            part_a, part_b = torch.empty(rows * 2 * Cc, **f32), torch.empty(rows * 2 * Cc, **f32)
+            sums_a, sums_b = torch.empty(2 * Cc, **f32), torch.empty(2 * Cc, **f32)
+            dza, dzb = torch.empty_like(za), torch.empty_like(zb)
+            ops.bn2_bwd_reduce(dtype, d, ctx.act_a, za, zb, M, Cc, ha["scale"], ha["shift"], ha["mean"], ha["rstd"], hb["mean"],
+                               hb["rstd"], part_a, part_b, sums_a, sums_b)
+            ops.bn2_bwd_apply(dtype, d, ctx.act_a, za, zb, M, Cc, ha["scale"], ha["shift"], ha["mean"], ha["rstd"],
+                              gamma_a.detach(), sums_a, hb["mean"], hb["rstd"], gamma_b.detach(), sums_b, dza, dzb)
+            dga, dba, dgb, dbb = sums_a[Cc:], sums_a[:Cc], sums_b[Cc:], sums_b[:Cc]
         else:
-            dzb, dgb, dbb = d, None, None
+            dza, dga, dba = bn_bwd(za, ctx.ha, gamma_a, ctx.act_a)
+            if ctx.hb is not None:
+                dzb, dgb, dbb = bn_bwd(zb, ctx.hb, gamma_b, ACT_NONE)
+            else:
+                dzb, dgb, dbb = d, None, None
         return dza, dga, dba, None, dzb, dgb, dbb, None, None, None
 
 

@@ -512,6 +512,27 @@ def bn_bwd_apply_affine(dtype, g1, act1, z, M, C_, scale, shift, mean, rstd, gam
                                                  _p(rstd), _p(gamma), _p(sums), _p(dz), _stream()), "pai_bn_bwd_apply_affine")
 
 
+def bn2_bwd_reduce(dtype, d, act_a, za, zb, M, C_, scale_a, shift_a, mean_a, rstd_a, mean_b, rstd_b, part_a, part_b, sums_a,
+                   sums_b):
+    """Pass 1 of BOTH BatchNorm backwards of a residual block's tail (+ their finalizes): pai_bn2_bwd_reduce."""
+    f = torch.float32
+    with _TimedBytes("bn_passes", 3 * M * C_ * _es(dtype)):
+        L.check(L.load().pai_bn2_bwd_reduce(code_of(dtype), _p(d), int(act_a), _p(za), _p(zb), M, C_, _p(scale_a, f),
+                                            _p(shift_a, f), _p(mean_a, f), _p(rstd_a, f), _p(mean_b, f), _p(rstd_b, f),
+                                            _p(part_a, f), _p(part_b, f), _p(sums_a, f), _p(sums_b, f), _stream()),
+                "pai_bn2_bwd_reduce")
+
+
+def bn2_bwd_apply(dtype, d, act_a, za, zb, M, C_, scale_a, shift_a, mean_a, rstd_a, gamma_a, sums_a, mean_b, rstd_b, gamma_b,
+                  sums_b, dza, dzb):
+    f = torch.float32
+    with _TimedBytes("bn_passes", 5 * M * C_ * _es(dtype)):
+        L.check(L.load().pai_bn2_bwd_apply(code_of(dtype), _p(d), int(act_a), _p(za), _p(zb), M, C_, _p(scale_a, f),
+                                           _p(shift_a, f), _p(mean_a, f), _p(rstd_a, f), _p(gamma_a, f), _p(sums_a, f),
+                                           _p(mean_b, f), _p(rstd_b, f), _p(gamma_b, f), _p(sums_b, f), _p(dza), _p(dzb),
+                                           _stream()), "pai_bn2_bwd_apply")
+
+
 def act_bwd(dtype, g1, act1, g2, act2, a, numel, du):
     L.check(L.load().pai_act_bwd(code_of(dtype), _p(g1), act1, _p(g2), act2, _p(a), numel, _p(du), _stream()),
             "pai_act_bwd")
