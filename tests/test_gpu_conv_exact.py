@@ -443,6 +443,9 @@ SAME_CASES = [
     ("res_1x1_cat_64", 1, 4, 128, 128, 64, 64, 64, ("pwx_k<128, 64>",), ("pwx_k<64, 128>",), WG),   # its skip convolution
     ("res_1x1_256_64", 1, 2, 128, 128, 128, 128, 64, ("pwx_k<256, 64>",), ("pwx_k<64, 256>",), WG), # level-1 decoder skip (128 | 128 -> 64)
     ("res_1x1_64_64", 1, 2, 128, 128, 64, 0, 64, ("pwx_k<64, 64>",), ("pwx_k<64, 64>",), WG),
+    # 128 x 256 / 256 x 128 filters: two waves of a workgroup take half of the output channels each
+    ("res_1x1_128_256", 1, 2, 128, 128, 128, 0, 256, ("pwx_k<128, 256>",), ("pwx_k<256, 128>",), WG),
+    ("res_1x1_cat_256_128", 1, 2, 128, 128, 128, 128, 128, ("pwx_k<256, 128>",), ("pwx_k<128, 256>",), WG),
     ("res_1x1_ragged", 1, 5, 100, 37, 64, 64, 128, ("pwx_k<128, 128>",), ("pwx_k<128, 128>",), WG + ("gg_simt",)),   # 18500 pixels: partial group, partial batch
     ("res_1x1_small", 1, 4, 32, 32, 64, 0, 128, TILE, TILE, WG),              # < 16384 pixels: the tile kernels
     ("tr_3x3_cat", 3, 8, 128, 128, 64, 64, 64, TILE, TILE, WG),               # TransUNet decoder block, configs[4] width
@@ -527,7 +530,8 @@ def test_same_convolutions_of_the_other_families_bit_exact(pai, case):
 # (N, H, W, Cin, Cout, k, groups): layers of the ResNeXt blocks that read their input through a prologue -- the pointwise
 # ones (pwx_k / gg_wgrad_mfma_k) and the grouped 3 x 3 (grouped3_k / grouped3_wgrad_k: zero padding must stay zero)
 PRO_CASES = [(4, 128, 128, 128, 64, 1, 1), (2, 128, 128, 128, 128, 1, 1), (4, 64, 64, 64, 128, 1, 1), (2, 128, 64, 64, 256, 1, 1),
-             (1, 128, 128, 256, 64, 1, 1), (2, 64, 64, 128, 128, 3, 32), (1, 16, 32, 128, 128, 3, 32)]
+             (1, 128, 128, 256, 64, 1, 1), (2, 64, 64, 128, 128, 3, 32), (1, 16, 32, 128, 128, 3, 32), (1, 128, 128, 128, 256, 1, 1),
+             (1, 128, 128, 256, 128, 1, 1)]
 
 
 @pytest.mark.parametrize("act", ["relu", "none"])
@@ -602,7 +606,8 @@ def test_prologue_is_refused_where_no_kernel_takes_it(pai):
 
 
 # (N, H, W, Cin, Cout): the input gradient of a pointwise layer (dx has Cin channels) with the producer's backward in the store
-PWX_BWD = [(2, 128, 128, 128, 64), (2, 128, 128, 64, 128), (1, 128, 128, 128, 128), (5, 100, 37, 64, 128), (1, 128, 128, 64, 256)]
+PWX_BWD = [(2, 128, 128, 128, 64), (2, 128, 128, 64, 128), (1, 128, 128, 128, 128), (5, 100, 37, 64, 128), (1, 128, 128, 64, 256),
+           (1, 128, 128, 256, 128), (1, 128, 128, 128, 256)]
 
 
 @pytest.mark.parametrize("act1", [2, 0], ids=["relu", "none"])

@@ -2,7 +2,8 @@
 // the residual blocks at the fine levels (reference models/res_unet.py:143-147, 74: ResidualBlockNeXt 1x1 -> grouped 3x3 ->
 // 1x1, conv_skip), bf16.
 //
-//   out[M][COUT] = in[M][CIN] x W[COUT][CIN]^T (+ bias)        CIN x COUT <= 128 x 128
+//   out[M][COUT] = in[M][CIN] x W[COUT][CIN]^T (+ bias)        CIN x COUT <= 128 x 128 per wave (128 x 256 / 256 x 128: two
+//                                                              waves share a pixel stream and split the output channels)
 //
 // At 512 x 512 x 16 images these layers move 1.6 GB for 69-137 GFLOP: HBM-bound by 5-10x.  The 128 x 128 tile kernel
 // (gg_fwd_mfma_k: operands through LDS, a staged epilogue, one tile per workgroup) ran them at 2.2-2.6 TB/s; this one
@@ -34,7 +35,9 @@ __device__ __forceinline__ float dpp_add16(float u) {      // sum over the 16 la
 // the instantiations of launch_pwx: the filter fits the registers of a wave (CIN x COUT <= 128 x 128)
 bool pwx_shape_ok(int cin, int cout) {
     return (cin == 64 && (cout == 64 || cout == 128 || cout == 256)) || (cin == 128 && (cout == 64 || cout == 128)) ||
-           (cin == 256 && cout == 64);
+           (cin == 256 && cout == 64) ||
+           // two waves of a workgroup share a pixel stream and take half of the output channels each
+           (pai_tunable("pwx_split", 1) && ((cin == 128 && cout == 256) || (cin == 256 && cout == 128)));
 }
 
 bool pwx_ok(int dtype, const GG& g, const FwdArgs& a) {
@@ -64,27 +67,31 @@ int pwx_rows(const GG& g) {
 
 // MODE 0: plain; 1: BatchNorm partial statistics of the output (forward); 2: the producer's backward in the store
 // (input gradient: du = act'(bz * bscale + bshift) * dgrad, partial sums of du and du * (bz - bmean))
-template <int CIN, int COUT, int T, int MODE, bool PRE>
+// NSPLIT (1 or 2): the waves (wid % NSPLIT) of a workgroup take COUT output channels each of a layer with NSPLIT * COUT, on the
+// same pixel groups (the second wave's reads of x are L1 / L2 hits): 128 -> 256 and 256 -> 128 channels
+template <int CIN, int COUT, int T, int MODE, bool PRE, int NSPLIT = 1>
 __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wave) {
     constexpr bool STATS = MODE != 0;
-    constexpr int KB = CIN / 32, NTT = COUT / 16, CL = COUT / 4, NCH = CL / 8;
-    __shared__ __attribute__((aligned(16))) float sbias[COUT];
+    constexpr int KB = CIN / 32, NTT = COUT / 16, CL = COUT / 4, NCH = CL / 8, CALL = COUT * NSPLIT;
+    __shared__ __attribute__((aligned(16))) float sbias[CALL];
     __shared__ float sred[4][2][STATS ? COUT : 1];
-    __shared__ __attribute__((aligned(16))) float sbwd[3][MODE == 2 ? COUT : 4];      // bscale | bshift | bmean
+    __shared__ __attribute__((aligned(16))) float sbwd[3][MODE == 2 ? CALL : 4];      // bscale | bshift | bmean
     __shared__ __attribute__((aligned(16))) float spre[2][PRE ? CIN : 4];      // prologue: scale | shift per input channel
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    const int cbase = (wid % NSPLIT) * COUT;        // this wave's first output channel
+    const int pw = wid / NSPLIT;                    // its pixel stream (4 / NSPLIT per workgroup)
     const bf16_t* x1 = (const bf16_t*)a.x1;
     const bf16_t* x2 = (const bf16_t*)a.x2;
-    const bf16_t* w = (const bf16_t*)a.w;
+    const bf16_t* w = (const bf16_t*)a.w + (size_t)cbase * CIN;
     const int C1 = g.C1, C2 = g.C2;
-    for (int c = tid; c < COUT; c += 256) sbias[c] = a.bias ? a.bias[c] : 0.f;
+    for (int c = tid; c < CALL; c += 256) sbias[c] = a.bias ? a.bias[c] : 0.f;
     if (PRE) {
         for (int c = tid; c < CIN; c += 256) { spre[0][c] = a.pscale[c]; spre[1][c] = a.pshift[c]; }
     }
     const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;      // prologue activation: ReLU or none
     if (MODE == 2) {
-        for (int c = tid; c < COUT; c += 256) {
+        for (int c = tid; c < CALL; c += 256) {
             sbwd[0][c] = a.bscale[c];
             sbwd[1][c] = a.bshift[c];
             sbwd[2][c] = a.bmean ? a.bmean[c] : 0.f;
@@ -106,9 +113,9 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
     int dstride[NCH];
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-        const int ch = 32 * h + 8 * fq;
+        const int ch = cbase + 32 * h + 8 * fq;
         if (g.D2 && ch >= g.D1) { dst[h] = (bf16_t*)a.y2 + (ch - g.D1); dstride[h] = g.D2; }
-        else { dst[h] = (bf16_t*)a.y1 + ch; dstride[h] = g.D2 ? g.D1 : COUT; }
+        else { dst[h] = (bf16_t*)a.y1 + ch; dstride[h] = g.D2 ? g.D1 : CALL; }
     }
     float s1[STATS ? CL : 1], s2[STATS ? CL : 1];
     if (STATS) {
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
     }
     __syncthreads();
     const int64_t ngroups = ((int64_t)g.M + 15) / 16;
-    const int64_t g0 = ((int64_t)blockIdx.x * 4 + wid) * groups_per_wave;
+    const int64_t g0 = ((int64_t)blockIdx.x * (4 / NSPLIT) + pw) * groups_per_wave;
     const int64_t g1 = min(ngroups, g0 + groups_per_wave);
 
     auto load = [&](int64_t gb, bf8_t (*xb)[KB]) {
@@ -162,12 +169,12 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
             if (MODE == 2) {        // the producer's raw output for this lane's chunks: in flight under the MFMAs
                 const int64_t pc = valid ? pix : 0;
 #pragma unroll
-                for (int h = 0; h < NCH; ++h) zq[h] = *(const uint4*)(bzp + pc * COUT + 32 * h + 8 * fq);
+                for (int h = 0; h < NCH; ++h) zq[h] = *(const uint4*)(bzp + pc * CALL + cbase + 32 * h + 8 * fq);
             }
             f4_t acc[NTT];
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt) {
-                acc[nt] = *(const f4_t*)&sbias[32 * (nt >> 1) + 8 * fq + 4 * (nt & 1)];
+                acc[nt] = *(const f4_t*)&sbias[cbase + 32 * (nt >> 1) + 8 * fq + 4 * (nt & 1)];
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kb], xb[t][kb], acc[nt], 0, 0, 0);
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
                         if (MODE == 1 && valid) { s1[4 * nt + r] += v[r]; s2[4 * nt + r] = fmaf(v[r], v[r], s2[4 * nt + r]); }
                     }
                     if (MODE == 2) {
-                        const int cb = 32 * h + 8 * fq + 4 * j;        // this tile's 4 channels
+                        const int cb = cbase + 32 * h + 8 * fq + 4 * j;        // this tile's 4 channels
                         const f4_t bsc = *(const f4_t*)&sbwd[0][cb], bsh = *(const f4_t*)&sbwd[1][cb], bmu = *(const f4_t*)&sbwd[2][cb];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -227,26 +234,27 @@ __global__ __launch_bounds__(256) void pwx_k(GG g, FwdArgs a, int groups_per_wav
         if (fr == 0) { sred[wid][0][ch] = u; sred[wid][1][ch] = q; }
     }
     __syncthreads();
-    for (int c = tid; c < COUT; c += 256) {
+    for (int c = tid; c < CALL; c += 256) {
+        const int half = c / COUT, cc = c - half * COUT;       // the waves wid % NSPLIT == half hold channel c
         float u = 0.f, q = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) { u += sred[wv][0][c]; q += sred[wv][1][c]; }
-        float* row = (MODE == 2 ? a.bpart : a.stats) + (size_t)blockIdx.x * 2 * COUT;
+        for (int wv = 0; wv < 4 / NSPLIT; ++wv) { u += sred[wv * NSPLIT + half][0][cc]; q += sred[wv * NSPLIT + half][1][cc]; }
+        float* row = (MODE == 2 ? a.bpart : a.stats) + (size_t)blockIdx.x * 2 * CALL;
         row[c] = u;
-        row[COUT + c] = MODE == 2 ? a.brstd[c] * q : q;       // producer backward: sum du * xhat = rstd * sum du * (z - mean)
+        row[CALL + c] = MODE == 2 ? a.brstd[c] * q : q;       // producer backward: sum du * xhat = rstd * sum du * (z - mean)
     }
 }
 
-template <int CIN, int COUT, int T>
+template <int CIN, int COUT, int T, int NSPLIT = 1>
 static void pwx_launch(const GG& g, const FwdArgs& a, int blocks, int gpw, hipStream_t s) {
     if (a.bz) {             // input gradient with the producer's backward in its store
-        PAI_LAUNCH((pwx_k<CIN, COUT, T, 2, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        PAI_LAUNCH((pwx_k<CIN, COUT, T, 2, false, NSPLIT>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
     } else if (a.pscale) {  // forward with the producer's BatchNorm on load
-        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, 1, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
-        else PAI_LAUNCH((pwx_k<CIN, COUT, T, 0, true>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, 1, true, NSPLIT>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        else PAI_LAUNCH((pwx_k<CIN, COUT, T, 0, true, NSPLIT>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
     } else {
-        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, 1, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
-        else PAI_LAUNCH((pwx_k<CIN, COUT, T, 0, false>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        if (a.stats) PAI_LAUNCH((pwx_k<CIN, COUT, T, 1, false, NSPLIT>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
+        else PAI_LAUNCH((pwx_k<CIN, COUT, T, 0, false, NSPLIT>), dim3(blocks), dim3(256), 0, s, g, a, gpw);
     }
 }
 template <int CIN, int COUT>
@@ -259,8 +267,19 @@ static void pwx_launch_t(const GG& g, const FwdArgs& a, int blocks, int gpw, int
 int launch_pwx(const GG& g, const FwdArgs& a, hipStream_t s) {
     const int blocks = pwx_rows(g);
     const int64_t ngroups = ((int64_t)g.M + 15) / 16;
-    const int gpw = (int)((ngroups + (int64_t)blocks * 4 - 1) / ((int64_t)blocks * 4));
     const int ci = g.Cin, co = g.Cout;
+    const int nsplit = ci * co > 128 * 128 ? 2 : 1;          // pixel streams per workgroup: 4 / nsplit
+    const int gpw = (int)((ngroups + (int64_t)blocks * (4 / nsplit) - 1) / ((int64_t)blocks * (4 / nsplit)));
+    if (nsplit == 2) {
+        if (ci == 128 && co == 256) pwx_launch<128, 128, 2, 2>(g, a, blocks, gpw, s);
+        else if (ci == 256 && co == 128) pwx_launch<256, 64, 2, 2>(g, a, blocks, gpw, s);
+        else {
+            pai_set_error("launch_pwx: no instantiation for %d -> %d channels", ci, co);
+            return 1;
+        }
+        PAI_LAUNCH_CHECK();
+        return 0;
+    }
     const int big = ci * co > 64 * 128;
     int t = pai_tunable("pwx_t", big ? 2 : 4);
     if (co == 256 && (a.stats || a.bz)) t = 1;                     // (the 64-register statistics on top of a 128-register filter)
