@@ -21,6 +21,11 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "plan.h"), os.path
 # copied all 64 of them through VGPRs every K-step (192 -> 138 registers, +1 wave per SIMD).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# Per-source additions.  -fno-slp-vectorize: the SLP pass pairs neighbouring fp32 operations of the tile epilogues into
+# v_pk_fma_f32 / v_pk_add_f32 on adjacent registers; at the 128-register line of gg_fwd_patch_k that allocation spilled
+# 118-157 registers around the fused producer-backward store (0-4 without the pass), and packed fp32 instructions are the
+# slow form beside MFMAs anyway (CDNA4 guide, cycle constants).
+EXTRA_FLAGS = {"gg_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -66,9 +71,10 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        new[os.path.basename(o)] = _digest([s] + HEADERS, " ".join(FLAGS))
+        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        new[os.path.basename(o)] = _digest([s] + HEADERS, " ".join(flags))
         if force or not os.path.exists(o) or stamps.get(os.path.basename(o)) != new[os.path.basename(o)]:
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -924,61 +924,75 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     }
 
     // ---- epilogue: bias, BN partial statistics, activation, LDS-staged row stores --------------
+    // No run-time switch per element (profiles/r06_isa_census.txt): bias / statistics / activation are wave-uniform
+    // branches around 16 elements, the activation is act_fwd (gg_tile.h), and the store loop below is compiled once per
+    // (producer backward, skip gradient, BatchNorm sums) combination.
     constexpr int CROW = BN * 2 + 16;
     constexpr int WM = BM / WPX;
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
     const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const float eslope = act_slope(eact);
     // lane (fq, fr) holds, for each of its 4 pixel rows mt*16 + fr, the 4 NT consecutive channels
     // wn*(BN/2) + 4 NT fq + (4 nt + r): bias, statistics, activation, then one or two 16-B LDS stores per row
     constexpr int CL = 4 * NT;               // channels per lane
     const int col0 = wn * BNW + CL * fq;
-    float bias_v[CL], csum[CL], csq[CL];
+    const bool has_bias = a.bias != nullptr, has_stats = a.stats != nullptr;
+    // two forms of the staging pass: bare (input gradients: neither bias nor statistics, no register arrays for them) and full
+    auto stage = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        float bias_v[FULL ? CL : 1], csum[FULL ? CL : 1], csq[FULL ? CL : 1];
+        if (FULL) {
 #pragma unroll
-    for (int c = 0; c < CL; ++c) { bias_v[c] = a.bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = wm * WPX + mt * 16 + fr;
-        unsigned pk[CL / 2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[mt][nt][r] + bias_v[4 * nt + r];
-                csum[4 * nt + r] += v[r];
-                csq[4 * nt + r] = fmaf(v[r], v[r], csq[4 * nt + r]);
-                if (eact == PAI_ACT_LRELU) v[r] = fmaxf(v[r], 0.2f * v[r]);
-                else if (eact == PAI_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-            }
-            pk[2 * nt] = pk2bf(v[0], v[1]);
-            pk[2 * nt + 1] = pk2bf(v[2], v[3]);
+            for (int c = 0; c < CL; ++c) { bias_v[c] = has_bias ? a.bias[n0 + col0 + c] : 0.f; csum[c] = csq[c] = 0.f; }
         }
 #pragma unroll
-        for (int h = 0; h < CL / 8; ++h)
-            *(uint4*)(Cs + row * CROW + (col0 + 8 * h) * 2) = make_uint4(pk[4 * h], pk[4 * h + 1], pk[4 * h + 2], pk[4 * h + 3]);
-    }
-    if (a.stats) {
-        // sum over the 16 pixels (lanes fr) of every row of 16 lanes: quad_perm, row_half_mirror, row_mirror
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wm * WPX + mt * 16 + fr;
 #pragma unroll
-        for (int c = 0; c < CL; ++c) {
-            float s = csum[c], q = csq[c];
-            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
-            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, false));
-            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
-            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));
-            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, false));
-            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x141, 0xF, 0xF, false));
-            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, false));
-            q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x140, 0xF, 0xF, false));
-            if (fr == 0) {
-                sstat[(wm * 2 + 0) * BN + col0 + c] = s;
-                sstat[(wm * 2 + 1) * BN + col0 + c] = q;
+            for (int h = 0; h < CL / 8; ++h) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    v[c] = acc[mt][(8 * h + c) >> 2][c & 3];
+                    if (FULL) {
+                        v[c] += bias_v[8 * h + c];
+                        csum[8 * h + c] += v[c];
+                        csq[8 * h + c] = fmaf(v[c], v[c], csq[8 * h + c]);
+                    }
+                }
+                if (eact != PAI_ACT_NONE) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = act_fwd(v[c], eslope);
+                }
+                *(uint4*)(Cs + row * CROW + (col0 + 8 * h) * 2) =
+                    make_uint4(pk2bf(v[0], v[1]), pk2bf(v[2], v[3]), pk2bf(v[4], v[5]), pk2bf(v[6], v[7]));
             }
         }
-    }
+        if (FULL && has_stats) {
+            // sum over the 16 pixels (lanes fr) of every row of 16 lanes: quad_perm, row_half_mirror, row_mirror
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                float s = csum[c], q = csq[c];
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+                q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, false));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+                q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, false));
+                q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x141, 0xF, 0xF, false));
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, false));
+                q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x140, 0xF, 0xF, false));
+                if (fr == 0) {
+                    sstat[(wm * 2 + 0) * BN + col0 + c] = s;
+                    sstat[(wm * 2 + 1) * BN + col0 + c] = q;
+                }
+            }
+        }
+    };
+    if (has_bias || has_stats) stage(std::true_type{});
+    else stage(std::false_type{});
     __syncthreads();
-    if (a.stats && tid < BN) {
+    if (has_stats && tid < BN) {
         float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + n0 + tid;
         float s = 0.f, q = 0.f;
 #pragma unroll
@@ -997,38 +1011,56 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     const bool bsum = bwd && a.bpart;
     constexpr int CPR = BN / 8;        // 16-B chunks per row
     constexpr int ORP = NTHR / CPR;    // rows per pass
+    static_assert(ORP % 16 == 0, "a pass covers whole 16-pixel tile rows");
     const int oc = tid % CPR, orow0 = tid / CPR;
     BwdParams BP;
     float bs1[8], bs2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
-    // producer chunks requested four passes at a time, ahead of that batch's stores (see gg_fwd_mfma_k)
-    constexpr int NP = BM / ORP, NB = NP < 4 ? NP : 4;
+    constexpr int NP = BM / ORP, NB = NP < 4 ? NP : 4, NBATCH = NP / NB;
     if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
-#pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += NB) {
-        size_t offs[NB];
+    // pass p of this thread: tile row orow0 + p ORP, i.e. ORP / 16 image rows further down.  Addresses = a 64-bit base that is
+    // uniform over the workgroup (scalar registers) + a 32-bit byte offset per thread + a uniform step per pass.
+    const size_t tile0 = ((size_t)(img * g.OH + gy0 * g.OS + g.poy[ph]) * g.OW + gx0 * g.OS + g.pox[ph]) * dstride + dcol;
+    const unsigned toff = (unsigned)((((orow0 >> 4) * g.OS * g.OW + (orow0 & 15) * g.OS) * dstride + oc * 8) * 2);
+    const unsigned pstep = (unsigned)((ORP / 16) * g.OS * g.OW * dstride * 2);
+    const char* zt = (const char*)(bzp + tile0);
+    const char* at = (const char*)(bap + tile0);
+    char* dt = (char*)(dst + tile0);
+    const float sl1 = act_slope(a.bact1), sl2 = act_slope(a.bact2);
+    // The chunks of the producer's tensors are requested four passes ahead of the stores they feed: the stores may alias them
+    // as far as the compiler knows, so the order is written out -- a pass's registers are re-requested for pass + 4 as soon
+    // as its chunk is computed.
+    auto store_tile = [&](auto bwd_tag, auto add_tag, auto sum_tag) {
+        constexpr bool BWD = decltype(bwd_tag)::value, ADD = decltype(add_tag)::value, SUM = decltype(sum_tag)::value;
         uint4 zq[NB], aq[NB];
+        auto request = [&](int pass, int slot) {
+            const unsigned off = toff + (unsigned)pass * pstep;
+            if (BWD) zq[slot] = *(const uint4*)(zt + off);
+            if (BWD && ADD) aq[slot] = *(const uint4*)(at + off);
+        };
 #pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            const int row = orow0 + (p0 + p) * ORP;
-            const int gy = gy0 + (row >> 4), gx = gx0 + (row & 15);
-            const size_t pix = (size_t)(img * g.OH + gy * g.OS + g.poy[ph]) * g.OW + gx * g.OS + g.pox[ph];
-            offs[p] = pix * dstride + dcol + oc * 8;
-            if (bwd) {
-                zq[p] = *(const uint4*)(bzp + offs[p]);
-                aq[p] = bap ? *(const uint4*)(bap + offs[p]) : make_uint4(0, 0, 0, 0);
+        for (int p = 0; p < NB; ++p) request(p, p);
+#pragma unroll
+        for (int b = 0; b < NBATCH; ++b) {
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const int pass = b * NB + p;
+                uint4 o = *(const uint4*)(Cs + (orow0 + pass * ORP) * CROW + oc * 16);
+                if (BWD) o = bwd_chunk_t<ADD, SUM>(o, zq[p], aq[p], sl1, sl2, BP, bs1, bs2);
+                if (b + 1 < NBATCH) request(pass + NB, p);   // rolling window: NB passes of producer chunks in flight
+                *(uint4*)(dt + (toff + (unsigned)pass * pstep)) = o;
+                // one pass at a time: left alone, hipcc unpacks the chunks of all four passes in flight up front (~100 live
+                // registers of floats) and spills the parameters and sums around them
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-#pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            const int row = orow0 + (p0 + p) * ORP;
-            uint4 o = *(const uint4*)(Cs + row * CROW + oc * 16);
-            if (bwd)
-                o = bwd_chunk(o, zq[p], aq[p], bap != nullptr, a.bscale != nullptr, bsum, a.bact1, a.bact2, BP, bs1, bs2);
-            *(uint4*)(dst + offs[p]) = o;
-        }
-    }
+    };
+    typedef std::true_type T_;
+    typedef std::false_type F_;
+    if (!bwd) store_tile(F_{}, F_{}, F_{});
+    else if (bap) { if (bsum) store_tile(T_{}, T_{}, T_{}); else store_tile(T_{}, T_{}, F_{}); }
+    else { if (bsum) store_tile(T_{}, F_{}, T_{}); else store_tile(T_{}, F_{}, F_{}); }
     if (bsum)
         bwd_write_partials<BN, CPR, NTHR / 64>(sstat, bs1, bs2, tid,
                                                a.bpart + ((size_t)(ph * mtiles + bm) * 2) * g.D1 + n0, g.D1,

@@ -57,35 +57,52 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // rounded to bf16; with `sums` the BatchNorm-backward sums are accumulated from the value as stored
 // (what pai_bn_bwd_apply reads back).  Same du as bn_bwd_reduce_k / act_bwd_k on the bf16-rounded gradient.
 struct BwdParams { float sc[8], sh[8]; };
-__device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdParams& P) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        P.sc[k] = a.bscale ? a.bscale[c + k] : 1.f;
-        P.sh[k] = a.bscale ? a.bshift[c + k] : 0.f;
-    }
+static __device__ const float g_unit_affine[16] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdParams& P) {   // c: a multiple of 8
+    // unconditional vector loads (a producer without BatchNorm reads scale 1 / shift 0 from a constant line): a load
+    // per element behind `a.bscale ? ... : 1.f` was sixteen scalar branches
+    const float* sp = a.bscale ? a.bscale + c : g_unit_affine;
+    const float* hp = a.bscale ? a.bshift + c : g_unit_affine + 8;
+    const float4 s0 = *(const float4*)sp, s1 = *(const float4*)(sp + 4);
+    const float4 h0 = *(const float4*)hp, h1 = *(const float4*)(hp + 4);
+    P.sc[0] = s0.x; P.sc[1] = s0.y; P.sc[2] = s0.z; P.sc[3] = s0.w; P.sc[4] = s1.x; P.sc[5] = s1.y; P.sc[6] = s1.z; P.sc[7] = s1.w;
+    P.sh[0] = h0.x; P.sh[1] = h0.y; P.sh[2] = h0.z; P.sh[3] = h0.w; P.sh[4] = h1.x; P.sh[5] = h1.y; P.sh[6] = h1.z; P.sh[7] = h1.w;
 }
-__device__ __forceinline__ float bwd_sel(float g, bool pos, int act) {   // act'(pre) * g
-    return act == PAI_ACT_RELU ? (pos ? g : 0.f) : (act == PAI_ACT_LRELU ? (pos ? g : 0.2f * g) : g);
+// Activations in a store without run-time branches.  act(v) = v > 0 ? v : v * slope with slope = 1 (none), 0.2
+// (LeakyReLU), 0 (ReLU): the selector used to be a run-time switch per ELEMENT, which hipcc compiled into four scalar
+// branches per element -- the epilogue of a 256 x 128 tile with the fused producer backward was 4200 instructions per
+// thread, more issue time than the 512 MFMAs of a K = 1024 layer (profiles/r06_isa_census.txt).  The product is formed as
+// fma(v, slope, +0): the same rounding as the multiplication, and -0 (ReLU of a negative value) becomes +0.
+__device__ __forceinline__ float act_slope(int act) { return act == PAI_ACT_RELU ? 0.f : (act == PAI_ACT_LRELU ? 0.2f : 1.f); }
+__device__ __forceinline__ float act_fwd(float v, float slope) {
+    const float sv = fmaf(v, slope, 0.f);
+    return v > 0.f ? v : sv;
+}
+__device__ __forceinline__ float bwd_sel(float g, bool pos, float slope) {   // act'(pre) * g
+    const float sg = fmaf(g, slope, 0.f);
+    return pos ? g : sg;
 }
 // s2 accumulates du * z; the tile's sum of du * xhat is rstd * (s2 - mean * s1), formed once per channel in
-// bwd_write_partials (3 vector-ALU operations per element fewer in a store that runs behind every MFMA loop)
-__device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool has_add, bool affine, bool sums,
-                                           int act1, int act2, const BwdParams& P, float* s1, float* s2) {
+// bwd_write_partials (3 vector-ALU operations per element fewer in a store that runs behind every MFMA loop).
+// P.sc / P.sh are 1 / 0 when the producer has no BatchNorm (bwd_load_params), so pre = fma(z, sc, sh) always.
+template <bool HAS_ADD, bool SUMS>
+__device__ __forceinline__ uint4 bwd_chunk_t(uint4 gq, uint4 zq, uint4 aq, float sl1, float sl2, const BwdParams& P,
+                                             float* s1, float* s2) {
     const unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w}, zw[4] = {zq.x, zq.y, zq.z, zq.w}, aw[4] = {aq.x, aq.y, aq.z, aq.w};
     unsigned o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float g0 = __uint_as_float(gw[k] << 16), g1 = __uint_as_float(gw[k] & 0xffff0000u);
         const float z0 = __uint_as_float(zw[k] << 16), z1 = __uint_as_float(zw[k] & 0xffff0000u);
-        const bool q0 = (affine ? fmaf(z0, P.sc[2 * k], P.sh[2 * k]) : z0) > 0.f;
-        const bool q1 = (affine ? fmaf(z1, P.sc[2 * k + 1], P.sh[2 * k + 1]) : z1) > 0.f;
-        float d0 = bwd_sel(g0, q0, act1), d1 = bwd_sel(g1, q1, act1);
-        if (has_add) {
-            d0 += bwd_sel(__uint_as_float(aw[k] << 16), q0, act2);
-            d1 += bwd_sel(__uint_as_float(aw[k] & 0xffff0000u), q1, act2);
+        const bool q0 = fmaf(z0, P.sc[2 * k], P.sh[2 * k]) > 0.f;
+        const bool q1 = fmaf(z1, P.sc[2 * k + 1], P.sh[2 * k + 1]) > 0.f;
+        float d0 = bwd_sel(g0, q0, sl1), d1 = bwd_sel(g1, q1, sl1);
+        if (HAS_ADD) {
+            d0 += bwd_sel(__uint_as_float(aw[k] << 16), q0, sl2);
+            d1 += bwd_sel(__uint_as_float(aw[k] & 0xffff0000u), q1, sl2);
         }
         o[k] = pk2bf(d0, d1);
-        if (sums) {
+        if (SUMS) {
             const float r0 = __uint_as_float(o[k] << 16), r1 = __uint_as_float(o[k] & 0xffff0000u);
             s1[2 * k] += r0;
             s1[2 * k + 1] += r1;
@@ -94,6 +111,15 @@ __device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool ha
         }
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// run-time form: one wave-uniform branch per CHUNK (not per element)
+__device__ __forceinline__ uint4 bwd_chunk(uint4 gq, uint4 zq, uint4 aq, bool has_add, bool /*affine*/, bool sums,
+                                           int act1, int act2, const BwdParams& P, float* s1, float* s2) {
+    const float sl1 = act_slope(act1), sl2 = act_slope(act2);
+    if (has_add) return sums ? bwd_chunk_t<true, true>(gq, zq, aq, sl1, sl2, P, s1, s2)
+                             : bwd_chunk_t<true, false>(gq, zq, aq, sl1, sl2, P, s1, s2);
+    return sums ? bwd_chunk_t<false, true>(gq, zq, aq, sl1, sl2, P, s1, s2)
+                : bwd_chunk_t<false, false>(gq, zq, aq, sl1, sl2, P, s1, s2);
 }
 // Per-tile reduction of the chunk sums: lanes of a wave that own the same chunk (lane % CPR) first, then the
 // waves through `sred` [NW][2][BN]; thread c < BN writes column c of the tile's partial row.
