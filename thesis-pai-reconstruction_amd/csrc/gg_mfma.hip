@@ -350,7 +350,7 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
     constexpr int WM = BM / WR;
     unsigned char* Cs = smem;
     float* sstat = (float*)(smem + BM * CROW);  // [WM][2][BN]
-    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const float eslope = act_slope(a.yact ? a.eact : PAI_ACT_NONE);
     float csum[NT], csq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -364,8 +364,7 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
                 const int row = wm * WR + mt * 16 + fq * 4 + r;
                 float v = acc[mt][nt][r] + b;
                 if (m0 + row < g.M) { s += v; q += v * v; }
-                if (eact == PAI_ACT_LRELU) v = fmaxf(v, 0.2f * v);
-                else if (eact == PAI_ACT_RELU) v = fmaxf(v, 0.f);
+                v = act_fwd(v, eslope);   // branch-free (gg_tile.h): slope 1 = no activation
                 *(bf16_t*)(Cs + row * CROW + col * 2) = f2bf(v);
             }
         }
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, const fl
     const int m = bm * FIN_ROWS + row;
     const int c0 = cb * FIN_COLS + cgl * 8;
     const bool valid = m < g.M && c0 < g.Cout;
-    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const float eslope = act_slope(a.yact ? a.eact : PAI_ACT_NONE);
     float v[8], bs1[8], bs2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = bs1[k] = bs2[k] = 0.f;
@@ -491,10 +490,7 @@ __global__ __launch_bounds__(256) void splitk_finish_k(GG g, FwdArgs a, const fl
     if (valid) {
         unsigned packed[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (eact == PAI_ACT_LRELU) v[k] = fmaxf(v[k], 0.2f * v[k]);
-            else if (eact == PAI_ACT_RELU) v[k] = fmaxf(v[k], 0.f);
-        }
+        for (int k = 0; k < 8; ++k) v[k] = act_fwd(v[k], eslope);
 #pragma unroll
         for (int k = 0; k < 4; ++k) packed[k] = pk2bf(v[2 * k], v[2 * k + 1]);
         int n, gy, gx;
@@ -937,6 +933,38 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     // wn*(BN/2) + 4 NT fq + (4 nt + r): bias, statistics, activation, then one or two 16-B LDS stores per row
     constexpr int CL = 4 * NT;               // channels per lane
     const int col0 = wn * BNW + CL * fq;
+    bf16_t* dst;
+    int dstride, dcol;
+    if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
+    else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
+    else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
+    const bool bwd = a.bz && !a.yact && n0 < g.D1;   // uniform per workgroup
+    const bf16_t* bzp = (const bf16_t*)a.bz;
+    const bf16_t* bap = (const bf16_t*)a.badd;
+    const bool bsum = bwd && a.bpart;
+    constexpr int CPR = BN / 8;        // 16-B chunks per row
+    constexpr int ORP = NTHR / CPR;    // rows per pass
+    static_assert(ORP % 16 == 0, "a pass covers whole 16-pixel tile rows");
+    const int oc = tid % CPR, orow0 = tid / CPR;
+    constexpr int NP = BM / ORP, NB = NP < 4 ? NP : 4, NBATCH = NP / NB;
+    // pass p of this thread: tile row orow0 + p ORP, i.e. ORP / 16 image rows further down.  Addresses = a 64-bit base that is
+    // uniform over the workgroup (scalar registers) + a 32-bit byte offset per thread + a uniform step per pass.
+    const size_t tile0 = ((size_t)(img * g.OH + gy0 * g.OS + g.poy[ph]) * g.OW + gx0 * g.OS + g.pox[ph]) * dstride + dcol;
+    const unsigned toff = (unsigned)((((orow0 >> 4) * g.OS * g.OW + (orow0 & 15) * g.OS) * dstride + oc * 8) * 2);
+    const unsigned pstep = (unsigned)((ORP / 16) * g.OS * g.OW * dstride * 2);
+    const char* zt = (const char*)(bzp + tile0);
+    const char* at = (const char*)(bap + tile0);
+    char* dt = (char*)(dst + tile0);
+    const float sl1 = act_slope(a.bact1), sl2 = act_slope(a.bact2);
+    // The first NB passes of the producer's chunks (fused backward) are requested HERE, ahead of the staging pass and its
+    // barrier: their HBM latency runs beside the staging instead of behind it.
+    // (the skip-gradient chunks follow behind the staging pass, when the accumulators' registers are free: all eight requests
+    //  up front did not fit beside 64 accumulators at the 128-register line)
+    uint4 zq[NB], aq[NB];
+    if (bwd) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) zq[p] = *(const uint4*)(zt + (toff + (unsigned)p * pstep));
+    }
     const bool has_bias = a.bias != nullptr, has_stats = a.stats != nullptr;
     // two forms of the staging pass: bare (input gradients: neither bias nor statistics, no register arrays for them) and full
     auto stage = [&](auto full_tag) {
@@ -991,6 +1019,17 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     };
     if (has_bias || has_stats) stage(std::true_type{});
     else stage(std::false_type{});
+    if (bwd && bap) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) aq[p] = *(const uint4*)(at + (toff + (unsigned)p * pstep));
+    }
+    // (behind the staging pass: at the 128-register line the 32 registers of parameters and sums beside the accumulators
+    //  and the chunks in flight made hipcc wait for every chunk and park it in scratch)
+    BwdParams BP;
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
+    if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
     __syncthreads();
     if (has_stats && tid < BN) {
         float* dst = a.stats + ((size_t)(ph * mtiles + bm) * 2) * g.Cout + n0 + tid;
@@ -1000,47 +1039,16 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         dst[0] = s;
         dst[g.Cout] = q;
     }
-    bf16_t* dst;
-    int dstride, dcol;
-    if (a.yact) { dst = (bf16_t*)a.yact; dstride = g.Cout; dcol = n0; }
-    else if (n0 < g.D1) { dst = (bf16_t*)a.y1; dstride = g.D1; dcol = n0; }
-    else { dst = (bf16_t*)a.y2; dstride = g.D2; dcol = n0 - g.D1; }
-    const bool bwd = a.bz && !a.yact && n0 < g.D1;   // uniform per workgroup
-    const bf16_t* bzp = (const bf16_t*)a.bz;
-    const bf16_t* bap = (const bf16_t*)a.badd;
-    const bool bsum = bwd && a.bpart;
-    constexpr int CPR = BN / 8;        // 16-B chunks per row
-    constexpr int ORP = NTHR / CPR;    // rows per pass
-    static_assert(ORP % 16 == 0, "a pass covers whole 16-pixel tile rows");
-    const int oc = tid % CPR, orow0 = tid / CPR;
-    BwdParams BP;
-    float bs1[8], bs2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = 0.f;
-    constexpr int NP = BM / ORP, NB = NP < 4 ? NP : 4, NBATCH = NP / NB;
-    if (bwd) bwd_load_params(a, dcol + oc * 8, BP);
-    // pass p of this thread: tile row orow0 + p ORP, i.e. ORP / 16 image rows further down.  Addresses = a 64-bit base that is
-    // uniform over the workgroup (scalar registers) + a 32-bit byte offset per thread + a uniform step per pass.
-    const size_t tile0 = ((size_t)(img * g.OH + gy0 * g.OS + g.poy[ph]) * g.OW + gx0 * g.OS + g.pox[ph]) * dstride + dcol;
-    const unsigned toff = (unsigned)((((orow0 >> 4) * g.OS * g.OW + (orow0 & 15) * g.OS) * dstride + oc * 8) * 2);
-    const unsigned pstep = (unsigned)((ORP / 16) * g.OS * g.OW * dstride * 2);
-    const char* zt = (const char*)(bzp + tile0);
-    const char* at = (const char*)(bap + tile0);
-    char* dt = (char*)(dst + tile0);
-    const float sl1 = act_slope(a.bact1), sl2 = act_slope(a.bact2);
     // The chunks of the producer's tensors are requested four passes ahead of the stores they feed: the stores may alias them
     // as far as the compiler knows, so the order is written out -- a pass's registers are re-requested for pass + 4 as soon
     // as its chunk is computed.
     auto store_tile = [&](auto bwd_tag, auto add_tag, auto sum_tag) {
         constexpr bool BWD = decltype(bwd_tag)::value, ADD = decltype(add_tag)::value, SUM = decltype(sum_tag)::value;
-        uint4 zq[NB], aq[NB];
         auto request = [&](int pass, int slot) {
             const unsigned off = toff + (unsigned)pass * pstep;
             if (BWD) zq[slot] = *(const uint4*)(zt + off);
             if (BWD && ADD) aq[slot] = *(const uint4*)(at + off);
         };
-#pragma unroll
-        for (int p = 0; p < NB; ++p) request(p, p);
 #pragma unroll
         for (int b = 0; b < NBATCH; ++b) {
 #pragma unroll
@@ -1230,7 +1238,7 @@ __global__ __launch_bounds__(256) void pw_k(GG g, FwdArgs a, int groups_per_wave
     const bf16_t* x = (const bf16_t*)a.x1;
     const bf16_t* w = (const bf16_t*)a.w;
     bf16_t* y = (bf16_t*)(a.yact ? a.yact : a.y1);
-    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const float eslope = act_slope(a.yact ? a.eact : PAI_ACT_NONE);
     // filter: MFMA row (nt, i = fr) carries output channel CL (i >> 2) + 4 nt + (i & 3)
     bf8_t wf[NTT][KB];
 #pragma unroll
@@ -1288,8 +1296,7 @@ __global__ __launch_bounds__(256) void pw_k(GG g, FwdArgs a, int groups_per_wave
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[nt][r] + bias_v[4 * nt + r];
                 if (a.stats && valid) { s1[4 * nt + r] += v[r]; s2[4 * nt + r] = fmaf(v[r], v[r], s2[4 * nt + r]); }
-                if (eact == PAI_ACT_LRELU) v[r] = fmaxf(v[r], 0.2f * v[r]);
-                else if (eact == PAI_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+                v[r] = act_fwd(v[r], eslope);
             }
             pk[2 * nt] = pk2bf(v[0], v[1]);
             pk[2 * nt + 1] = pk2bf(v[2], v[3]);
