@@ -593,6 +593,17 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 #ifndef PATCH_ABL
 #define PATCH_ABL 0
 #endif
+// timing ablations of the fused-backward store (results WRONG): 1 no z loads, 2 no chunk arithmetic, 4 no stores
+#ifndef EPI_ABL
+#define EPI_ABL 0
+#endif
+// (Round 6, built and dropped -- it does not fit the register line: waves 4-7 of the 256-row tile half a step behind waves 0-3 -- the
+// second K half of step i - 1 multiplied from fragments fetched BEFORE the barrier of step i (guide, "two waves per SIMD",
+// item 9).  The pending fragment set is 32 registers beside 64 accumulators and the 32 of the step in flight: 142+ in a
+// 128-register kernel; hipcc spills the fill offsets and reloads them from scratch in front of every weight-tile fill.)
+#ifndef PATCH_COLSWZ_ALL
+#define PATCH_COLSWZ_ALL 0   // 1: the immediate-offset operand addressing also for the kernels at the 128-register line
+#endif
 #ifndef PATCH_SETPRIO
 #define PATCH_SETPRIO 0   // 1: raise the wave's issue priority over its MFMA cluster (guide T5)
 #endif
@@ -663,6 +674,22 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     }
     wby16 = __builtin_amdgcn_readfirstlane(wby16);
     wbx16 = __builtin_amdgcn_readfirstlane(wbx16);
+    // the per-tap tables of this phase in three scalar registers (round 6): weight tap slots 4 bits per (window, tap), patch
+    // offsets (ty, tx) 2 bits per (window, tap), ReLU-on-load flags.  Indexed through the by-value structs they were an
+    // s_load_dword + s_waitcnt lgkmcnt(0) behind the barrier of EVERY step, in front of the weight-tile fill.
+    unsigned wtlo = 0, wthi = 0, toff2 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned slot = (pg.wt4[ph][q] >> (8 * k)) & 15u, to = (pg.toff4[ph][q] >> (8 * k)) & 0xffu;
+            if (q < 2) wtlo |= slot << (16 * q + 4 * k); else wthi |= slot << (16 * (q - 2) + 4 * k);
+            toff2 |= ((to / PATCH_W) * 2u + (to % PATCH_W)) << (8 * q + 2 * k);
+        }
+    wtlo = __builtin_amdgcn_readfirstlane(wtlo);
+    wthi = __builtin_amdgcn_readfirstlane(wthi);
+    toff2 = __builtin_amdgcn_readfirstlane(toff2);
+    const unsigned relu_bits = __builtin_amdgcn_readfirstlane((g.relu1 ? 1u : 0u) | (g.relu2 ? 2u : 0u));
 
     // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
     const int sc = lane & 7, sr = wid * 8 + (lane >> 3);
@@ -757,7 +784,8 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     };
     auto fire_b = [&](int gi, int k, int buf) {
         const int c0 = (gi >> gsh) * MBK, q = gi & (pg.groups - 1);
-        const unsigned woff = (unsigned)((int)((pg.wt4[ph][q] >> (8 * k)) & 0xffu) * g.Cin + c0) * 2u;
+        const unsigned slot = (((q & 2) ? wthi : wtlo) >> (16 * (q & 1) + 4 * k)) & 15u;
+        const unsigned woff = (unsigned)((int)slot * g.Cin + c0) * 2u;
         if (abl & 1) return;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) FP_BLDS16(wrs, wrow[j], woff, Bs + buf * (BN * 128) + (j * RPP + wid * 8) * 128);
@@ -826,7 +854,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         };
         for (int gi = 0; gi < ngroups; ++gi) {
             const int c0g = (gi >> gsh) * MBK;
-            const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
+            const int relu = (int)((relu_bits >> (c0g >= g.C1 ? 1 : 0)) & 1u);
             const bool more = gi + 1 < ngroups;
             step(std::integral_constant<int, 0>{}, gi, relu, more);
             step(std::integral_constant<int, 1>{}, gi, relu, more);
@@ -837,12 +865,12 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         int buf = 0;
         for (int gi = 0; gi < ngroups; ++gi) {
             const int c0g = (gi >> gsh) * MBK;
-            const int relu = c0g >= g.C1 ? g.relu2 : g.relu1;
-            const unsigned toff4 = pg.toff4[ph][gi & (pg.groups - 1)];
+            const int relu = (int)((relu_bits >> (c0g >= g.C1 ? 1 : 0)) & 1u);
+            const unsigned toff8 = toff2 >> (8 * (gi & (pg.groups - 1)));
             const bool more = gi + 1 < ngroups;
     #pragma unroll 1
             for (int k = 0; k < 4; ++k) {
-                const int toff = (int)((toff4 >> (8 * k)) & 0xffu);
+                const int t2 = (int)((toff8 >> (2 * k)) & 3u), toff = (t2 >> 1) * PATCH_W + (t2 & 1);
                 unsigned abase[MT];
     #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -961,7 +989,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     // (the skip-gradient chunks follow behind the staging pass, when the accumulators' registers are free: all eight requests
     //  up front did not fit beside 64 accumulators at the 128-register line)
     uint4 zq[NB], aq[NB];
-    if (bwd) {
+    if (bwd && !(EPI_ABL & 1)) {
 #pragma unroll
         for (int p = 0; p < NB; ++p) zq[p] = *(const uint4*)(zt + (toff + (unsigned)p * pstep));
     }
@@ -1046,7 +1074,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         constexpr bool BWD = decltype(bwd_tag)::value, ADD = decltype(add_tag)::value, SUM = decltype(sum_tag)::value;
         auto request = [&](int pass, int slot) {
             const unsigned off = toff + (unsigned)pass * pstep;
-            if (BWD) zq[slot] = *(const uint4*)(zt + off);
+            if (BWD && !(EPI_ABL & 1)) zq[slot] = *(const uint4*)(zt + off);
             if (BWD && ADD) aq[slot] = *(const uint4*)(at + off);
         };
 #pragma unroll
@@ -1055,9 +1083,11 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
             for (int p = 0; p < NB; ++p) {
                 const int pass = b * NB + p;
                 uint4 o = *(const uint4*)(Cs + (orow0 + pass * ORP) * CROW + oc * 16);
-                if (BWD) o = bwd_chunk_t<ADD, SUM>(o, zq[p], aq[p], sl1, sl2, BP, bs1, bs2);
+                if (EPI_ABL & 1) zq[p] = o;
+                if (BWD && !(EPI_ABL & 2)) o = bwd_chunk_t<ADD, SUM>(o, zq[p], aq[p], sl1, sl2, BP, bs1, bs2);
+                if (BWD && (EPI_ABL & 2)) { o.x ^= zq[p].x; if (ADD) o.y ^= aq[p].y; }
                 if (b + 1 < NBATCH) request(pass + NB, p);   // rolling window: NB passes of producer chunks in flight
-                *(uint4*)(dt + (toff + (unsigned)pass * pstep)) = o;
+                if (!(EPI_ABL & 4) || o.x == 0x12345u) *(uint4*)(dt + (toff + (unsigned)pass * pstep)) = o;
                 // one pass at a time: left alone, hipcc unpacks the chunks of all four passes in flight up front (~100 live
                 // registers of floats) and spills the parameters and sums around them
                 __builtin_amdgcn_sched_barrier(0);
@@ -1078,7 +1108,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 template <int BM, int BN, bool DBB>
 __global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
     // (BM, BN, DBB) = (256, 128, *) and (128, 128, false) are the configurations at the register line, see COLSWZ
-    gg_fwd_patch_body<BM, BN, DBB, 2, 64, !(BN == 128 && (BM == 256 || !DBB))>(g, a, pg, mtiles, ntiles);
+    gg_fwd_patch_body<BM, BN, DBB, 2, 64, PATCH_COLSWZ_ALL || !(BN == 128 && (BM == 256 || !DBB))>(g, a, pg, mtiles, ntiles);
 }
 // 64 output channels, one wave column: BM / 64 waves of 64 x 64 (see gg_fwd_patch_body, WN = 1)
 template <int BM, int BN, bool DBB>

@@ -411,14 +411,36 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
         pq[i] = (us8_t){0, 0, 0, 0, 0, 0, 0, 0};
         if ((int64_t)p0 + (int64_t)i * pstep < g.M) pq[i] = gather_fast(p0 + i * pstep);
     }
+    // BWD: z of the elements an iteration stores, requested ZA iterations ahead like the gathers (round 6: the request used
+    // to sit at the top of the iteration that consumes it -- one exposed HBM round trip per iteration, 185 us against 56 us
+    // without the fused sums for decoders[7]'s input gradient).  rows >= M: out of range, read as zero (and the value stored
+    // for them is dropped); offsets beyond the tensor likewise.
+#ifndef THIN_ZA
+#define THIN_ZA 2
+#endif
+    constexpr int ZA = THIN_ZA;
+    u4_t zql[BWD ? ZA : 1], zqh[BWD ? ZA : 1];
+    if (BWD) {
+#pragma unroll
+        for (int i = 0; i < ZA; ++i) {
+            zql[i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(o_r1 + (unsigned)i * s_r1), 0, 0);
+            zqh[i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(o_r1 + (unsigned)i * s_r1) + 64, 0, 0);
+        }
+    }
     for (; p0 < g.M; p0 += pstep) {
         us8_t pnext = {0, 0, 0, 0, 0, 0, 0, 0};
         if ((int64_t)p0 + (int64_t)AHEAD * pstep < g.M) pnext = gather_fast(p0 + AHEAD * pstep);
         const bf8_t bfrag = __builtin_bit_cast(bf8_t, pq[0]);
         u4_t zlo = {0u, 0u, 0u, 0u}, zhi = {0u, 0u, 0u, 0u};
-        if (BWD) {      // rows >= M: out of range, read as zero (and the value stored for them is dropped)
-            zlo = __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)o_r1, 0, 0);
-            zhi = __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)o_r1 + 64, 0, 0);
+        if (BWD) {
+            zlo = zql[0]; zhi = zqh[0];
+#pragma unroll
+            for (int i = 0; i + 1 < ZA; ++i) { zql[i] = zql[i + 1]; zqh[i] = zqh[i + 1]; }
+            // (an offset past 2^32 cannot occur: out_ok bounds M x Cout x 2 by 2^32 and ZA x s_r1 is added to a valid row)
+            const unsigned long long zo = (unsigned long long)o_r1 + (unsigned long long)ZA * s_r1;
+            const int zoff = zo < (unsigned long long)raw1_bytes ? (int)(unsigned)zo : (int)0x80000000u;
+            zql[ZA - 1] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zoff, 0, 0);
+            zqh[ZA - 1] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zoff + 64, 0, 0);
         }
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
