@@ -141,10 +141,26 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+# (per-GPU batch, image size) of the BASELINE.json configuration each model family is quoted on
+BASELINE_CONFIG = {"pix2pix": (1, 64, 256), "attention_unet": (2, 64, 256), "resnext_unet": (3, 16, 512), "trans_unet": (4, 32, 256)}
+
+
+def workload_name(args):
+    k, b, size = BASELINE_CONFIG[args.model]
+    what = {"pix2pix": "Pix2Pix generator+PatchGAN GAN step",
+            "attention_unet": "Attention U-Net generator+PatchGAN GAN step",
+            "resnext_unet": "Residual U-Net (ResNeXt blocks) generator+PatchGAN GAN step",
+            "trans_unet": f"TransUNet (ViT bottleneck, patch size {args.patch_size}) generator+PatchGAN GAN step"}[args.model]
+    is_cfg = args.batch == b and args.size == size and "bf16" in args.precision and (args.model != "trans_unet" or args.patch_size == 4)
+    tag = f" (BASELINE configs[{k}])" if is_cfg else f" (NOT a BASELINE configuration: configs[{k}] is {b} images/GPU at {size}x{size}, bf16)"
+    return f"{what}, {args.size}x{args.size}x1 pairs, {args.batch} images/GPU{tag}"
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling: fixed as N grows)")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -156,6 +172,10 @@ def main():
                          "order as the eager step; eager: every launch issued from Python (PAI_PLAN=0 does the same)")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="wire format of the gradient buckets (dist.GradReducer)")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size in MB (default 32, or PAI_DDP_BUCKET_MB)")
+    ap.add_argument("--rccl-algo", default=None, choices=["Ring", "Tree"], help="force NCCL_ALGO (default: RCCL's own choice)")
+    ap.add_argument("--rccl-proto", default=None, choices=["Simple", "LL", "LL128"], help="force NCCL_PROTO")
+    ap.add_argument("--rccl-channels", type=int, default=None, help="force NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS")
     ap.add_argument("--precision", default="bf16-mixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -180,6 +200,8 @@ def main():
     pai = pai_bootstrap.load()
     from thesis_pai_reconstruction_amd import dist as pdist, ops
 
+    if args.rccl_algo or args.rccl_proto or args.rccl_channels:
+        pdist.configure_rccl(algo=args.rccl_algo, proto=args.rccl_proto, min_channels=args.rccl_channels, max_channels=args.rccl_channels)
     rank, local, world = pdist.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -212,7 +234,8 @@ def main():
     reducer = None
     if world > 1:
         pdist.broadcast_parameters(model)
-        reducer = pdist.GradReducer(grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
+        reducer = pdist.GradReducer(grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32,
+                                    bucket_bytes=None if args.bucket_mb is None else int(args.bucket_mb * (1 << 20)))
         reducer.attach(model)
 
         class _T:  # the hooks UnetWrapper needs from a trainer
@@ -316,15 +339,17 @@ def main():
             dom = max(fam, key=lambda k: fam[k]["ms"])
         f = fam[dom]
         achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/): they were taken on the DEFAULT
             # workload (BASELINE configs[1]); a kernel of that name in another family's step runs other layers
             if args.model == "pix2pix" and args.batch == 64:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))[dom]["hbm_bytes_per_launch"]
+                traffic_source = ("profiles/pmc_traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "workload on the builder's GPU box (scripts/profile_round.sh), NOT measured by this run")
         except (OSError, KeyError, ValueError):
             pass
         return dom, {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": dom,
                      "launches_per_step": f["launches"] / nsteps,
                      "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
@@ -397,27 +422,23 @@ def main():
         gflop = (sum(p[2] for p in prof) / args.steps / args.batch / 1e9) if prof else float("nan")
         gflop_src = "sum of ops.conv_flops over the executed convolution-family launches (incl. nn.Linear as 1 x 1)"
     out = {
-        "metric": ("train images/sec (256x256, bs=64) Pix2Pix step" if args.model == "pix2pix" else
+        "metric": (f"train images/sec ({args.size}x{args.size}, bs={args.batch}) Pix2Pix step" if args.model == "pix2pix" else
                    f"train images/sec ({args.size}x{args.size}, bs={args.batch}) {args.model} GAN step"),
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": "bf16" if "bf16" in args.precision else "f32",
         "data": "synthetic",
-        "config": {"workload": ("Attention U-Net generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
-                                "(BASELINE configs[2])" if args.model == "attention_unet" else
-                                f"Residual U-Net (ResNeXt blocks) generator+PatchGAN GAN step, {args.size}x{args.size}x1 "
-                                f"pairs, {args.batch} images/GPU (BASELINE configs[3])" if args.model == "resnext_unet" else
-                                f"TransUNet (ViT bottleneck, patch size {args.patch_size}) generator+PatchGAN GAN step, "
-                                f"256x256x1 pairs, {args.batch} images/GPU (BASELINE configs[4])" if args.model == "trans_unet" else
-                                "Pix2Pix generator+PatchGAN GAN step, 256x256x1 pairs, 64 images/GPU "
-                                "(BASELINE configs[1])"),
+        # the workload as RUN (batch and size from the flags); the "(BASELINE configs[k])" tag only when they are that
+        # configuration's own -- a --batch 8 line must not read as the configs[1] workload
+        "config": {"workload": workload_name(args),
                    **({"tunables": tunables} if tunables else {}),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "channel_mults": list(mults), "loss_type": "gan",
                    "generator_forwards_per_step": 1 if reuse else 2, "parallelism": f"dp{world}",
                    "grad_bucket_dtype": args.grad_dtype,
                    **({"backend": torch.distributed.get_backend(), "gpus_visible": torch.cuda.device_count(),
-                       "rccl_ranks": reducer.rccl_ranks() if reducer is not None else 0} if world > 1 else {})},
+                       "rccl_ranks": reducer.rccl_ranks() if reducer is not None else 0,
+                       "gradient_exchange": reducer.describe() if reducer is not None else None} if world > 1 else {})},
         "host_issue_ms_per_step": round(host_issue_ms, 3),
         "launch_mode": ("launch plan (pai_plan_run: one C call per step)" if planned is not None and planned.replays > 0 else
                         "eager" + (f" (plan refused: {planned.disabled})" if planned is not None and planned.disabled else "")),

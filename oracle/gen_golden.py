@@ -176,6 +176,71 @@ def run_case(name, mults, size, n, loss_type, seed, steps, full_tensors, search=
     print("wrote", name, {k: float(v) for k, v in rec.items() if ".log." in k})
 
 
+def blob_batch(seed, n, size):
+    """Learnable synthetic pairs (depth-attenuated Gaussian blobs + noise -> the clean blobs): the same arithmetic as
+    ``dataset.synthetic_pairs(kind='blobs')`` of the package, restated here so that fixtures regenerate from a seed without
+    importing the product."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    t = np.zeros((n, 1, size, size), np.float32)
+    for i in range(n):
+        for _ in range(int(rng.integers(3, 9))):
+            cy, cx, r = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(3, 18)
+            t[i, 0] += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r)) * rng.uniform(0.4, 1.0)
+    t = np.clip(t, 0, 1)
+    depth = np.exp(-yy / size * 2.5)[None, None]
+    x = np.clip(t * depth + 0.05 * rng.standard_normal(t.shape).astype(np.float32), 0, 1)
+    return torch.from_numpy(x * 2 - 1), torch.from_numpy(t * 2 - 1)
+
+
+def run_trained_case(name, mults, size, n, seed, steps, family):
+    """a TRAINED state of the real reference at a configuration's own width.  The reference's own
+    ``training_step`` runs ``steps`` GAN steps on one batch of blob pairs; recorded: the whole logged trajectory, the
+    eval-mode prediction at the end (full tensor: the yardstick the bf16 HIP path is held to -- at random initialisation
+    the BatchNorms amplify storage rounding and the prediction pins nothing), per-image SSIM / RMSE of that prediction
+    and fingerprints of the final state.  Nothing of the state itself is committed (0.1-4 GB): the GPU test re-trains
+    from the same portable initialisation in fp32 and is held to this trajectory."""
+    import time
+    from oracle.fingerprint import fingerprint
+    from oracle.metrics_ref import ssim_full
+    m = build_reference_model(mults, "gan", seed, family)
+    x, t = blob_batch(seed + 100, n, size)
+    rec = OrderedDict()
+    rec["meta.mults"] = np.array(mults)
+    rec["meta.size"] = np.array(size)
+    rec["meta.n"] = np.array(n)
+    rec["meta.seed"] = np.array(seed)
+    rec["meta.steps"] = np.array(steps)
+    rec["meta.family"] = np.array(family)
+    keys = None
+    traj = []
+    t0 = time.time()
+    for s in range(steps):
+        m.logged = {}
+        torch.manual_seed(1000 + s)
+        m.training_step((x, t), s)
+        if keys is None:
+            keys = sorted(m.logged.keys())
+        traj.append([float(m.logged[k]) for k in keys])
+        print(f"[{name}] step {s} ({time.time() - t0:.0f} s):", {k: round(float(m.logged[k]), 5) for k in keys}, flush=True)
+    rec["traj.keys"] = np.array(keys)
+    rec["traj.values"] = np.array(traj, dtype=np.float64)
+    m.eval()
+    m.logged = {}
+    with torch.no_grad():
+        m.validation_step((x, t), 0)
+        pred_eval = m(x)
+    for k, v in m.logged.items():
+        rec[f"val.log.{k}"] = np.array(float(v), dtype=np.float64)
+    rec["val.pred_full"] = pred_eval.numpy()
+    rec["val.ssim_per_image"] = ssim_full((pred_eval + 1) / 2, (t + 1) / 2)[0].numpy().astype(np.float64)   # on the denormalised pair
+    rec["val.rmse_per_image"] = (pred_eval - t).pow(2).mean((1, 2, 3)).sqrt().numpy().astype(np.float64)
+    for k, v in m.unet.state_dict().items():
+        rec[f"final.gstate.{k}"] = fingerprint(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("wrote", name, {k: float(v) for k, v in rec.items() if k.startswith("val.log.")})
+
+
 def run_forward_case(name, mults, size, n, seed, family="pix2pix"):
     """Train-mode forward only: per-level activations of the reference Unet and
     the PatchGAN logits, recorded with forward hooks on the reference modules."""
@@ -234,6 +299,14 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     _REF = _import_reference()
+    if "--trained" in sys.argv:       # trained states at the real widths of configs[3] / configs[4]
+        torch.set_num_threads(int(os.environ.get("GEN_THREADS", "6")))
+        steps = int(os.environ.get("GEN_STEPS", "40"))
+        if "--trans-only" not in sys.argv:
+            run_trained_case("ref_resnext_trained_full", (1, 2, 4, 8, 8, 8, 8, 8), 512, 2, seed=311, steps=steps, family="resnext")
+        if "--resnext-only" not in sys.argv:
+            run_trained_case("ref_trans4_trained_full", (1, 2, 2, 4, 4), 256, 2, seed=321, steps=steps, family="trans4")
+        sys.exit(0)
     if "--full-width" in sys.argv:    # BASELINE configs[3] / configs[4] at their REAL widths (kind 2: fingerprints)
         # configs[3]: ResUnetGAN("next", class-default channel_mults (1, 2, 4, 8, 8, 8, 8, 8)) at the configuration's own
         # 512 x 512 (Q17).  (At 256 x 256 and N = 2 the 1 x 1 bottleneck normalises over TWO samples: the reference's own

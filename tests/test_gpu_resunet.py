@@ -233,6 +233,46 @@ def test_side_stream_weight_gradients_equal_main_stream_ones(pai, golden_dir, dt
         assert g.norm() == 0 or 0.5 < ratio < 4.0, (k, ratio)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_parameter_used_by_two_nodes_of_one_graph(pai, dtype):
+    """a convolution applied TWICE in one graph.  The first use's weight gradient goes to the side stream; the
+    second use runs on the main stream (autograd adds the two there, before the end-of-pass join) and must first wait for
+    the side stream -- otherwise the sum reads a gradient that is still being written.  Against PAI_NO_OVERLAP-style
+    single-stream issue, over several repetitions (a race shows up as run-to-run differences)."""
+    from thesis_pai_reconstruction_amd import nnops
+
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(64, 64, 1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(64).to(DEV)
+    big = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)      # a long weight gradient in front of the re-used layer
+    x = torch.randn(8, 64, 128, 128, device=DEV)
+    got = {}
+    assert nnops.WGRAD.on
+    for mode in ("main", "side", "side", "side"):
+        for m in (conv, bn, big):
+            for p in m.parameters():
+                p.grad = None
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        nnops.WGRAD.on = mode != "main"
+        try:
+            h = nnops.to_nhwc(x, dtype)
+            h = nnops.conv_bn_act(h, big, None, nnops.ACT_NONE, True, 1, dtype)
+            h = nnops.conv_bn_act(h, conv, bn, nnops.ACT_RELU, True, 1, dtype)     # first use
+            h = nnops.conv_bn_act(h, conv, bn, nnops.ACT_RELU, True, 1, dtype)     # second use of the same parameters
+            h.float().square().mean().backward()
+            assert not nnops.WGRAD.pending
+        finally:
+            nnops.WGRAD.on = True
+        torch.cuda.synchronize()
+        got.setdefault(mode, []).append({"conv": conv.weight.grad.clone(), "big": big.weight.grad.clone(),
+                                         "gamma": bn.weight.grad.clone()})
+    ref = got["main"][0]
+    for run in got["side"]:
+        for k, g in ref.items():
+            err = float((run[k] - g).norm())
+            assert err <= 1e-5 * float(g.norm()) + 1e-12, (k, err, float(g.norm()))
+
+
 def test_batchnorm_on_load_equals_batchnorm_as_a_pass(pai, monkeypatch, res_type="next"):
     """bf16: where the next convolution of a block can read its input through a prologue (``nnops.can_prologue``: the grouped
     3 x 3 and the 1 x 1 behind it of a ResNeXt block at >= 16384 pixels; reference models/res_unet.py:143-147), the BatchNorm +

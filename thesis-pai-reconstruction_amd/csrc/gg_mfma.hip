@@ -1474,7 +1474,10 @@ __global__ __launch_bounds__(256) void gg_wgrad_mfma_k(GG g, WgradArgs a, int co
     }
     // prologue (pai_conv_wgrad_pro, pointwise layers): x is read as pact(x * pscale[c] + pshift[c]).  A B fragment is 8
     // pixels of ONE input channel per lane (column j0 + 64 wn + 16 nt + fi), so scale and shift are lane scalars.  Rows past
-    // the end come from the zero line, turn into pact(pshift) and meet a zero dY row: no contribution.
+    // the end come from the zero line, turn into pact(pshift) and meet a zero dY row: no contribution.  (Requires finite
+    // coefficients: with a non-finite scale / shift of a channel the out-of-range rows feed 0 x Inf = NaN into that
+    // channel's dW column -- as the in-range rows of that channel do anyway, there and in the reference's own arithmetic,
+    // so the result is the reference's NaN column, not a new failure)
     const bool pre = a.pscale != nullptr;
     float psc[4], psh[4];
     const float plo = a.pact == PAI_ACT_RELU ? 0.f : -INFINITY;

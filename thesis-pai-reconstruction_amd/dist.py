@@ -80,6 +80,28 @@ def _stream_wait(waiting, signalling):
     ops.stream_wait(waiting, signalling)
 
 
+RCCL_KNOBS = {"algo": "NCCL_ALGO", "proto": "NCCL_PROTO", "min_channels": "NCCL_MIN_NCHANNELS", "max_channels": "NCCL_MAX_NCHANNELS"}
+
+
+def configure_rccl(algo=None, proto=None, min_channels=None, max_channels=None):
+    """Collective-algorithm knobs of RCCL, to be called BEFORE the communicator exists (``init_from_env`` /
+    ``make_rccl_comm``): RCCL reads them when it builds its channels.  ``None`` leaves a knob to RCCL -- the default, and
+    what the 228 MB gradient exchange of the Pix2Pix generator should take on a fully connected 8-GPU xGMI node: RCCL's
+    topology search lays its ring channels over DIFFERENT Hamiltonian cycles of the 7-link clique, so "Ring" there is a
+    multi-link algorithm (all seven links of a GPU carry a share of every bucket; SURVEY section 5's 0.18-0.36 ms figure
+    for a direct reduce-scatter + all-gather is its bandwidth term), not the one-link ring of 1.25-2.5 ms.  ``algo``
+    ("Ring" | "Tree"), ``proto`` ("Simple" | "LL" | "LL128") and the channel bounds exist for the first hardware run:
+    forcing "Tree" or a low channel count is how one would SEE a link-bound exchange in the bench line.  Returns the
+    settings in force (also the ones inherited from the environment)."""
+    import os
+    for key, val in (("algo", algo), ("proto", proto), ("min_channels", min_channels), ("max_channels", max_channels)):
+        if val is not None:
+            if dist.is_initialized():
+                raise RuntimeError("configure_rccl: the process group already exists; RCCL reads its knobs at communicator creation")
+            os.environ[RCCL_KNOBS[key]] = str(val)
+    return {k: os.environ.get(v) for k, v in RCCL_KNOBS.items()}
+
+
 def make_rccl_comm(process_group=None):
     """A C-ABI RCCL communicator (ops.Comm: pai_comm_init / pai_allreduce) spanning the ranks of the initialised
     torch.distributed job; the 128-byte id travels through torch.distributed's object broadcast."""
@@ -95,7 +117,7 @@ class GradReducer:
     the buckets are then reduced by ``pai_allreduce`` on a communication stream of this object instead of
     ``torch.distributed.all_reduce``; bucketing, overlap and averaging are the same."""
 
-    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, comm=None,
+    def __init__(self, process_group=None, bucket_bytes: Optional[int] = None, overlap: bool = True, comm=None,
                  grad_dtype: Optional[torch.dtype] = None):
         """``grad_dtype``: wire format of the arena buckets, torch.float32 (default) or torch.bfloat16 (also
         PAI_GRAD_DTYPE=bf16).  With bf16 every bucket is cast into a persistent bf16 staging arena, reduced there and
@@ -103,6 +125,13 @@ class GradReducer:
         generator) at bf16 rounding of the summands; the master gradients stay fp32."""
         import os
         self.pg = process_group
+        # Bucket size (also PAI_DDP_BUCKET_MB).  32 MB: an all-reduce over R = 8 ranks is 2 (R - 1) = 14 chunk hops of
+        # B / R bytes; at ~10 us per hop and ~300 GB/s of all-reduce bus bandwidth over seven xGMI links a 32 MB bucket is
+        # ~0.14 ms of hop latency + ~0.19 ms of bytes, a 64 MB one 0.14 + 0.37 -- but the 218 MB arena then leaves in four
+        # pieces instead of seven and the last one (encoders[0..2], final only at the very end of the backward pass) is the
+        # exposed one: smaller tail, more overlap.  Below ~8 MB the hop latency is the whole cost.
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("PAI_DDP_BUCKET_MB", "32")) * (1 << 20))
         if grad_dtype is None:
             grad_dtype = torch.bfloat16 if os.environ.get("PAI_GRAD_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
         if grad_dtype not in (torch.float32, torch.bfloat16):
@@ -132,6 +161,22 @@ class GradReducer:
         torch.distributed path, host nodes for the collectives.  What cannot be replayed is a gradient the staging
         launches cannot read as it stands: not fp32, or not contiguous (``torch`` would copy it first)."""
         return all(p.dtype == torch.float32 and p.is_contiguous() for p in self._foreign_params)
+
+    def describe(self) -> dict:
+        """What the exchange of this reducer looks like, for the bench line: transport, ranks, RCCL knobs in force, bucket
+        size, wire type, and the buckets / bytes the last step(s) sent (``stats``)."""
+        import os
+        backend = None
+        if dist.is_initialized():
+            backend = dist.get_backend(self.pg)
+        return {"transport": ("pai_allreduce (C-ABI RCCL communicator)" if self.comm is not None else
+                              f"torch.distributed.all_reduce, backend {backend}"),
+                "rccl_ranks": self.rccl_ranks(), "world": int(self.world),
+                "rccl_knobs": {k: os.environ.get(v) for k, v in RCCL_KNOBS.items()},
+                "algorithm": os.environ.get("NCCL_ALGO") or "RCCL default (topology search; multi-channel rings over all xGMI links)",
+                "bucket_bytes": int(self.bucket_elems) * 4, "wire_dtype": str(self.grad_dtype).replace("torch.", ""),
+                "overlap_with_backward": bool(self.overlap),
+                "buckets_sent": int(self.stats.get("buckets", 0)), "bytes_sent": int(self.stats.get("bytes", 0))}
 
     def rccl_ranks(self) -> int:
         """Ranks of the RCCL communicator the buckets actually travel over: the C-ABI communicator's own count, or the
@@ -185,7 +230,10 @@ class GradReducer:
                 b["members"].append((p, off, n))
                 b["numel"] = off + n
             self._fmap[id(p)] = (b, len(b["members"]) - 1)
-            if hasattr(p, "register_post_accumulate_grad_hook"):
+            # a hook keeps the parameter's weight gradient on the main stream (nnops._WgradStream._hooked): only where it
+            # buys something -- more than one rank AND buckets that leave during the backward pass.  Otherwise finish()
+            # gathers from p.grad (its `not hooks` path).
+            if self.world > 1 and self.overlap and hasattr(p, "register_post_accumulate_grad_hook"):
                 self._foreign_hooks.append(p.register_post_accumulate_grad_hook(self._foreign_ready))
 
     def _fbuf(self, b, like, dtype):
@@ -405,9 +453,12 @@ class GradReducer:
                 _scale(st["arena"].flat, 1.0 / self.world)
             self._subs.pop(id(st["arena"]), None)
             st["sent"], st["works"], st["active"], st["post"] = 0, [], False, False
-        self._ev_next = 0
         if self._fbuckets and self.world > 1:
             self._finish_foreign()
+        # rewound only when every handle of this step has been waited for: buckets _finish_foreign launches draw FRESH
+        # events (re-recording one a hook-launched bucket still holds made its wait resolve later than needed), and the
+        # next step starts at event 0 again -- the same events in the same order every step, which recorded plans rely on
+        self._ev_next = 0
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, process_group=None):

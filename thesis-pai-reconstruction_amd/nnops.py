@@ -13,6 +13,7 @@ expansion / extraction of the filter is host-side plumbing on a 147 K-element te
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -63,7 +64,7 @@ def _grad_from_fwd_pack(dw: torch.Tensor, weight: torch.Tensor, groups: int) -> 
     return out
 
 
-_PREPACK = {}       # id(weight) -> (w_fwd, w_dgrad) bf16 packs made by prepack() for the forward pass that follows; single use
+_PREPACK = {}       # id(weight) -> (w_fwd, w_dgrad, weakref, version): bf16 packs made by prepack() for the forward pass that follows; single use (take_prepacked)
 
 
 def prepack(module: torch.nn.Module, dtype) -> None:
@@ -91,8 +92,21 @@ def prepack(module: torch.nn.Module, dtype) -> None:
         wf, wd = buf[off:off + n], buf[off + n:off + 2 * n]
         off += 2 * n
         items.append((c.weight.detach(), c.out_channels, 1, c.in_channels, wf, wd))
-        _PREPACK[id(c.weight)] = (wf, wd)
+        _PREPACK[id(c.weight)] = (wf, wd, weakref.ref(c.weight), c.weight._version)
     ops.pack_weights_multi(items)
+
+
+def take_prepacked(weight):
+    """The pair of bf16 packs ``prepack`` made for ``weight``, or None.  An entry is only good for the tensor it was made
+    from, at the version it had then: one left behind by a forward pass that never reached its convolution (an exception, a
+    conditional path) must not serve a later call after an optimizer step / EMA swap, nor a new tensor that got the id."""
+    ent = _PREPACK.pop(id(weight), None)
+    if ent is None:
+        return None
+    wf, wd, ref, version = ent
+    if ref() is not weight or weight._version != version:
+        return None
+    return wf, wd
 
 
 _ZEROS = {}
@@ -154,9 +168,15 @@ class _WgradStream:
         live = [p for p in params if p is not None]
         again = any(id(p) in self.seen for p in live)
         self.seen.update(id(p) for p in live)
-        if again or any(p.grad is not None or self._hooked(p) for p in live):
-            return fn()[0]
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        if again or any(p.grad is not None or self._hooked(p) for p in live):
+            # main-stream fallback.  Weight gradients of this pass may still be running on the side stream: autograd adds
+            # the first use's gradient of a re-used parameter to this one ON THE MAIN STREAM before the end-of-pass join,
+            # a hook reads it the moment it is returned, and the library's slab workspace serves one launch at a time --
+            # so the main stream first waits for what the side stream has been given.
+            if idx in self.pending:
+                ops.stream_wait_last(torch.cuda.current_stream(idx), self.streams[idx])
+            return fn()[0]
         if not self.pending:
             try:
                 self.budget = min(self.KEEP_BYTES, torch.cuda.mem_get_info(idx)[0] // 2)
@@ -233,7 +253,7 @@ class ConvBNAct(torch.autograd.Function):
             ops.ensure_scratch(ops.scratch_bytes_for([d]), x.device)
         # weight-gradient workspace: pixel-split slabs of the patch kernels, partial blocks of the grouped 3 x 3 gradient
         ops.ensure_wgrad_workspace([d], x.device)
-        packed = _PREPACK.pop(id(weight), None) if (k == 1 and groups == 1 and dtype == torch.bfloat16) else None
+        packed = take_prepacked(weight) if (k == 1 and groups == 1 and dtype == torch.bfloat16) else None
         wm = _dense_fwd_pack(weight, groups)
         if packed is not None:
             wf, wd = packed
