@@ -674,21 +674,12 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
     }
     wby16 = __builtin_amdgcn_readfirstlane(wby16);
     wbx16 = __builtin_amdgcn_readfirstlane(wbx16);
-    // the per-tap tables of this phase in three scalar registers (round 6): weight tap slots 4 bits per (window, tap), patch
-    // offsets (ty, tx) 2 bits per (window, tap), ReLU-on-load flags.  Indexed through the by-value structs they were an
+    // the per-tap tables of this phase in three scalar registers (round 6; packed on the host, patch_geo_pack): weight tap
+    // slots 4 bits per (window, tap), patch offsets (ty, tx) 2 bits per (window, tap); plus the ReLU-on-load flags.  Indexed through the by-value structs they were an
     // s_load_dword + s_waitcnt lgkmcnt(0) behind the barrier of EVERY step, in front of the weight-tile fill.
-    unsigned wtlo = 0, wthi = 0, toff2 = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned slot = (pg.wt4[ph][q] >> (8 * k)) & 15u, to = (pg.toff4[ph][q] >> (8 * k)) & 0xffu;
-            if (q < 2) wtlo |= slot << (16 * q + 4 * k); else wthi |= slot << (16 * (q - 2) + 4 * k);
-            toff2 |= ((to / PATCH_W) * 2u + (to % PATCH_W)) << (8 * q + 2 * k);
-        }
-    wtlo = __builtin_amdgcn_readfirstlane(wtlo);
-    wthi = __builtin_amdgcn_readfirstlane(wthi);
-    toff2 = __builtin_amdgcn_readfirstlane(toff2);
+    const unsigned wtlo = __builtin_amdgcn_readfirstlane(pg.wt_lo[ph]);
+    const unsigned wthi = __builtin_amdgcn_readfirstlane(pg.wt_hi[ph]);
+    const unsigned toff2 = __builtin_amdgcn_readfirstlane(pg.toff2[ph]);
     const unsigned relu_bits = __builtin_amdgcn_readfirstlane((g.relu1 ? 1u : 0u) | (g.relu2 ? 2u : 0u));
 
     // ---- patch fill map: thread -> (pixel p = 32 j + tid / 8, 16-B slot tid % 8) ----------------
@@ -707,10 +698,14 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
         const int y = (gy0 + py) * g.S, x = (gx0 + px) * g.S;
         const int pixb = (img * g.H + y) * g.W + x;
         unsigned m = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        auto inside = [&](int q) {
             const int yy = y + (int)((wby16 >> (4 * q)) & 15u) - 8, xx = x + (int)((wbx16 >> (4 * q)) & 15u) - 8;
-            if (q < pg.groups && p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
+            if (p < PATCH_PIX && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) m |= 1u << q;
+        };
+        inside(0);
+        if (pg.groups > 1) {   // (wave-uniform: the one-window phases of the transposed forms skip three quarters of this)
+#pragma unroll
+            for (int q = 1; q < 4; ++q) inside(q);
         }
         pfill[j] = ((unsigned)pixb & 0xffffffu) | (m << 24) | ((unsigned)(sc ^ ((COLSWZ ? px : sr) & 6)) << 28);
     }

@@ -328,8 +328,11 @@ __global__ __launch_bounds__(256) void thin_fwd_k(GG g, FwdArgs a, int fast_ok) 
 //   store (pai_conv_dgrad_bn with act1 = none, no second gradient: du IS the value stored): z of the same elements is
 //   read beside the store and one partial row [2][64] = (sum du, sum du * xhat) is written per workgroup -- decoders[6]
 //   behind the head's input gradient: bn_bwd_reduce_k (88 us in the step: 268 MB read) becomes 134 MB read here.
+#ifndef THIN_BWD_WAVES
+#define THIN_BWD_WAVES 1
+#endif
 template <int T, bool RAW, int ACTM, int NG, bool BWD = false>      // NG: 64-channel groups (Cout / 64)
-__global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
+__global__ __launch_bounds__(256, BWD ? THIN_BWD_WAVES : 1) void thin_fwd2_k(GG g, FwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16_t* w = (const bf16_t*)a.w;
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(256) void thin_fwd2_k(GG g, FwdArgs a) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                bias4[gq][q][r] = a.bias ? a.bias[64 * gq + 32 * (q >> 1) + 8 * fq + 4 * (q & 1) + r] : 0.f;
+                // (BWD = an input gradient: no bias; the zero accumulator is then an inline constant, not 32 registers)
+                bias4[gq][q][r] = (!BWD && a.bias) ? a.bias[64 * gq + 32 * (q >> 1) + 8 * fq + 4 * (q & 1) + r] : 0.f;
     const int pdx0 = g.dx[0][(8 * fq < KT) ? (8 * fq) / T : 0];
     const int pdyA = g.dy[0][(8 * fq < KT) ? (8 * fq) / T : 0];
     const int pdyB = g.dy[0][(8 * fq + 4 < KT) ? (8 * fq + 4) / T : 0];

@@ -153,6 +153,9 @@ struct PatchGeo {
     signed char by[4][4], bx[4][4];  // [phase][window] source offset of patch pixel (0,0) from (gy0*S, gx0*S)
     unsigned toff4[4][4];          // 4 x 8 bit: patch offset ty*17+tx of the window's taps
     unsigned wt4[4][4];            // 4 x 8 bit: weight tap slot of the window's taps
+    // the same per phase, packed for the forward kernel's scalar registers (patch_geo_pack): weight tap slots 4 bits per
+    // (window, tap) -- windows 0-1 in wt_lo, 2-3 in wt_hi -- and patch offsets (ty, tx) 2 bits per (window, tap)
+    unsigned wt_lo[4], wt_hi[4], toff2[4];
 };
 constexpr int PATCH_W = 17;
 // BM = 128: 8 x 16 output pixels, 4 waves;  BM = 256: 16 x 16 output pixels, 8 waves (4 x 2) -- the weight
@@ -167,7 +170,24 @@ template <int BM, int WN = 2, int WPX = 64> struct PatchDims {   // WN: waves si
     static constexpr int BYTES = PJ * RPP * 128;
 };
 
+static inline void patch_geo_pack(PatchGeo* pg) {
+    for (int ph = 0; ph < 4; ++ph) {
+        pg->wt_lo[ph] = pg->wt_hi[ph] = pg->toff2[ph] = 0;
+        for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 4; ++k) {
+                const unsigned slot = (pg->wt4[ph][q] >> (8 * k)) & 15u, to = (pg->toff4[ph][q] >> (8 * k)) & 0xffu;
+                if (q < 2) pg->wt_lo[ph] |= slot << (16 * q + 4 * k); else pg->wt_hi[ph] |= slot << (16 * (q - 2) + 4 * k);
+                pg->toff2[ph] |= ((to / PATCH_W) * 2u + (to % PATCH_W)) << (8 * q + 2 * k);
+            }
+    }
+}
+static inline bool patch_geo_raw(const GG& g, int th, PatchGeo* pg, int tw);
 static inline bool patch_geo(const GG& g, int th, PatchGeo* pg, int tw = 16) {   // th x tw: output pixels of a tile
+    if (!patch_geo_raw(g, th, pg, tw)) return false;
+    patch_geo_pack(pg);
+    return true;
+}
+static inline bool patch_geo_raw(const GG& g, int th, PatchGeo* pg, int tw) {
     if ((g.OWg % tw) || (g.OHg % th)) return false;
     memset(pg, 0, sizeof(*pg));
     pg->TY = g.OHg / th;

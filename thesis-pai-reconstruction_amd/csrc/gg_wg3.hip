@@ -52,9 +52,66 @@ template <int BMC> __device__ __forceinline__ int yswz3(int row) {
     return BMC == 128 ? tr_swz3(row) : ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
 }
 
+#ifndef WG3_SPREAD
+#define WG3_SPREAD 0   // 1: the next step's LDS-DMA pieces between the MFMAs of k-half 0 instead of in one block in front of them (measured: 1964-1970 against 1917-1947 us over the wgrad layers, step 5.82 against 5.79 ms -- dropped)
+#endif
 #ifndef WG3_ABL
 #define WG3_ABL 0     // timing ablations (results WRONG): 1 no dW store, 2 no MFMA, 4 no fills, 8 no fragment reads
 #endif
+
+// ---- pinned fragment registers (round 6) ------------------------------------------------------------------------------
+// The two 8-byte halves of an MFMA operand come from two ds_read_b64_tr_b16 (inline asm: the compiler must not see the
+// reads, see the K loop).  With "=v" outputs the allocator rarely placed a fragment's halves side by side and `compose`
+// became a v_mov_b64 per half: 32 per 64 MFMAs of a wave that is ALONE on its SIMD (one workgroup per CU beside the
+// input-gradient stream), where every vector instruction between two MFMAs delays the next one.  The 24 fragments of a
+// step (2 k-halves x 12) therefore live in FIXED registers v[160 + 4 F .. 163 + 4 F]: the reads deliver into the halves
+// in place and the composition is free.  MEASURED AND NOT THE DEFAULT (WG3_PIN = 0: the allocator's choice): the moves
+// disappear from the ISA (32 -> 0 v_mov_b64 per 64 MFMAs outside the bias branch) and the launches get 1.6 % SLOWER
+// (convbench w: 1990-1998 against 1958 us over all layers; step 5.95 against 5.94 ms) -- vector instructions per MFMA
+// are not what bounds this kernel.
+#ifndef WG3_PIN
+#define WG3_PIN 0
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned wg3_u2_t;
+#define WG3_PIN_CASES(X) X(0, 160, 161, 162, 163) X(1, 164, 165, 166, 167) X(2, 168, 169, 170, 171) X(3, 172, 173, 174, 175) X(4, 176, 177, 178, 179) X(5, 180, 181, 182, 183) X(6, 184, 185, 186, 187) X(7, 188, 189, 190, 191) X(8, 192, 193, 194, 195) X(9, 196, 197, 198, 199) X(10, 200, 201, 202, 203) X(11, 204, 205, 206, 207) X(12, 208, 209, 210, 211) X(13, 212, 213, 214, 215) X(14, 216, 217, 218, 219) X(15, 220, 221, 222, 223) X(16, 224, 225, 226, 227) X(17, 228, 229, 230, 231) X(18, 232, 233, 234, 235) X(19, 236, 237, 238, 239) X(20, 240, 241, 242, 243) X(21, 244, 245, 246, 247) X(22, 248, 249, 250, 251) X(23, 252, 253, 254, 255)
+template <int F, unsigned OFF>
+__device__ __forceinline__ void wg3_rd_pair(wg3_u2_t& lo, wg3_u2_t& hi, unsigned o0, unsigned o1) {
+#if WG3_PIN
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_) {                                                                                           \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "={v[" #R0 ":" #R1 "]}"(lo) : "v"(o0), "n"(OFF));          \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "={v[" #R2 ":" #R3 "]}"(hi) : "v"(o1), "n"(OFF));          \
+    }
+    WG3_PIN_CASES(X)
+#undef X
+#else
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(o0), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(o1), "n"(OFF));
+#endif
+}
+// ties the halves (and then the composed operand) to this point of the program, in their registers
+template <int F>
+__device__ __forceinline__ bf8_t wg3_compose(wg3_u2_t lo, wg3_u2_t hi) {
+#if WG3_PIN
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_) asm volatile("" : "={v[" #R0 ":" #R1 "]}"(lo), "={v[" #R2 ":" #R3 "]}"(hi) : "0"(lo), "1"(hi));
+    WG3_PIN_CASES(X)
+#undef X
+    bf8_t f = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#define X(F_, R0, R1, R2, R3) \
+    if constexpr (F == F_) asm volatile("" : "={v[" #R0 ":" #R3 "]}"(f) : "0"(f));
+    WG3_PIN_CASES(X)
+#undef X
+    return f;
+#else
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#endif
+}
+template <int N, typename FN, int... I>
+__device__ __forceinline__ void wg3_sfor_impl(FN&& fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
+template <int N, typename FN>
+__device__ __forceinline__ void wg3_sfor(FN&& fn) { wg3_sfor_impl<N>(fn, std::make_integer_sequence<int, N>{}); }
 
 // BW: width of the K step's pixel block: 16 (4 x 16 pixels, images >= 16 wide) or 8 (8 x 8 pixels: 8 x 8 images)
 template <int BMC, int CI, int BW = 16>
@@ -189,12 +246,15 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
             xofs[jj] = inb ? xthr[jj] + xsof : OOB;
         }
     };
-    auto fire = [&](int st) {
+    // piece j of a stage's fill: j < YJ dY rows, then the X patch
+    auto fire_piece = [&](int st, int j) {
         if (WG3_ABL & 4) return;
+        if (j < YJ) WG3_BLDS16(yrs, ythr, ysof + (unsigned)j * yjstep, st * STAGE + (YRPI * j + wid * (YRPI / 4)) * YROW);
+        else WG3_BLDS16(xrs, xofs[j - YJ], 0, st * STAGE + YBUF + ((j - YJ) * XPPI + wid * (XPPI / 4)) * XPB);
+    };
+    auto fire = [&](int st) {
 #pragma unroll
-        for (int j = 0; j < YJ; ++j) WG3_BLDS16(yrs, ythr, ysof + (unsigned)j * yjstep, st * STAGE + (YRPI * j + wid * (YRPI / 4)) * YROW);
-#pragma unroll
-        for (int jj = 0; jj < XJ; ++jj) WG3_BLDS16(xrs, xofs[jj], 0, st * STAGE + YBUF + (jj * XPPI + wid * (XPPI / 4)) * XPB);
+        for (int j = 0; j < YJ + XJ; ++j) fire_piece(st, j);
     };
     if (kb0 < kb1) {
         prepare(kb0);
@@ -223,27 +283,19 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         // `compose` (called right behind each lgkmcnt(0)) ties them to that point with empty asm statements and only then
         // forms the fragments.  (Composed inside read_frag, an unrelated edit of the tile decode changed the allocation
         // and the bias sums of the <64, 128> form came out wrong, differently from run to run.)
-        u2_t fal[2][MT], fah[2][MT], fbl[2][NT], fbh[2][NT];
+        wg3_u2_t fal[2][MT], fah[2][MT], fbl[2][NT], fbh[2][NT];
         // fragment `i` of k-half KK: i < NT: X tile i, else dY tile i - NT (X first: every MFMA row needs all of them)
-        auto read_frag = [&](auto kk_tag, int i) {
-            constexpr int KK = decltype(kk_tag)::value;
-            if (i < NT) {
+        auto read_frag = [&](auto kk_tag, auto i_tag) {
+            constexpr int KK = decltype(kk_tag)::value, i = decltype(i_tag)::value;
+            if constexpr (i < NT) {
                 unsigned o0 = xbase[KK][0], o1 = xbase[KK][1];
                 if (i) { WG3_XOR(o0, xbase[KK][0], i << 5); WG3_XOR(o1, xbase[KK][1], i << 5); }
-                u2_t lo, hi;
-                WG3_RD(lo, o0, SB);
-                WG3_RD(hi, o1, SB);
-                fbl[KK][i] = lo;
-                fbh[KK][i] = hi;
+                wg3_rd_pair<KK * 12 + i, SB>(fbl[KK][i], fbh[KK][i], o0, o1);
             } else {
-                const int mt = i - NT;
+                constexpr int mt = i - NT;
                 unsigned a0 = ybase[0], a1 = ybase[1];
                 if (mt) { WG3_XOR(a0, ybase[0], mt << 5); WG3_XOR(a1, ybase[1], mt << 5); }
-                u2_t lo, hi;
-                WG3_RD(lo, a0, SB + KK * (32 * YROW));
-                WG3_RD(hi, a1, SB + KK * (32 * YROW));
-                fal[KK][mt] = lo;
-                fah[KK][mt] = hi;
+                wg3_rd_pair<KK * 12 + i, SB + KK * (32 * YROW)>(fal[KK][mt], fah[KK][mt], a0, a1);
             }
         };
         typedef std::integral_constant<int, 0> K0;
@@ -251,22 +303,11 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         auto compose = [&](auto kk_c) {
             constexpr int KK = decltype(kk_c)::value;
             if (WG3_ABL & 8) return;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                u2_t lo = fbl[KK][nt], hi = fbh[KK][nt];
-                asm volatile("" : "+v"(lo), "+v"(hi));
-                fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                u2_t lo = fal[KK][mt], hi = fah[KK][mt];
-                asm volatile("" : "+v"(lo), "+v"(hi));
-                fa[KK][mt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-            }
+            wg3_sfor<NT>([&](auto t) { constexpr int nt = decltype(t)::value; fb[KK][nt] = wg3_compose<KK * 12 + nt>(fbl[KK][nt], fbh[KK][nt]); });
+            wg3_sfor<MT>([&](auto t) { constexpr int mt = decltype(t)::value; fa[KK][mt] = wg3_compose<KK * 12 + NT + mt>(fal[KK][mt], fah[KK][mt]); });
         };
         if (!(WG3_ABL & 8)) {
-#pragma unroll
-            for (int i = 0; i < NT + MT; ++i) read_frag(K0{}, i);
+            wg3_sfor<NT + MT>([&](auto t) { read_frag(K0{}, t); });
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -276,9 +317,14 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
                 for (int nt = 0; nt < NT; ++nt) fb[kk][nt] = __builtin_bit_cast(bf8_t, make_uint4(xbase[kk][0], SB, nt, kk));
             }
         }
-        if (kb + 1 < kb1) {
+        // Round 6: the next step's fill is no longer issued here, in front of the wait, as one block of YJ + XJ LDS-DMA
+        // instructions (each ~60-180 cycles of issue, CDNA4 guide; this wave is ALONE on its SIMD when the launch runs one
+        // workgroup per CU, so nothing multiplied meanwhile): the pieces go between the MFMAs of k-half 0, behind the reads
+        // of k-half 1 (WG3_SPREAD, default 1).  The other stage was last read in the previous step, before its barrier.
+        const bool nxt = kb + 1 < kb1;
+        if (nxt) {
             prepare(kb + 1);
-            fire(ST ^ 1);
+            if (!WG3_SPREAD) fire(ST ^ 1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -307,14 +353,22 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt][0][0] += (float)fa[kk][mt][0] + (float)fb[kk][mt % NT][0];
             } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(fa[kk][mt]), "v"(fb[kk][nt]));
-                        // the other k-half's fragments, one between two MFMAs (its X tiles first)
-                        if (kk == 0 && !(WG3_ABL & 8) && (mt * NT + nt) < NT + MT) read_frag(K1{}, mt * NT + nt);
+                wg3_sfor<MT * NT>([&](auto t) {
+                    constexpr int idx = decltype(t)::value, mt = idx / NT, nt = idx % NT;
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(fa[kk][mt]), "v"(fb[kk][nt]));
+                    // the other k-half's fragments, one between two MFMAs (its X tiles first)
+                    if constexpr (idx < NT + MT) { if (kk == 0 && !(WG3_ABL & 8)) read_frag(K1{}, t); }
+                    // (WG3_SPREAD: ... then the pieces of the next step's fill, one every FSTEP MFMAs)
+                    if (WG3_SPREAD && kk == 0) {
+                        constexpr int NP = YJ + XJ, FIRST = NT + MT, FSTEP = (MT * NT - FIRST) / NP > 0 ? (MT * NT - FIRST) / NP : 1;
+                        constexpr int pidx = idx - FIRST;
+                        if (pidx >= 0 && pidx % FSTEP == 0 && pidx / FSTEP < NP) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (nxt) fire_piece(ST ^ 1, pidx / FSTEP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
+                });
             }
             if (kk == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
