@@ -1953,8 +1953,22 @@ bool wgrad_mfma_can_overwrite(const GG& g) {
     return !wgrad_mfma_uses_patch(g) && wgrad_mfma_splits(g, &rows) == 1;
 }
 
+// 128-channel tiles unless the layer would then run as at most one un-split workgroup per CU (the bottleneck layers:
+// <= 512 tiles, <= 2048 pixels): every K step of a lone workgroup is an exposed fill -> barrier -> multiply round trip, and
+// 64-channel tiles put two or more workgroups on a CU (tunable wgrad_narrow; convbench, us: encoders[5] 51.9 -> 37.5, [6] 24.7 ->
+// 18.4, [7] 19.2 -> 13.8, decoders[0] 19.5 -> 14.5, [1] 35.1 -> 31.3, [2] 63.5 -> 62.5; bit-identical on integer data)
+static bool wgrad_mfma_big(const GG& g) {
+    if ((g.Cout % 128) != 0) return false;
+    const int narrow = pai_tunable("wgrad_narrow", 512);      // 64-channel tiles up to this many 128-channel tiles (0: never)
+    if (narrow && !wgrad_mfma_uses_patch(g)) {
+        const int tiles128 = (g.Cout / 128) * cdiv(g.ntaps * g.Cin, 128) * g.nphase;
+        if (tiles128 <= narrow && g.M <= 2048) return false;
+    }
+    return true;
+}
+
 static int wgrad_mfma_splits(const GG& g, int* rows_out) {
-    const bool big = (g.Cout % 128) == 0;
+    const bool big = wgrad_mfma_big(g);
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
     const int jtiles = cdiv(g.ntaps * g.Cin, 128);
     const int tiles = cotiles * jtiles * g.nphase;
@@ -1998,7 +2012,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
         return 1;
     }
     if (wgrad3_ok(g)) return launch_wgrad3(g, a, s);
-    const bool big = (g.Cout % 128) == 0;
+    const bool big = wgrad_mfma_big(g);
     const int cotiles = big ? g.Cout / 128 : cdiv(g.Cout, 64);
     const int jtiles = cdiv(g.ntaps * g.Cin, 128);
     const int tiles = cotiles * jtiles * g.nphase;
@@ -2038,7 +2052,7 @@ int launch_wgrad_mfma(const GG& g, const WgradArgs& a, hipStream_t s) {
 
 const char* wgrad_mfma_kernel_name(const GG& g) {
     if (wgrad3_ok(g)) return wgrad3_kernel_name(g);
-    const bool big = (g.Cout % 128) == 0;
+    const bool big = wgrad_mfma_big(g);
     const bool no_patch = getenv("PAI_NO_WPATCH") && atoi(getenv("PAI_NO_WPATCH")) != 0;
     PatchGeo pg;
     if (!no_patch && wgrad_patch_shape_ok(g) && patch_geo(g, 4, &pg))
