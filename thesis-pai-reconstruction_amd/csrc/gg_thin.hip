@@ -960,8 +960,11 @@ struct ThinW {
 __device__ __forceinline__ int tw_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ unsigned tw_off(int row, int ch) { return (unsigned)(256 * row + 16 * (ch ^ tw_swz(row))); }
 
+#ifndef THIN_WG_WAVES
+#define THIN_WG_WAVES 1
+#endif
 template <int T>
-__global__ __launch_bounds__(256) void thin_wgrad_k(ThinW p, int chunks_per_block) {
+__global__ __launch_bounds__(256, THIN_WG_WAVES) void thin_wgrad_k(ThinW p, int chunks_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 64 x 256 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
