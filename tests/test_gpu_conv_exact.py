@@ -28,8 +28,8 @@ CASES = [
     ("dec_patch256", 1, 8, 64, 128, 0, 128, 1, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
     ("dec_patch256x64", 1, 8, 64, 128, 128, 64, 1, ("gg_fwd_patch_k<128, 64, false>", "gg_fwd_patch_k<128, 128, true>", "gg_wgrad_patch3_k<64, 128, 16>")),
     ("enc_dgrad256", 0, 8, 128, 128, 0, 128, 0, ("gg_fwd_patch_k<128, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
-    ("enc_splitk", 0, 4, 8, 256, 0, 256, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
-    ("dec_splitk", 1, 4, 4, 256, 256, 256, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<128>")),
+    ("enc_splitk", 0, 4, 8, 256, 0, 256, 0, (SPLIT, SPLIT, "gg_wgrad_mfma_k<64>")),      # 64-channel tiles: <= 512 un-split 128-channel tiles (wgrad_narrow, round 6)
+    ("dec_splitk", 1, 4, 4, 256, 256, 256, 1, (SPLIT, SPLIT, "gg_wgrad_mfma_k<64>")),
     # BASELINE configs[1] layer shapes at the benchmark batch (64; the discriminator sees 2 x 64 in its own phase)
     ("cfg2_enc2", 0, 64, 64, 128, 0, 256, 0, ("gg_fwd_patch_k<256, 128, true>", "gg_fwd_patch_k<256, 128, true>", "gg_wgrad_patch3_k<128, 64, 16>")),
     ("cfg2_enc4", 0, 64, 16, 512, 0, 512, 0, (SPLIT, SPLIT, "gg_wgrad_patch3_k<128, 64, 8>")),

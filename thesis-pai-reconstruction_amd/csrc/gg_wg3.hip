@@ -114,7 +114,11 @@ template <int N, typename FN>
 __device__ __forceinline__ void wg3_sfor(FN&& fn) { wg3_sfor_impl<N>(fn, std::make_integer_sequence<int, N>{}); }
 
 // BW: width of the K step's pixel block: 16 (4 x 16 pixels, images >= 16 wide) or 8 (8 x 8 pixels: 8 x 8 images)
-template <int BMC, int CI, int BW = 16>
+// NST: LDS stages.  2: the tiles of step k + 1 are in flight while step k is multiplied.  3 (round 6): those of steps k + 1
+// AND k + 2 -- with one workgroup per CU (the grid that is right beside the input-gradient stream) a single fill in flight
+// is 28 KB per ~1.2 us of LDS-DMA round trip = ~20-25 GB/s per CU, which is what the launch ran at (184 us per 128 steps,
+// 149 with the fills compiled out; the matrix time of a step is 0.45 us): the kernel was bound by ONE outstanding fill.
+template <int BMC, int CI, int BW = 16, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
                                                             int splits, int blocks_per_split, int ph_inner) {
     static_assert((BMC == 128 && CI == 64) || (BMC == 64 && CI == 128), "wave tile 128 x 64 or 64 x 128");
@@ -211,6 +215,15 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
             xbase[kk][h] = (unsigned)YBUF + p * XPB + (xseg_swz3<CI, BW>(p) << 5) + tp * 8;
         }
     }
+    // stage-2 bases (three stages only): STAGE is a multiple of 4096 and every base is below it, so the XORs of the tile index
+    // (address bits 5-7) commute with the addition
+    unsigned ybase2[2], xbase2[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        ybase2[h] = ybase[h] + (unsigned)STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xbase2[kk][h] = xbase[kk][h] + (unsigned)STAGE;
+    }
 #define WG3_XOR(dst, src, imm) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(dst) : "v"(src), "s"(imm))
 #define WG3_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(size_t)(unsigned)(addr))
 #define WG3_BLDS16(rs, voff, soff, laddr) \
@@ -259,7 +272,13 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     if (kb0 < kb1) {
         prepare(kb0);
         fire(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NST > 2 && kb0 + 1 < kb1) {
+            prepare(kb0 + 1);
+            fire(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YJ + XJ) : "memory");      // the first fill has landed, the second is in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
     }
     // The K loop is scheduled by hand.  hipcc puts an s_waitcnt vmcnt(0) in front of the first LDS read it can see behind
@@ -285,17 +304,22 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         // and the bias sums of the <64, 128> form came out wrong, differently from run to run.)
         wg3_u2_t fal[2][MT], fah[2][MT], fbl[2][NT], fbh[2][NT];
         // fragment `i` of k-half KK: i < NT: X tile i, else dY tile i - NT (X first: every MFMA row needs all of them)
+        // (the DS offset field is 16 bits: the third stage starts at 56-64 KB, so its reads go through a second set of base
+        //  registers that already carry one stage)
+        constexpr unsigned SBI = ST == 2 ? SB - (unsigned)STAGE : SB;
         auto read_frag = [&](auto kk_tag, auto i_tag) {
             constexpr int KK = decltype(kk_tag)::value, i = decltype(i_tag)::value;
             if constexpr (i < NT) {
-                unsigned o0 = xbase[KK][0], o1 = xbase[KK][1];
-                if (i) { WG3_XOR(o0, xbase[KK][0], i << 5); WG3_XOR(o1, xbase[KK][1], i << 5); }
-                wg3_rd_pair<KK * 12 + i, SB>(fbl[KK][i], fbh[KK][i], o0, o1);
+                const unsigned b0 = ST == 2 ? xbase2[KK][0] : xbase[KK][0], b1 = ST == 2 ? xbase2[KK][1] : xbase[KK][1];
+                unsigned o0 = b0, o1 = b1;
+                if (i) { WG3_XOR(o0, b0, i << 5); WG3_XOR(o1, b1, i << 5); }
+                wg3_rd_pair<KK * 12 + i, SBI>(fbl[KK][i], fbh[KK][i], o0, o1);
             } else {
                 constexpr int mt = i - NT;
-                unsigned a0 = ybase[0], a1 = ybase[1];
-                if (mt) { WG3_XOR(a0, ybase[0], mt << 5); WG3_XOR(a1, ybase[1], mt << 5); }
-                wg3_rd_pair<KK * 12 + i, SB + KK * (32 * YROW)>(fal[KK][mt], fah[KK][mt], a0, a1);
+                const unsigned b0 = ST == 2 ? ybase2[0] : ybase[0], b1 = ST == 2 ? ybase2[1] : ybase[1];
+                unsigned a0 = b0, a1 = b1;
+                if (mt) { WG3_XOR(a0, b0, mt << 5); WG3_XOR(a1, b1, mt << 5); }
+                wg3_rd_pair<KK * 12 + i, SBI + KK * (32 * YROW)>(fal[KK][mt], fah[KK][mt], a0, a1);
             }
         };
         typedef std::integral_constant<int, 0> K0;
@@ -321,10 +345,11 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         // instructions (each ~60-180 cycles of issue, CDNA4 guide; this wave is ALONE on its SIMD when the launch runs one
         // workgroup per CU, so nothing multiplied meanwhile): the pieces go between the MFMAs of k-half 0, behind the reads
         // of k-half 1 (WG3_SPREAD, default 1).  The other stage was last read in the previous step, before its barrier.
-        const bool nxt = kb + 1 < kb1;
+        constexpr int FST = (ST + NST - 1) % NST;        // the stage this step refills: the one the PREVIOUS step read (behind its barrier)
+        const bool nxt = kb + (NST - 1) < kb1;
         if (nxt) {
-            prepare(kb + 1);
-            if (!WG3_SPREAD) fire(ST ^ 1);
+            prepare(kb + NST - 1);
+            if (!WG3_SPREAD) fire(FST);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
                         constexpr int pidx = idx - FIRST;
                         if (pidx >= 0 && pidx % FSTEP == 0 && pidx / FSTEP < NP) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (nxt) fire_piece(ST ^ 1, pidx / FSTEP);
+                            if (nxt) fire_piece(FST, pidx / FSTEP);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -376,17 +401,31 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
                 compose(K1{});
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the NEXT step's tiles have landed (they have had one step, or two with three stages, to do so); with three stages
+        // the fill issued in this step stays in flight across the barrier (LDS-DMA only in this loop: one kind per count)
+        if (NST > 2 && nxt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YJ + XJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
     typedef std::integral_constant<int, 0> St0;
     typedef std::integral_constant<int, 1> St1;
+    typedef std::integral_constant<int, 2> St2;
     int kb = kb0;
-    for (; kb + 1 < kb1; kb += 2) {
-        step(St0{}, kb);
-        step(St1{}, kb + 1);
+    if constexpr (NST == 2) {
+        for (; kb + 1 < kb1; kb += 2) {
+            step(St0{}, kb);
+            step(St1{}, kb + 1);
+        }
+        if (kb < kb1) step(St0{}, kb);
+    } else {
+        for (; kb + 2 < kb1; kb += 3) {
+            step(St0{}, kb);
+            step(St1{}, kb + 1);
+            step(St2{}, kb + 2);
+        }
+        if (kb < kb1) step(St0{}, kb);
+        if (kb + 1 < kb1) step(St1{}, kb + 1);
     }
-    if (kb < kb1) step(St0{}, kb);
     // MFMA results are read by vector instructions below: the hazard distance is the compiler's job for ITS MFMAs only
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     if (do_bias) {
@@ -556,27 +595,31 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     }
     static PerDeviceOnce attr;
     if (attr.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipSuccess;
+        const void* fns[6] = {reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16>),
+                              reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16, 3>),
+                              reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16, 3>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8, 3>)};
+        for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
     }
     const dim3 grid(c.tiles * c.psplits);
     const int ph_inner = g.nphase > 1 && pai_tunable("wgrad3_ph_inner", 1);
+    // tunable wgrad3_stages = 3: three LDS stages (two fills in flight), 84-96 KB per workgroup.  MEASURED, NOT THE DEFAULT: every
+    // layer within +-2 % (convbench w, one process: 1818.3 us over all layers either way), step 5.71-5.74 against 5.73-5.74 ms --
+    // a second fill in flight does not buy what compiling the fills out does (184 -> 149 us on decoders[4])
+    const int nst = pai_tunable("wgrad3_stages", 2) >= 3 ? 3 : 2;
     if (variant == 1) {
-        const size_t lds = 2 * (64 * 256 + 96 * 128);
-        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        const size_t lds = (size_t)nst * (64 * 256 + 96 * 128);
+        if (nst == 3) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16, 3>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        else PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     } else if (variant == 2) {
-        const size_t lds = 2 * (64 * 128 + 96 * 256);
-        PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        const size_t lds = (size_t)nst * (64 * 128 + 96 * 256);
+        if (nst == 3) PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16, 3>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        else PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     } else {
-        const size_t lds = 2 * (64 * 256 + 128 * 128);
-        PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        const size_t lds = (size_t)nst * (64 * 256 + 128 * 128);
+        if (nst == 3) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8, 3>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        else PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     }
     PAI_LAUNCH_CHECK();
     if (slab) return launch_wgrad_slab_sum(a.dw, slab, c.psplits, dwn, a.overwrite, s);
