@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
     const bf16_t* w = (const bf16_t*)a.w;
     bf16_t* yraw = (bf16_t*)a.y1;
     bf16_t* yact = (bf16_t*)a.yact;
-    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const float eslope = act_slope(a.yact ? a.eact : PAI_ACT_NONE);      // branch-free activation (common.h)
 
     // this lane's share of a K step: tap 2 ks + (fq >> 1) (tap 9 is padding), 8 channels at (fq & 1) * 8 of the slice
     int pofs[5];
@@ -195,10 +195,7 @@ __global__ __launch_bounds__(256, 2) void grouped3_k(GG g, FwdArgs a, int tiles,
             if (yraw) *(uint2*)(yraw + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
             if (yact) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (eact == PAI_ACT_LRELU) v4[r] = fmaxf(v4[r], 0.2f * v4[r]);
-                    else if (eact == PAI_ACT_RELU) v4[r] = fmaxf(v4[r], 0.f);
-                }
+                for (int r = 0; r < 4; ++r) v4[r] = act_fwd(v4[r], eslope);
                 *(uint2*)(yact + o) = make_uint2(pk2bf(v4[0], v4[1]), pk2bf(v4[2], v4[3]));
             }
         }

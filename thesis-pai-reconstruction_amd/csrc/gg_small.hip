@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void small_fwd_k(GG g, FwdArgs a, int groups_p
             bias[nt][r] = a.bias ? a.bias[co0 + 16 * nt + 4 * fq + r] : 0.f;
             csum[nt][r] = csq[nt][r] = 0.f;
         }
-    const int eact = a.yact ? a.eact : PAI_ACT_NONE;
+    const float eslope = act_slope(a.yact ? a.eact : PAI_ACT_NONE);      // branch-free activation (common.h)
     bf16_t* yraw = (bf16_t*)a.y1;
     bf16_t* yact = (bf16_t*)a.yact;
 
@@ -147,10 +147,7 @@ __global__ __launch_bounds__(256) void small_fwd_k(GG g, FwdArgs a, int groups_p
             if (yraw) *(uint2*)(yraw + o) = make_uint2(pk2bf(v[0], v[1]), pk2bf(v[2], v[3]));
             if (yact) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (eact == PAI_ACT_LRELU) v[r] = fmaxf(v[r], 0.2f * v[r]);
-                    else if (eact == PAI_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-                }
+                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], eslope);
                 *(uint2*)(yact + o) = make_uint2(pk2bf(v[0], v[1]), pk2bf(v[2], v[3]));
             }
         }

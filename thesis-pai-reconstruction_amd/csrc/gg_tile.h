@@ -68,16 +68,7 @@ __device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdPara
     P.sc[0] = s0.x; P.sc[1] = s0.y; P.sc[2] = s0.z; P.sc[3] = s0.w; P.sc[4] = s1.x; P.sc[5] = s1.y; P.sc[6] = s1.z; P.sc[7] = s1.w;
     P.sh[0] = h0.x; P.sh[1] = h0.y; P.sh[2] = h0.z; P.sh[3] = h0.w; P.sh[4] = h1.x; P.sh[5] = h1.y; P.sh[6] = h1.z; P.sh[7] = h1.w;
 }
-// Activations in a store without run-time branches.  act(v) = v > 0 ? v : v * slope with slope = 1 (none), 0.2
-// (LeakyReLU), 0 (ReLU): the selector used to be a run-time switch per ELEMENT, which hipcc compiled into four scalar
-// branches per element -- the epilogue of a 256 x 128 tile with the fused producer backward was 4200 instructions per
-// thread, more issue time than the 512 MFMAs of a K = 1024 layer (profiles/r06_isa_census.txt).  The product is formed as
-// fma(v, slope, +0): the same rounding as the multiplication, and -0 (ReLU of a negative value) becomes +0.
-__device__ __forceinline__ float act_slope(int act) { return act == PAI_ACT_RELU ? 0.f : (act == PAI_ACT_LRELU ? 0.2f : 1.f); }
-__device__ __forceinline__ float act_fwd(float v, float slope) {
-    const float sv = fmaf(v, slope, 0.f);
-    return v > 0.f ? v : sv;
-}
+// (act_slope / act_fwd: branch-free activations, common.h)
 __device__ __forceinline__ float bwd_sel(float g, bool pos, float slope) {   // act'(pre) * g
     const float sg = fmaf(g, slope, 0.f);
     return pos ? g : sg;

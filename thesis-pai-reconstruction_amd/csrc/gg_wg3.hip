@@ -441,26 +441,30 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     // ---- the wave's BMC x CI tile: into this split's slab (plain stores), or into dW ----------------------------
     const int wt = (int)((pg.wt4[ph][q] >> (8 * wid)) & 0xffu);
     float* out = a.slab ? a.slab + (size_t)split * ((size_t)g.Cout * g.wtaps * g.Cin) : a.dw;
+    // one wave-uniform switch around the 128 stores (round 6: it sat inside the element loop -- four scalar branches per
+    // store, 868 in the kernel); addresses = one 64-bit base per lane + a uniform row step
+    float* pw0 = out + (size_t)(co0 + fg * 4) * g.wtaps * g.Cin + (size_t)wt * g.Cin + ci0 + fi;
+    const size_t rstep = (size_t)g.wtaps * g.Cin;
+    auto store_tile = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;      // 0 plain store (slab / overwrite), 1 read-modify-write, 2 atomic
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const size_t cbase = (size_t)wt * g.Cin + ci0 + nt * 16 + fi;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + mt * 16 + fg * 4 + r;
-                float* pw = out + (size_t)co * g.wtaps * g.Cin + cbase;
-                if (WG3_ABL & 1) { if (acc[mt][nt][r] == 123.456f) *pw = 0.f; }
-                else if (a.slab) *pw = acc[mt][nt][r];
-                else if (splits == 1) {
-                    if (a.overwrite) *pw = acc[mt][nt][r];
-                    else *pw += acc[mt][nt][r];
-                } else {
-                    atomicAdd(pw, acc[mt][nt][r]);
+                float* prow = pw0 + (size_t)(mt * 16 + r) * rstep;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float* pw = prow + nt * 16;
+                    if (WG3_ABL & 1) { if (acc[mt][nt][r] == 123.456f) *pw = 0.f; }
+                    else if (MODE == 0) *pw = acc[mt][nt][r];
+                    else if (MODE == 1) *pw += acc[mt][nt][r];
+                    else atomicAdd(pw, acc[mt][nt][r]);
                 }
             }
-        }
-    }
+    };
+    if (a.slab || (splits == 1 && a.overwrite)) store_tile(std::integral_constant<int, 0>{});
+    else if (splits == 1) store_tile(std::integral_constant<int, 1>{});
+    else store_tile(std::integral_constant<int, 2>{});
 }
 
 // dW (+)= sum over the splits' slabs (deterministic: fixed association).  Block = 64 float4 elements x 4 split lanes:
