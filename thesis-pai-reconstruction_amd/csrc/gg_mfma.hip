@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void gg_fwd_patch_body(const GG& g, const FwdArgs& a,
 }
 
 template <int BM, int BN, bool DBB>
-__global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? 3 : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
+__global__ __launch_bounds__(BM * 2, (BM == 128 && DBB) ? (BN == 64 ? 4 : 3) : (BN == 64 ? 5 : 4)) void gg_fwd_patch_k(GG g, FwdArgs a, PatchGeo pg, int mtiles, int ntiles) {
     // (BM, BN, DBB) = (256, 128, *) and (128, 128, false) are the configurations at the register line, see COLSWZ
     gg_fwd_patch_body<BM, BN, DBB, 2, 64, PATCH_COLSWZ_ALL || !(BN == 128 && (BM == 256 || !DBB))>(g, a, pg, mtiles, ntiles);
 }
