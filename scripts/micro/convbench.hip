@@ -207,6 +207,10 @@ int main(int argc, char** argv) {
                 pai_bwd_epilogue e;
                 e.z = bz; e.add = L.tr ? nullptr : badd; e.scale = bnp; e.shift = bnp + L.C1; e.mean = bnp + 2 * L.C1; e.rstd = bnp + 3 * L.C1;
                 e.partials = bnpart; e.act1 = L.tr ? PAI_ACT_RELU : PAI_ACT_LRELU; e.act2 = L.tr ? PAI_ACT_NONE : PAI_ACT_RELU;
+                // the thin head (decoders[7], one output channel): the engine's call -- decoders[6] is read WITHOUT an activation, so
+                // du IS the gradient stored: no scale / shift, act1 = none (thin_fwd2_k<..., BWD>; round 6: the ReLU form above took
+                // the two-launch path and never reached that kernel)
+                if (L.tr && L.Cout <= 2) { e.scale = nullptr; e.shift = nullptr; e.act1 = PAI_ACT_NONE; }
                 int rows = 0;
                 PCHECK(pai_conv_dgrad_bn(&d, dy, wd, dx1[k], dx2[k], &e, &rows, st));
             } else if (op == 'd') PCHECK(pai_conv_dgrad(&d, dy, wd, dx1[k], dx2[k], 0, st));

@@ -605,7 +605,7 @@ static int patch_rows(const GG& g, const FwdCfg& c) {
 #define PATCH_COLSWZ_ALL 0   // 1: the immediate-offset operand addressing also for the kernels at the 128-register line
 #endif
 #ifndef PATCH_SETPRIO
-#define PATCH_SETPRIO 0   // 1: raise the wave's issue priority over its MFMA cluster (guide T5)
+#define PATCH_SETPRIO 1   // raise the wave's issue priority over its MFMA cluster (guide T5).  Round 6, same box, interleaved: alone on the chip +1 % time (fused-backward input gradients 1893 -> 1911 us), in the step 5.726 / 5.719 / 5.702 -> 5.701 / 5.702 / 5.675 ms (beside the weight-gradient waves of the side stream)
 #endif
 // (A v_mfma_f32_32x32x16_bf16 form of this body -- 2 x 2 accumulator tiles of 32 x 32, other LDS swizzle and epilogue
 // mapping -- was built and measured in round 2: bit-exact and within +-3 % of this one on every layer, because neither
