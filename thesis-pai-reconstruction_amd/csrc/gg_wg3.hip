@@ -52,6 +52,9 @@ template <int BMC> __device__ __forceinline__ int yswz3(int row) {
     return BMC == 128 ? tr_swz3(row) : ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
 }
 
+#ifndef WG3_PRIO
+#define WG3_PRIO 0      // static s_setprio of the weight-gradient waves (1-3 measured in the step: 5.70-5.73 against 5.66-5.70 ms -- not used)
+#endif
 #ifndef WG3_SPREAD
 #define WG3_SPREAD 0   // 1: the next step's LDS-DMA pieces between the MFMAs of k-half 0 instead of in one block in front of them (measured: 1964-1970 against 1917-1947 us over the wgrad layers, step 5.82 against 5.79 ms -- dropped)
 #endif
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     constexpr int XPPI = 256 / XCH;              // patch pixels per block-wide fill instruction
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    if (WG3_PRIO) __builtin_amdgcn_s_setprio(WG3_PRIO);         // static issue priority of the weight-gradient waves (see WG3_PRIO)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = tap of the window
     int bid = xcd_remap(blockIdx.x, gridDim.x);
