@@ -139,6 +139,9 @@ int fwd_mfma_mtiles(const GG& g) {
 // k+1 is issued before tile k is consumed and retired with a COUNTED s_waitcnt vmcnt + raw s_barrier
 // (a __syncthreads() would drain it: guide "Pipelining across barriers").
 
+#ifndef FWDK_SETPRIO
+#define FWDK_SETPRIO 0   // 1: s_setprio 1 around the MFMA clusters of gg_fwd_mfma_k (as PATCH_SETPRIO); measured in the step: 5.697-5.701 against 5.664-5.680 ms -- not used
+#endif
 template <int BM, int BN, bool SPLITK, bool DB, int WR = 64>   // WR: output rows per wave (64 or 32)
 __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, int mtiles, int ntiles, int ksplit,
                                                                float* ws) {
@@ -288,11 +291,13 @@ __global__ __launch_bounds__(BM / WR * 128) void gg_fwd_mfma_k(GG g, FwdArgs a, 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) af[mt] = relu_frag(af[mt]);
             }
+            if (FWDK_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+            if (FWDK_SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
     };
 
