@@ -173,7 +173,8 @@ class GradReducer:
                               f"torch.distributed.all_reduce, backend {backend}"),
                 "rccl_ranks": self.rccl_ranks(), "world": int(self.world),
                 "rccl_knobs": {k: os.environ.get(v) for k, v in RCCL_KNOBS.items()},
-                "algorithm": os.environ.get("NCCL_ALGO") or "RCCL default (topology search; multi-channel rings over all xGMI links)",
+                "algorithm": (os.environ.get("NCCL_ALGO") or "RCCL default (topology search; multi-channel rings over all xGMI links)")
+                             if self.rccl_ranks() else f"not RCCL ({backend}: host all-reduce; a plumbing run, not a scaling figure)",
                 "bucket_bytes": int(self.bucket_elems) * 4, "wire_dtype": str(self.grad_dtype).replace("torch.", ""),
                 "overlap_with_backward": bool(self.overlap),
                 "buckets_sent": int(self.stats.get("buckets", 0)), "bytes_sent": int(self.stats.get("bytes", 0))}
