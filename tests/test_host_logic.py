@@ -248,3 +248,20 @@ def test_ema_callback_matches_torch_ema_semantics(pai):
     for p, l in zip(net.parameters(), live):
         assert torch.equal(p, l)
     assert cb.state_dict()["num_updates"] == 5
+
+
+def test_rccl_knobs_and_self_description_of_the_gradient_exchange(pai, monkeypatch):
+    """the collective's knobs are settable before the communicator exists and the bench line can say
+    what exchange it ran (transport, ranks, knobs in force, bucket bytes, wire type)."""
+    from thesis_pai_reconstruction_amd import dist as pdist
+    for v in pdist.RCCL_KNOBS.values():
+        monkeypatch.delenv(v, raising=False)
+    assert pdist.configure_rccl() == {"algo": None, "proto": None, "min_channels": None, "max_channels": None}
+    got = pdist.configure_rccl(algo="Tree", min_channels=2, max_channels=2)
+    assert got["algo"] == "Tree" and os.environ["NCCL_ALGO"] == "Tree" and os.environ["NCCL_MIN_NCHANNELS"] == "2"
+    monkeypatch.setenv("PAI_DDP_BUCKET_MB", "8")
+    r = pdist.GradReducer()                      # no process group: one rank
+    d = r.describe()
+    assert d["world"] == 1 and d["rccl_ranks"] == 0 and d["bucket_bytes"] == 8 << 20 and d["wire_dtype"] == "float32"
+    assert d["rccl_knobs"]["algo"] == "Tree" and "not RCCL" in d["algorithm"]
+    assert pdist.GradReducer(bucket_bytes=4 << 20).describe()["bucket_bytes"] == 4 << 20
