@@ -319,6 +319,77 @@ def test_fused_producer_backward_bit_exact(pai, cfg):
         assert float((P[1] - s2).abs().max()) <= 1e-5 * float((du_bf.abs() * 8).double().sum((0, 2, 3)).max())
 
 
+@pytest.mark.parametrize("name", ["enc_patch256", "dec_patch256", "enc_splitk"])
+def test_relu_epilogue_of_minus_infinity_is_zero(pai, name):
+    """The forward epilogue's activation (y_act = act(conv + bias)) on a -inf pre-activation: aten's relu gives 0 and
+    LeakyReLU -inf; the branch-free form v > 0 ? v : v x slope would make the ReLU a NaN.  One +inf input pixel under
+    negative weights puts -inf into every output it reaches."""
+    from thesis_pai_reconstruction_amd import ops
+    case = next(c for c in CASES if c[0] == name)
+    _, tr, N, H, C1, C2, Cout, relu, _ = case
+    Cin, dt = C1 + C2, torch.bfloat16
+    OH = H * 2 if tr else H // 2
+    w = _ints((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4), 3, -2, -1)
+    x = _ints((N, Cin, H, H), 1, 0, 1)
+    x[0, 0, H // 2, H // 2] = float("inf")
+    bias = _ints((Cout,), 7, -3, 3)
+    pre = F.conv_transpose2d(x, w, bias, stride=2, padding=1) if tr else F.conv2d(x, w, bias, stride=2, padding=1)
+    assert (pre == float("-inf")).any() and not torch.isnan(pre).any()
+    wm = fwd_pack(w, bool(tr))
+    wf = torch.empty(wm.numel(), dtype=dt, device=dev())
+    ops.pack_weights(dt, wm, Cout, 16, Cin, wf, None)
+    X1 = nhwc(x[:, :C1], dt)
+    X2 = nhwc(x[:, C1:], dt) if C2 else None
+    for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_LRELU, lambda v: F.leaky_relu(v, 0.2))):
+        d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, 0, 0, act)
+        ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+        ya = torch.empty(N * OH * OH * Cout, dtype=dt, device=dev())
+        ops.conv_fwd(d, X1, X2, wf, bias.to(dev()), y_act=ya)
+        torch.cuda.synchronize()
+        got = from_nhwc(ya, N, OH, OH, Cout)
+        assert not torch.isnan(got).any(), (name, act, int(torch.isnan(got).sum()))
+        assert torch.equal(got, fn(pre).bfloat16().float()), (name, act)
+
+
+@pytest.mark.parametrize("name", ["dec_patch256", "dec_splitk"])
+def test_infinite_gradient_behind_a_relu_producer_is_zero(pai, name):
+    """threshold_backward (the ReLU backward aten runs for reference models/pix2pix.py:99-106) SELECTS: an infinite gradient
+    at a position whose pre-activation is <= 0 gives 0, not inf x 0 = NaN.  The fused store computes the negative side as
+    g x slope for LeakyReLU; for ReLU it must select a literal zero.  One +inf in dy, positive weights (no inf - inf)."""
+    from thesis_pai_reconstruction_amd import ops
+    case = next(c for c in CASES if c[0] == name)
+    _, tr, N, H, C1, C2, Cout, relu, _ = case
+    Cin, dt = C1 + C2, torch.bfloat16
+    OH = H * 2 if tr else H // 2
+    w = _ints((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4), 3, 1, 2)
+    dy = torch.zeros(N, Cout, OH, OH)
+    dy[0, 1, OH // 2, OH // 2 + 1] = float("inf")
+    dy[N - 1, 0, 0, 0] = 3.0
+    x = torch.zeros(N, Cin, H, H, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, stride=2, padding=1) if tr else F.conv2d(x, w, None, stride=2, padding=1)
+    y.backward(dy)
+    g = x.grad[:, :C1]
+    assert torch.isinf(g).any() and not torch.isnan(g).any()
+    z = _ints((N, C1, H, H), 11, -3, 3)
+    want = torch.where(z > 0, g, torch.zeros_like(g)).bfloat16().float()
+    assert torch.isinf(want).any() and (torch.isinf(g) & (z <= 0)).any()
+
+    d = ops.make_desc(dt, tr, N, H, H, C1, C2, Cout, 2, 0, 0, ops.ACT_NONE)
+    ops.ensure_workspace(max(ops.conv_workspace_bytes(d, 0), ops.conv_workspace_bytes(d, 1)), dev())
+    wd = torch.empty(w.numel(), dtype=dt, device=dev())
+    ops.pack_weights(dt, fwd_pack(w, bool(tr)), Cout, 16, Cin, None, wd)
+    dx1 = torch.empty(N * H * H * C1, dtype=dt, device=dev())
+    dx2 = torch.empty(N * H * H * C2, dtype=dt, device=dev()) if C2 else None
+    part = torch.empty(ops.conv_dgrad_bn_rows_max(d) * 2 * C1, device=dev())
+    mean, rstd = torch.zeros(C1, device=dev()), torch.ones(C1, device=dev())
+    rows = ops.conv_dgrad_bn(d, nhwc(dy, dt), wd, dx1, dx2, nhwc(z, dt), ops.ACT_RELU, None, ops.ACT_NONE, None, None, mean, rstd, part)
+    torch.cuda.synchronize()
+    assert rows > 0
+    got = from_nhwc(dx1, N, H, H, C1)
+    assert not torch.isnan(got).any(), int(torch.isnan(got).sum())
+    assert torch.equal(got, want), name
+
+
 @pytest.mark.parametrize("shape", [(64, 128), (3, 16)], ids=["cfg2_dec7", "small"])
 def test_fused_producer_backward_of_the_thin_head_bit_exact(pai, shape):
     """pai_conv_dgrad_bn on the head (ConvTranspose2d(64|64 -> 1), reference models/pix2pix.py:185-193): the input

@@ -42,10 +42,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsi
 // (LeakyReLU), 0 (ReLU): the selector used to be a run-time switch per ELEMENT, which hipcc compiled into four scalar
 // branches per element -- the epilogue of a 256 x 128 tile with the fused producer backward was 4200 instructions per
 // thread, more issue time than the 512 MFMAs of a K = 1024 layer (profiles/r06_isa_census.txt).  The product is formed as
-// fma(v, slope, +0): the same rounding as the multiplication, and -0 (ReLU of a negative value) becomes +0.
+// fma(v, slope, +0): the same rounding as the multiplication, and -0 (ReLU of a negative value) becomes +0.  ReLU of
+// -inf must be 0 (aten), not -inf x 0 = NaN: slope == 0 selects a literal zero (a wave-uniform condition: one v_cndmask).
 __device__ __forceinline__ float act_slope(int act) { return act == PAI_ACT_RELU ? 0.f : (act == PAI_ACT_LRELU ? 0.2f : 1.f); }
 __device__ __forceinline__ float act_fwd(float v, float slope) {
-    const float sv = fmaf(v, slope, 0.f);
+    const float sv = slope == 0.f ? 0.f : fmaf(v, slope, 0.f);
     return v > 0.f ? v : sv;
 }
 __device__ __forceinline__ unsigned pk2bf(float a, float b) {

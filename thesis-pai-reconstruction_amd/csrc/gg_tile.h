@@ -70,7 +70,7 @@ __device__ __forceinline__ void bwd_load_params(const FwdArgs& a, int c, BwdPara
 }
 // (act_slope / act_fwd: branch-free activations, common.h)
 __device__ __forceinline__ float bwd_sel(float g, bool pos, float slope) {   // act'(pre) * g
-    const float sg = fmaf(g, slope, 0.f);
+    const float sg = slope == 0.f ? 0.f : fmaf(g, slope, 0.f);      // ReLU: 0 also for an infinite gradient (not inf x 0)
     return pos ? g : sg;
 }
 // s2 accumulates du * z; the tile's sum of du * xhat is rstd * (s2 - mean * s1), formed once per channel in
