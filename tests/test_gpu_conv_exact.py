@@ -322,8 +322,8 @@ def test_fused_producer_backward_bit_exact(pai, cfg):
 @pytest.mark.parametrize("name", ["enc_patch256", "dec_patch256", "enc_splitk"])
 def test_relu_epilogue_of_minus_infinity_is_zero(pai, name):
     """The forward epilogue's activation (y_act = act(conv + bias)) on a -inf pre-activation: aten's relu gives 0 and
-    LeakyReLU -inf; the branch-free form v > 0 ? v : v x slope would make the ReLU a NaN.  One +inf input pixel under
-    negative weights puts -inf into every output it reaches."""
+    LeakyReLU -inf; the branch-free form v > 0 ? v : v x slope would make the ReLU a NaN (checked on the chip with
+    scripts/micro/inf_probe.hip).  One +inf input pixel under negative weights puts -inf into every output it reaches."""
     from thesis_pai_reconstruction_amd import ops
     case = next(c for c in CASES if c[0] == name)
     _, tr, N, H, C1, C2, Cout, relu, _ = case
@@ -332,9 +332,10 @@ def test_relu_epilogue_of_minus_infinity_is_zero(pai, name):
     w = _ints((Cin, Cout, 4, 4) if tr else (Cout, Cin, 4, 4), 3, -2, -1)
     x = _ints((N, Cin, H, H), 1, 0, 1)
     x[0, 0, H // 2, H // 2] = float("inf")
+    x[1, 0, 1, 2] = float("nan")                       # and a NaN stays a NaN through both activations (aten)
     bias = _ints((Cout,), 7, -3, 3)
     pre = F.conv_transpose2d(x, w, bias, stride=2, padding=1) if tr else F.conv2d(x, w, bias, stride=2, padding=1)
-    assert (pre == float("-inf")).any() and not torch.isnan(pre).any()
+    assert (pre == float("-inf")).any() and not torch.isnan(pre[0]).any() and torch.isnan(pre[1]).any()
     wm = fwd_pack(w, bool(tr))
     wf = torch.empty(wm.numel(), dtype=dt, device=dev())
     ops.pack_weights(dt, wm, Cout, 16, Cin, wf, None)
@@ -346,9 +347,9 @@ def test_relu_epilogue_of_minus_infinity_is_zero(pai, name):
         ya = torch.empty(N * OH * OH * Cout, dtype=dt, device=dev())
         ops.conv_fwd(d, X1, X2, wf, bias.to(dev()), y_act=ya)
         torch.cuda.synchronize()
-        got = from_nhwc(ya, N, OH, OH, Cout)
-        assert not torch.isnan(got).any(), (name, act, int(torch.isnan(got).sum()))
-        assert torch.equal(got, fn(pre).bfloat16().float()), (name, act)
+        got, want = from_nhwc(ya, N, OH, OH, Cout), fn(pre).bfloat16().float()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), (name, act, int(torch.isnan(got).sum()), int(torch.isnan(want).sum()))
+        assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(want, nan=7.0)), (name, act)
 
 
 @pytest.mark.parametrize("name", ["dec_patch256", "dec_splitk"])

@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsi
 __device__ __forceinline__ float act_slope(int act) { return act == PAI_ACT_RELU ? 0.f : (act == PAI_ACT_LRELU ? 0.2f : 1.f); }
 __device__ __forceinline__ float act_fwd(float v, float slope) {
     const float sv = slope == 0.f ? 0.f : fmaf(v, slope, 0.f);
-    return v > 0.f ? v : sv;
+    return !(v <= 0.f) ? v : sv;         // a NaN stays a NaN under ReLU too (aten's clamp_min), at no instruction more
 }
 __device__ __forceinline__ unsigned pk2bf(float a, float b) {
     const pai_f2_t v = {a, b};
