@@ -64,64 +64,93 @@ template <int BMC> __device__ __forceinline__ int yswz3(int row) {
 
 // ---- pinned fragment registers (round 6) ------------------------------------------------------------------------------
 // The two 8-byte halves of an MFMA operand come from two ds_read_b64_tr_b16 (inline asm: the compiler must not see the
-// reads, see the K loop).  With "=v" outputs the allocator rarely placed a fragment's halves side by side and `compose`
-// became a v_mov_b64 per half: 32 per 64 MFMAs of a wave that is ALONE on its SIMD (one workgroup per CU beside the
-// input-gradient stream), where every vector instruction between two MFMAs delays the next one.  The 24 fragments of a
-// step (2 k-halves x 12) therefore live in FIXED registers v[160 + 4 F .. 163 + 4 F]: the reads deliver into the halves
-// in place and the composition is free.  MEASURED AND NOT THE DEFAULT (WG3_PIN = 0: the allocator's choice): the moves
-// disappear from the ISA (32 -> 0 v_mov_b64 per 64 MFMAs outside the bias branch) and the launches get 1.6 % SLOWER
-// (convbench w: 1990-1998 against 1958 us over all layers; step 5.95 against 5.94 ms) -- vector instructions per MFMA
-// are not what bounds this kernel.
+// reads, see the K loop).  With "=v" outputs the allocator does not place a fragment's halves side by side (an inline-asm
+// definition is not coalesced into a sub-register of the operand tuple) and `compose` becomes a v_mov_b64 per half.
+// Pinned fragments live in FIXED registers v[160 + 4 F .. 163 + 4 F] (F = 12 k-half + fragment): the reads deliver into
+// the halves in place and the composition is free.
+//   round-3 loop: measured with ALL 24 fragments pinned and not used (32 -> 0 v_mov_b64 per 64 MFMAs, launches 1.6 % slower:
+//                 vector instructions per MFMA are not what bounds a loop whose matrix pipe idles behind every barrier).
+//   pipelined loop (WG3_PIN, default 1): the dY fragments are pinned; the X fragments go through the ReLU (max(x, rlo) on
+//                 the halves: compiler-generated, so ITS results are placed in the tuple) and need no copy either.
 #ifndef WG3_PIN
-#define WG3_PIN 0
+#define WG3_PIN 1
 #endif
 typedef __attribute__((ext_vector_type(2))) unsigned wg3_u2_t;
 #define WG3_PIN_CASES(X) X(0, 160, 161, 162, 163) X(1, 164, 165, 166, 167) X(2, 168, 169, 170, 171) X(3, 172, 173, 174, 175) X(4, 176, 177, 178, 179) X(5, 180, 181, 182, 183) X(6, 184, 185, 186, 187) X(7, 188, 189, 190, 191) X(8, 192, 193, 194, 195) X(9, 196, 197, 198, 199) X(10, 200, 201, 202, 203) X(11, 204, 205, 206, 207) X(12, 208, 209, 210, 211) X(13, 212, 213, 214, 215) X(14, 216, 217, 218, 219) X(15, 220, 221, 222, 223) X(16, 224, 225, 226, 227) X(17, 228, 229, 230, 231) X(18, 232, 233, 234, 235) X(19, 236, 237, 238, 239) X(20, 240, 241, 242, 243) X(21, 244, 245, 246, 247) X(22, 248, 249, 250, 251) X(23, 252, 253, 254, 255)
-template <int F, unsigned OFF>
+template <int F, unsigned OFF, bool PINNED>
 __device__ __forceinline__ void wg3_rd_pair(wg3_u2_t& lo, wg3_u2_t& hi, unsigned o0, unsigned o1) {
-#if WG3_PIN
+    if constexpr (PINNED) {
 #define X(F_, R0, R1, R2, R3)                                                                                          \
     if constexpr (F == F_) {                                                                                           \
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "={v[" #R0 ":" #R1 "]}"(lo) : "v"(o0), "n"(OFF));          \
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "={v[" #R2 ":" #R3 "]}"(hi) : "v"(o1), "n"(OFF));          \
     }
+        WG3_PIN_CASES(X)
+#undef X
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(o0), "n"(OFF));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(o1), "n"(OFF));
+    }
+}
+// The pipelined loop's forms: ONE asm statement per fragment -- address XORs (tile index, see the fragment addresses) and
+// both reads; between separate statements hipcc pads with an s_nop each (it cannot see what they do), and every instruction of
+// a wave that is alone on its SIMD is an issue slot.  XI: the tile's XOR immediate (0: none).
+template <unsigned OFF>
+__device__ __forceinline__ void wg3_rdx_pair(wg3_u2_t& lo, wg3_u2_t& hi, unsigned b0, unsigned b1, unsigned xi) {
+    unsigned t0, t1;
+    asm volatile("v_xor_b32 %2, %6, %4\n\tv_xor_b32 %3, %6, %5\n\tds_read_b64_tr_b16 %0, %2 offset:%7\n\tds_read_b64_tr_b16 %1, %3 offset:%7"
+                 : "=&v"(lo), "=&v"(hi), "=&v"(t0), "=&v"(t1) : "v"(b0), "v"(b1), "s"(xi), "n"(OFF));
+}
+template <int F, unsigned OFF>
+__device__ __forceinline__ void wg3_rdx_pair_pinned(wg3_u2_t& lo, wg3_u2_t& hi, unsigned b0, unsigned b1, unsigned xi) {
+    unsigned t0, t1;
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_)                                                                                             \
+        asm volatile("v_xor_b32 %2, %6, %4\n\tv_xor_b32 %3, %6, %5\n\tds_read_b64_tr_b16 %0, %2 offset:%7\n\tds_read_b64_tr_b16 %1, %3 offset:%7" \
+                     : "={v[" #R0 ":" #R1 "]}"(lo), "={v[" #R2 ":" #R3 "]}"(hi), "=&v"(t0), "=&v"(t1) : "v"(b0), "v"(b1), "s"(xi), "n"(OFF));
     WG3_PIN_CASES(X)
 #undef X
-#else
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(o0), "n"(OFF));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(o1), "n"(OFF));
-#endif
+}
+// MFMA whose A operand is the pinned slot F: the register tuple is NAMED in the instruction, its halves are inputs pinned to the
+// same registers (no copy, no composition, and the compiler still sees who reads what the fragment reads deliver)
+template <int F>
+__device__ __forceinline__ void wg3_mfma_pinned(f4_t& acc, wg3_u2_t lo, wg3_u2_t hi, bf8_t b) {
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_)                                                                                             \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[" #R0 ":" #R3 "], %1, %0" : "+v"(acc) : "v"(b), "{v[" #R0 ":" #R1 "]}"(lo), "{v[" #R2 ":" #R3 "]}"(hi));
+    WG3_PIN_CASES(X)
+#undef X
 }
 // ties the halves (and then the composed operand) to this point of the program, in their registers
-template <int F>
+template <int F, bool PINNED>
 __device__ __forceinline__ bf8_t wg3_compose(wg3_u2_t lo, wg3_u2_t hi) {
-#if WG3_PIN
+    if constexpr (PINNED) {
 #define X(F_, R0, R1, R2, R3)                                                                                          \
     if constexpr (F == F_) asm volatile("" : "={v[" #R0 ":" #R1 "]}"(lo), "={v[" #R2 ":" #R3 "]}"(hi) : "0"(lo), "1"(hi));
-    WG3_PIN_CASES(X)
+        WG3_PIN_CASES(X)
 #undef X
-    bf8_t f = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        bf8_t f = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
 #define X(F_, R0, R1, R2, R3) \
     if constexpr (F == F_) asm volatile("" : "={v[" #R0 ":" #R3 "]}"(f) : "0"(f));
-    WG3_PIN_CASES(X)
+        WG3_PIN_CASES(X)
 #undef X
-    return f;
-#else
-    asm volatile("" : "+v"(lo), "+v"(hi));
-    return __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-#endif
+        return f;
+    } else {
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        return __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    }
 }
+__device__ __forceinline__ void wg3_tie(wg3_u2_t& lo, wg3_u2_t& hi) { asm volatile("" : "+v"(lo), "+v"(hi)); }
 template <int N, typename FN, int... I>
 __device__ __forceinline__ void wg3_sfor_impl(FN&& fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
 template <int N, typename FN>
 __device__ __forceinline__ void wg3_sfor(FN&& fn) { wg3_sfor_impl<N>(fn, std::make_integer_sequence<int, N>{}); }
 
 // BW: width of the K step's pixel block: 16 (4 x 16 pixels, images >= 16 wide) or 8 (8 x 8 pixels: 8 x 8 images)
-// NST: LDS stages.  2: the tiles of step k + 1 are in flight while step k is multiplied.  3 (round 6): those of steps k + 1
-// AND k + 2 -- with one workgroup per CU (the grid that is right beside the input-gradient stream) a single fill in flight
-// is 28 KB per ~1.2 us of LDS-DMA round trip = ~20-25 GB/s per CU, which is what the launch ran at (184 us per 128 steps,
-// 149 with the fills compiled out; the matrix time of a step is 0.45 us): the kernel was bound by ONE outstanding fill.
-template <int BMC, int CI, int BW = 16, int NST = 2>
+// PIPE: 1 = the pipelined K loop (round 6, see there), 0 = the round-3 loop (tunable wgrad3_pipe).  Both keep TWO LDS stages;
+// a third one (the fills of steps k + 1 AND k + 2 in flight, 84-96 KB per workgroup) was built and measured in round 6: every
+// layer within +-2 %, step 5.71-5.74 against 5.73-5.74 ms -- removed.
+template <int BMC, int CI, int BW = 16, int PIPE = 1>
 __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, PatchGeo pg, int cotiles, int jtiles,
                                                             int splits, int blocks_per_split, int ph_inner) {
     static_assert((BMC == 128 && CI == 64) || (BMC == 64 && CI == 128), "wave tile 128 x 64 or 64 x 128");
@@ -183,14 +212,17 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     const unsigned yjstep = (unsigned)(((((YRPI >> LBW) << los) << g.ldw)) * g.Cout) * 2u;   // YRPI rows = YRPI / BW pixel rows further
     // X patch fill map: thread -> (pixel XPPI jj + tid / XCH, 16-B chunk tid % XCH)
     const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
-    int xty[XJ], xtx[XJ];
+    // (row, column) of the thread's patch pixel as two 16-bit fields: the in-image test of a step is one packed add of the
+    // block origin, one packed unsigned min against (H - 1, W - 1) and one compare (was: two adds, two compares, an and; and
+    // two registers per piece in a loop that has none to spare).  Rows beyond the patch carry 0x7fff: no image has them.
+    typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+    us2_t xyt[XJ];
     unsigned xthr[XJ];
 #pragma unroll
     for (int jj = 0; jj < XJ; ++jj) {
         const int p = jj * XPPI + tid / XCH;
         const int py_ = p / PW, px_ = p - py_ * PW;
-        xty[jj] = (py_ > BH || px_ > BW) ? 0x40000000 : py_ * g.S + wby;      // beyond the patch: a row no image has
-        xtx[jj] = px_ * g.S + wbx;
+        xyt[jj] = (us2_t){(unsigned short)((py_ > BH || px_ > BW) ? 0x7fff : py_ * g.S + wby), (unsigned short)(px_ * g.S + wbx)};
         const int c = tid % XCH;                 // physical chunk: segment c >> 1 holds source segment (c >> 1) ^ f(p)
         const int xch = (second ? ci0 - g.C1 : ci0) + (((((c >> 1) ^ (int)xseg_swz3<CI, BW>((unsigned)p)) << 1) | (c & 1)) * 8);
         xthr[jj] = (unsigned)(((py_ * g.S + wby) * g.W + px_ * g.S + wbx) * xcs + xch) * 2u;
@@ -219,15 +251,6 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
             xbase[kk][h] = (unsigned)YBUF + p * XPB + (xseg_swz3<CI, BW>(p) << 5) + tp * 8;
         }
     }
-    // stage-2 bases (three stages only): STAGE is a multiple of 4096 and every base is below it, so the XORs of the tile index
-    // (address bits 5-7) commute with the addition
-    unsigned ybase2[2], xbase2[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        ybase2[h] = ybase[h] + (unsigned)STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) xbase2[kk][h] = xbase[kk][h] + (unsigned)STAGE;
-    }
 #define WG3_XOR(dst, src, imm) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(dst) : "v"(src), "s"(imm))
 #define WG3_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(size_t)(unsigned)(addr))
 #define WG3_BLDS16(rs, voff, soff, laddr) \
@@ -244,24 +267,38 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     // fragments of channel tiles w * MT/4 .. of the steps with kb % jtiles == jt, so the jtiles workgroups that read the
     // same dY share the work (a few vector instructions per step each) and no workgroup is slower than the others.
     constexpr int BT = MT / 4;
-    const bool do_bias = a.dbias != nullptr;
+    const bool do_bias = !PIPE && a.dbias != nullptr;      // the pipelined loop carries no bias sums (host: launch_wgrad3)
     float bsum[BT];
 #pragma unroll
     for (int i = 0; i < BT; ++i) bsum[i] = 0.f;
 
-    unsigned ysof = 0, xofs[XJ];
+    // addresses of a step's fill, in pieces (the pipelined loop spreads them over the gaps between MFMAs)
+    unsigned ysof = 0, xofs[XJ], p_xsof = 0;
+    int p_gx0 = 0, p_gy0 = 0, p_n = 0;
+    us2_t p_oyx = {0, 0};
+    const us2_t xylim = {(unsigned short)(g.H - 1), (unsigned short)(g.W - 1)};
+    auto prep_a = [&](int kb) {
+        p_gx0 = (kb & ((1 << lbx) - 1)) << LBW;
+        p_gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << LBH;
+        p_n = kb >> (lbx + lby);
+    };
+    auto prep_b = [&]() { ysof = (unsigned)(((((p_n << g.ldh) + (p_gy0 << los) + poy) << g.ldw) + (p_gx0 << los) + pox) * g.Cout) * 2u; };
+    auto prep_c = [&]() {
+        const int oy = p_gy0 * g.S, ox = p_gx0 * g.S;
+        p_oyx = (us2_t){(unsigned short)oy, (unsigned short)ox};
+        p_xsof = (unsigned)(((((p_n << g.lsh) + oy) << g.lsw) + ox) * xcs) * 2u;
+    };
+    auto prep_x = [&](int jj) {
+        const us2_t t = xyt[jj] + p_oyx;
+        const bool inb = __builtin_bit_cast(unsigned, __builtin_elementwise_min(t, xylim)) == __builtin_bit_cast(unsigned, t);
+        xofs[jj] = inb ? xthr[jj] + p_xsof : OOB;
+    };
     auto prepare = [&](int kb) {
-        const int gx0 = (kb & ((1 << lbx) - 1)) << LBW;
-        const int gy0 = ((kb >> lbx) & ((1 << lby) - 1)) << LBH;
-        const int n = kb >> (lbx + lby);
-        ysof = (unsigned)(((((n << g.ldh) + (gy0 << los) + poy) << g.ldw) + (gx0 << los) + pox) * g.Cout) * 2u;
-        const int oy = gy0 * g.S, ox = gx0 * g.S;
-        const unsigned xsof = (unsigned)(((((n << g.lsh) + oy) << g.lsw) + ox) * xcs) * 2u;
+        prep_a(kb);
+        prep_b();
+        prep_c();
 #pragma unroll
-        for (int jj = 0; jj < XJ; ++jj) {
-            const bool inb = (unsigned)(xty[jj] + oy) < (unsigned)g.H && (unsigned)(xtx[jj] + ox) < (unsigned)g.W;
-            xofs[jj] = inb ? xthr[jj] + xsof : OOB;
-        }
+        for (int jj = 0; jj < XJ; ++jj) prep_x(jj);
     };
     // piece j of a stage's fill: j < YJ dY rows, then the X patch
     auto fire_piece = [&](int st, int j) {
@@ -273,162 +310,301 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
 #pragma unroll
         for (int j = 0; j < YJ + XJ; ++j) fire_piece(st, j);
     };
-    if (kb0 < kb1) {
-        prepare(kb0);
-        fire(0);
-        if (NST > 2 && kb0 + 1 < kb1) {
-            prepare(kb0 + 1);
-            fire(1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YJ + XJ) : "memory");      // the first fill has landed, the second is in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-    }
     // The K loop is scheduled by hand.  hipcc puts an s_waitcnt vmcnt(0) in front of the first LDS read it can see behind
     // an LDS-DMA (the DMA is a pending LDS write as far as it knows, and it cannot tell the two stages apart): with the
     // fragment reads as compiler-visible loads the "two stages" of gg_wg2.hip were fire -> wait -> multiply, i.e. no
-    // overlap at all.  Here the fragment reads and the MFMAs are inline asm, the waits are explicit:
-    //   step(ST):  reads of k-half 0 -> set 0;  fire the NEXT step's tiles into the other stage;  lgkmcnt(0);
-    //              32 MFMAs on set 0 with the reads of k-half 1 -> set 1 between them;  lgkmcnt(0);  32 MFMAs on set 1;
-    //              vmcnt(0) (the next tiles have had a whole step to land);  barrier.
+    // overlap at all.  Here the fragment reads and the MFMAs are inline asm, the waits are explicit.
     // (asm volatile statements keep their order; a sched_barrier behind every wait keeps compiler-scheduled code -- the
     //  ReLU of the fragments, the bias sums -- from moving above it, guide rule 18.)
-    typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
-#define WG3_RD(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
-    auto step = [&](auto st_tag, int kb) {
-        constexpr int ST = decltype(st_tag)::value;
+    //
+    // The 8-byte halves the reads deliver.  The compiler knows nothing about WHEN an asm read delivers: anything it
+    // derives from these registers -- including the copies that assemble two halves into one operand tuple when the
+    // allocator did not place them side by side -- must come behind the wait.  So the halves stay as they are until
+    // `compose` (called right behind each lgkmcnt(0)) ties them to that point with empty asm statements and only then
+    // forms the fragments.  (Composed inside read_frag, an unrelated edit of the tile decode changed the allocation
+    // and the bias sums of the <64, 128> form came out wrong, differently from run to run.)
+    typedef std::integral_constant<int, 0> K0;
+    typedef std::integral_constant<int, 1> K1;
+    typedef std::integral_constant<int, 0> St0;
+    typedef std::integral_constant<int, 1> St1;
+    constexpr bool PINY = PIPE != 0 && WG3_PIN != 0;       // dY fragments in fixed registers (see WG3_PIN)
+    bf8_t fa[2][MT], fb[2][NT];
+    wg3_u2_t fal[2][MT], fah[2][MT], fbl[2][NT], fbh[2][NT];
+    // fragment `i` of k-half KK out of stage ST: i < NT: X tile i, else dY tile i - NT (X first: every MFMA row needs all of
+    // them).  The DS offset field is 16 bits: two stages of at most 32 KB + the k-half's 8 KB fit.
+    auto read_frag = [&](auto st_tag, auto kk_tag, auto i_tag) {
+        constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, i = decltype(i_tag)::value;
         constexpr unsigned SB = (unsigned)(ST * STAGE);
-        bf8_t fa[2][MT], fb[2][NT];
-        // The 8-byte halves the reads deliver.  The compiler knows nothing about WHEN an asm read delivers: anything it
-        // derives from these registers -- including the copies that assemble two halves into one operand tuple when the
-        // allocator did not place them side by side -- must come behind the wait.  So the halves stay as they are until
-        // `compose` (called right behind each lgkmcnt(0)) ties them to that point with empty asm statements and only then
-        // forms the fragments.  (Composed inside read_frag, an unrelated edit of the tile decode changed the allocation
-        // and the bias sums of the <64, 128> form came out wrong, differently from run to run.)
-        wg3_u2_t fal[2][MT], fah[2][MT], fbl[2][NT], fbh[2][NT];
-        // fragment `i` of k-half KK: i < NT: X tile i, else dY tile i - NT (X first: every MFMA row needs all of them)
-        // (the DS offset field is 16 bits: the third stage starts at 56-64 KB, so its reads go through a second set of base
-        //  registers that already carry one stage)
-        constexpr unsigned SBI = ST == 2 ? SB - (unsigned)STAGE : SB;
-        auto read_frag = [&](auto kk_tag, auto i_tag) {
-            constexpr int KK = decltype(kk_tag)::value, i = decltype(i_tag)::value;
-            if constexpr (i < NT) {
-                const unsigned b0 = ST == 2 ? xbase2[KK][0] : xbase[KK][0], b1 = ST == 2 ? xbase2[KK][1] : xbase[KK][1];
-                unsigned o0 = b0, o1 = b1;
-                if (i) { WG3_XOR(o0, b0, i << 5); WG3_XOR(o1, b1, i << 5); }
-                wg3_rd_pair<KK * 12 + i, SBI>(fbl[KK][i], fbh[KK][i], o0, o1);
-            } else {
-                constexpr int mt = i - NT;
-                const unsigned b0 = ST == 2 ? ybase2[0] : ybase[0], b1 = ST == 2 ? ybase2[1] : ybase[1];
-                unsigned a0 = b0, a1 = b1;
-                if (mt) { WG3_XOR(a0, b0, mt << 5); WG3_XOR(a1, b1, mt << 5); }
-                wg3_rd_pair<KK * 12 + i, SBI + KK * (32 * YROW)>(fal[KK][mt], fah[KK][mt], a0, a1);
-            }
-        };
-        typedef std::integral_constant<int, 0> K0;
-        typedef std::integral_constant<int, 1> K1;
-        auto compose = [&](auto kk_c) {
-            constexpr int KK = decltype(kk_c)::value;
-            if (WG3_ABL & 8) return;
-            wg3_sfor<NT>([&](auto t) { constexpr int nt = decltype(t)::value; fb[KK][nt] = wg3_compose<KK * 12 + nt>(fbl[KK][nt], fbh[KK][nt]); });
-            wg3_sfor<MT>([&](auto t) { constexpr int mt = decltype(t)::value; fa[KK][mt] = wg3_compose<KK * 12 + NT + mt>(fal[KK][mt], fah[KK][mt]); });
-        };
-        if (!(WG3_ABL & 8)) {
-            wg3_sfor<NT + MT>([&](auto t) { read_frag(K0{}, t); });
+        if (WG3_ABL & 8) return;
+        if constexpr (i < NT) {
+            unsigned o0 = xbase[KK][0], o1 = xbase[KK][1];
+            if (i) { WG3_XOR(o0, xbase[KK][0], i << 5); WG3_XOR(o1, xbase[KK][1], i << 5); }
+            wg3_rd_pair<KK * 12 + i, SB, false>(fbl[KK][i], fbh[KK][i], o0, o1);
         } else {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) fa[kk][mt] = __builtin_bit_cast(bf8_t, make_uint4(ybase[0], SB, mt, kk));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fb[kk][nt] = __builtin_bit_cast(bf8_t, make_uint4(xbase[kk][0], SB, nt, kk));
-            }
+            constexpr int mt = i - NT;
+            unsigned a0 = ybase[0], a1 = ybase[1];
+            if (mt) { WG3_XOR(a0, ybase[0], mt << 5); WG3_XOR(a1, ybase[1], mt << 5); }
+            wg3_rd_pair<KK * 12 + i, SB + KK * (32 * YROW), PINY>(fal[KK][mt], fah[KK][mt], a0, a1);
         }
-        // Round 6: the next step's fill is no longer issued here, in front of the wait, as one block of YJ + XJ LDS-DMA
-        // instructions (each ~60-180 cycles of issue, CDNA4 guide; this wave is ALONE on its SIMD when the launch runs one
-        // workgroup per CU, so nothing multiplied meanwhile): the pieces go between the MFMAs of k-half 0, behind the reads
-        // of k-half 1 (WG3_SPREAD, default 1).  The other stage was last read in the previous step, before its barrier.
-        constexpr int FST = (ST + NST - 1) % NST;        // the stage this step refills: the one the PREVIOUS step read (behind its barrier)
-        const bool nxt = kb + (NST - 1) < kb1;
-        if (nxt) {
-            prepare(kb + NST - 1);
-            if (!WG3_SPREAD) fire(FST);
+    };
+    auto compose = [&](auto kk_c) {
+        constexpr int KK = decltype(kk_c)::value;
+        if (WG3_ABL & 8) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[KK][mt] = __builtin_bit_cast(bf8_t, make_uint4(ybase[0], ybase[1], mt, KK));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(xbase[KK][0], xbase[KK][1], nt, KK));
+            return;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        compose(K0{});
-        const bool bias_step = do_bias && (kb % jtiles) == jt;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (xrelu) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fb[kk][nt] = relu_frag(fb[kk][nt]);
-            }
-            if (bias_step) {
+        if constexpr (!PIPE)     // (the pipelined loop forms the X fragments in its ReLU, one per gap)
+            wg3_sfor<NT>([&](auto t) { constexpr int nt = decltype(t)::value; fb[KK][nt] = wg3_compose<KK * 12 + nt, false>(fbl[KK][nt], fbh[KK][nt]); });
+        else
+            wg3_sfor<NT>([&](auto t) { constexpr int nt = decltype(t)::value; wg3_tie(fbl[KK][nt], fbh[KK][nt]); });
+        wg3_sfor<MT>([&](auto t) { constexpr int mt = decltype(t)::value; fa[KK][mt] = wg3_compose<KK * 12 + NT + mt, PINY>(fal[KK][mt], fah[KK][mt]); });
+    };
+    // bias sums of the dY fragments of k-half kk (a few steps of a few workgroups only)
+    auto bias_add = [&](auto kk_tag) {
+        constexpr int kk = decltype(kk_tag)::value;
+        // wave w adds up the channel tiles w * BT ..: four uniform branches with constant fragment indices (a chain of selects on
+        // wid became an indexed copy of the fragments in scratch memory)
+        wg3_sfor<4>([&](auto w_tag) {
+            constexpr int w = decltype(w_tag)::value;
+            if (wid == w) {
+                asm volatile("" ::: "memory");       // keeps the four branches apart (merged, they index the fragments again)
 #pragma unroll
                 for (int i = 0; i < BT; ++i) {
-                    const uint4 v = BT == 2 ? (wid == 0 ? __builtin_bit_cast(uint4, fa[kk][0 + i]) : wid == 1 ? __builtin_bit_cast(uint4, fa[kk][2 + i])
-                                               : wid == 2 ? __builtin_bit_cast(uint4, fa[kk][4 + i]) : __builtin_bit_cast(uint4, fa[kk][6 + i]))
-                                            : (wid == 0 ? __builtin_bit_cast(uint4, fa[kk][0]) : wid == 1 ? __builtin_bit_cast(uint4, fa[kk][1])
-                                               : wid == 2 ? __builtin_bit_cast(uint4, fa[kk][2]) : __builtin_bit_cast(uint4, fa[kk][3]));
+                    const uint4 v = __builtin_bit_cast(uint4, fa[kk][w * BT + i]);
                     const unsigned d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(d[e] << 16) + __uint_as_float(d[e] & 0xffff0000u);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (WG3_ABL & 2) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][0][0] += (float)fa[kk][mt][0] + (float)fb[kk][mt % NT][0];
-            } else {
-                wg3_sfor<MT * NT>([&](auto t) {
-                    constexpr int idx = decltype(t)::value, mt = idx / NT, nt = idx % NT;
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(fa[kk][mt]), "v"(fb[kk][nt]));
-                    // the other k-half's fragments, one between two MFMAs (its X tiles first)
-                    if constexpr (idx < NT + MT) { if (kk == 0 && !(WG3_ABL & 8)) read_frag(K1{}, t); }
-                    // (WG3_SPREAD: ... then the pieces of the next step's fill, one every FSTEP MFMAs)
-                    if (WG3_SPREAD && kk == 0) {
-                        constexpr int NP = YJ + XJ, FIRST = NT + MT, FSTEP = (MT * NT - FIRST) / NP > 0 ? (MT * NT - FIRST) / NP : 1;
-                        constexpr int pidx = idx - FIRST;
-                        if (pidx >= 0 && pidx % FSTEP == 0 && pidx / FSTEP < NP) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (nxt) fire_piece(FST, pidx / FSTEP);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                });
-            }
-            if (kk == 0) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                compose(K1{});
-            }
-        }
-        // the NEXT step's tiles have landed (they have had one step, or two with three stages, to do so); with three stages
-        // the fill issued in this step stays in flight across the barrier (LDS-DMA only in this loop: one kind per count)
-        if (NST > 2 && nxt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YJ + XJ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        });
     };
-    typedef std::integral_constant<int, 0> St0;
-    typedef std::integral_constant<int, 1> St1;
-    typedef std::integral_constant<int, 2> St2;
-    int kb = kb0;
-    if constexpr (NST == 2) {
+#define WG3_MFMA(mt, nt, kk) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(fa[kk][mt]), "v"(fb[kk][nt]))
+
+    if constexpr (!PIPE) {
+        // ---- the round-3 loop (tunable wgrad3_pipe = 0) ---------------------------------------------------------------
+        //   step(ST):  reads of k-half 0 -> set 0;  fire the NEXT step's tiles into the other stage;  lgkmcnt(0);
+        //              32 MFMAs on set 0 with the reads of k-half 1 -> set 1 between them;  lgkmcnt(0);  32 MFMAs on set 1;
+        //              vmcnt(0) (the next tiles have had a whole step to land);  barrier.
+        if (kb0 < kb1) {
+            prepare(kb0);
+            fire(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        auto step = [&](auto st_tag, int kb) {
+            constexpr int ST = decltype(st_tag)::value;
+            wg3_sfor<NT + MT>([&](auto t) { read_frag(st_tag, K0{}, t); });
+            const bool nxt = kb + 1 < kb1;
+            if (nxt) {
+                prepare(kb + 1);
+                fire(ST ^ 1);        // the stage the PREVIOUS step read (behind its barrier)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            compose(K0{});
+            const bool bias_step = do_bias && (kb % jtiles) == jt;
+            wg3_sfor<2>([&](auto kk_tag) {
+                constexpr int kk = decltype(kk_tag)::value;
+                if (xrelu) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) fb[kk][nt] = relu_frag(fb[kk][nt]);
+                }
+                if (bias_step) bias_add(kk_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                if (WG3_ABL & 2) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][0][0] += (float)fa[kk][mt][0] + (float)fb[kk][mt % NT][0];
+                } else {
+                    wg3_sfor<MT * NT>([&](auto t) {
+                        constexpr int idx = decltype(t)::value, mt = idx / NT, nt = idx % NT;
+                        WG3_MFMA(mt, nt, kk);
+                        // the other k-half's fragments, one between two MFMAs (its X tiles first)
+                        if constexpr (idx < NT + MT && kk == 0) read_frag(st_tag, K1{}, t);
+                    });
+                }
+                if constexpr (kk == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    compose(K1{});
+                }
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the NEXT step's tiles have landed: they have had one step to do so
+            __builtin_amdgcn_s_barrier();
+        };
+        int kb = kb0;
         for (; kb + 1 < kb1; kb += 2) {
             step(St0{}, kb);
             step(St1{}, kb + 1);
         }
         if (kb < kb1) step(St0{}, kb);
     } else {
-        for (; kb + 2 < kb1; kb += 3) {
-            step(St0{}, kb);
-            step(St1{}, kb + 1);
-            step(St2{}, kb + 2);
+        // ---- the pipelined loop (round 6, default) ---------------------------------------------------------------------
+        // What bounds the loop above with ONE workgroup per CU (the grid beside the input-gradient stream) is the issue rate
+        // of a wave that is alone on its SIMD: one instruction per ~4-5 cycles, whatever its kind.  A step carries 64 MFMAs
+        // (1024 matrix cycles) and ~280 other instructions (48 fragment reads + their address XORs, the 7 LDS-DMA pieces of
+        // the next fill at >= 60 cycles of issue each, the fill's address arithmetic, ReLU, copies, waits): only the k-half-1
+        // reads sat between MFMAs, everything else -- and the LDS latency of the k-half-0 reads behind the barrier -- ran with
+        // the matrix pipe idle: 2790 cycles per step, 2260 with the fills compiled out (profiles/r06_ab_summary.txt, r06l).
+        // Here every instruction of a step has a place in the shadow of an MFMA (16 cycles each, ~3 issue slots):
+        //   M0: 32 MFMAs on k-half 0;  between them the reads of k-half 1, the scalar part of the addresses of the fill after
+        //       next, the ReLU of the X fragments just read.
+        //   vmcnt(0) (this wave's pieces of the NEXT step's tiles, issued one step ago);  barrier: the other stage is
+        //       complete and everyone has finished reading this one.
+        //   M1: 32 MFMAs on k-half 1;  between them the reads of the NEXT step's k-half 0 (other stage), the pieces of the
+        //       fill after next (into this stage) with the in-image test of each X piece one gap ahead, the ReLU.
+        // One barrier per step as before, but nothing waits for LDS behind it: fragments are read one k-half ahead.
+        //
+        // Registers.  128 accumulators + two sets of 12 fragments + their halves did not fit in 256 with the fill's addresses
+        // (the first form of this loop spilled the loop's own invariants, and every scratch reload is a vmcnt wait that also
+        // waits for the LDS-DMA in flight).  So the fragments along the tile's LONG side (dY for the 128 x 64 wave tile) are
+        // not double-buffered: fragment mt is used by NT consecutive MFMAs and its successor is read INTO THE SAME REGISTERS
+        // right behind the last of them (an MFMA has read its operands long before a later ds_read delivers).  Only the last
+        // one would be read too late for the barrier (everyone must have finished reading the stage): it alternates between
+        // two slots, so MT + 1 fixed slots v[220 ..] (WG3_PIN_CASES) hold the long side.  The short side (X: NT fragments used
+        // by every row of MFMAs) stays double-buffered and goes through the ReLU -- max(x, rlo) on signed 16-bit lanes with
+        // rlo = 0 or -32768 (no ReLU), compiler-generated, so the results sit in the operand tuples without a copy and there
+        // is no branch inside the MFMA sequence.
+        const short rlo = xrelu ? (short)0 : (short)-32768;
+        typedef short s4_t __attribute__((ext_vector_type(4)));
+        auto relu_half = [&](wg3_u2_t h) {
+            s4_t x = __builtin_bit_cast(s4_t, h);
+            const s4_t z = {rlo, rlo, rlo, rlo};
+            x = __builtin_elementwise_max(x, z);
+            return __builtin_bit_cast(wg3_u2_t, x);
+        };
+        // X fragment nt of set KK out of its halves (tied to the wait first), through the ReLU
+        auto form_b = [&](auto kk_tag, auto nt_tag) {
+            constexpr int KK = decltype(kk_tag)::value, nt = decltype(nt_tag)::value;
+            if (WG3_ABL & 8) { fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(xbase[KK][0], xbase[KK][1], nt, KK)); return; }
+            wg3_tie(fbl[KK][nt], fbh[KK][nt]);
+            const wg3_u2_t lo = relu_half(fbl[KK][nt]), hi = relu_half(fbh[KK][nt]);
+            fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        };
+        // dY fragment mt of k-half KK lives in slot mt, the last one in slot MT - 1 + KK; slot s = registers v[252 - 4 s ..]
+        wg3_u2_t fyl[MT + 1], fyh[MT + 1];
+        auto read_y = [&](auto st_tag, auto kk_tag, auto mt_tag) {
+            constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, mt = decltype(mt_tag)::value;
+            constexpr int slot = mt < MT - 1 ? mt : MT - 1 + KK;
+            if (WG3_ABL & 8) { fyl[slot] = (wg3_u2_t){ybase[0], (unsigned)mt}; fyh[slot] = (wg3_u2_t){ybase[1], (unsigned)KK}; return; }
+            wg3_rdx_pair_pinned<23 - slot, (unsigned)(ST * STAGE + KK * (32 * YROW))>(fyl[slot], fyh[slot], ybase[0], ybase[1], (unsigned)(mt << 5));
+        };
+        auto read_x = [&](auto st_tag, auto kk_tag, auto nt_tag) {
+            constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, nt = decltype(nt_tag)::value;
+            if (WG3_ABL & 8) return;
+            wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xbase[KK][0], xbase[KK][1], (unsigned)(nt << 5));
+        };
+        constexpr int NP = YJ + XJ;                       // LDS-DMA pieces of a fill (7-8 per wave)
+        // the gaps (index of the MFMA in front) of a k-half's 32:
+        //   0 .. NT-1              X fragment nt of the next k-half (other set)
+        //   NT+1                   the LAST dY fragment of the next k-half (its spare slot)
+        //   (mt+1) NT, mt < MT-1   dY fragment mt of the next k-half, right behind the last MFMA on the current one
+        //   XW .. XW+NT-1          counted wait for the X reads (the dY reads issued since stay in flight), then one ReLU per gap
+        //   30                     lgkmcnt(0): the dY fragments are where the MFMAs of the next k-half name them
+        constexpr int XW = NT == 4 ? 13 : 17;
+        constexpr int XW_PENDING = NT == 4 ? 8 : 6;       // DS instructions issued behind the last X read when MFMA XW is issued
+        static_assert((NT == 4 && MT == 8) || (NT == 8 && MT == 4), "gap plan");
+        constexpr int FIRE0 = NT == 4 ? 14 : 10;          // M1: fill piece j behind MFMA FIRE0 + 2 j (8 pieces end at 28 / 24)
+        static_assert(FIRE0 + 2 * (NP - 1) <= 29, "fill pieces fit between the MFMAs of a k-half");
+        // one k-half: MFMAs on (fy slots of KK, fb[KK]) with the reads of the following k-half NK out of stage RS between them
+        auto half = [&](auto kk_tag, auto rs_tag, bool rd, auto&& extra) {
+            constexpr int KK = decltype(kk_tag)::value;
+            typedef std::integral_constant<int, KK ^ 1> NK;
+            wg3_sfor<MT * NT>([&](auto t) {
+                constexpr int idx = decltype(t)::value, mt = idx / NT, nt = idx % NT;
+                constexpr int slot = mt < MT - 1 ? mt : MT - 1 + KK;
+                if (WG3_ABL & 2) acc[mt][nt][0] += __uint_as_float(fyl[slot].x) + (float)fb[KK][nt][0];
+                else wg3_mfma_pinned<23 - slot>(acc[mt][nt], fyl[slot], fyh[slot], fb[KK][nt]);
+                if (rd) {
+                    if constexpr (idx < NT) read_x(rs_tag, NK{}, t);
+                    if constexpr (idx == NT + 1) read_y(rs_tag, NK{}, std::integral_constant<int, MT - 1>{});
+                    if constexpr (idx >= NT && idx % NT == 0 && idx / NT - 1 < MT - 1) read_y(rs_tag, NK{}, std::integral_constant<int, idx / NT - 1>{});
+                    if constexpr (idx == XW) {
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XW_PENDING) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (idx >= XW && idx < XW + NT) {
+                        form_b(NK{}, std::integral_constant<int, idx - XW>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (idx == 30) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                extra(t);
+            });
+        };
+        if (kb0 < kb1) {
+            prepare(kb0);
+            fire(0);
+            if (kb0 + 1 < kb1) {
+                prepare(kb0 + 1);
+                fire(1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");       // the first fill has landed, the second is in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            wg3_sfor<NT>([&](auto t) { read_x(St0{}, K0{}, t); });
+            wg3_sfor<MT>([&](auto t) { read_y(St0{}, K0{}, t); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            wg3_sfor<NT>([&](auto t) { form_b(K0{}, t); });
         }
-        if (kb < kb1) step(St0{}, kb);
-        if (kb + 1 < kb1) step(St1{}, kb + 1);
+        // hipcc re-loads the kernel arguments the address arithmetic of the loop shifts by right in front of the loop and waits
+        // for them at their first use INSIDE it -- an lgkmcnt(0) that also waits for the fragment reads in flight, every step.
+        // Used here, they are loaded and waited for here.
+        asm volatile("" ::"s"(g.ldh), "s"(g.ldw), "s"(g.lsh), "s"(g.lsw), "s"(g.S), "s"(g.Cout));
+        auto pstep = [&](auto st_tag, auto fast_tag, int kb) {
+            constexpr int ST = decltype(st_tag)::value;
+            constexpr bool FAST = decltype(fast_tag)::value;         // the steady state: both following steps exist
+            typedef std::integral_constant<int, ST ^ 1> Other;
+            const bool nxt1 = FAST || kb + 1 < kb1, nxt2 = FAST || kb + 2 < kb1;
+            __builtin_amdgcn_sched_barrier(0);
+            half(K0{}, st_tag, true, [&](auto t) {
+                constexpr int idx = decltype(t)::value;
+                // the scalar part of the addresses of the fill after next, a few instructions per gap
+                if constexpr ((NT == 4 && idx >= 18 && idx < 21) || (NT == 8 && idx >= 25 && idx < 28)) {
+                    constexpr int c = idx - (NT == 4 ? 18 : 25);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nxt2) {
+                        if constexpr (c == 0) prep_a(kb + 2);
+                        else if constexpr (c == 1) prep_b();
+                        else prep_c();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            half(K1{}, Other{}, nxt1, [&](auto t) {
+                constexpr int idx = decltype(t)::value;
+                if constexpr (idx >= FIRE0 && ((idx - FIRE0) & 1) == 0 && (idx - FIRE0) / 2 < NP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nxt2) fire_piece(ST, (idx - FIRE0) / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // (the in-image test of an X piece one gap in front of it: its offset lives for two MFMAs)
+                if constexpr (idx + 1 >= FIRE0 + 2 * YJ && ((idx + 1 - FIRE0) & 1) == 0 && (idx + 1 - FIRE0) / 2 < NP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nxt2) prep_x((idx + 1 - FIRE0) / 2 - YJ);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        };
+        typedef std::integral_constant<bool, true> Fast;
+        typedef std::integral_constant<bool, false> Tail;
+        int kb = kb0;
+        for (; kb + 3 < kb1; kb += 2) {
+            pstep(St0{}, Fast{}, kb);
+            pstep(St1{}, Fast{}, kb + 1);
+        }
+        if (kb < kb1) pstep(St0{}, Tail{}, kb);
+        if (kb + 1 < kb1) pstep(St1{}, Tail{}, kb + 1);
+        if (kb + 2 < kb1) pstep(St0{}, Tail{}, kb + 2);
     }
     // MFMA results are read by vector instructions below: the hazard distance is the compiler's job for ITS MFMAs only
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -644,29 +820,28 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     if (attr.first()) {
         hipError_t e = hipSuccess;
         const void* fns[6] = {reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16>),
-                              reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16, 3>),
-                              reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16, 3>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8, 3>)};
+                              reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 16, 0>),
+                              reinterpret_cast<const void*>(&gg_wgrad_patch3_k<64, 128, 16, 0>), reinterpret_cast<const void*>(&gg_wgrad_patch3_k<128, 64, 8, 0>)};
         for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         PAI_CHECK(e == hipSuccess, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
     }
     const dim3 grid(c.tiles * c.psplits);
     const int ph_inner = g.nphase > 1 && pai_tunable("wgrad3_ph_inner", 1);
-    // tunable wgrad3_stages = 3: three LDS stages (two fills in flight), 84-96 KB per workgroup.  MEASURED, NOT THE DEFAULT: every
-    // layer within +-2 % (convbench w, one process: 1818.3 us over all layers either way), step 5.71-5.74 against 5.73-5.74 ms --
-    // a second fill in flight does not buy what compiling the fills out does (184 -> 149 us on decoders[4])
-    const int nst = pai_tunable("wgrad3_stages", 2) >= 3 ? 3 : 2;
+    // the pipelined K loop (see the kernel): not with a bias gradient (the bias sums live in the round-3 loop only) and not for the
+    // 64 x 128 wave tile (its eight double-buffered X fragments leave no room: 56 spilled registers inside the loop)
+    const int pipe = pai_tunable("wgrad3_pipe", 1) && !a.dbias && variant != 2;
     if (variant == 1) {
-        const size_t lds = (size_t)nst * (64 * 256 + 96 * 128);
-        if (nst == 3) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16, 3>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
-        else PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        const size_t lds = (size_t)2 * (64 * 256 + 96 * 128);
+        if (pipe) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        else PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16, 0>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     } else if (variant == 2) {
-        const size_t lds = (size_t)nst * (64 * 128 + 96 * 256);
-        if (nst == 3) PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16, 3>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
-        else PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        const size_t lds = (size_t)2 * (64 * 128 + 96 * 256);
+        if (pipe) PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        else PAI_LAUNCH((gg_wgrad_patch3_k<64, 128, 16, 0>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     } else {
-        const size_t lds = (size_t)nst * (64 * 256 + 128 * 128);
-        if (nst == 3) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8, 3>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
-        else PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        const size_t lds = (size_t)2 * (64 * 256 + 128 * 128);
+        if (pipe) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
+        else PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 8, 0>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
     }
     PAI_LAUNCH_CHECK();
     if (slab) return launch_wgrad_slab_sum(a.dw, slab, c.psplits, dwn, a.overwrite, s);
