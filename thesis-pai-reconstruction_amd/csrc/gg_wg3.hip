@@ -58,6 +58,9 @@ template <int BMC> __device__ __forceinline__ int yswz3(int row) {
 #ifndef WG3_SPREAD
 #define WG3_SPREAD 0   // 1: the next step's LDS-DMA pieces between the MFMAs of k-half 0 instead of in one block in front of them (measured: 1964-1970 against 1917-1947 us over the wgrad layers, step 5.82 against 5.79 ms -- dropped)
 #endif
+#ifndef WG3_ADDR
+#define WG3_ADDR 1    // pipelined loop: 1 = one address register per fragment tile (32 registers), 0 = base ^ tile index in front of each read
+#endif
 #ifndef WG3_ABL
 #define WG3_ABL 0     // timing ablations (results WRONG): 1 no dW store, 2 no MFMA, 4 no fills, 8 no fragment reads
 #endif
@@ -100,6 +103,22 @@ __device__ __forceinline__ void wg3_rdx_pair(wg3_u2_t& lo, wg3_u2_t& hi, unsigne
     unsigned t0, t1;
     asm volatile("v_xor_b32 %2, %6, %4\n\tv_xor_b32 %3, %6, %5\n\tds_read_b64_tr_b16 %0, %2 offset:%7\n\tds_read_b64_tr_b16 %1, %3 offset:%7"
                  : "=&v"(lo), "=&v"(hi), "=&v"(t0), "=&v"(t1) : "v"(b0), "v"(b1), "s"(xi), "n"(OFF));
+}
+// ... and with the address of every tile in a register of its own (WG3_ADDR): two reads, nothing else -- the XOR in front of a
+// read is a vector instruction the read depends on, and a lone wave pays ~9 matrix cycles for every instruction between MFMAs
+// (the reads and their XORs compiled out: decoders[4] 157 -> 108 us)
+template <unsigned OFF>
+__device__ __forceinline__ void wg3_rd2(wg3_u2_t& lo, wg3_u2_t& hi, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1), "n"(OFF));
+}
+template <int F, unsigned OFF>
+__device__ __forceinline__ void wg3_rd2_pinned(wg3_u2_t& lo, wg3_u2_t& hi, unsigned a0, unsigned a1) {
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_)                                                                                             \
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                      \
+                     : "={v[" #R0 ":" #R1 "]}"(lo), "={v[" #R2 ":" #R3 "]}"(hi) : "v"(a0), "v"(a1), "n"(OFF));
+    WG3_PIN_CASES(X)
+#undef X
 }
 template <int F, unsigned OFF>
 __device__ __forceinline__ void wg3_rdx_pair_pinned(wg3_u2_t& lo, wg3_u2_t& hi, unsigned b0, unsigned b1, unsigned xi) {
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     const bf16_t* xsrc = second ? (const bf16_t*)a.x2 : (const bf16_t*)a.x1;
     const int xcs = second ? g.C2 : g.C1;
     const int xrelu = second ? g.relu2 : g.relu1;
-    constexpr unsigned OOB = 0x80000000u;        // beyond every buffer: the LDS-DMA writes zeros
+    // (an offset of 0x80000000 is beyond every buffer: the LDS-DMA writes zeros)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.dy), 0, (unsigned)((g.N << (g.ldh + g.ldw)) * g.Cout) * 2u, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -288,10 +307,14 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         p_oyx = (us2_t){(unsigned short)oy, (unsigned short)ox};
         p_xsof = (unsigned)(((((p_n << g.lsh) + oy) << g.lsw) + ox) * xcs) * 2u;
     };
+    // (asm: hipcc keeps the limits and the out-of-range offset in vector registers of their own otherwise -- the loop has none)
+    const unsigned xylim_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, xylim));
     auto prep_x = [&](int jj) {
-        const us2_t t = xyt[jj] + p_oyx;
-        const bool inb = __builtin_bit_cast(unsigned, __builtin_elementwise_min(t, xylim)) == __builtin_bit_cast(unsigned, t);
-        xofs[jj] = inb ? xthr[jj] + p_xsof : OOB;
+        unsigned t, m, oob;
+        asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(__builtin_bit_cast(unsigned, xyt[jj])), "s"(__builtin_bit_cast(unsigned, p_oyx)));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(t), "s"(xylim_s));
+        asm("v_bfrev_b32 %0, 1" : "=v"(oob));        // 0x80000000 = OOB
+        xofs[jj] = m == t ? xthr[jj] + p_xsof : oob;
     };
     auto prepare = [&](int kb) {
         prep_a(kb);
@@ -483,18 +506,34 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
             const wg3_u2_t lo = relu_half(fbl[KK][nt]), hi = relu_half(fbh[KK][nt]);
             fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
         };
+        // (every dY tile, every second X tile: the odd X tiles keep the XOR -- eight registers the loop does not have)
+        unsigned yaddr[MT][2], xaddr[2][NT / 2][2];
+        if constexpr (WG3_ADDR) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) yaddr[mt][h] = ybase[h] ^ (unsigned)(mt << 5);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt += 2) xaddr[kk][nt / 2][h] = xbase[kk][h] ^ (unsigned)(nt << 5);
+            }
+        }
         // dY fragment mt of k-half KK lives in slot mt, the last one in slot MT - 1 + KK; slot s = registers v[252 - 4 s ..]
         wg3_u2_t fyl[MT + 1], fyh[MT + 1];
         auto read_y = [&](auto st_tag, auto kk_tag, auto mt_tag) {
             constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, mt = decltype(mt_tag)::value;
             constexpr int slot = mt < MT - 1 ? mt : MT - 1 + KK;
             if (WG3_ABL & 8) { fyl[slot] = (wg3_u2_t){ybase[0], (unsigned)mt}; fyh[slot] = (wg3_u2_t){ybase[1], (unsigned)KK}; return; }
-            wg3_rdx_pair_pinned<23 - slot, (unsigned)(ST * STAGE + KK * (32 * YROW))>(fyl[slot], fyh[slot], ybase[0], ybase[1], (unsigned)(mt << 5));
+            if constexpr (WG3_ADDR) wg3_rd2_pinned<23 - slot, (unsigned)(ST * STAGE + KK * (32 * YROW))>(fyl[slot], fyh[slot], yaddr[mt][0], yaddr[mt][1]);
+            else wg3_rdx_pair_pinned<23 - slot, (unsigned)(ST * STAGE + KK * (32 * YROW))>(fyl[slot], fyh[slot], ybase[0], ybase[1], (unsigned)(mt << 5));
         };
         auto read_x = [&](auto st_tag, auto kk_tag, auto nt_tag) {
             constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, nt = decltype(nt_tag)::value;
             if (WG3_ABL & 8) return;
-            wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xbase[KK][0], xbase[KK][1], (unsigned)(nt << 5));
+            if constexpr (WG3_ADDR && (nt & 1) == 0) wg3_rd2<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xaddr[KK][nt / 2][0], xaddr[KK][nt / 2][1]);
+            else if constexpr (WG3_ADDR) wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xaddr[KK][nt / 2][0], xaddr[KK][nt / 2][1], 32u);
+            else wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xbase[KK][0], xbase[KK][1], (unsigned)(nt << 5));
         };
         constexpr int NP = YJ + XJ;                       // LDS-DMA pieces of a fill (7-8 per wave)
         // the gaps (index of the MFMA in front) of a k-half's 32:
