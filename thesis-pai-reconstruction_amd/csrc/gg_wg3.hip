@@ -159,6 +159,25 @@ __device__ __forceinline__ bf8_t wg3_compose(wg3_u2_t lo, wg3_u2_t hi) {
         return __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
     }
 }
+// the same with the B operand in the pinned slot (64 x 128 wave tile: the X fragments are the long side)
+template <int F>
+__device__ __forceinline__ void wg3_mfma_pinned_b(f4_t& acc, bf8_t a, wg3_u2_t lo, wg3_u2_t hi) {
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_)                                                                                             \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, v[" #R0 ":" #R3 "], %0" : "+v"(acc) : "v"(a), "{v[" #R0 ":" #R1 "]}"(lo), "{v[" #R2 ":" #R3 "]}"(hi));
+    WG3_PIN_CASES(X)
+#undef X
+}
+// ReLU of a pinned fragment in place: max(x, rlo) on signed 16-bit lanes, rlo2 = two copies of 0 or of -32768 (no ReLU)
+template <int F>
+__device__ __forceinline__ void wg3_relu_pinned(wg3_u2_t& lo, wg3_u2_t& hi, unsigned rlo2) {
+#define X(F_, R0, R1, R2, R3)                                                                                          \
+    if constexpr (F == F_)                                                                                             \
+        asm volatile("v_pk_max_i16 v" #R0 ", v" #R0 ", %2\n\tv_pk_max_i16 v" #R1 ", v" #R1 ", %2\n\tv_pk_max_i16 v" #R2 ", v" #R2 ", %2\n\tv_pk_max_i16 v" #R3 ", v" #R3 ", %2" \
+                     : "={v[" #R0 ":" #R1 "]}"(lo), "={v[" #R2 ":" #R3 "]}"(hi) : "s"(rlo2), "0"(lo), "1"(hi));
+    WG3_PIN_CASES(X)
+#undef X
+}
 __device__ __forceinline__ void wg3_tie(wg3_u2_t& lo, wg3_u2_t& hi) { asm volatile("" : "+v"(lo), "+v"(hi)); }
 template <int N, typename FN, int... I>
 __device__ __forceinline__ void wg3_sfor_impl(FN&& fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
@@ -228,7 +247,10 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
     const int ysr = tid / YCH, ysc = tid % YCH;
     const int ygch = ysc ^ yswz3<BMC>(ysr);      // the swizzle only looks at row bits 0-3: the same for every j
     const unsigned ythr = (unsigned)(((((ysr >> LBW) << los) << g.ldw) + ((ysr & (BW - 1)) << los)) * g.Cout + co0 + ygch * 8) * 2u;
-    const unsigned yjstep = (unsigned)(((((YRPI >> LBW) << los) << g.ldw)) * g.Cout) * 2u;   // YRPI rows = YRPI / BW pixel rows further
+    // YRPI rows = YRPI / BW pixel rows further.  readfirstlane: hipcc kept this uniform value in a VECTOR register in the 64 x 128
+    // form and put a waterfall loop around the second dY piece of every fill -- a branch in the middle of the MFMA sequence,
+    // and a block boundary across which it copied fragment registers the reads had not delivered into yet (see WG3_PIN)
+    const unsigned yjstep = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(((((YRPI >> LBW) << los) << g.ldw)) * g.Cout) * 2u));
     // X patch fill map: thread -> (pixel XPPI jj + tid / XCH, 16-B chunk tid % XCH)
     const int wby = pg.by[ph][q], wbx = pg.bx[ph][q];
     // (row, column) of the thread's patch pixel as two 16-bit fields: the in-image test of a step is one packed add of the
@@ -506,8 +528,11 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
             const wg3_u2_t lo = relu_half(fbl[KK][nt]), hi = relu_half(fbh[KK][nt]);
             fb[KK][nt] = __builtin_bit_cast(bf8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
         };
-        // (every dY tile, every second X tile: the odd X tiles keep the XOR -- eight registers the loop does not have)
-        unsigned yaddr[MT][2], xaddr[2][NT / 2][2];
+        // (every dY tile, every second X tile -- every fourth of the 64 x 128 wave tile's eight: the others keep the XOR, the
+        //  loop does not have the registers)
+        constexpr bool LX = NT > MT;          // 64 x 128 wave tile: the X fragments are the long side (see there)
+        constexpr int XAS = LX ? 4 : 2;
+        unsigned yaddr[MT][2], xaddr[2][NT / XAS][2];
         if constexpr (WG3_ADDR) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -516,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt += 2) xaddr[kk][nt / 2][h] = xbase[kk][h] ^ (unsigned)(nt << 5);
+                    for (int nt = 0; nt < NT; nt += XAS) xaddr[kk][nt / XAS][h] = xbase[kk][h] ^ (unsigned)(nt << 5);
             }
         }
         // dY fragment mt of k-half KK lives in slot mt, the last one in slot MT - 1 + KK; slot s = registers v[252 - 4 s ..]
@@ -531,9 +556,40 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         auto read_x = [&](auto st_tag, auto kk_tag, auto nt_tag) {
             constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, nt = decltype(nt_tag)::value;
             if (WG3_ABL & 8) return;
-            if constexpr (WG3_ADDR && (nt & 1) == 0) wg3_rd2<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xaddr[KK][nt / 2][0], xaddr[KK][nt / 2][1]);
-            else if constexpr (WG3_ADDR) wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xaddr[KK][nt / 2][0], xaddr[KK][nt / 2][1], 32u);
+            if constexpr (WG3_ADDR && (nt % XAS) == 0) wg3_rd2<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xaddr[KK][nt / XAS][0], xaddr[KK][nt / XAS][1]);
+            else if constexpr (WG3_ADDR) wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xaddr[KK][nt / XAS][0], xaddr[KK][nt / XAS][1], (unsigned)((nt % XAS) << 5));
             else wg3_rdx_pair<(unsigned)(ST * STAGE)>(fbl[KK][nt], fbh[KK][nt], xbase[KK][0], xbase[KK][1], (unsigned)(nt << 5));
+        };
+        // ---- 64 x 128 wave tile (LX): the roles are swapped.  The EIGHT X fragments of a k-half are the long side: MFMA order
+        // X tile outermost, each X fragment used by MT = 4 consecutive MFMAs and re-read into its slot behind them (NT + 1
+        // pinned slots v[252 - 4 s ..]); the four dY fragments are the double-buffered short side.  The X fragments go through the ReLU IN PLACE (asm on the named registers): fragment 0
+        // of the next k-half behind this half's last wait, fragment nt >= 1 two MFMAs in front of its first use.
+        wg3_u2_t fxl[NT + 1], fxh[NT + 1];
+        const unsigned rlo2 = xrelu ? 0u : 0x80008000u;
+        auto read_ys = [&](auto st_tag, auto kk_tag, auto mt_tag) {
+            constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, mt = decltype(mt_tag)::value;
+            if (WG3_ABL & 8) return;
+            wg3_rd2<(unsigned)(ST * STAGE + KK * (32 * YROW))>(fal[KK][mt], fah[KK][mt], yaddr[mt][0], yaddr[mt][1]);
+        };
+        // (NOT pinned: hipcc copied pinned halves of this loop-carried set out of their registers right behind the reads -- before
+        //  the data had arrived -- and back in front of the tie; formed by the compiler behind the tie, a copy per half)
+        auto form_ys = [&](auto kk_tag, auto mt_tag) {
+            constexpr int KK = decltype(kk_tag)::value, mt = decltype(mt_tag)::value;
+            if (WG3_ABL & 8) { fa[KK][mt] = __builtin_bit_cast(bf8_t, make_uint4(ybase[0], ybase[1], mt, KK)); return; }
+            fa[KK][mt] = wg3_compose<0, false>(fal[KK][mt], fah[KK][mt]);
+        };
+        auto read_xl = [&](auto st_tag, auto kk_tag, auto nt_tag) {
+            constexpr int ST = decltype(st_tag)::value, KK = decltype(kk_tag)::value, nt = decltype(nt_tag)::value;
+            constexpr int slot = nt < NT - 1 ? nt : NT - 1 + KK;
+            if (WG3_ABL & 8) { fxl[slot] = (wg3_u2_t){xbase[KK][0], (unsigned)nt}; fxh[slot] = (wg3_u2_t){xbase[KK][1], (unsigned)KK}; return; }
+            if constexpr ((nt % XAS) == 0) wg3_rd2_pinned<23 - slot, (unsigned)(ST * STAGE)>(fxl[slot], fxh[slot], xaddr[KK][nt / XAS][0], xaddr[KK][nt / XAS][1]);
+            else wg3_rdx_pair_pinned<23 - slot, (unsigned)(ST * STAGE)>(fxl[slot], fxh[slot], xaddr[KK][nt / XAS][0], xaddr[KK][nt / XAS][1], (unsigned)((nt % XAS) << 5));
+        };
+        auto relu_xl = [&](auto kk_tag, auto nt_tag) {
+            constexpr int KK = decltype(kk_tag)::value, nt = decltype(nt_tag)::value;
+            constexpr int slot = nt < NT - 1 ? nt : NT - 1 + KK;
+            if (WG3_ABL & 8) return;
+            wg3_relu_pinned<23 - slot>(fxl[slot], fxh[slot], rlo2);
         };
         constexpr int NP = YJ + XJ;                       // LDS-DMA pieces of a fill (7-8 per wave)
         // the gaps (index of the MFMA in front) of a k-half's 32:
@@ -542,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         //   (mt+1) NT, mt < MT-1   dY fragment mt of the next k-half, right behind the last MFMA on the current one
         //   XW .. XW+NT-1          counted wait for the X reads (the dY reads issued since stay in flight), then one ReLU per gap
         //   30                     lgkmcnt(0): the dY fragments are where the MFMAs of the next k-half name them
-        constexpr int XW = NT == 4 ? 13 : 17;
-        constexpr int XW_PENDING = NT == 4 ? 8 : 6;       // DS instructions issued behind the last X read when MFMA XW is issued
+        constexpr int XW = 13;                            // (LX: the same plan with the sides swapped)
+        constexpr int XW_PENDING = 8;                     // DS instructions issued behind the last short-side read when MFMA XW is issued
         static_assert((NT == 4 && MT == 8) || (NT == 8 && MT == 4), "gap plan");
         constexpr int FIRE0 = NT == 4 ? 14 : 10;          // M1: fill piece j behind MFMA FIRE0 + 2 j (8 pieces end at 28 / 24)
         static_assert(FIRE0 + 2 * (NP - 1) <= 29, "fill pieces fit between the MFMAs of a k-half");
@@ -551,6 +607,38 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
         auto half = [&](auto kk_tag, auto rs_tag, bool rd, auto&& extra) {
             constexpr int KK = decltype(kk_tag)::value;
             typedef std::integral_constant<int, KK ^ 1> NK;
+            if constexpr (LX) {
+                wg3_sfor<MT * NT>([&](auto t) {
+                    constexpr int idx = decltype(t)::value, nt = idx / MT, mt = idx % MT;
+                    constexpr int slot = nt < NT - 1 ? nt : NT - 1 + KK;
+                    if (WG3_ABL & 2) acc[mt][nt][0] += __uint_as_float(fxl[slot].x) + (float)fa[KK][mt][0];
+                    else wg3_mfma_pinned_b<23 - slot>(acc[mt][nt], fa[KK][mt], fxl[slot], fxh[slot]);
+                    // the ReLU of THIS k-half's X fragment nt >= 1, two MFMAs in front of its first use
+                    if constexpr (idx >= 2 && (idx + 2) % MT == 0 && (idx + 2) / MT < NT) {
+                        relu_xl(kk_tag, std::integral_constant<int, (idx + 2) / MT>{});
+                    }
+                    if (rd) {
+                        if constexpr (idx < MT) read_ys(rs_tag, NK{}, t);
+                        if constexpr (idx == MT + 1) read_xl(rs_tag, NK{}, std::integral_constant<int, NT - 1>{});
+                        if constexpr (idx >= MT && idx % MT == 0 && idx / MT - 1 < NT - 1) read_xl(rs_tag, NK{}, std::integral_constant<int, idx / MT - 1>{});
+                        if constexpr (idx == XW) {
+                            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XW_PENDING) : "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (idx >= XW && idx < XW + MT) {
+                            form_ys(NK{}, std::integral_constant<int, idx - XW>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (idx == 30) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            relu_xl(NK{}, std::integral_constant<int, 0>{});
+                        }
+                    }
+                    extra(t);
+                });
+                return;
+            }
             wg3_sfor<MT * NT>([&](auto t) {
                 constexpr int idx = decltype(t)::value, mt = idx / NT, nt = idx % NT;
                 constexpr int slot = mt < MT - 1 ? mt : MT - 1 + KK;
@@ -587,11 +675,20 @@ __global__ __launch_bounds__(256, 2) void gg_wgrad_patch3_k(GG g, WgradArgs a, P
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
-            wg3_sfor<NT>([&](auto t) { read_x(St0{}, K0{}, t); });
-            wg3_sfor<MT>([&](auto t) { read_y(St0{}, K0{}, t); });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            wg3_sfor<NT>([&](auto t) { form_b(K0{}, t); });
+            if constexpr (LX) {
+                wg3_sfor<MT>([&](auto t) { read_ys(St0{}, K0{}, t); });
+                wg3_sfor<NT>([&](auto t) { read_xl(St0{}, K0{}, t); });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                wg3_sfor<MT>([&](auto t) { form_ys(K0{}, t); });
+                relu_xl(K0{}, std::integral_constant<int, 0>{});
+            } else {
+                wg3_sfor<NT>([&](auto t) { read_x(St0{}, K0{}, t); });
+                wg3_sfor<MT>([&](auto t) { read_y(St0{}, K0{}, t); });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                wg3_sfor<NT>([&](auto t) { form_b(K0{}, t); });
+            }
         }
         // hipcc re-loads the kernel arguments the address arithmetic of the loop shifts by right in front of the loop and waits
         // for them at their first use INSIDE it -- an lgkmcnt(0) that also waits for the fragment reads in flight, every step.
@@ -866,9 +963,8 @@ int launch_wgrad3(const GG& g, const WgradArgs& a0, hipStream_t s) {
     }
     const dim3 grid(c.tiles * c.psplits);
     const int ph_inner = g.nphase > 1 && pai_tunable("wgrad3_ph_inner", 1);
-    // the pipelined K loop (see the kernel): not with a bias gradient (the bias sums live in the round-3 loop only) and not for the
-    // 64 x 128 wave tile (its eight double-buffered X fragments leave no room: 56 spilled registers inside the loop)
-    const int pipe = pai_tunable("wgrad3_pipe", 1) && !a.dbias && variant != 2;
+    // the pipelined K loop (see the kernel): not with a bias gradient (the bias sums live in the round-3 loop only)
+    const int pipe = pai_tunable("wgrad3_pipe", 1) && !a.dbias;
     if (variant == 1) {
         const size_t lds = (size_t)2 * (64 * 256 + 96 * 128);
         if (pipe) PAI_LAUNCH((gg_wgrad_patch3_k<128, 64, 16>), grid, dim3(256), lds, s, g, a, pg, c.cotiles, c.jtiles, c.psplits, c.per, ph_inner);
