@@ -22,7 +22,11 @@ static __device__ uint4 g_zero_line[16];  // 256 B of zeros: source of padding /
 
 typedef __attribute__((ext_vector_type(8))) short s8_t;
 
+#ifndef RELU_ABL
+#define RELU_ABL 0     // timing ablation (results WRONG): 1 = no ReLU on the fragments
+#endif
 __device__ __forceinline__ bf8_t relu_frag(bf8_t f) {
+    if (RELU_ABL) return f;
     // ReLU on packed bf16: as signed 16-bit integers every negative float is negative
     // (v_pk_max_i16 x4).  Done on one 8-lane vector: element-wise writes to a 4 x u32 vector in an
     // unrolled loop were folded to a broadcast of element 0 by hipcc 7.2.
