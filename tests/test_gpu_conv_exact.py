@@ -149,6 +149,27 @@ def test_mfma_kernels_bit_exact_on_integer_data(pai, case, workspace):
         assert used[0] == SPLIT[0] and used[1] == SPLIT[0], used
 
 
+# ---- the pipelined K loop of gg_wgrad_patch3_k: every way a pixel split can end ---------------------------------------
+# The loop runs pairs of steps while two more follow and finishes with 1-3 steps whose look-ahead (next fragments, fill after
+# next) is switched off one by one; a split of ONE step skips the second fill of the prologue.  (tr, N, H, C1, C2, Cout,
+# relu, wgrad3_target): the split count the target gives makes the splits 1 .. 7 steps long, for the three forms of the
+# kernel (128 x 64 wave tile, its 8 x 8-pixel form, 64 x 128)
+PIPE_TAILS = [(0, 1, 32, 64, 0, 128, 0, 16), (0, 2, 32, 64, 0, 128, 0, 12), (0, 2, 32, 64, 0, 128, 0, 8), (0, 3, 32, 64, 0, 128, 0, 20),
+              (0, 5, 32, 64, 0, 128, 0, 12), (0, 7, 32, 128, 0, 128, 0, 24),
+              (1, 1, 16, 128, 128, 64, 1, 16), (1, 3, 16, 128, 128, 64, 1, 40), (1, 5, 16, 128, 128, 64, 1, 24),
+              (0, 5, 16, 64, 0, 128, 0, 12), (1, 3, 8, 128, 0, 128, 1, 24)]
+
+
+@pytest.mark.parametrize("cfg", PIPE_TAILS, ids=str)
+def test_pipelined_weight_gradient_loop_on_every_split_length(pai, cfg):
+    from thesis_pai_reconstruction_amd import ops
+    tr, N, H, C1, C2, Cout, relu, target = cfg
+    case = ("pipe_tail", tr, N, H, C1, C2, Cout, relu, None)
+    for pipe in (1, 0):
+        used = _run_case(pai, case, tunables=(("wgrad3_target", target), ("wgrad3_minrows", 64), ("wgrad3_pipe", pipe)))
+        assert used[2].startswith("gg_wgrad_patch3_k"), used
+
+
 OLD_WGRAD = {"enc_patch": "gg_wgrad_patch_k<128>", "dec_patch": "gg_wgrad_patch_k<128>", "dec_patch256x64": "gg_wgrad_patch_k<64>",
              "cfg2_dec5": "gg_wgrad_patch_k<128>"}
 
