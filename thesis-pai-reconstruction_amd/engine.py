@@ -802,7 +802,8 @@ class UnetEngine:
             C = self.enc_c[i]
             dz = G["dz_enc"][i]       # written by encoder i+1's input-gradient call (pai_conv_dgrad_bn_apply)
             d = P["enc_desc"][i]
-            # (PAI_HINT_SOLO for the last 1-3 encoders' weight gradients re-measured in round 6: 5.64 ms/step with and without)
+            # (PAI_HINT_SOLO for the last 1-3 encoders' weight gradients re-measured in round 6, with the round-3 loop and with the
+            #  pipelined one: 5.64 / 5.62 ms/step with and without)
             wgrad(P["enc_desc"][i], S["a"][i - 1], None, dz, conv, False)   # bias grad == 0 (BN)
             _, wd = self.enc_packs[i].get(dtype)
             fused_rows = enc_dgrad(i, dz, wd)
