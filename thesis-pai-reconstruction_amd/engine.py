@@ -695,14 +695,37 @@ class UnetEngine:
         # segments GradArena.begin_backward cleared in one launch
         conv_wgrad = ops.conv_wgrad_overwrite_w if fresh else ops.conv_wgrad
 
+        # The weight gradients of the bottleneck layers (<= 1024 output pixels: encoders[5-7], decoders[0-2]) are issued THREE at a
+        # time behind one fork: a fork is an event record on the main queue and a wait on the side queue, ~5 us of queue latency
+        # each between launches of 8-50 us, and the side stream lags the main one there anyway.  Same box, six interleaved
+        # runs each: 5.741 ms/step with a fork per layer, 5.723 in pairs, **5.692** in threes, 5.742 in fours; with the
+        # 8 x 8-pixel layers included 5.77-5.81 (PAI_WGRAD_BATCH / PAI_WGRAD_BATCH_PIX: the A/B switches).
+        batch_n = int(os.environ.get("PAI_WGRAD_BATCH", "3"))
+        held = []
+
+        def flush_held():
+            if held:
+                with torch.cuda.stream(side.fork()):
+                    for run in held:
+                        run()
+                held.clear()
+
         def wgrad(d, x1, x2, dz, conv, with_bias):
             """Weight (and bias) gradient of one layer on the side stream, beside its own input gradient.  (Round 4 measured
             the alternatives: holding the first decoders' weight gradients back until the main stream is in the bottleneck
             chain, 6.34-6.48 against 6.25-6.27 ms/step; two workgroups per CU for the last one of a pass, no change.)"""
-            with torch.cuda.stream(side.fork(d)):
+            def run():
                 fn = ops.conv_wgrad if min(_cin_cout(conv)) <= 2 else conv_wgrad
                 fn(d, x1, x2, dz, A.seg(conv.weight), A.seg(conv.bias) if with_bias else None)
                 done(conv.bias)
+            if batch_n > 1 and dz.numel() // max(1, conv.weight.shape[1] if isinstance(conv, nn.ConvTranspose2d) else conv.weight.shape[0]) <= int(os.environ.get("PAI_WGRAD_BATCH_PIX", "1024")):
+                held.append(run)
+                if len(held) >= batch_n:
+                    flush_held()
+                return
+            flush_held()
+            with torch.cuda.stream(side.fork(d)):
+                run()
 
         # head: tanh' then the bare ConvTranspose2d (pix2pix.py:185-193,216)
         j = L - 1
@@ -809,6 +832,7 @@ class UnetEngine:
             fused_rows = enc_dgrad(i, dz, wd)
         # encoder 0 (its dz came out of encoder 1's input gradient): on the tail stream, beside encoder 1's
         conv0 = self.enc_conv[0]
+        flush_held()
         with torch.cuda.stream(side.fork_tail()):
             (ops.conv_wgrad if min(_cin_cout(conv0)) <= 2 else conv_wgrad)(
                 P["enc_desc"][0], S["x"], None, G["dz_enc"][0], A.seg(conv0.weight), A.seg(conv0.bias))
