@@ -408,6 +408,38 @@ def test_streaming_adam_equals_the_step_at_the_end(pai, monkeypatch, dtype):
     assert og.arm_streaming() is False
     ma.unet.engine.grad_ready_hook = None
 
+def test_weight_gradients_issued_in_threes_equal_those_issued_one_by_one(pai, monkeypatch):
+    """engine.py holds the weight gradients of the bottleneck layers (<= 1024 output pixels) back and issues three behind one
+    fork of the side stream (PAI_WGRAD_BATCH, default 3).  Only the ORDER OF ISSUE changes: the gradient arena of a backward
+    pass is the same -- bit for bit on the dense layers' weights (slab sums in split order), to rounding noise where fp32
+    atomics add (bias gradients, thin layers)."""
+    mults, seed = (1, 2, 2, 4), 41
+    x, t = synth_batch(seed + 100, 4, 32)           # 4 x 16 x 16 output pixels and fewer: every layer is a held one
+    batch = (x.to(DEV), t.to(DEV))
+    monkeypatch.setenv("PAI_NO_STREAM_ADAM", "1")   # gradients stay in the arena until step()
+    grads = []
+    for n in ("1", "3", "2"):
+        monkeypatch.setenv("PAI_WGRAD_BATCH", n)
+        m, _, _ = build(pai, mults, "gan", seed, dtype=torch.bfloat16)
+        og = m.optimizers()[0]
+        seen = []
+        orig = og.step
+        og.step = lambda *a, orig=orig, og=og, **k: seen.append(og._engine.arena().flat.clone()) or orig(*a, **k)
+        m.training_step(batch, 0)
+        torch.cuda.synchronize()
+        assert len(seen) == 1
+        grads.append((seen[0], m.unet.engine))
+    g1, eng = grads[0]
+    arena = eng.arena()
+    for g, _ in grads[1:]:
+        assert torch.isfinite(g).all()
+        scale = float(g1.abs().max())
+        assert float((g - g1).abs().max()) <= 1e-5 * scale
+        for conv in eng.enc_conv[1:] + eng.dec_conv[:-1]:
+            a, n = arena.offsets[id(conv.weight)]
+            assert torch.equal(g[a:a + n], g1[a:a + n]), conv
+
+
 
 def test_dropout2d_step_matches_reference_fixture(pai, golden_dir):
     """Dropout2d(0.5) in the widest decoder blocks (the reference's class default, models/pix2pix.py:108,
